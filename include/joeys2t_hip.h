@@ -1,0 +1,227 @@
+/*
+ * joeys2t_hip.h — C ABI of libjoeys2t_hip.so, the MI355X (gfx950 / CDNA4) kernel library behind the
+ * JoeyS2T speech-to-text hot path.
+ *
+ * The reference (may-/joeys2t) is pure Python: its "native layer" is the set of ATen / cuDNN / torchaudio
+ * operators its modules call.  Each entry point below replaces one of those operator call sites; the
+ * reference file:line it stands in for is cited on every declaration (paths relative to the reference
+ * repo root).  The Python host side (package joeys2t_amd) binds these with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless a parameter says "host";
+ *  - the caller allocates every output and workspace; the library never allocates, frees or keeps a
+ *    pointer after the call returns;
+ *  - work is enqueued on `stream` and never synchronised;
+ *  - return value 0 = enqueued, negative = rejected (nothing enqueued); js2t_last_error() gives the
+ *    thread-local message;
+ *  - tensors are dense row-major unless strides are passed; "dt" arguments are JS2T_F32 / JS2T_BF16
+ *    (bf16 carried as raw 16-bit words); all arithmetic accumulates in f32.
+ */
+#ifndef JOEYS2T_HIP_H
+#define JOEYS2T_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* js2t_stream; /* hipStream_t */
+
+enum { JS2T_F32 = 0, JS2T_BF16 = 1 };
+enum { JS2T_ACT_NONE = 0, JS2T_ACT_RELU = 1, JS2T_ACT_GELU = 2, JS2T_ACT_SWISH = 3, JS2T_ACT_TANH = 4 };
+enum { JS2T_OK = 0, JS2T_ERR_INVALID = -1, JS2T_ERR_LAUNCH = -2, JS2T_ERR_UNSUPPORTED = -3 };
+
+/* Library identity / error channel. */
+int js2t_abi_version(void);
+const char* js2t_last_error(void);
+
+/* --------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue (MFMA).  Replaces every nn.Linear / torch.matmul / nn.Conv1d call on the
+ * path: transformer_layers.py:75-77,89,102,107 (q/k/v/out projections, QK^T, PV),
+ * transformer_layers.py:147-153 (position-wise feed-forward), decoders.py:620-623 (vocabulary and CTC
+ * projections), encoders.py:338-346,364-366 (Conv1d k=5,s=2 as implicit GEMM) and their autograd
+ * backward passes.
+ *
+ *   acc(m,n)  = sum_k A(m,k) * B(n,k)                      (f32 accumulate)
+ *   v         = alpha * [*alpha_dev] * acc + bias[n]
+ *   [preact(m,n) = v]           v = act(v)
+ *   v         = dropout(v)       (Philox keep-mask over (m,n), scaled 1/(1-p))
+ *   v        += res_scale * residual(m,n)
+ *   v         = gate(m,n) > 0 ? v * gate_scale : 0         (ReLU/dropout backward gate)
+ *   C(m,n)    = v + beta * C(m,n)
+ *
+ * Operand addressing:  A(m,k) = A[m*lda + k] (trans_a=0) or A[k*lda + m] (trans_a=1);
+ *                      B(n,k) = B[n*ldb + k] (trans_b=0, i.e. an nn.Linear weight) or B[k*ldb + n].
+ * Batched: problem z in [0,batch) splits as zo = z / batch_inner, zi = z % batch_inner and every
+ * operand pointer advances by zo*stride_o + zi*stride_i (elements) — this is how [B,T,H,dh] heads are
+ * addressed without transposes.
+ * conv != 0 turns A into an implicit im2col view of x[Bc, conv_tin, conv_c]: the A index that runs
+ * along lda ("row" for trans_a=0, "k" for trans_a=1) is (b*conv_tout + t), the contiguous index is
+ * kw*conv_c + c, and A = x[b, t*conv_stride - conv_pad + kw, c] (0 outside [0,conv_tin)).
+ * dtype_ab = BF16 needs 16-byte aligned operands and leading dimensions that are multiples of 8.
+ */
+typedef struct js2t_gemm_desc {
+  int32_t M, N, K;
+  int32_t batch, batch_inner;
+  int32_t dtype_ab, dtype_c;
+  int32_t trans_a, trans_b;
+  const void* A; int64_t lda, a_stride_o, a_stride_i;
+  const void* B; int64_t ldb, b_stride_o, b_stride_i;
+  void* C;       int64_t ldc, c_stride_o, c_stride_i;
+  float alpha;
+  const float* alpha_dev;   /* optional device scalar folded into alpha */
+  const float* bias;        /* optional f32[N] */
+  int32_t act;              /* JS2T_ACT_* */
+  void* preact;             /* optional, C's dtype/layout: value before the activation */
+  float dropout_p;          /* 0 = off */
+  const uint64_t* rng_state;/* device {seed, offset}; required when dropout_p > 0 */
+  uint32_t rng_stream;      /* call-site id mixed into the counter */
+  const void* residual;     /* optional, C's dtype and batch strides */
+  int64_t ldr;
+  float res_scale;
+  const void* gate;         /* optional, C's dtype and batch strides, leading dim ldg */
+  int64_t ldg;
+  float gate_scale;
+  float beta;
+  int32_t conv, conv_tin, conv_tout, conv_c, conv_stride, conv_pad;
+} js2t_gemm_desc;
+
+int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * Element-wise / data-movement kernels.
+ */
+
+/* out[i] = a*x[i] + b*y[i] (y may be NULL) — residual-branch gradient sums (transformer_layers.py:283,384,397
+ * backward) and loss interpolation scaling (loss.py:164). */
+int js2t_axpby(const void* x, float a, const void* y, float b, void* out, int64_t n, int dt, js2t_stream stream);
+
+/* dst[i] = (dst_dt) src[i].  Autocast-style parameter/activation casts (training.py:558 autocast). */
+int js2t_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, js2t_stream stream);
+
+/* y[r,c] = x[r,c] * sigmoid(x[r,c+C]) for x[rows,2C] — F.glu(dim=1) of encoders.py:366 in [B,T,C] layout. */
+int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream);
+/* dx[rows,2C] from dy[rows,C] and the saved x. */
+int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int dt, js2t_stream stream);
+
+/* y[b,t,:] = dropout(x[b,t,:] + pe[t,:] (+ extra[b,t,:])) — PositionalEncoding.forward
+ * (transformer_layers.py:204-213) + emb_dropout (encoders.py:273-276, decoders.py:599-602).
+ * pe is f32[>=T, D]; extra (prompt-mask embedding) may be NULL. */
+int js2t_add_pe_dropout(const void* x, const float* pe, const void* extra, void* y, int64_t B, int64_t T,
+                        int64_t D, int dt, float p, const uint64_t* rng_state, uint32_t rng_stream,
+                        js2t_stream stream);
+
+/* dx = dy * keep(row,col) / (1-p) with the same Philox mask the forward drew for (rng_stream). */
+int js2t_dropout_bwd(const void* dy, void* dx, int64_t rows, int64_t cols, int dt, float p,
+                     const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream);
+
+/* dz = scale * dh * act'(z) — backward of the activations of builders.py:24-41 (relu, gelu, swish, tanh).
+ * For ReLU, z may be the saved (post-dropout) output: its sign carries both the ReLU and the keep mask. */
+int js2t_act_bwd(const void* dh, const void* z, void* dz, int64_t n, int act, int dt, float scale,
+                 js2t_stream stream);
+
+/* out[i,:] = table[ids[i],:] * scale — Embeddings.forward (embeddings.py:55-64). */
+int js2t_embed_fwd(const int64_t* ids, const void* table, int table_dt, void* out, int out_dt,
+                   int64_t n_ids, int64_t D, int64_t vocab, float scale, js2t_stream stream);
+/* dtable[ids[i],:] += scale * dout[i,:] (f32 atomics); rows with ids[i]==pad_idx are skipped
+ * (nn.Embedding padding_idx, embeddings.py:51). */
+int js2t_embed_bwd(const int64_t* ids, const void* dout, int dout_dt, float* dtable, int64_t n_ids,
+                   int64_t D, int64_t vocab, float scale, int64_t pad_idx, js2t_stream stream);
+
+/* out[c] = sum_r x[r,c] (f32) — bias gradients of every nn.Linear / nn.Conv1d on the path.
+ * partial is a caller-provided f32[colsum_partial_rows(rows) * cols] workspace. */
+int64_t js2t_colsum_partial_rows(int64_t rows);
+int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols,
+                js2t_stream stream);
+
+/* Conv1d weight repack: w[Cout,Cin,K] (torch layout, encoders.py:339-345) <-> wp[Cout, K*Cin] (GEMM layout). */
+int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_t cout, int64_t cin, int64_t k,
+                          js2t_stream stream);
+int js2t_conv_weight_unpack_grad(const float* dwp_t, float* dw, int64_t cout, int64_t cin, int64_t k,
+                                 js2t_stream stream); /* dwp_t is [K*Cin, Cout] (transposed wgrad) */
+/* dx[b,tau,c] = sum over taps of dcol[(b*tout+t), kw*C+c] with t*stride-pad+kw == tau (conv dgrad gather). */
+int js2t_col2im(const void* dcol, void* dx, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
+                int64_t stride, int64_t pad, int dt, js2t_stream stream);
+
+/* out_len = floor((len + 2*(k/2) - (k-1) - 1)/2 + 1) per conv layer — Conv1dSubsampler.get_out_seq_lens_tensor
+ * (encoders.py:348-352) followed by lengths_to_padding_mask (helpers.py:459-469): mask[b,t] = t < out_len[b].
+ * kernel_sizes is a HOST array. */
+int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_lengths, uint8_t* mask, int64_t B,
+                                int64_t T_out, const int32_t* kernel_sizes, int32_t n_layers,
+                                js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * LayerNorm(eps=1e-6) — transformer_layers.py:146,248,339-340; encoders.py:223-226; decoders.py:549-552.
+ * mean/rstd are f32[rows] (saved for backward).  gamma/beta f32[D].
+ */
+int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int64_t rows, int64_t D, float eps, int dt, js2t_stream stream);
+/* dx (dt) = LN'(dy) [+ add_scale * add]  (add: optional residual-branch gradient, same shape as dx);
+ * dgamma/dbeta f32[D] (may both be NULL); partial = f32[2 * js2t_colsum_partial_rows(rows) * D] workspace. */
+int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, const void* add, float add_scale, float* dgamma,
+                       float* dbeta, float* partial, int64_t rows, int64_t D, int dt, js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * Masked softmax (+ dropout) over attention scores — transformer_layers.py:93-98.
+ * S,P,Pd: [Z, Tq, ld] with Z = B*H; mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k]
+ * (mask_sq = 0 for a [B,1,Tk] key-padding mask); masked scores act as -inf.  Columns [Tk, ld) of P/Pd
+ * are written as zeros so that P can feed the PV GEMM with K = ld.  Pd (dropout applied) may alias P
+ * when p == 0.
+ */
+int js2t_softmax_fwd(const void* S, const uint8_t* mask, void* P, void* Pd, int64_t B, int64_t H,
+                     int64_t Tq, int64_t Tk, int64_t ld, int64_t mask_sb, int64_t mask_sq, int dt,
+                     float p, const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream);
+/* dS = P * (dP - sum_k dP*P) with dP = dPd * keep/(1-p). */
+int js2t_softmax_bwd(const void* P, const void* dPd, void* dS, int64_t Z, int64_t Tq, int64_t Tk,
+                     int64_t ld, int dt, float p, const uint64_t* rng_state, uint32_t rng_stream,
+                     js2t_stream stream);
+/* out[b,q,k] = (1/H) sum_h P[b,h,q,k]  (f32) — head-averaged weights, transformer_layers.py:109-114. */
+int js2t_attn_head_mean(const void* P, float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
+                        int64_t ld, int dt, js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * Vocabulary-sized rows: log-softmax, label-smoothed cross-entropy, CTC.
+ */
+
+/* lse[r] = log sum_v exp(x[r,v]); argmax[r] (optional) = first index of the row maximum.
+ * F.log_softmax statistics of model.py:121,126 and search.py:562; argmax of model.py:139-143. */
+int js2t_row_lse(const void* x, float* lse, int64_t* argmax, int64_t rows, int64_t V, int dt, js2t_stream stream);
+
+/* y = x - lse(x) row-wise — F.log_softmax(dim=-1) (model.py:121,126; search.py:258,562). */
+int js2t_log_softmax(const void* x, int dt, void* y, int y_dt, int64_t rows, int64_t V, js2t_stream stream);
+
+/* XentLoss on logits (loss.py:16-107 after model.py:121): per row r with gold trg[r]
+ *   smoothing > 0: KLDivLoss(sum) against the smoothed target (eps/(V-2) off-gold, 1-eps gold, pad column 0,
+ *                  all-zero row when gold == pad) in closed form;  smoothing <= 0: NLLLoss(ignore_index=pad, sum).
+ * loss_rows / correct_rows / lse are f32[rows]; correct_rows[r] = 1 if argmax == gold and gold != pad
+ * (n_correct of model.py:137-143).  Sum them with js2t_sum_f32. */
+int js2t_xent_fwd(const void* logits, int dt, const int64_t* trg, float* loss_rows, float* correct_rows,
+                  float* lse, int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream);
+/* dlogits = scale * (*g_dev) * (softmax - target)  (g_dev: optional device scalar = upstream gradient). */
+int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, const float* lse, const float* g_dev,
+                  float scale, void* dlogits, int64_t rows, int64_t V, int64_t pad_idx, float smoothing,
+                  js2t_stream stream);
+
+/* out[0] = sum_i x[i] (single block, fixed order => bit-reproducible). */
+int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream);
+
+/* nn.CTCLoss(blank, reduction='sum', zero_infinity) of loss.py:128-130,156-161 on LOGITS [B,T,V]
+ * (batch-major; the reference's transpose(0,1) and log_softmax are folded in through `lse` = js2t_row_lse).
+ * targets int64[B,Lmax] (padded), in_len/tgt_len int64[B].  alpha: f32[B,T,2*Lmax+1] (kept for backward),
+ * nll: f32[B] raw negative log-likelihoods (inf when infeasible), loss_rows: f32[B] after zero_infinity. */
+int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
+                   const int64_t* tgt_len, float* alpha, float* nll, float* loss_rows, int64_t B, int64_t T,
+                   int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream);
+/* beta recursion + dlogits[b,t,v] = scale*(*g_dev)*(softmax_t(v) - sum_{s:ext(s)=v} exp(alpha+beta-lp+nll)),
+ * zero for t >= in_len[b] and for infeasible utterances when zero_infinity.  beta: f32[B,T,2*Lmax+1] workspace. */
+int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
+                 const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
+                 float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
+                 int zero_infinity, js2t_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOEYS2T_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libjoeys2t_hip.so (the C ABI declared in include/joeys2t_hip.h).
+
+There is no fallback: if the shared library is missing or a call is rejected, we raise.
+"""
+import ctypes as C
+import re
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libjoeys2t_hip.so"
+HEADER_PATH = PKG_DIR.parent / "include" / "joeys2t_hip.h"
+
+F32, BF16 = 0, 1
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4}
+
+
+class Js2tError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    """Mirror of js2t_gemm_desc (include/joeys2t_hip.h)."""
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("batch", C.c_int32), ("batch_inner", C.c_int32),
+        ("dtype_ab", C.c_int32), ("dtype_c", C.c_int32),
+        ("trans_a", C.c_int32), ("trans_b", C.c_int32),
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_stride_o", C.c_int64), ("a_stride_i", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_stride_o", C.c_int64), ("b_stride_i", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_stride_o", C.c_int64), ("c_stride_i", C.c_int64),
+        ("alpha", C.c_float),
+        ("alpha_dev", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("act", C.c_int32),
+        ("preact", C.c_void_p),
+        ("dropout_p", C.c_float),
+        ("rng_state", C.c_void_p),
+        ("rng_stream", C.c_uint32),
+        ("residual", C.c_void_p), ("ldr", C.c_int64), ("res_scale", C.c_float),
+        ("gate", C.c_void_p), ("ldg", C.c_int64), ("gate_scale", C.c_float),
+        ("beta", C.c_float),
+        ("conv", C.c_int32), ("conv_tin", C.c_int32), ("conv_tout", C.c_int32), ("conv_c", C.c_int32),
+        ("conv_stride", C.c_int32), ("conv_pad", C.c_int32),
+    ]
+
+
+def declared_symbols(header: Path = HEADER_PATH):
+    """Names of every function declared in the public header."""
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(js2t_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise Js2tError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+            )
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.js2t_last_error.restype = C.c_char_p
+        _lib.js2t_colsum_partial_rows.restype = C.c_int64
+        _lib.js2t_colsum_partial_rows.argtypes = [C.c_int64]
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().js2t_last_error().decode("utf-8", "replace")
+        raise Js2tError(f"libjoeys2t_hip: {what} failed (rc={rc}): {msg}")

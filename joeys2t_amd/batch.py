@@ -1,0 +1,107 @@
+"""Mini-batch container whose attributes are the keyword arguments of Model.forward (reference batch.py:17-231):
+`model(return_type=..., **vars(batch))` (training.py:560-562).  Integer / bool bookkeeping only."""
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from joeys2t_amd.helpers import adjust_mask_size
+
+
+class Batch:
+    def __init__(self, src: Tensor, src_length: Tensor, src_prompt_mask: Optional[Tensor], trg: Optional[Tensor],
+                 trg_length: Optional[Tensor], trg_prompt_mask: Optional[Tensor], indices: Tensor, device: torch.device,
+                 pad_index: int, eos_index: int, is_train: bool = True, task: str = "MT", n_gpu: Optional[int] = None):
+        self.src: Tensor = src
+        self.src_length: Tensor = src_length
+        self.src_mask: Optional[Tensor] = None
+        self.src_prompt_mask: Optional[Tensor] = src_prompt_mask
+        self.trg_input: Optional[Tensor] = None
+        self.trg: Optional[Tensor] = None
+        self.trg_length: Optional[Tensor] = None
+        self.trg_mask: Optional[Tensor] = None
+        self.trg_prompt_mask: Optional[Tensor] = None
+        self.indices: Tensor = indices
+        self.nseqs: int = src.size(0)
+        self.ntokens: Optional[int] = None
+        self.has_trg: bool = trg is not None
+        self.is_train: bool = is_train
+        if self.is_train:
+            assert self.has_trg
+
+        if self.has_trg:
+            assert trg_length is not None
+            # teacher-forcing input: EOS replaced by PAD, last column dropped when an EOS is present (batch.py:82-84)
+            has_eos = bool(torch.any(trg == eos_index).item())
+            trg_input = torch.where(trg == eos_index, torch.full_like(trg, pad_index), trg)
+            self.trg_input = trg_input[:, :-1] if has_eos else trg_input
+            self.trg = trg[:, 1:]  # shifted by one (BOS dropped)
+            self.trg_length = trg_length - 1
+            self.trg_mask = (self.trg != pad_index).unsqueeze(1)
+            self.ntokens = int(self.trg_mask.sum().item())
+            if trg_prompt_mask is not None:
+                self.trg_prompt_mask = adjust_mask_size(trg_prompt_mask, self.nseqs, self.trg_input.size(1))
+
+        if torch.device(device).type == "cuda":
+            self._make_cuda(device)
+
+        self.task: str = task
+        if self.task == "MT":
+            self.src_mask = (self.src != pad_index).unsqueeze(1)
+        elif self.task == "S2T":
+            self.src_max_len: int = self.src.size(1)
+            # the reference re-pads when several GPUs are visible (batch.py:109) — a DataParallel concern
+            self.repad: bool = (torch.cuda.device_count() if n_gpu is None else n_gpu) > 1
+        assert self.nseqs > 0, self.nseqs
+
+    def _make_cuda(self, device: torch.device) -> None:
+        for name in ("src", "src_length", "src_mask", "indices", "src_prompt_mask", "trg_input", "trg", "trg_length",
+                     "trg_mask", "trg_prompt_mask"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t.to(device, non_blocking=True))
+
+    def normalize(self, tensor: Tensor, normalization: str = "none", n_gpu: int = 1, n_accumulation: int = 1) -> Tensor:
+        """sum over GPUs, / nseqs|ntokens|1, / n_gpu, / n_accumulation (reference batch.py:135-175)."""
+        if tensor is None:
+            return None
+        assert torch.is_tensor(tensor), tensor
+        if n_gpu > 1:
+            tensor = tensor.sum()
+        if normalization == "sum":
+            return tensor
+        normalizer = {"batch": self.nseqs, "tokens": self.ntokens, "none": 1}[normalization]
+        out = tensor / normalizer
+        if n_gpu > 1:
+            out = out / n_gpu
+        if n_accumulation > 1:
+            out = out / n_accumulation
+        return out
+
+    def sort_by_src_length(self) -> List[int]:
+        """Sort by source length (descending); returns the index list that undoes the sort."""
+        _, perm = self.src_length.sort(0, descending=True)
+        rev = [0] * perm.size(0)
+        for new_pos, old_pos in enumerate(perm.cpu().numpy()):
+            rev[old_pos] = new_pos
+        for name in ("src", "src_length", "src_mask", "indices", "src_prompt_mask"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t[perm])
+        if self.has_trg:
+            for name in ("trg_input", "trg_mask", "trg_length", "trg", "trg_prompt_mask"):
+                t = getattr(self, name)
+                if t is not None:
+                    setattr(self, name, t[perm])
+        return rev
+
+    @staticmethod
+    def score(log_probs: Tensor, trg: Tensor, pad_index: int) -> np.ndarray:
+        lp, tg = log_probs.detach().float().cpu().numpy(), trg.detach().cpu().numpy()
+        rows = [np.array([lp[i, j, ind] for j, ind in enumerate(tg[i]) if ind != pad_index]) for i in range(lp.shape[0])]
+        return np.array(rows, dtype=object)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(nseqs={self.nseqs}, ntokens={self.ntokens}, "
+                f"has_trg={self.has_trg}, is_train={self.is_train})")

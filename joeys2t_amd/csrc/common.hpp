@@ -1,0 +1,156 @@
+// Shared device helpers for the joeys2t_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/joeys2t_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------- error plumbing
+void js2t_set_error(const char* fmt, ...);
+#define JS2T_CHECK(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      js2t_set_error(__VA_ARGS__);       \
+      return JS2T_ERR_INVALID;           \
+    }                                    \
+  } while (0)
+#define JS2T_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      js2t_set_error("launch failed: %s", hipGetErrorString(e__));       \
+      return JS2T_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------- dtype helpers
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32 on gfx950: RNE, NaN stays NaN
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<uint16_t> {  // bf16 carried as raw bits
+  static __device__ __forceinline__ float ld(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  static __device__ __forceinline__ void st(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+};
+
+// generic element load/store by runtime dtype code
+__device__ __forceinline__ float ld_elem(const void* p, int64_t i, int dt) {
+  return dt == JS2T_F32 ? ((const float*)p)[i] : bf16_bits_to_f32(((const uint16_t*)p)[i]);
+}
+__device__ __forceinline__ void st_elem(void* p, int64_t i, int dt, float v) {
+  if (dt == JS2T_F32) ((float*)p)[i] = v;
+  else ((uint16_t*)p)[i] = f32_to_bf16_bits(v);
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum; `red` is a __shared__ float[>= blockDim/64]; all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = -INFINITY;
+  for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// ---------------------------------------------------------------- counter-based RNG (Philox4x32-7)
+// One call yields 4 uniform 32-bit words for counter (c0..c3) under key (k0,k1).
+struct philox4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  return {c0, c1, c2, c3};
+}
+// Dropout keep-decision for 4 consecutive columns (col4*4 .. col4*4+3) of `row`.
+// rng_state = {seed, offset} in device memory; `stream` separates call sites.
+// Returns a 4-bit keep mask (bit i = keep column col4*4+i).
+__device__ __forceinline__ uint32_t dropout_keep4(const uint64_t* rng_state, uint32_t stream,
+                                                  uint32_t row, uint32_t col4, float p) {
+  const uint64_t seed = rng_state[0], off = rng_state[1];
+  const philox4 r = philox4x32_7(col4, row, (uint32_t)off, (uint32_t)(off >> 32) ^ stream,
+                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+  // keep iff u >= p, u = word * 2^-32
+  const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+  return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+}
+__device__ __forceinline__ bool dropout_keep1(const uint64_t* rng_state, uint32_t stream,
+                                              uint32_t row, uint32_t col, float p) {
+  return (dropout_keep4(rng_state, stream, row, col >> 2, p) >> (col & 3)) & 1u;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case JS2T_ACT_RELU: return fmaxf(v, 0.f);
+    case JS2T_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case JS2T_ACT_SWISH: return v / (1.f + __expf(-v));
+    case JS2T_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_grad(float z, int act) {  // d act(z) / dz
+  switch (act) {
+    case JS2T_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case JS2T_ACT_GELU: {
+      const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+      return cdf + z * pdf;
+    }
+    case JS2T_ACT_SWISH: {
+      const float s = 1.f / (1.f + __expf(-z));
+      return s * (1.f + z * (1.f - s));
+    }
+    case JS2T_ACT_TANH: {
+      const float t = tanhf(z);
+      return 1.f - t * t;
+    }
+    default: return 1.f;
+  }
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,17 @@
+// Error channel and identity of libjoeys2t_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/joeys2t_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void js2t_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* js2t_last_error(void) { return g_err; }
+extern "C" int js2t_abi_version(void) { return 1; }

@@ -1,0 +1,395 @@
+// HBM-bound element-wise and data-movement kernels of the path (casts, GLU, positional encoding +
+// dropout, dropout / activation backward, embedding gather / scatter, column sums, Conv1d weight repack,
+// col2im gather, subsampled lengths + padding mask).  All are grid-stride, 16-byte-per-lane where the
+// layout allows; math in f32.
+#include "common.hpp"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_grid(int64_t work_items) {
+  int64_t g = (work_items + EW_THREADS - 1) / EW_THREADS;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;  // 256 CUs x 16 blocks, grid-stride beyond
+  return (int)g;
+}
+
+// ---- vector-of-4 accessors (4 consecutive elements; caller guarantees 4-element alignment) ----------
+template <typename T> struct vec4;
+template <> struct vec4<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const float4 x = *(const float4*)p; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct vec4<uint16_t> {
+  static __device__ __forceinline__ void ld(const uint16_t* p, float (&v)[4]) {
+    const uint2 x = *(const uint2*)p;
+    v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
+    v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(uint16_t* p, const float (&v)[4]) {
+    uint2 x;
+    x.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+    x.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+    *(uint2*)p = x;
+  }
+};
+
+// ---------------------------------------------------------------- cast
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[4];
+    vec4<S>::ld(src + 4 * i, v);
+    vec4<D>::st(dst + 4 * i, v);
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    io<D>::st(dst + i, io<S>::ld(src + i));
+}
+
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, float a, const T* __restrict__ y, float b, T* __restrict__ out,
+                             int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = a * io<T>::ld(x + i);
+    if (y) v += b * io<T>::ld(y + i);
+    io<T>::st(out + i, v);
+  }
+}
+
+// ---------------------------------------------------------------- GLU
+template <typename T>
+__global__ void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t C) {
+  const int64_t total = rows * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C, c = i - r * C;
+    const float a = io<T>::ld(x + r * 2 * C + c), b = io<T>::ld(x + r * 2 * C + C + c);
+    io<T>::st(y + i, a / (1.f + __expf(-b)));
+  }
+}
+template <typename T>
+__global__ void glu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t rows,
+                               int64_t C) {
+  const int64_t total = rows * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C, c = i - r * C;
+    const float a = io<T>::ld(x + r * 2 * C + c), b = io<T>::ld(x + r * 2 * C + C + c);
+    const float g = io<T>::ld(dy + i);
+    const float s = 1.f / (1.f + __expf(-b));
+    io<T>::st(dx + r * 2 * C + c, g * s);
+    io<T>::st(dx + r * 2 * C + C + c, g * a * s * (1.f - s));
+  }
+}
+
+// ---------------------------------------------------------------- y = dropout(x + pe (+ extra))
+template <typename T>
+__global__ void add_pe_dropout_kernel(const T* __restrict__ x, const float* __restrict__ pe, const T* __restrict__ extra,
+                                      T* __restrict__ y, int64_t B, int64_t T_, int64_t D, float p,
+                                      const uint64_t* rng, uint32_t stream) {
+  // one thread per 4 columns (D % 4 == 0 enforced by the host)
+  const int64_t D4 = D >> 2, total = B * T_ * D4;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / D4, c4 = i - row * D4, t = row % T_;
+    float v[4], e[4];
+    vec4<T>::ld(x + row * D + 4 * c4, v);
+    const float4 pv = *(const float4*)(pe + t * D + 4 * c4);
+    v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+    if (extra) {
+      vec4<T>::ld(extra + row * D + 4 * c4, e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += e[k];
+    }
+    if (p > 0.f) {
+      const uint32_t keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)c4, p);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ((keep >> k) & 1u) ? v[k] * sc : 0.f;
+    }
+    vec4<T>::st(y + row * D + 4 * c4, v);
+  }
+}
+
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int64_t rows, int64_t cols, float p,
+                                   const uint64_t* rng, uint32_t stream) {
+  const int64_t c4n = (cols + 3) >> 2, total = rows * c4n;
+  const float sc = 1.f / (1.f - p);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / c4n, c4 = i - row * c4n;
+    const uint32_t keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)c4, p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t c = 4 * c4 + k;
+      if (c < cols) {
+        const float g = io<T>::ld(dy + row * cols + c);
+        io<T>::st(dx + row * cols + c, ((keep >> k) & 1u) ? g * sc : 0.f);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ z, T* __restrict__ dz, int64_t n, int act,
+                               float scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    io<T>::st(dz + i, io<T>::ld(dh + i) * act_grad(io<T>::ld(z + i), act) * scale);
+}
+
+// ---------------------------------------------------------------- embedding
+template <typename TT, typename TO>
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const TT* __restrict__ table, TO* __restrict__ out,
+                                 int64_t n_ids, int64_t D, int64_t vocab, float scale) {
+  const int64_t total = n_ids * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D, c = i - r * D;
+    const int64_t id = ids[r];
+    const float v = (id >= 0 && id < vocab) ? io<TT>::ld(table + id * D + c) * scale : 0.f;
+    io<TO>::st(out + i, v);
+  }
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout, float* __restrict__ dtable,
+                                 int64_t n_ids, int64_t D, int64_t vocab, float scale, int64_t pad_idx) {
+  const int64_t total = n_ids * D;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D, c = i - r * D;
+    const int64_t id = ids[r];
+    if (id < 0 || id >= vocab || id == pad_idx) continue;
+    atomicAdd(dtable + id * D + c, scale * io<T>::ld(dout + i));
+  }
+}
+
+// ---------------------------------------------------------------- column sums (two-stage, deterministic)
+constexpr int CS_ROWS_PER_BLOCK = 128;
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t rows, int64_t cols) {
+  // block (bx, by): columns [bx*256, +256), rows [by*128, +128); thread = one column
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK, r1 = min(rows, r0 + CS_ROWS_PER_BLOCK);
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += io<T>::ld(x + r * cols + c);
+  partial[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts, int64_t cols) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < nparts; ++p) s += partial[p * cols + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------- conv weight repack
+template <typename D>
+__global__ void conv_pack_kernel(const float* __restrict__ w, D* __restrict__ wp, int64_t cout, int64_t cin, int64_t k) {
+  const int64_t total = cout * cin * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // destination index i = (o, kw, c)
+    const int64_t o = i / (k * cin), rem = i - o * k * cin, kw = rem / cin, c = rem - kw * cin;
+    io<D>::st(wp + i, w[(o * cin + c) * k + kw]);
+  }
+}
+__global__ void conv_unpack_grad_kernel(const float* __restrict__ dwp_t, float* __restrict__ dw, int64_t cout, int64_t cin,
+                                        int64_t k) {
+  const int64_t total = cout * cin * k;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // destination index i = (o, c, kw) in torch layout; source [(kw*cin + c), o]
+    const int64_t o = i / (cin * k), rem = i - o * cin * k, c = rem / k, kw = rem - c * k;
+    dw[i] = dwp_t[(kw * cin + c) * cout + o];
+  }
+}
+
+template <typename T>
+__global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int64_t B, int64_t tin, int64_t tout,
+                              int64_t C, int64_t K, int64_t stride, int64_t pad) {
+  const int64_t total = B * tin * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / (tin * C), rem = i - b * tin * C, tau = rem / C, c = rem - tau * C;
+    float s = 0.f;
+    for (int64_t kw = 0; kw < K; ++kw) {
+      const int64_t num = tau + pad - kw;
+      if (num < 0 || num % stride) continue;
+      const int64_t t = num / stride;
+      if (t >= tout) continue;
+      s += io<T>::ld(dcol + (b * tout + t) * (K * C) + kw * C + c);
+    }
+    io<T>::st(dx + i, s);
+  }
+}
+
+__global__ void subsample_len_mask_kernel(const int64_t* __restrict__ lengths, int64_t* __restrict__ out_lengths,
+                                          uint8_t* __restrict__ mask, int64_t B, int64_t T_out, int k0, int k1, int k2, int k3,
+                                          int n_layers) {
+  const int ks[4] = {k0, k1, k2, k3};
+  const int64_t total = B * T_out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / T_out, t = i - b * T_out;
+    int64_t len = lengths[b];
+    for (int l = 0; l < n_layers; ++l) {
+      // ((len + 2*(k//2) - (k-1) - 1) / 2 + 1).floor() evaluated in float like the reference
+      const float f = ((float)len + 2.f * (float)(ks[l] / 2) - (float)(ks[l] - 1) - 1.f) / 2.f + 1.f;
+      len = (int64_t)floorf(f);
+    }
+    if (t == 0) out_lengths[b] = len;
+    mask[i] = t < len ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_DT(dt, T, ...)                                  \
+  do {                                                           \
+    if ((dt) == JS2T_F32) { typedef float T; __VA_ARGS__; }      \
+    else if ((dt) == JS2T_BF16) { typedef uint16_t T; __VA_ARGS__; } \
+    else { js2t_set_error("bad dtype %d", (int)(dt)); return JS2T_ERR_INVALID; } \
+  } while (0)
+
+extern "C" int js2t_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, js2t_stream stream) {
+  if (n == 0) return JS2T_OK;
+  JS2T_CHECK(src && dst && n > 0, "cast: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = ew_grid(n / 4 + 1);
+  DISPATCH_DT(src_dt, S, DISPATCH_DT(dst_dt, D, hipLaunchKernelGGL((cast_kernel<S, D>), dim3(g), dim3(EW_THREADS), 0, s,
+                                                                    (const S*)src, (D*)dst, n)));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_axpby(const void* x, float a, const void* y, float b, void* out, int64_t n, int dt, js2t_stream stream) {
+  if (n == 0) return JS2T_OK;
+  JS2T_CHECK(x && out && n > 0, "axpby: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((axpby_kernel<T>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                                        (const T*)x, a, (const T*)y, b, (T*)out, n));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream) {
+  if (rows * C == 0) return JS2T_OK;
+  JS2T_CHECK(x && y && rows > 0 && C > 0, "glu_fwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((glu_fwd_kernel<T>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0,
+                                        (hipStream_t)stream, (const T*)x, (T*)y, rows, C));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+extern "C" int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int dt, js2t_stream stream) {
+  if (rows * C == 0) return JS2T_OK;
+  JS2T_CHECK(x && dy && dx && rows > 0 && C > 0, "glu_bwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((glu_bwd_kernel<T>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0,
+                                        (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, rows, C));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_add_pe_dropout(const void* x, const float* pe, const void* extra, void* y, int64_t B, int64_t T_,
+                                   int64_t D, int dt, float p, const uint64_t* rng_state, uint32_t rng_stream,
+                                   js2t_stream stream) {
+  if (B * T_ * D == 0) return JS2T_OK;
+  JS2T_CHECK(x && pe && y, "add_pe_dropout: null pointer");
+  JS2T_CHECK(D % 4 == 0, "add_pe_dropout: D must be a multiple of 4 (got %lld)", (long long)D);
+  JS2T_CHECK(p >= 0.f && p < 1.f && (p == 0.f || rng_state), "add_pe_dropout: bad dropout arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((add_pe_dropout_kernel<T>), dim3(ew_grid(B * T_ * D / 4)), dim3(EW_THREADS), 0,
+                                        (hipStream_t)stream, (const T*)x, pe, (const T*)extra, (T*)y, B, T_, D, p,
+                                        rng_state, rng_stream));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_dropout_bwd(const void* dy, void* dx, int64_t rows, int64_t cols, int dt, float p,
+                                const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream) {
+  if (rows * cols == 0) return JS2T_OK;
+  JS2T_CHECK(dy && dx && rng_state && p > 0.f && p < 1.f, "dropout_bwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((dropout_bwd_kernel<T>), dim3(ew_grid(rows * ((cols + 3) / 4))), dim3(EW_THREADS),
+                                        0, (hipStream_t)stream, (const T*)dy, (T*)dx, rows, cols, p, rng_state, rng_stream));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_act_bwd(const void* dh, const void* z, void* dz, int64_t n, int act, int dt, float scale,
+                            js2t_stream stream) {
+  if (n == 0) return JS2T_OK;
+  JS2T_CHECK(dh && z && dz && n > 0, "act_bwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                                        (const T*)dh, (const T*)z, (T*)dz, n, act, scale));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_embed_fwd(const int64_t* ids, const void* table, int table_dt, void* out, int out_dt, int64_t n_ids,
+                              int64_t D, int64_t vocab, float scale, js2t_stream stream) {
+  if (n_ids * D == 0) return JS2T_OK;
+  JS2T_CHECK(ids && table && out, "embed_fwd: null pointer");
+  DISPATCH_DT(table_dt, TT, DISPATCH_DT(out_dt, TO, hipLaunchKernelGGL((embed_fwd_kernel<TT, TO>), dim3(ew_grid(n_ids * D)),
+                                                                       dim3(EW_THREADS), 0, (hipStream_t)stream, ids,
+                                                                       (const TT*)table, (TO*)out, n_ids, D, vocab, scale)));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+extern "C" int js2t_embed_bwd(const int64_t* ids, const void* dout, int dout_dt, float* dtable, int64_t n_ids, int64_t D,
+                              int64_t vocab, float scale, int64_t pad_idx, js2t_stream stream) {
+  if (n_ids * D == 0) return JS2T_OK;
+  JS2T_CHECK(ids && dout && dtable, "embed_bwd: null pointer");
+  DISPATCH_DT(dout_dt, T, hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(ew_grid(n_ids * D)), dim3(EW_THREADS), 0,
+                                             (hipStream_t)stream, ids, (const T*)dout, dtable, n_ids, D, vocab, scale, pad_idx));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int64_t js2t_colsum_partial_rows(int64_t rows) { return (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK; }
+
+extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, js2t_stream stream) {
+  if (cols == 0) return JS2T_OK;
+  JS2T_CHECK(x && out && partial && rows > 0, "colsum: bad arguments");
+  const int64_t nparts = js2t_colsum_partial_rows(rows);
+  JS2T_CHECK(nparts <= 65535, "colsum: too many rows");
+  const dim3 g1(cdiv(cols, EW_THREADS), (unsigned)nparts);
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), g1, dim3(EW_THREADS), 0, (hipStream_t)stream,
+                                        (const T*)x, partial, rows, cols));
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, EW_THREADS)), dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+                     out, nparts, cols);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_t cout, int64_t cin, int64_t k,
+                                     js2t_stream stream) {
+  JS2T_CHECK(w && wp && cout > 0 && cin > 0 && k > 0, "conv_weight_pack: bad arguments");
+  DISPATCH_DT(wp_dt, D, hipLaunchKernelGGL((conv_pack_kernel<D>), dim3(ew_grid(cout * cin * k)), dim3(EW_THREADS), 0,
+                                           (hipStream_t)stream, w, (D*)wp, cout, cin, k));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+extern "C" int js2t_conv_weight_unpack_grad(const float* dwp_t, float* dw, int64_t cout, int64_t cin, int64_t k,
+                                            js2t_stream stream) {
+  JS2T_CHECK(dwp_t && dw && cout > 0 && cin > 0 && k > 0, "conv_weight_unpack_grad: bad arguments");
+  hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3(ew_grid(cout * cin * k)), dim3(EW_THREADS), 0, (hipStream_t)stream, dwp_t,
+                     dw, cout, cin, k);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+extern "C" int js2t_col2im(const void* dcol, void* dx, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
+                           int64_t stride, int64_t pad, int dt, js2t_stream stream) {
+  if (B * tin * C == 0) return JS2T_OK;
+  JS2T_CHECK(dcol && dx && stride > 0 && K > 0, "col2im: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((col2im_kernel<T>), dim3(ew_grid(B * tin * C)), dim3(EW_THREADS), 0,
+                                        (hipStream_t)stream, (const T*)dcol, (T*)dx, B, tin, tout, C, K, stride, pad));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_lengths, uint8_t* mask, int64_t B,
+                                           int64_t T_out, const int32_t* kernel_sizes, int32_t n_layers, js2t_stream stream) {
+  JS2T_CHECK(lengths && out_lengths && mask && B > 0 && T_out > 0, "subsample_lengths_mask: bad arguments");
+  JS2T_CHECK(n_layers >= 0 && n_layers <= 4 && (n_layers == 0 || kernel_sizes), "subsample_lengths_mask: 0..4 conv layers");
+  int ks[4] = {1, 1, 1, 1};
+  for (int i = 0; i < n_layers; ++i) ks[i] = kernel_sizes[i];
+  hipLaunchKernelGGL(subsample_len_mask_kernel, dim3(ew_grid(B * T_out)), dim3(EW_THREADS), 0, (hipStream_t)stream, lengths,
+                     out_lengths, mask, B, T_out, ks[0], ks[1], ks[2], ks[3], n_layers);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

@@ -1,0 +1,400 @@
+// MFMA GEMM with fused epilogue for gfx950.  Two kernels behind one C entry point (js2t_gemm):
+//
+//  * gemm_bf16_kernel<TA,TB> — the hot kernel.  128x128x64 block tile, 4 waves (2x2), each wave a 64x64
+//    sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators.  Operands are staged global -> registers ->
+//    LDS (issue-early / write-late, double-buffered LDS, one barrier per K tile).  A k-contiguous operand
+//    tile is kept as [row][64 k] with a 16-byte-chunk XOR swizzle (conflict-free ds_read_b128); an operand
+//    whose reduction index is the slow one in memory (trans_a / trans_b) is kept as [k][row] and read
+//    with ds_read_b64_tr_b16, so NN / TN products (dgrad, wgrad, P.V) need no transposed copies.
+//    The MFMA is issued "swapped" (A-operand = B tile, B-operand = A tile) so that every lane ends up with
+//    4 consecutive output columns of one row -> 8/16-byte epilogue accesses.
+//
+//  * gemm_generic_kernel — any shape / alignment / dtype, v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
+//    This is the fp32 "parity mode" kernel and the fallback for bf16 operands the fast kernel rejects.
+//
+// Reference call sites replaced: see include/joeys2t_hip.h (js2t_gemm).
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// operand addressing shared by both kernels
+// ------------------------------------------------------------------------------------------------
+// Element offset of A at (slow, fast): slow runs along lda, fast is contiguous.  In conv mode slow is
+// the (b, t_out) output-frame index and fast is kw*C + c; returns false for zero padding.
+__device__ __forceinline__ bool a_elem_offset(const js2t_gemm_desc& d, int slow, int fast, int64_t& off) {
+  if (!d.conv) {
+    off = (int64_t)slow * d.lda + fast;
+    return true;
+  }
+  const int b = slow / d.conv_tout, t = slow - b * d.conv_tout;
+  const int kw = fast / d.conv_c;
+  const int tin = t * d.conv_stride - d.conv_pad + kw;
+  off = ((int64_t)b * d.conv_tin + (t * d.conv_stride - d.conv_pad)) * d.conv_c + fast;
+  return tin >= 0 && tin < d.conv_tin;
+}
+
+// Epilogue for 4 consecutive columns n..n+3 of row m (see header for the order of operations).
+__device__ __forceinline__ void gemm_epilogue4(const js2t_gemm_desc& d, int z, int64_t c_boff, int m, int n,
+                                               f32x4_t acc, float alpha) {
+  if (m >= d.M || n >= d.N) return;
+  const int nv = min(4, d.N - n);
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = acc[i] * alpha;
+  if (d.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) v[i] += d.bias[n + i];
+  }
+  const int64_t coff = c_boff + (int64_t)m * d.ldc + n;
+  if (d.preact) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) st_elem(d.preact, coff + i, d.dtype_c, v[i]);
+  }
+  if (d.act != JS2T_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i], d.act);
+  }
+  if (d.dropout_p > 0.f) {
+    const uint32_t keep = dropout_keep4(d.rng_state, d.rng_stream, (uint32_t)(z * d.M + m), (uint32_t)(n >> 2),
+                                        d.dropout_p);
+    const float sc = 1.f / (1.f - d.dropout_p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * sc : 0.f;
+  }
+  if (d.residual) {
+    const int64_t roff = (int64_t)m * d.ldr + n;  // residual / gate are only accepted for batch == 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) v[i] += d.res_scale * ld_elem(d.residual, roff + i, d.dtype_c);
+  }
+  if (d.gate) {
+    const int64_t goff = (int64_t)m * d.ldg + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) v[i] = ld_elem(d.gate, goff + i, d.dtype_c) > 0.f ? v[i] * d.gate_scale : 0.f;
+  }
+  if (d.beta != 0.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) v[i] += d.beta * ld_elem(d.C, coff + i, d.dtype_c);
+  }
+  if (nv == 4 && ((coff & 3) == 0)) {
+    if (d.dtype_c == JS2T_F32) {
+      *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+      *(uint2*)((uint16_t*)d.C + coff) = pk;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nv) st_elem(d.C, coff + i, d.dtype_c, v[i]);
+  }
+}
+
+__device__ __forceinline__ void batch_offsets(const js2t_gemm_desc& d, int z, int64_t& ao, int64_t& bo, int64_t& co) {
+  const int zo = z / d.batch_inner, zi = z - zo * d.batch_inner;
+  ao = (int64_t)zo * d.a_stride_o + (int64_t)zi * d.a_stride_i;
+  bo = (int64_t)zo * d.b_stride_o + (int64_t)zi * d.b_stride_i;
+  co = (int64_t)zo * d.c_stride_o + (int64_t)zi * d.c_stride_i;
+}
+
+// bijective XCD-aware remap of a linear block id (blocks b and b+8 share an XCD)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel: 64x64x16 tile, f32 MFMA 16x16x4, element-wise bounds-checked staging
+// ------------------------------------------------------------------------------------------------
+constexpr int G_BM = 64, G_BN = 64, G_BK = 16, G_LD = 80;
+
+__global__ __launch_bounds__(256) void gemm_generic_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+  __shared__ float As[G_BK][G_LD];
+  __shared__ float Bs[G_BK][G_LD];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int z = blockIdx.y;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * G_BM, n0 = (lid % tiles_n) * G_BN;
+  int64_t ao, bo, co;
+  batch_offsets(d, z, ao, bo, co);
+  const int wm = w >> 1, wn = w & 1;
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < d.K; k0 += G_BK) {
+    // stage A
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int m, k;
+      if (!d.trans_a) { k = t & 15; m = (t >> 4) + 16 * r; }
+      else            { m = t & 63; k = (t >> 6) + 4 * r; }
+      float v = 0.f;
+      const int gm = m0 + m, gk = k0 + k;
+      if (gm < d.M && gk < d.K) {
+        int64_t off;
+        const bool ok = d.trans_a ? a_elem_offset(d, gk, gm, off) : a_elem_offset(d, gm, gk, off);
+        if (ok) v = ld_elem(d.A, ao + off, d.dtype_ab);
+      }
+      As[k][m] = v;
+    }
+    // stage B
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n, k;
+      if (!d.trans_b) { k = t & 15; n = (t >> 4) + 16 * r; }
+      else            { n = t & 63; k = (t >> 6) + 4 * r; }
+      float v = 0.f;
+      const int gn = n0 + n, gk = k0 + k;
+      if (gn < d.N && gk < d.K) {
+        const int64_t off = d.trans_b ? (int64_t)gk * d.ldb + gn : (int64_t)gn * d.ldb + gk;
+        v = ld_elem(d.B, bo + off, d.dtype_ab);
+      }
+      Bs[k][n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < G_BK / 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      float bn[2], am[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bn[j] = Bs[kr][wn * 32 + 16 * j + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) am[i] = As[kr][wm * 32 + 16 * i + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bn[j], am[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 32 + 16 * i + (lane & 15);
+      const int n = n0 + wn * 32 + 16 * j + 4 * (lane >> 4);
+      gemm_epilogue4(d, z, co, m, n, acc[i][j], alpha);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 fast kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int F_BM = 128, F_BN = 128, F_BK = 64;
+constexpr int KC_ROW_BYTES = 128;          // [row][64 k] bf16
+constexpr int TR_ROW_BYTES = 288;          // [k][128 rows] bf16 + 32 B pad
+constexpr int KC_TILE_BYTES = 128 * KC_ROW_BYTES;  // 16384
+constexpr int TR_TILE_BYTES = 64 * TR_ROW_BYTES;   // 18432
+
+// 8 bf16 of operand X at (slow, fast..fast+7); zero outside [0,slow_max) x [0,fast_max).
+template <bool IS_A>
+__device__ __forceinline__ uint4 load8(const js2t_gemm_desc& d, const uint16_t* base, int64_t ld, int slow,
+                                       int fast, int slow_max, int fast_max) {
+  uint4 r = make_uint4(0u, 0u, 0u, 0u);
+  if (slow >= slow_max || fast >= fast_max) return r;
+  int64_t off;
+  bool ok = true;
+  if (IS_A) ok = a_elem_offset(d, slow, fast, off);
+  else off = (int64_t)slow * ld + fast;
+  if (!ok) return r;
+  if (fast + 8 <= fast_max) return *(const uint4*)(base + off);
+  uint16_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = (fast + i < fast_max) ? base[off + i] : (uint16_t)0;
+  r.x = e[0] | ((uint32_t)e[1] << 16); r.y = e[2] | ((uint32_t)e[3] << 16);
+  r.z = e[4] | ((uint32_t)e[5] << 16); r.w = e[6] | ((uint32_t)e[7] << 16);
+  return r;
+}
+
+// global -> registers for one 128 x 64 operand tile (4 x 16 B per thread)
+template <bool TR, bool IS_A>
+__device__ __forceinline__ void stage_load(const js2t_gemm_desc& d, const uint16_t* base, int64_t ld, int rowbase,
+                                           int k0, int rows_max, int K, int t, uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!TR) {
+      const int row = (t >> 3) + 32 * i, c = t & 7;
+      r[i] = load8<IS_A>(d, base, ld, rowbase + row, k0 + 8 * c, rows_max, K);
+    } else {
+      const int kr = (t >> 4) + 16 * i, c = t & 15;
+      r[i] = load8<IS_A>(d, base, ld, k0 + kr, rowbase + 8 * c, K, rows_max);
+    }
+  }
+}
+// registers -> LDS
+template <bool TR>
+__device__ __forceinline__ void stage_store(unsigned char* tile, int t, const uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!TR) {
+      const int row = (t >> 3) + 32 * i, c = t & 7;
+      *(uint4*)(tile + row * KC_ROW_BYTES + ((c ^ (row & 7)) << 4)) = r[i];
+    } else {
+      const int kr = (t >> 4) + 16 * i, c = t & 15;
+      *(uint4*)(tile + kr * TR_ROW_BYTES + ((c << 4) ^ (((kr >> 3) & 1) << 7))) = r[i];
+    }
+  }
+}
+// LDS -> MFMA fragment: 8 k-values (kk*32 + 8*(lane>>4) + 0..7) of tile row (sub + (lane&15))
+template <bool TR>
+__device__ __forceinline__ bf16x8_t frag_load(const unsigned char* tile, int sub, int kk, int lane) {
+  if (!TR) {
+    const int row = sub + (lane & 15), c = kk * 4 + (lane >> 4);
+    return *(const bf16x8_t*)(tile + row * KC_ROW_BYTES + ((c ^ (row & 7)) << 4));
+  } else {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3;
+    const int kb = kk * 32 + 8 * (lane >> 4);
+    const int colb = (sub + 4 * p) * 2;
+    const int k1 = kb + q, k2 = kb + 4 + q;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_p)(tile + k1 * TR_ROW_BYTES + (colb ^ (((k1 >> 3) & 1) << 7))));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_p)(tile + k2 * TR_ROW_BYTES + (colb ^ (((k2 >> 3) & 1) << 7))));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int A_BYTES = TA ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int B_BYTES = TB ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int z = blockIdx.y;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * F_BM, n0 = (lid % tiles_n) * F_BN;
+  int64_t ao, bo, co;
+  batch_offsets(d, z, ao, bo, co);
+  const uint16_t* Ab = (const uint16_t*)d.A + ao;
+  const uint16_t* Bb = (const uint16_t*)d.B + bo;
+  const int wm = w >> 1, wn = w & 1;
+  // conv mode: A's "rows" are output frames; M (or K for trans_a) bounds still apply through M/K.
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  const int nk = (d.K + F_BK - 1) / F_BK;
+  stage_load<TA, true>(d, Ab, d.lda, m0, 0, d.M, d.K, t, ra);
+  stage_load<TB, false>(d, Bb, d.ldb, n0, 0, d.N, d.K, t, rb);
+  stage_store<TA>(smem, t, ra);
+  stage_store<TB>(smem + A_BYTES, t, rb);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      stage_load<TA, true>(d, Ab, d.lda, m0, (kt + 1) * F_BK, d.M, d.K, t, ra);
+      stage_load<TB, false>(d, Bb, d.ldb, n0, (kt + 1) * F_BK, d.N, d.K, t, rb);
+    }
+    const unsigned char* At = smem + cur * STAGE;
+    const unsigned char* Bt = At + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t fn[4], fm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fn[j] = frag_load<TB>(Bt, wn * 64 + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fm[i] = frag_load<TA>(At, wm * 64 + 16 * i, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      unsigned char* An = smem + (cur ^ 1) * STAGE;
+      stage_store<TA>(An, t, ra);
+      stage_store<TB>(An + A_BYTES, t, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+      const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
+      gemm_epilogue4(d, z, co, m, n, acc[i][j], alpha);
+    }
+}
+
+template <bool TA, bool TB>
+int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
+  constexpr int A_BYTES = TA ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int B_BYTES = TB ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int LDS = 2 * (A_BYTES + B_BYTES);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TA, TB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tm = cdiv(d.M, F_BM), tn = cdiv(d.N, F_BN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB>), dim3(tm * tn, d.batch), dim3(256), LDS, s, d, tm, tn);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
+  JS2T_CHECK(dp != nullptr, "gemm: null descriptor");
+  js2t_gemm_desc d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  JS2T_CHECK(d.M >= 0 && d.N >= 0 && d.K >= 0 && d.batch >= 0, "gemm: negative size");
+  if (d.M == 0 || d.N == 0 || d.batch == 0) return JS2T_OK;
+  JS2T_CHECK(d.A && d.B && d.C, "gemm: null operand");
+  JS2T_CHECK(d.batch_inner >= 1, "gemm: batch_inner must be >= 1");
+  JS2T_CHECK(d.dtype_ab == JS2T_F32 || d.dtype_ab == JS2T_BF16, "gemm: bad dtype_ab");
+  JS2T_CHECK(d.dtype_c == JS2T_F32 || d.dtype_c == JS2T_BF16, "gemm: bad dtype_c");
+  JS2T_CHECK(d.dropout_p >= 0.f && d.dropout_p < 1.f, "gemm: dropout_p out of range");
+  JS2T_CHECK(d.dropout_p == 0.f || d.rng_state, "gemm: dropout needs rng_state");
+  JS2T_CHECK(!d.residual || d.ldr > 0, "gemm: residual needs ldr");
+  JS2T_CHECK(!d.gate || d.ldg > 0, "gemm: gate needs ldg");
+  JS2T_CHECK(d.batch <= 65535, "gemm: batch too large");
+  if (d.conv) {
+    JS2T_CHECK(d.conv_c > 0 && d.conv_tin > 0 && d.conv_tout > 0 && d.conv_stride > 0, "gemm: bad conv geometry");
+  }
+  JS2T_CHECK(!(d.residual || d.gate) || d.batch == 1, "gemm: residual / gate need batch == 1");
+  bool fast = d.dtype_ab == JS2T_BF16 && aligned16(d.A) && aligned16(d.B) && (d.lda % 8 == 0) && (d.ldb % 8 == 0) &&
+              (d.a_stride_o % 8 == 0) && (d.a_stride_i % 8 == 0) && (d.b_stride_o % 8 == 0) && (d.b_stride_i % 8 == 0) &&
+              (!d.conv || d.conv_c % 8 == 0) && d.K > 0;
+  if (fast) {
+    if (!d.trans_a && !d.trans_b) return launch_bf16<false, false>(d, s);
+    if (!d.trans_a && d.trans_b) return launch_bf16<false, true>(d, s);
+    if (d.trans_a && !d.trans_b) return launch_bf16<true, false>(d, s);
+    return launch_bf16<true, true>(d, s);
+  }
+  const int tm = cdiv(d.M, G_BM), tn = cdiv(d.N, G_BN);
+  hipLaunchKernelGGL(gemm_generic_kernel, dim3(tm * tn, d.batch), dim3(256), 0, s, d, tm, tn);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

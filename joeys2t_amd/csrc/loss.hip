@@ -1,0 +1,382 @@
+// Loss-side kernels: row log-sum-exp / log-softmax over the vocabulary, label-smoothed cross-entropy
+// (closed form — the [N,V] smoothed target of loss.py:35-58 is never materialised), CTC alpha/beta
+// recursions in log space and the CTC gradient w.r.t. the logits, plus small deterministic reductions.
+// All HBM-bound: one pass over the logits per kernel, wavefront-shuffle + LDS block reductions.
+#include "common.hpp"
+
+namespace {
+
+constexpr int LB = 256;  // threads per row-block
+
+__device__ __forceinline__ float logaddexp(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b);
+  return m + log1pf(__expf(-fabsf(a - b)));
+}
+
+// ---------------------------------------------------------------- row statistics over V
+// lse[r] = log sum_v exp(x[r,v]); argmax[r] = first index of the row maximum (optional).
+template <typename T>
+__global__ __launch_bounds__(LB) void row_lse_kernel(const T* __restrict__ x, float* __restrict__ lse,
+                                                     int64_t* __restrict__ argmax, int64_t rows, int64_t V) {
+  __shared__ float red[LB / 64];
+  __shared__ int redi[LB / 64];
+  const int64_t r = blockIdx.x;
+  const T* xr = x + r * V;
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int64_t v = threadIdx.x; v < V; v += LB) {
+    const float f = io<T>::ld(xr + v);
+    if (f > mx) { mx = f; mi = (int)v; }
+  }
+  const float bmx = block_max(mx, red);
+  float s = 0.f;
+  for (int64_t v = threadIdx.x; v < V; v += LB) s += __expf(io<T>::ld(xr + v) - bmx);
+  s = block_sum(s, red);
+  if (argmax) {
+    int cand = (mx == bmx) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int best = redi[0];
+      for (int i = 1; i < LB / 64; ++i) best = min(best, redi[i]);
+      argmax[r] = best;
+    }
+  }
+  if (threadIdx.x == 0) lse[r] = bmx + __logf(s);
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(LB) void log_softmax_kernel(const T* __restrict__ x, TO* __restrict__ y, int64_t rows, int64_t V) {
+  __shared__ float red[LB / 64];
+  const int64_t r = blockIdx.x;
+  const T* xr = x + r * V;
+  float mx = -INFINITY;
+  for (int64_t v = threadIdx.x; v < V; v += LB) mx = fmaxf(mx, io<T>::ld(xr + v));
+  mx = block_max(mx, red);
+  float s = 0.f;
+  for (int64_t v = threadIdx.x; v < V; v += LB) s += __expf(io<T>::ld(xr + v) - mx);
+  s = block_sum(s, red);
+  const float lse = mx + __logf(s);
+  for (int64_t v = threadIdx.x; v < V; v += LB) io<TO>::st(y + r * V + v, io<T>::ld(xr + v) - lse);
+}
+
+// ---------------------------------------------------------------- label-smoothed cross-entropy
+// Per row r with gold g = trg[r] (loss.py:35-58,100):  target t[v] = 1-eps at g, eps/(V-2) elsewhere, 0 at pad,
+// whole row 0 when g == pad;  loss_r = sum_v t (log t - lp[v]).  eps <= 0: NLL with ignore_index = pad.
+template <typename T>
+__global__ __launch_bounds__(LB) void xent_fwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ trg,
+                                                      float* __restrict__ loss_rows, float* __restrict__ correct_rows,
+                                                      float* __restrict__ lse_out, int64_t rows, int64_t V, int64_t pad,
+                                                      float eps) {
+  __shared__ float red[LB / 64];
+  __shared__ int redi[LB / 64];
+  const int64_t r = blockIdx.x;
+  const T* xr = x + r * V;
+  const int64_t g = trg[r];
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  float sx = 0.f;
+  for (int64_t v = threadIdx.x; v < V; v += LB) {
+    const float f = io<T>::ld(xr + v);
+    sx += f;
+    if (f > mx) { mx = f; mi = (int)v; }
+  }
+  const float bmx = block_max(mx, red);
+  sx = block_sum(sx, red);
+  float s = 0.f;
+  for (int64_t v = threadIdx.x; v < V; v += LB) s += __expf(io<T>::ld(xr + v) - bmx);
+  s = block_sum(s, red);
+  int cand = (mx == bmx) ? mi : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = redi[0];
+    for (int i = 1; i < LB / 64; ++i) best = min(best, redi[i]);
+    const float lse = bmx + __logf(s);
+    lse_out[r] = lse;
+    float loss = 0.f, ok = 0.f;
+    if (g != pad && g >= 0 && g < V) {
+      const float lpg = io<T>::ld(xr + g) - lse;
+      if (eps > 0.f) {
+        const float u = eps / (float)(V - 2);
+        const float lpp = (pad >= 0 && pad < V) ? io<T>::ld(xr + pad) - lse : 0.f;
+        const float sum_lp = sx - (float)V * lse;
+        const float cent = (1.f - eps) * __logf(1.f - eps) + eps * __logf(u);
+        loss = cent - ((1.f - eps) * lpg + u * (sum_lp - lpg - lpp));
+      } else {
+        loss = -lpg;
+      }
+      ok = (best == (int)g) ? 1.f : 0.f;
+    }
+    loss_rows[r] = loss;
+    correct_rows[r] = ok;
+  }
+}
+
+// dx[r,v] = gscale * (softmax - t)   (0 for pad rows);  gscale = scale * (*g_dev)
+template <typename T>
+__global__ __launch_bounds__(LB) void xent_bwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ trg,
+                                                      const float* __restrict__ lse, const float* __restrict__ g_dev,
+                                                      float scale, T* __restrict__ dx, int64_t rows, int64_t V, int64_t pad,
+                                                      float eps) {
+  const int64_t r = blockIdx.x;
+  const int64_t g = trg[r];
+  const float gs = scale * (g_dev ? *g_dev : 1.f);
+  const T* xr = x + r * V;
+  T* dr = dx + r * V;
+  if (g == pad || g < 0 || g >= V) {
+    for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, 0.f);
+    return;
+  }
+  const float l = lse[r];
+  const float u = eps > 0.f ? eps / (float)(V - 2) : 0.f;
+  const float tg = eps > 0.f ? 1.f - eps : 1.f;
+  for (int64_t v = threadIdx.x; v < V; v += LB) {
+    const float sm = __expf(io<T>::ld(xr + v) - l);
+    const float t = (v == g) ? tg : ((v == pad) ? 0.f : u);
+    io<T>::st(dr + v, gs * (sm - t));
+  }
+}
+
+// ---------------------------------------------------------------- deterministic small reductions
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// ---------------------------------------------------------------- CTC
+// Extended label sequence of utterance b: ext(s) = blank for even s, targets[b, s/2] for odd s; S = 2L+1.
+// Emission lp_t(s) = x[b,t,ext(s)] - lse[b,t].  alpha/beta are stored as f32 [B, T, Smax].
+constexpr int CTC_THREADS = 256;
+constexpr int CTC_MAX_S = 1024;
+constexpr int CTC_CHUNK_FLOATS = 8192;  // emission staging: 32 KB of LDS
+
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_recursion_kernel(
+    const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
+    const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ out /*alpha|beta*/,
+    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+  __shared__ float a[2][CTC_MAX_S + 2];
+  __shared__ int ext[CTC_MAX_S];
+  __shared__ float em[CTC_CHUNK_FLOATS];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t Tb = min(in_len[b], Tmax);
+  const int L = (int)min(tgt_len[b], Lmax);
+  const int S = 2 * L + 1;
+  for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
+  float* ob = out + (int64_t)b * Tmax * Smax;
+  // rows t >= Tb are never read by the gradient kernel; keep them defined
+  for (int64_t i = Tb * Smax + tid; i < Tmax * Smax; i += CTC_THREADS) ob[i] = -INFINITY;
+  __syncthreads();
+  if (Tb <= 0) {
+    if (!BACKWARD && tid == 0) nll[b] = INFINITY;
+    return;
+  }
+  const int chunk_T = max(1, min(64, CTC_CHUNK_FLOATS / S));
+  int cur = 0;
+  for (int64_t c0 = 0; c0 < Tb; c0 += chunk_T) {
+    const int nt = (int)min((int64_t)chunk_T, Tb - c0);
+    // stage emissions of this chunk of time steps (gather from the logits row)
+    for (int i = tid; i < nt * S; i += CTC_THREADS) {
+      const int tt = i / S, s = i - tt * S;
+      const int64_t t = BACKWARD ? (Tb - 1 - (c0 + tt)) : (c0 + tt);
+      const int lab = ext[s];
+      const float v = (lab >= 0 && lab < V) ? io<T>::ld(x + ((int64_t)b * Tmax + t) * V + lab) - lse[(int64_t)b * Tmax + t]
+                                            : -INFINITY;
+      em[i] = v;
+    }
+    __syncthreads();
+    for (int tt = 0; tt < nt; ++tt) {
+      const int64_t step = c0 + tt;  // 0 .. Tb-1 in recursion order
+      const int64_t t = BACKWARD ? (Tb - 1 - step) : step;
+      const float* prev = a[cur ^ 1];
+      float* now = a[cur];
+      for (int s = tid; s < S; s += CTC_THREADS) {
+        const float e = em[tt * S + s];
+        float v;
+        if (step == 0) {
+          const bool start = BACKWARD ? (s >= S - 2) : (s < 2);
+          v = start ? e : -INFINITY;
+        } else if (!BACKWARD) {
+          float acc = prev[s];
+          if (s >= 1) acc = logaddexp(acc, prev[s - 1]);
+          if (s >= 2 && ext[s] != (int)blank && ext[s] != ext[s - 2]) acc = logaddexp(acc, prev[s - 2]);
+          v = acc + e;
+        } else {
+          float acc = prev[s];
+          if (s + 1 < S) acc = logaddexp(acc, prev[s + 1]);
+          if (s + 2 < S && ext[s + 2] != (int)blank && ext[s + 2] != ext[s]) acc = logaddexp(acc, prev[s + 2]);
+          v = acc + e;
+        }
+        now[s] = v;
+        ob[t * Smax + s] = v;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  if (!BACKWARD && tid == 0) {
+    const float* last = a[cur ^ 1];
+    float ll = last[S - 1];
+    if (S > 1) ll = logaddexp(ll, last[S - 2]);
+    nll[b] = -ll;
+  }
+}
+
+// loss_b = zero_infinity ? (isinf(nll) ? 0 : nll) : nll
+__global__ void ctc_loss_rows_kernel(const float* __restrict__ nll, float* __restrict__ loss_rows, int64_t B, int zero_inf) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < B) {
+    const float v = nll[i];
+    loss_rows[i] = (zero_inf && isinf(v)) ? 0.f : v;
+  }
+}
+
+// dx[b,t,v] = gs * ( softmax_t(v) - sum_{s: ext(s)=v} exp(alpha_t(s) + beta_t(s) - lp_t(s) + nll_b) ), 0 for t >= T_b
+template <typename T>
+__global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, const float* __restrict__ lse,
+                                                      const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                      const float* __restrict__ nll, const int64_t* __restrict__ targets,
+                                                      const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len,
+                                                      const float* __restrict__ g_dev, float scale, T* __restrict__ dx,
+                                                      int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank,
+                                                      int zero_inf) {
+  extern __shared__ float row[];  // V floats
+  const int64_t bt = blockIdx.x, b = bt / Tmax, t = bt - b * Tmax;
+  T* dr = dx + bt * V;
+  const float nl = nll[b];
+  const int64_t Tb = min(in_len[b], Tmax);
+  const bool dead = t >= Tb || (zero_inf && isinf(nl));
+  if (dead) {
+    for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, 0.f);
+    return;
+  }
+  const float gs = scale * (g_dev ? *g_dev : 1.f);
+  const T* xr = x + bt * V;
+  const float l = lse[bt];
+  for (int64_t v = threadIdx.x; v < V; v += LB) row[v] = __expf(io<T>::ld(xr + v) - l);
+  __syncthreads();
+  const int L = (int)min(tgt_len[b], Lmax), S = 2 * L + 1;
+  const float* ar = alpha + bt * Smax;
+  const float* br = beta + bt * Smax;
+  for (int s = threadIdx.x; s < S; s += LB) {
+    const int lab = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
+    if (lab < 0 || lab >= V) continue;
+    const float lp = io<T>::ld(xr + lab) - l;
+    const float occ = ar[s] + br[s] - lp + nl;
+    if (occ > -80.f) atomicAdd(&row[lab], -__expf(occ));
+  }
+  __syncthreads();
+  for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, gs * row[v]);
+}
+
+}  // namespace
+
+#define DISPATCH_DT(dt, T, ...)                                  \
+  do {                                                           \
+    if ((dt) == JS2T_F32) { typedef float T; __VA_ARGS__; }      \
+    else if ((dt) == JS2T_BF16) { typedef uint16_t T; __VA_ARGS__; } \
+    else { js2t_set_error("bad dtype %d", (int)(dt)); return JS2T_ERR_INVALID; } \
+  } while (0)
+
+extern "C" int js2t_row_lse(const void* x, float* lse, int64_t* argmax, int64_t rows, int64_t V, int dt, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(x && lse && rows > 0 && V > 0, "row_lse: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((row_lse_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
+                                        (const T*)x, lse, argmax, rows, V));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_log_softmax(const void* x, int dt, void* y, int y_dt, int64_t rows, int64_t V, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(x && y && rows > 0 && V > 0, "log_softmax: bad arguments");
+  DISPATCH_DT(dt, T, DISPATCH_DT(y_dt, TO, hipLaunchKernelGGL((log_softmax_kernel<T, TO>), dim3((unsigned)rows), dim3(LB), 0,
+                                                              (hipStream_t)stream, (const T*)x, (TO*)y, rows, V)));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_xent_fwd(const void* logits, int dt, const int64_t* trg, float* loss_rows, float* correct_rows, float* lse,
+                             int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(logits && trg && loss_rows && correct_rows && lse && V > 2, "xent_fwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((xent_fwd_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
+                                        (const T*)logits, trg, loss_rows, correct_rows, lse, rows, V, pad_idx, smoothing));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, const float* lse, const float* g_dev, float scale,
+                             void* dlogits, int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(logits && trg && lse && dlogits && V > 2, "xent_bwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((xent_bwd_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
+                                        (const T*)logits, trg, lse, g_dev, scale, (T*)dlogits, rows, V, pad_idx, smoothing));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream) {
+  JS2T_CHECK(x && out && n >= 0, "sum_f32: bad arguments");
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
+                              const int64_t* tgt_len, float* alpha, float* nll, float* loss_rows, int64_t B, int64_t T_,
+                              int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream) {
+  if (B == 0) return JS2T_OK;
+  JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && nll && loss_rows, "ctc_alpha: null pointer");
+  JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_alpha: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
+  const int64_t Smax = 2 * Lmax + 1;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, false>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
+                                        (const T*)logits, lse, targets, in_len, tgt_len, alpha, nll, T_, V, Lmax, Smax, blank));
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ctc_loss_rows_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, nll, loss_rows, B, zero_infinity);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
+                            const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
+                            float scale, void* dlogits, int64_t B, int64_t T_, int64_t V, int64_t Lmax, int64_t blank,
+                            int zero_infinity, js2t_stream stream) {
+  if (B == 0) return JS2T_OK;
+  JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && beta && nll && dlogits, "ctc_bwd: null pointer");
+  JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_bwd: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
+  JS2T_CHECK(V * 4 <= 160 * 1024 - 1024, "ctc_bwd: vocabulary %lld too large for the LDS-staged gradient row", (long long)V);
+  const int64_t Smax = 2 * Lmax + 1;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, true>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
+                                        (const T*)logits, lse, targets, in_len, tgt_len, beta, (float*)nullptr, T_, V, Lmax,
+                                        Smax, blank));
+  JS2T_LAUNCH_CHECK();
+  const size_t lds = (size_t)V * sizeof(float);
+  if (dt == JS2T_F32) {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const float*)logits, lse, alpha,
+                       beta, nll, targets, in_len, tgt_len, g_dev, scale, (float*)dlogits, T_, V, Lmax, Smax, blank,
+                       zero_infinity);
+  } else {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ctc_grad_kernel<uint16_t>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const uint16_t*)logits, lse,
+                       alpha, beta, nll, targets, in_len, tgt_len, g_dev, scale, (uint16_t*)dlogits, T_, V, Lmax, Smax, blank,
+                       zero_infinity);
+  }
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

@@ -1,0 +1,279 @@
+// Row-wise HBM-bound kernels with wavefront-shuffle reductions: LayerNorm fwd/bwd and the masked
+// attention softmax (+ dropout) fwd/bwd, plus the head-mean of attention weights.
+// One 64-lane wave owns one row; a 256-thread block holds 4 rows.
+#include "common.hpp"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
+
+// ---------------------------------------------------------------- LayerNorm forward
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int64_t rows, int64_t D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * D;
+  float s = 0.f;
+  for (int64_t c = lane; c < D; c += 64) s += io<T>::ld(xr + c);
+  const float mu = wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int64_t c = lane; c < D; c += 64) {
+    const float d = io<T>::ld(xr + c) - mu;
+    v += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(v) / (float)D + eps);
+  T* yr = y + row * D;
+  for (int64_t c = lane; c < D; c += 64) io<T>::st(yr + c, (io<T>::ld(xr + c) - mu) * rs * gamma[c] + beta[c]);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward (dx) + partial dgamma/dbeta
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, T* __restrict__ dx,
+                                                               const T* __restrict__ add, float add_scale,
+                                                               int64_t rows, int64_t D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mu = mean[row], rs = rstd[row];
+  const T* xr = x + row * D;
+  const T* gr = dy + row * D;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t c = lane; c < D; c += 64) {
+    const float g = io<T>::ld(gr + c) * gamma[c];
+    const float xh = (io<T>::ld(xr + c) - mu) * rs;
+    s1 += g;
+    s2 += g * xh;
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+  T* dr = dx + row * D;
+  for (int64_t c = lane; c < D; c += 64) {
+    const float g = io<T>::ld(gr + c) * gamma[c];
+    const float xh = (io<T>::ld(xr + c) - mu) * rs;
+    float v = rs * (g - s1 - xh * s2);
+    if (add) v += add_scale * io<T>::ld(add + row * D + c);
+    io<T>::st(dr + c, v);
+  }
+}
+// partial[(2*part + 0)*D + c] = sum_r dy*xhat ; partial[(2*part+1)*D + c] = sum_r dy   over a 128-row slab
+constexpr int LN_SLAB = 128;
+template <typename T>
+__global__ void layernorm_bwd_param_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   float* __restrict__ partial, int64_t rows, int64_t D) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const int64_t r0 = (int64_t)blockIdx.y * LN_SLAB, r1 = min(rows, r0 + LN_SLAB);
+  float sg = 0.f, sb = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float g = io<T>::ld(dy + r * D + c);
+    sg += g * (io<T>::ld(x + r * D + c) - mean[r]) * rstd[r];
+    sb += g;
+  }
+  partial[((int64_t)blockIdx.y * 2 + 0) * D + c] = sg;
+  partial[((int64_t)blockIdx.y * 2 + 1) * D + c] = sb;
+}
+__global__ void layernorm_bwd_param_final_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, int64_t nparts, int64_t D) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float sg = 0.f, sb = 0.f;
+  for (int64_t p = 0; p < nparts; ++p) {
+    sg += partial[(p * 2 + 0) * D + c];
+    sb += partial[(p * 2 + 1) * D + c];
+  }
+  dgamma[c] = sg;
+  dbeta[c] = sb;
+}
+
+// ---------------------------------------------------------------- masked softmax (+dropout) forward
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* S, const uint8_t* __restrict__ mask,
+                                                          T* P, T* Pd, int64_t B, int64_t H,
+                                                          int64_t Tq, int64_t Tk, int64_t ld, int64_t mask_sb,
+                                                          int64_t mask_sq, float p, const uint64_t* rng, uint32_t stream) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);  // over Z*Tq
+  if (row >= B * H * Tq) return;
+  const int64_t z = row / Tq, q = row - z * Tq, b = z / H;
+  const T* sr = S + row * ld;
+  const uint8_t* mr = mask ? mask + b * mask_sb + q * mask_sq : nullptr;
+  float mx = -INFINITY;
+  for (int64_t k = lane; k < Tk; k += 64) {
+    const bool on = !mr || mr[k];
+    if (on) mx = fmaxf(mx, io<T>::ld(sr + k));
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int64_t k = lane; k < Tk; k += 64) {
+    const bool on = !mr || mr[k];
+    if (on) sum += __expf(io<T>::ld(sr + k) - mx);
+  }
+  sum = wave_sum(sum);
+  // A fully masked row yields NaN exactly as softmax over all -inf does in the reference.
+  const float inv = 1.f / sum;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  T* pr = P + row * ld;
+  T* pdr = Pd + row * ld;
+  for (int64_t k4 = lane; k4 * 4 < ld; k4 += 64) {
+    uint32_t keep = 0xFu;
+    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = 4 * k4 + i;
+      if (k >= ld) break;
+      float v = 0.f;
+      if (k < Tk) {
+        const bool on = !mr || mr[k];
+        v = on ? __expf(io<T>::ld(sr + k) - mx) * inv : (sum > 0.f ? 0.f : NAN);
+      }
+      io<T>::st(pr + k, v);
+      if (Pd != P) io<T>::st(pdr + k, ((keep >> i) & 1u) ? v * sc : 0.f);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const T* __restrict__ dPd,
+                                                          T* __restrict__ dS, int64_t nrows, int64_t Tk, int64_t ld, float p,
+                                                          const uint64_t* rng, uint32_t stream) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const T* pr = P + row * ld;
+  const T* gr = dPd + row * ld;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float dot = 0.f;
+  for (int64_t k4 = lane; k4 * 4 < Tk; k4 += 64) {
+    uint32_t keep = 0xFu;
+    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = 4 * k4 + i;
+      if (k < Tk && ((keep >> i) & 1u)) dot += io<T>::ld(gr + k) * sc * io<T>::ld(pr + k);
+    }
+  }
+  dot = wave_sum(dot);
+  T* dr = dS + row * ld;
+  for (int64_t k4 = lane; k4 * 4 < ld; k4 += 64) {
+    uint32_t keep = 0xFu;
+    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = 4 * k4 + i;
+      if (k >= ld) break;
+      float v = 0.f;
+      if (k < Tk) {
+        const float g = ((keep >> i) & 1u) ? io<T>::ld(gr + k) * sc : 0.f;
+        v = io<T>::ld(pr + k) * (g - dot);
+      }
+      io<T>::st(dr + k, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ void attn_head_mean_kernel(const T* __restrict__ P, float* __restrict__ out, int64_t B, int64_t H, int64_t Tq,
+                                      int64_t Tk, int64_t ld) {
+  const int64_t total = B * Tq * Tk;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / (Tq * Tk), rem = i - b * Tq * Tk, q = rem / Tk, k = rem - q * Tk;
+    float s = 0.f;
+    for (int64_t h = 0; h < H; ++h) s += io<T>::ld(P + ((b * H + h) * Tq + q) * ld + k);
+    out[i] = s / (float)H;
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_DT(dt, T, ...)                                  \
+  do {                                                           \
+    if ((dt) == JS2T_F32) { typedef float T; __VA_ARGS__; }      \
+    else if ((dt) == JS2T_BF16) { typedef uint16_t T; __VA_ARGS__; } \
+    else { js2t_set_error("bad dtype %d", (int)(dt)); return JS2T_ERR_INVALID; } \
+  } while (0)
+
+extern "C" int64_t js2t_colsum_partial_rows(int64_t rows);
+
+extern "C" int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  int64_t rows, int64_t D, float eps, int dt, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0, "layernorm_fwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, D, eps));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, const void* add, float add_scale, float* dgamma, float* dbeta, float* partial,
+                                  int64_t rows, int64_t D, int dt, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0, "layernorm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s,
+                                        (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (const T*)add, add_scale,
+                                        rows, D));
+  JS2T_LAUNCH_CHECK();
+  if (dgamma && dbeta) {
+    JS2T_CHECK(partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
+    const int64_t nparts = (rows + LN_SLAB - 1) / LN_SLAB;
+    JS2T_CHECK(nparts <= 65535, "layernorm_bwd: too many rows");
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_param_partial_kernel<T>), dim3(cdiv(D, 256), (unsigned)nparts),
+                                          dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, partial, rows, D));
+    JS2T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, partial, dgamma, dbeta, nparts,
+                       D);
+    JS2T_LAUNCH_CHECK();
+  }
+  return JS2T_OK;
+}
+
+extern "C" int js2t_softmax_fwd(const void* S, const uint8_t* mask, void* P, void* Pd, int64_t B, int64_t H, int64_t Tq,
+                                int64_t Tk, int64_t ld, int64_t mask_sb, int64_t mask_sq, int dt, float p,
+                                const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream) {
+  if (B * H * Tq == 0) return JS2T_OK;
+  JS2T_CHECK(S && P && Pd && Tk > 0 && ld >= Tk, "softmax_fwd: bad arguments");
+  JS2T_CHECK(p >= 0.f && p < 1.f && (p == 0.f || (rng_state && Pd != P)), "softmax_fwd: bad dropout arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((softmax_fwd_kernel<T>), dim3(cdiv(B * H * Tq, ROWS_PER_BLOCK)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)S, mask, (T*)P, (T*)Pd, B, H, Tq, Tk, ld, mask_sb,
+                                        mask_sq, p, rng_state, rng_stream));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_softmax_bwd(const void* P, const void* dPd, void* dS, int64_t Z, int64_t Tq, int64_t Tk, int64_t ld,
+                                int dt, float p, const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream) {
+  if (Z * Tq == 0) return JS2T_OK;
+  JS2T_CHECK(P && dPd && dS && Tk > 0 && ld >= Tk, "softmax_bwd: bad arguments");
+  JS2T_CHECK(p >= 0.f && p < 1.f && (p == 0.f || rng_state), "softmax_bwd: bad dropout arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3(cdiv(Z * Tq, ROWS_PER_BLOCK)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)P, (const T*)dPd, (T*)dS, Z * Tq, Tk, ld, p, rng_state,
+                                        rng_stream));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_attn_head_mean(const void* P, float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld,
+                                   int dt, js2t_stream stream) {
+  if (B * Tq * Tk == 0) return JS2T_OK;
+  JS2T_CHECK(P && out && H > 0, "attn_head_mean: bad arguments");
+  int64_t g = (B * Tq * Tk + 255) / 256;
+  if (g > 4096) g = 4096;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((attn_head_mean_kernel<T>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)P, out, B, H, Tq, Tk, ld));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

@@ -1,0 +1,75 @@
+"""Transformer decoder with the reference's module / parameter names (joeynmt/decoders.py:498-635),
+computed by HIP kernels; includes the CTC projection of the encoder output (:560-565,622-623)."""
+from torch import Tensor, nn
+import torch
+
+from joeys2t_amd import functional as Fn
+from joeys2t_amd.helpers import freeze_params, subsequent_mask
+from joeys2t_amd.runtime import runtime_of
+from joeys2t_amd.transformer_layers import PositionalEncoding, TransformerDecoderLayer
+
+
+class Decoder(nn.Module):
+    """Base decoder class."""
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+
+class TransformerDecoder(Decoder):
+    def __init__(self, num_layers: int = 4, num_heads: int = 8, hidden_size: int = 512, ff_size: int = 2048,
+                 dropout: float = 0.1, emb_dropout: float = 0.1, vocab_size: int = 1, freeze: bool = False, **kwargs):
+        super().__init__()
+        self._hidden_size = hidden_size
+        self._output_size = vocab_size
+        self.layers = nn.ModuleList([
+            TransformerDecoderLayer(size=hidden_size, ff_size=ff_size, num_heads=num_heads, dropout=dropout,
+                                    alpha=kwargs.get("alpha", 1.0), layer_norm=kwargs.get("layer_norm", "post"),
+                                    activation=kwargs.get("activation", "relu")) for _ in range(num_layers)
+        ])
+        self.pe = PositionalEncoding(hidden_size)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-6) if kwargs.get("layer_norm", "post") == "pre" else None
+        self.emb_dropout = nn.Dropout(p=emb_dropout)
+        self.output_layer = nn.Linear(hidden_size, vocab_size, bias=False)
+        if freeze:
+            freeze_params(self)
+        self.ctc_output_layer = None
+        encoder_output_size = kwargs.get("encoder_output_size_for_ctc", None)
+        if encoder_output_size is not None:
+            self.ctc_output_layer = nn.Linear(encoder_output_size, vocab_size, bias=False)
+
+    def project(self, layer: nn.Linear, x: Tensor, out_dtype) -> Tensor:
+        rt = runtime_of(self)
+        x = rt.act_in(x)
+        bias = None if layer.bias is None else layer.bias
+        return Fn.LinearFn.apply(x, rt.weight([layer.weight]), layer.weight, bias, out_dtype)
+
+    def forward(self, trg_embed: Tensor, encoder_output: Tensor, encoder_hidden: Tensor, src_mask: Tensor,
+                unroll_steps: int, hidden: Tensor, trg_mask: Tensor, **kwargs):
+        """-> (logits [B,L,V] fp32, hidden [B,L,d], cross-attention weights of the last layer | None, None,
+        CTC logits [B,T',V] | None)."""
+        assert trg_mask is not None, "trg_mask required for Transformer"
+        rt = runtime_of(self)
+        x = self.pe(trg_embed, extra=kwargs.get("trg_prompt_mask", None), dropout=self.emb_dropout.p,
+                    training=self.training)
+        L = trg_embed.size(1)
+        trg_mask = (trg_mask & subsequent_mask(L, device=trg_mask.device)).contiguous()  # [B|1, L, L]
+        last_layer = len(self.layers) - 1
+        return_attention = kwargs.get("return_attention", False)
+        att = None
+        for i, layer in enumerate(self.layers):
+            x, att = layer(x=x, memory=encoder_output, src_mask=src_mask, trg_mask=trg_mask,
+                           return_attention=(return_attention and i == last_layer))
+        if self.layer_norm is not None:
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias)
+        out = self.project(self.output_layer, x, torch.float32)
+        ctc_output = None
+        if self.ctc_output_layer is not None and kwargs.get("compute_ctc", True):
+            ctc_output = self.project(self.ctc_output_layer, encoder_output, rt.compute_dtype)
+        return out, x, att, None, ctc_output
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(num_layers={len(self.layers)}, "
+                f"num_heads={self.layers[0].trg_trg_att.num_heads}, alpha={self.layers[0].alpha}, "
+                f'layer_norm="{self.layers[0]._layer_norm_position}", ctc_layer={self.ctc_output_layer is not None})')

@@ -1,0 +1,124 @@
+"""Speech encoder with the reference's module / parameter names (joeynmt/encoders.py): Conv1dSubsampler
+(:311-373) and TransformerEncoder (:175-308), computed by HIP kernels.
+
+Layout note: the reference transposes to [B,C,T] for nn.Conv1d and back (:363,:368); here activations stay
+[B,T,C] end to end and each Conv1d(k, stride 2)+GLU is an implicit-im2col GEMM (functional.Conv1dGluFn)."""
+from typing import List, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from joeys2t_amd import functional as Fn
+from joeys2t_amd import ops
+from joeys2t_amd.helpers import freeze_params, lengths_to_padding_mask, pad
+from joeys2t_amd.runtime import runtime_of
+from joeys2t_amd.transformer_layers import PositionalEncoding, TransformerEncoderLayer
+
+
+class Encoder(nn.Module):
+    """Base encoder class."""
+
+    @property
+    def output_size(self):
+        return self._output_size
+
+
+class Conv1dSubsampler(nn.Module):
+    """Stack of Conv1d(k, stride=2, padding=k//2) + GLU (reference :311-373).  `conv_layers.{i}.weight` keeps
+    torch's [C_out, C_in, k] layout for checkpoint compatibility."""
+
+    def __init__(self, in_channels: int, mid_channels: int, out_channels: int = None, kernel_sizes: List[int] = (3, 3)):
+        super().__init__()
+        self.kernel_sizes = list(kernel_sizes)
+        self.n_layers = len(self.kernel_sizes)
+        self.conv_layers = nn.ModuleList(
+            nn.Conv1d(in_channels if i == 0 else mid_channels // 2,
+                      mid_channels if i < self.n_layers - 1 else out_channels * 2, k, stride=2, padding=k // 2)
+            for i, k in enumerate(self.kernel_sizes))
+
+    def get_out_seq_lens_tensor(self, in_seq_lens_tensor: Tensor) -> Tensor:
+        """floor((len + 2*(k//2) - (k-1) - 1)/2 + 1) per layer (reference :348-352), for host tensors / tests.
+        The device path computes the same integers in js2t_subsample_lengths_mask."""
+        out = in_seq_lens_tensor.clone()
+        for k in self.kernel_sizes:
+            out = ((out.float() + 2 * (k // 2) - (k - 1) - 1) / 2 + 1).floor().long()
+        return out
+
+    def out_len(self, t_in: int) -> int:
+        for k in self.kernel_sizes:
+            t_in = Fn.conv_out_len(t_in, k)
+        return t_in
+
+    def forward(self, src_tokens: Tensor, src_lengths: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """-> (x [B,T',C], out_seq_lens [B], padding mask [B,1,T']).  The input is expected to be cropped to the
+        longest utterance already (pad_features guarantees it, helpers_for_audio.py:159-161); the reference's
+        re-crop (:356-359) costs a host sync and is only taken for host-side length tensors."""
+        rt = runtime_of(self)
+        if not src_lengths.is_cuda:
+            max_len = int(src_lengths.max())
+            assert max_len > 0, "empty batch!"
+            if src_tokens.size(1) != max_len:
+                src_tokens = src_tokens[:, :max_len, :]
+            src_lengths = src_lengths.to(src_tokens.device)
+        x = rt.act_in(src_tokens.contiguous())
+        for conv in self.conv_layers:
+            x = Fn.Conv1dGluFn.apply(x, conv.weight, conv.bias, rt.compute_dtype)
+        out_lens, mask = ops.subsample_lengths_mask(src_lengths, x.size(1), self.kernel_sizes)
+        return x, out_lens, mask
+
+
+class TransformerEncoder(Encoder):
+    """Transformer encoder (reference :175-308)."""
+
+    def __init__(self, hidden_size: int = 512, ff_size: int = 2048, num_layers: int = 8, num_heads: int = 4,
+                 dropout: float = 0.1, emb_dropout: float = 0.1, freeze: bool = False, **kwargs):
+        super().__init__()
+        self._output_size = hidden_size
+        self.layers = nn.ModuleList([
+            TransformerEncoderLayer(size=hidden_size, ff_size=ff_size, num_heads=num_heads, dropout=dropout,
+                                    alpha=kwargs.get("alpha", 1.0), layer_norm=kwargs.get("layer_norm", "pre"),
+                                    activation=kwargs.get("activation", "relu")) for _ in range(num_layers)
+        ])
+        self.pe = PositionalEncoding(hidden_size)
+        self.emb_dropout = nn.Dropout(p=emb_dropout)
+        # final norm only for pre-LN stacks; note the differing defaults ("pre" for layers, "post" here), as in
+        # the reference (:215 vs :225)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-6) if kwargs.get("layer_norm", "post") == "pre" else None
+        if freeze:
+            freeze_params(self)
+        self.subsample = kwargs.get("subsample", False)
+        if self.subsample:
+            self.subsampler = Conv1dSubsampler(kwargs["in_channels"], kwargs["conv_channels"], hidden_size,
+                                               kwargs.get("conv_kernel_sizes", [3, 3]))
+            self.pad_index = kwargs.get("pad_index", 1)
+            assert self.pad_index is not None
+
+    def forward(self, src_embed: Tensor, src_length: Tensor, mask: Tensor = None, **kwargs):
+        """-> (hidden states [B,T',d], None, mask [B,1,T'])."""
+        if self.subsample:
+            src_embed, src_length, ss_mask = self.subsampler(src_embed, src_length)
+            if mask is None:
+                mask = ss_mask
+        if mask is None:
+            mask = lengths_to_padding_mask(src_length, src_embed.size(1)).unsqueeze(1)
+        x = self.pe(src_embed, extra=kwargs.get("src_prompt_mask", None), dropout=self.emb_dropout.p,
+                    training=self.training)
+        for layer in self.layers:
+            x = layer(x, mask)
+        if self.layer_norm is not None:
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias)
+        if kwargs.get("repad", False) and "src_max_len" in kwargs and self.subsample:
+            x, mask = self._repad(x, mask, kwargs["src_max_len"])
+        assert src_length.size() == (x.size(0), ), (src_length.size(), x.size())
+        assert mask.size() == (x.size(0), 1, x.size(1)), (mask.size(), x.size())
+        return x, None, mask
+
+    def _repad(self, x, mask, src_max_len):
+        """Pad x / mask to the subsampled length of src_max_len (reference :290-298; mask padded with True)."""
+        src_max_len = self.subsampler.out_len(int(src_max_len))
+        return pad(x, src_max_len, pad_index=self.pad_index, dim=1), pad(mask, src_max_len, pad_index=self.pad_index, dim=-1)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(num_layers={len(self.layers)}, "
+                f"num_heads={self.layers[0].src_src_att.num_heads}, alpha={self.layers[0].alpha}, "
+                f'layer_norm="{self.layers[0]._layer_norm_position}", subsample={self.subsample})')

@@ -1,0 +1,434 @@
+"""Differentiable building blocks of the JoeyS2T hot path, each backed by HIP kernels only.
+
+Granularity: one torch.autograd.Function per *residual block* (self-attention, cross-attention,
+feed-forward) plus a few leaf functions (conv+GLU, positional encoding, embedding, layer norm, linear).
+Inside a block, forward and backward are explicit sequences of C-ABI launches (ops.py) so that every
+FLOP of the path — including residual-gradient sums and dropout masks — runs in our kernels; torch's
+autograd engine only routes gradients between blocks and into `param.grad`.
+
+Reference semantics reproduced (file:line in the reference repo):
+  * MultiHeadedAttention.forward      transformer_layers.py:49-115  (k,v,q order; q scaled by 1/sqrt(dh))
+  * PositionwiseFeedForward.forward   transformer_layers.py:159-168
+  * TransformerEncoderLayer.forward   transformer_layers.py:267-289
+  * TransformerDecoderLayer.forward   transformer_layers.py:348-407
+  * Conv1dSubsampler.forward          encoders.py:354-373
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+from joeys2t_amd import ops
+from joeys2t_amd.ops import DropoutRng
+
+LN_EPS = 1e-6  # every nn.LayerNorm on the path uses eps=1e-6 (transformer_layers.py:146,248,339-340)
+
+
+# ------------------------------------------------------------------------------------------------
+# plain (non-autograd) helpers: forward / backward of the primitive pieces
+# ------------------------------------------------------------------------------------------------
+def _row_major_2d(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ops.Js2tError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
+               out_dtype=None, preact=None, alpha=1.0):
+    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch."""
+    _row_major_2d(x2d), _row_major_2d(w)
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    ops.gemm(x2d, w, y, M=M, N=N, K=K, lda=x2d.stride(0), ldb=w.stride(0), ldc=N, bias=b, act=act, preact=preact,
+             dropout_p=dropout_p, rng=rng, rng_stream=site, residual=residual,
+             ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha)
+    return y
+
+
+def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None):
+    """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32)."""
+    _row_major_2d(dz2d), _row_major_2d(x2d), _row_major_2d(w)
+    M, N = dz2d.shape
+    K = x2d.shape[1]
+    dx = dw = db = None
+    if need_dx:
+        # dx[M,K] = dz[M,N] . W[N,K]   (B(n'=k, red=n) lives at W[n*ldw + k] -> trans_b)
+        dx = torch.empty((M, K), dtype=dx_dtype or x2d.dtype, device=x2d.device)
+        ops.gemm(dz2d, w, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w.stride(0), ldc=K, trans_b=True, gate=gate,
+                 ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+    if need_dw:
+        # dW[N,K] = dz^T[N,M] . x[M,K]  (both operands reduction-major -> trans_a, trans_b), f32 output
+        dw = torch.empty((N, K), dtype=torch.float32, device=x2d.device)
+        ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True)
+    if need_db:
+        db = ops.colsum(dz2d if dz2d.is_contiguous() else dz2d.contiguous())
+    return dx, dw, db
+
+
+class AttnShape:
+    __slots__ = ("B", "Tq", "Tk", "H", "dh", "ld")
+
+    def __init__(self, B, Tq, Tk, H, dh):
+        self.B, self.Tq, self.Tk, self.H, self.dh = B, Tq, Tk, H, dh
+        self.ld = ops.round_up(Tk, 8)  # score row stride: 16-byte rows for the bf16 GEMMs
+
+
+def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, site):
+    """softmax(mask(q k^T / sqrt(dh))) v for all heads; q_t/k_t/v_t are [B*T, ld*] row-major 2-D buffers whose
+    head h lives at column off + h*dh.  Returns (ctx[B*Tq, H*dh], P, Pd)."""
+    B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
+    dev, dt = q_t.device, q_t.dtype
+    Z = B * H
+    S = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
+    ops.gemm(q_t, k_t, S, M=Tq, N=Tk, K=dh, lda=q_t.stride(0), ldb=k_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
+             a_strides=(Tq * q_t.stride(0), dh), b_strides=(Tk * k_t.stride(0), dh), c_strides=(H * Tq * ld, Tq * ld),
+             a_off=q_off, b_off=k_off, alpha=1.0 / math.sqrt(dh))
+    P, Pd = ops.softmax_fwd(S, mask, B, H, Tq, Tk, ld, p, rng, site)
+    ctx = torch.empty((B * Tq, H * dh), dtype=dt, device=dev)
+    ops.gemm(Pd, v_t, ctx, M=Tq, N=dh, K=Tk, lda=ld, ldb=v_t.stride(0), ldc=H * dh, trans_b=True, batch=Z, batch_inner=H,
+             a_strides=(H * Tq * ld, Tq * ld), b_strides=(Tk * v_t.stride(0), dh), c_strides=(Tq * H * dh, dh), b_off=v_off)
+    return ctx, P, Pd
+
+
+def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, shp: AttnShape, P, Pd, p,
+             rng, site):
+    """Writes dq/dk/dv into the given (row-major 2-D) gradient buffers at the given column offsets."""
+    B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
+    Z = B * H
+    dev, dt = dctx.device, dctx.dtype
+    sP = (H * Tq * ld, Tq * ld)
+    scale = 1.0 / math.sqrt(dh)
+    # dPd[q,k] = dctx[q,:] . v[k,:]
+    dPd = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
+    ops.gemm(dctx, v_t, dPd, M=Tq, N=Tk, K=dh, lda=dctx.stride(0), ldb=v_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
+             a_strides=(Tq * dctx.stride(0), dh), b_strides=(Tk * v_t.stride(0), dh), c_strides=sP, b_off=v_off)
+    dS = ops.softmax_bwd(P, dPd, Z, Tq, Tk, ld, p, rng, site)
+    # dv[k,:] = sum_q Pd[q,k] dctx[q,:]
+    ops.gemm(Pd, dctx, dv_t, M=Tk, N=dh, K=Tq, lda=ld, ldb=dctx.stride(0), ldc=dv_t.stride(0), trans_a=True, trans_b=True,
+             batch=Z, batch_inner=H, a_strides=sP, b_strides=(Tq * dctx.stride(0), dh),
+             c_strides=(Tk * dv_t.stride(0), dh), c_off=dv_off)
+    # dq[q,:] = scale * sum_k dS[q,k] k[k,:]
+    ops.gemm(dS, k_t, dq_t, M=Tq, N=dh, K=Tk, lda=ld, ldb=k_t.stride(0), ldc=dq_t.stride(0), trans_b=True, batch=Z,
+             batch_inner=H, a_strides=sP, b_strides=(Tk * k_t.stride(0), dh), c_strides=(Tq * dq_t.stride(0), dh),
+             b_off=k_off, c_off=dq_off, alpha=scale)
+    # dk[k,:] = scale * sum_q dS[q,k] q[q,:]
+    ops.gemm(dS, q_t, dk_t, M=Tk, N=dh, K=Tq, lda=ld, ldb=q_t.stride(0), ldc=dk_t.stride(0), trans_a=True, trans_b=True,
+             batch=Z, batch_inner=H, a_strides=sP, b_strides=(Tq * q_t.stride(0), dh),
+             c_strides=(Tk * dk_t.stride(0), dh), b_off=q_off, c_off=dk_off, alpha=scale)
+
+
+def _split_rows(t: Optional[torch.Tensor], sizes: List[int]):
+    if t is None:
+        return [None] * len(sizes)
+    return list(torch.split(t, sizes, dim=0))
+
+
+# ------------------------------------------------------------------------------------------------
+# block descriptors: what a residual block needs to know (weights are passed as tensors)
+# ------------------------------------------------------------------------------------------------
+class BlockCfg:
+    """Static configuration of one residual block (no tensors)."""
+
+    def __init__(self, *, kind, num_heads=1, alpha=1.0, ln_mode="pre", act="relu", training=True, attn_dropout=0.0,
+                 out_dropout=0.0, need_weights=False):
+        assert ln_mode in ("pre", "post", "none")
+        self.kind = kind  # "self" | "cross" | "ffn"
+        self.H = num_heads
+        # p_in: dropout on attention probabilities (self/cross) or on the activated hidden layer (ffn);
+        # p_out: dropout on the block's last projection, before the residual add.
+        self.p_in = float(attn_dropout) if training else 0.0
+        self.p_out = float(out_dropout) if training else 0.0
+        self.alpha = float(alpha)
+        self.ln_mode = ln_mode
+        self.act = act
+        self.need_weights = need_weights
+
+    @property
+    def any_dropout(self) -> bool:
+        return self.p_in > 0 or self.p_out > 0
+
+
+def _ln_fwd(x2d, gamma, beta):
+    return ops.layernorm_fwd(x2d, gamma, beta, LN_EPS)
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """One residual block:  pre-LN:  y = drop(core(LN(x))) + alpha*x ;  post-LN: y = LN(drop(core(x)) + alpha*x).
+
+    forward(ctx, cfg, rng, x, memory, mask, wts, *params)
+      x       [B,T,d] activations (compute dtype)
+      memory  [B,S,d] encoder states for kind == "cross", else None
+      mask    bool [B,1|T,Tk] or None
+      wts     dict of compute-dtype weight tensors (possibly fused views):
+                self : w_in [3d,d] (k;v;q), b_in [3d], w_out [d,d], b_out [d]
+                cross: w_q [d,d], b_q, w_kv [2d,d], b_kv, w_out, b_out
+                ffn  : w1 [ff,d], b1, w2 [d,ff], b2
+              plus ln_g, ln_b (f32)
+      params  the leaf nn.Parameters in the order `param_order(kind)`; gradients are returned in this order.
+    For cfg.ln_mode == "none" the ln_g/ln_b entries and the two trailing params are omitted.
+    Returns y (and head-averaged attention weights for kind == "cross" when cfg.need_weights).
+    """
+
+    @staticmethod
+    def forward(ctx, cfg: BlockCfg, rng: Optional[DropoutRng], x, memory, mask, wts, *params):
+        B, T, d = x.shape
+        x2 = x.reshape(B * T, d)
+        p_in, p_out = cfg.p_in, cfg.p_out
+        sites = [rng.next_site() if rng is not None else 0 for _ in range(2)]
+        saved = {}
+        if cfg.ln_mode == "pre":
+            n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
+            saved.update(mean=mean, rstd=rstd)
+        else:
+            n = x2
+        att_w = None
+        if cfg.kind == "self":
+            H, dh = cfg.H, d // cfg.H
+            qkv = linear_fwd(n, wts["w_in"], wts["b_in"])  # columns: [k | v | q]
+            shp = AttnShape(B, T, T, H, dh)
+            c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0])
+            saved.update(qkv=qkv, P=P, Pd=Pd, shp=shp)
+        elif cfg.kind == "cross":
+            H, dh = cfg.H, d // cfg.H
+            S = memory.shape[1]
+            m2 = memory.reshape(B * S, memory.shape[2])
+            q = linear_fwd(n, wts["w_q"], wts["b_q"])
+            kv = linear_fwd(m2, wts["w_kv"], wts["b_kv"])  # columns: [k | v]
+            shp = AttnShape(B, T, S, H, dh)
+            c, P, Pd = attn_fwd(q, 0, kv, 0, kv, d, shp, mask, p_in, rng, sites[0])
+            if cfg.need_weights:
+                att_w = ops.attn_head_mean(P, B, H, T, S, shp.ld)
+            saved.update(q=q, kv=kv, m2=m2, P=P, Pd=Pd, shp=shp)
+        else:  # ffn
+            pre = None
+            if cfg.act != "relu" and cfg.act is not None:
+                pre = torch.empty((B * T, wts["w1"].shape[0]), dtype=x.dtype, device=x.device)
+            c = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre)
+            saved.update(pre=pre)
+        w_last, b_last = (wts["w2"], wts["b2"]) if cfg.kind == "ffn" else (wts["w_out"], wts["b_out"])
+        u = linear_fwd(c, w_last, b_last, dropout_p=p_out, rng=rng, site=sites[1],
+                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha)
+        if cfg.ln_mode != "post":
+            y = u
+        else:
+            y, mean, rstd = _ln_fwd(u, wts["ln_g"], wts["ln_b"])
+            saved.update(mean=mean, rstd=rstd, u=u)
+        ctx.cfg, ctx.rng, ctx.sites, ctx.wts, ctx.saved = cfg, rng, sites, wts, saved
+        ctx.x2, ctx.n, ctx.c = x2, n, c
+        ctx.shape = (B, T, d)
+        ctx.mem_shape = None if memory is None else tuple(memory.shape)
+        ctx.nparams = len(params)
+        y = y.view(B, T, d)
+        if cfg.kind == "cross":
+            if att_w is not None:
+                ctx.mark_non_differentiable(att_w)
+            return y, att_w
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        cfg, rng, sites, wts, sv = ctx.cfg, ctx.rng, ctx.sites, ctx.wts, ctx.saved
+        B, T, d = ctx.shape
+        p, p_out = cfg.p_in, cfg.p_out
+        x2, n, c = ctx.x2, ctx.n, ctx.c
+        dy2 = dy.reshape(B * T, d)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        g = {}
+        if cfg.ln_mode != "post":
+            du = dy2
+        else:
+            du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"])
+        dz_o = ops.dropout_bwd(du, p_out, rng, sites[1]) if p_out > 0 else du
+        dmem = None
+        if cfg.kind == "ffn":
+            relu = cfg.act == "relu"
+            # dh = dz_o . W2, gated by the saved post-dropout activations for ReLU (sign carries both masks)
+            dh, g["w2"], g["b2"] = linear_bwd(dz_o, c, wts["w2"], gate=c if relu else None,
+                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0)
+            if relu or cfg.act is None:
+                dz1 = dh
+                if cfg.act is None and p > 0:
+                    dz1 = ops.dropout_bwd(dh, p, rng, sites[0])
+            else:
+                dz1 = ops.dropout_bwd(dh, p, rng, sites[0]) if p > 0 else dh
+                dz1 = ops.act_bwd(dz1, sv["pre"], cfg.act)
+            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"])
+        elif cfg.kind == "self":
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"])
+            qkv = sv["qkv"]
+            dqkv = torch.empty_like(qkv)
+            attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
+                     sites[0])
+            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"])
+        else:  # cross
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"])
+            q, kv = sv["q"], sv["kv"]
+            dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+            attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0])
+            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"])
+            dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3])
+            dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
+        if cfg.ln_mode == "pre":
+            dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
+                                                          add_scale=cfg.alpha)
+        elif cfg.alpha != 0.0:
+            dx2 = ops.axpby(dn, 1.0, du, cfg.alpha)
+        else:
+            dx2 = dn
+        grads = _route_param_grads(cfg.kind, g, d, cfg.ln_mode != "none")
+        assert len(grads) == ctx.nparams
+        return (None, None, dx2.view(B, T, d), dmem, None, None, *grads)
+
+
+def param_order(kind: str) -> List[str]:
+    """Order in which a block's leaf parameters are passed to / returned from ResidualBlockFn."""
+    if kind == "self":
+        return ["k.w", "v.w", "q.w", "k.b", "v.b", "q.b", "o.w", "o.b", "ln.g", "ln.b"]
+    if kind == "cross":
+        return ["k.w", "v.w", "q.w", "k.b", "v.b", "q.b", "o.w", "o.b", "ln.g", "ln.b"]
+    return ["w1", "b1", "w2", "b2", "ln.g", "ln.b"]
+
+
+def _route_param_grads(kind, g, d, has_ln):
+    ln = [g["ln_g"], g["ln_b"]] if has_ln else []
+    if kind == "self":
+        wk, wv, wq = _split_rows(g["w_in"], [d, d, d])
+        bk, bv, bq = _split_rows(g["b_in"], [d, d, d])
+        return [wk, wv, wq, bk, bv, bq, g["w_out"], g["b_out"], *ln]
+    if kind == "cross":
+        wk, wv = _split_rows(g["w_kv"], [d, d])
+        bk, bv = _split_rows(g["b_kv"], [d, d])
+        return [wk, wv, g["w_q"], bk, bv, g["b_q"], g["w_out"], g["b_out"], *ln]
+    return [g["w1"], g["b1"], g["w2"], g["b2"], *ln]
+
+
+# ------------------------------------------------------------------------------------------------
+# leaf functions
+# ------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(d, eps=1e-6) — final encoder/decoder norm (encoders.py:281-282, decoders.py:617-618)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, LN_EPS)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shape = shape
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
+        return dx.view(ctx.shape), dg, db
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) — vocabulary / CTC projections (decoders.py:620-623), Conformer input linear."""
+
+    @staticmethod
+    def forward(ctx, x, w_compute, weight, bias, out_dtype):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        y = linear_fwd(x2, w_compute, bias, out_dtype=out_dtype)
+        ctx.x2, ctx.w = x2, w_compute
+        ctx.has_bias = bias is not None
+        ctx.shape = shape
+        return y.view(*shape[:-1], w_compute.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.x2, ctx.w
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if dy2.dtype != x2.dtype:
+            dy2 = ops.cast(dy2, x2.dtype)
+        dx, dw, db = linear_bwd(dy2, x2, w, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[2],
+                                need_db=ctx.has_bias and ctx.needs_input_grad[3])
+        return (None if dx is None else dx.view(ctx.shape)), None, dw, db, None
+
+
+class AddPeDropoutFn(torch.autograd.Function):
+    """dropout(x + pe[:T] (+ extra)) — transformer_layers.py:204-213 + encoders.py:273-276 / decoders.py:599-602."""
+
+    @staticmethod
+    def forward(ctx, x, pe, extra, p, rng):
+        site = rng.next_site() if (rng is not None and p > 0) else 0
+        y = ops.add_pe_dropout(x.contiguous(), pe, None if extra is None else extra.contiguous(), p, rng, site)
+        ctx.p, ctx.rng, ctx.site = p, rng, site
+        ctx.has_extra = extra is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ops.dropout_bwd(dy, ctx.p, ctx.rng, ctx.site) if ctx.p > 0 else dy
+        return dx, None, (dx if ctx.has_extra else None), None, None
+
+
+class EmbedFn(torch.autograd.Function):
+    """lut(ids) * sqrt(d) — Embeddings.forward (embeddings.py:55-64)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, scale, pad_idx, out_dtype):
+        ctx.ids, ctx.scale, ctx.pad_idx, ctx.vocab = ids, scale, pad_idx, table.shape[0]
+        return ops.embed_fwd(ids, table, scale, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return None, ops.embed_bwd(ctx.ids, dout, ctx.vocab, ctx.scale, ctx.pad_idx), None, None, None
+
+
+def conv_out_len(t_in: int, k: int, stride: int = 2) -> int:
+    """Conv1d(k, stride=2, padding=k//2) output length (encoders.py:339-345)."""
+    return (t_in + 2 * (k // 2) - (k - 1) - 1) // stride + 1
+
+
+class Conv1dGluFn(torch.autograd.Function):
+    """GLU(Conv1d(k, stride 2, pad k//2)(x)) on [B,T,C] activations — one layer of Conv1dSubsampler
+    (encoders.py:362-368) as an implicit-im2col MFMA GEMM + GLU epilogue kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, compute_dtype):
+        B, T, Cin = x.shape
+        Cout, _, K = weight.shape
+        stride, pad = 2, K // 2
+        Tout = conv_out_len(T, K, stride)
+        x = x.contiguous()
+        wp = ops.conv_weight_pack(weight, compute_dtype)  # [Cout, K*Cin]
+        M = B * Tout
+        pre = torch.empty((M, Cout), dtype=compute_dtype, device=x.device)
+        conv = (T, Tout, Cin, stride, pad)
+        ops.gemm(x, wp, pre, M=M, N=Cout, K=K * Cin, lda=stride * Cin, ldb=K * Cin, ldc=Cout, bias=bias, conv=conv)
+        y = ops.glu_fwd(pre)
+        ctx.x, ctx.wp, ctx.pre, ctx.conv = x, wp, pre, conv
+        ctx.dims = (B, T, Cin, Cout, K, Tout)
+        return y.view(B, Tout, Cout // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, Cin, Cout, K, Tout = ctx.dims
+        M = B * Tout
+        x, wp, pre, conv = ctx.x, ctx.wp, ctx.pre, ctx.conv
+        dy2 = dy.reshape(M, Cout // 2)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dpre = ops.glu_bwd(pre, dy2)
+        db = ops.colsum(dpre)
+        # dWp^T[K*Cin, Cout] = im2col(x)^T[K*Cin, M] . dpre[M, Cout]
+        dwp_t = torch.empty((K * Cin, Cout), dtype=torch.float32, device=x.device)
+        ops.gemm(x, dpre, dwp_t, M=K * Cin, N=Cout, K=M, lda=conv[3] * Cin, ldb=Cout, ldc=Cout, trans_a=True, trans_b=True,
+                 conv=conv)
+        dw = ops.conv_weight_unpack_grad(dwp_t, Cout, Cin, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = torch.empty((M, K * Cin), dtype=pre.dtype, device=x.device)
+            ops.gemm(dpre, wp, dcol, M=M, N=K * Cin, K=Cout, lda=Cout, ldb=K * Cin, ldc=K * Cin, trans_b=True)
+            dx = ops.col2im(dcol, B, T, Tout, Cin, K, conv[3], conv[4])
+        return dx, dw, db, None

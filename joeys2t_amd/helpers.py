@@ -1,0 +1,78 @@
+"""Host-side helpers of the hot path (integer / bool logic; reference helpers.py).
+
+subsequent_mask (:81-90), tile (:264-293), adjust_mask_size (:307-326), expand_reverse_index (:384-406),
+lengths_to_padding_mask (:459-469), pad (:472-497), set_seed (:93-104), freeze_params (:296-304).
+These build masks / index maps; they carry no floating-point arithmetic of the path."""
+import random
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+
+def subsequent_mask(size: int, device=None) -> Tensor:
+    """Lower-triangular bool mask of shape (1, size, size)."""
+    return torch.ones(size, size, dtype=torch.bool, device=device).tril_().unsqueeze(0)
+
+
+def set_seed(seed: int) -> None:
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        torch.cuda.manual_seed_all(seed)
+
+
+def tile(x: Tensor, count: int, dim: int = 0) -> Tensor:
+    """Repeat every slice along `dim` `count` times, keeping copies adjacent: [a,b] -> [a,a,b,b]."""
+    if isinstance(x, tuple):
+        return tuple(tile(t, count, dim) for t in x)
+    return x.repeat_interleave(count, dim=dim)
+
+
+def freeze_params(module: nn.Module) -> None:
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+def adjust_mask_size(mask: Optional[Tensor], batch_size: int, hyp_len: int) -> Optional[Tensor]:
+    """Pad with zeros / crop a (batch, len) prompt mask to hyp_len columns."""
+    if mask is None:
+        return None
+    cur = mask.size(1)
+    if cur < hyp_len:
+        out = mask.new_zeros((batch_size, hyp_len))
+        out[:, :cur] = mask
+        return out
+    return mask[:, :hyp_len] if cur > hyp_len else mask
+
+
+def expand_reverse_index(reverse_index: List[int], n_best: int = 1) -> List[int]:
+    if n_best == 1:
+        return reverse_index
+    return [ix * n_best + n for ix in reverse_index for n in range(n_best)]
+
+
+def lengths_to_padding_mask(lengths: Tensor, max_len: Optional[int] = None) -> Tensor:
+    """mask[b, t] = t < lengths[b]  (True on valid positions).  Pass max_len to avoid the host sync of
+    `lengths.max().item()` that the reference pays (helpers.py:466)."""
+    if max_len is None:
+        max_len = int(lengths.max().item())
+    steps = torch.arange(max_len, device=lengths.device).unsqueeze(0)
+    return steps < lengths.view(-1, 1)
+
+
+def pad(x: Tensor, max_len: int, pad_index: int = 1, dim: int = 1) -> Tensor:
+    """Right-pad dim 1 (of a 3-D tensor) or the last dim with pad_index up to max_len; bool masks are padded
+    with True because pad_index == 1 (reference quirk, encoders.py:297)."""
+    if pad_index is None:
+        pad_index = 1
+    cur = x.size(dim)
+    if cur >= max_len:
+        assert cur == max_len, (x.size(), max_len)
+        return x
+    shape = list(x.shape)
+    shape[dim] = max_len - cur
+    filler = torch.full(shape, pad_index, dtype=x.dtype, device=x.device)
+    return torch.cat([x, filler], dim=dim if dim >= 0 else x.dim() + dim)

@@ -1,0 +1,112 @@
+"""Loss modules with the reference's names and return conventions, computed on LOGITS by HIP kernels.
+
+Mirrors joeynmt/loss.py: XentLoss (:16-107) and XentCTCLoss (:110-177).  The reference applies
+F.log_softmax in Model.forward (model.py:121,126) and then KLDivLoss / NLLLoss / CTCLoss on the log-probs;
+here the log-softmax is folded into the loss kernels (one pass over the [N,V] logits, closed-form smoothed
+target), so `forward` takes logits.  Values are identical up to fp32 rounding.
+"""
+from typing import Tuple
+
+import torch
+from torch import Tensor, nn
+
+from joeys2t_amd import ops
+
+
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, trg, pad_index, smoothing):
+        V = logits.shape[-1]
+        l2 = logits.reshape(-1, V)
+        if not l2.is_contiguous():
+            l2 = l2.contiguous()
+        t1 = trg.reshape(-1).contiguous()
+        loss_rows, correct_rows, lse = ops.xent_fwd(l2, t1, pad_index, smoothing)
+        ctx.l2, ctx.t1, ctx.lse = l2, t1, lse
+        ctx.pad_index, ctx.smoothing, ctx.shape = pad_index, smoothing, logits.shape
+        loss = ops.sum_f32(loss_rows)
+        n_correct = ops.sum_f32(correct_rows)
+        ctx.mark_non_differentiable(n_correct)
+        return loss, n_correct
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        g = g.contiguous().float()
+        d = ops.xent_bwd(ctx.l2, ctx.t1, ctx.lse, g, 1.0, ctx.pad_index, ctx.smoothing)
+        return d.view(ctx.shape), None, None, None
+
+
+class _CtcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, in_len, tgt_len, blank, zero_infinity):
+        B, T, V = logits.shape
+        l3 = logits.contiguous()
+        targets = targets.contiguous()
+        in_len = in_len.to(torch.int64).contiguous()
+        tgt_len = tgt_len.to(torch.int64).contiguous()
+        lse, _ = ops.row_lse(l3.view(B * T, V))
+        alpha, nll, loss_rows = ops.ctc_alpha(l3, lse, targets, in_len, tgt_len, blank, zero_infinity)
+        ctx.saved = (l3, lse, targets, in_len, tgt_len, alpha, nll)
+        ctx.blank, ctx.zero_infinity = blank, zero_infinity
+        return ops.sum_f32(loss_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        l3, lse, targets, in_len, tgt_len, alpha, nll = ctx.saved
+        g = g.contiguous().float()
+        d = ops.ctc_bwd(l3, lse, targets, in_len, tgt_len, alpha, nll, g, 1.0, ctx.blank, ctx.zero_infinity)
+        return d, None, None, None, None, None
+
+
+class XentLoss(nn.Module):
+    """Cross-entropy with optional label smoothing (reference loss.py:16-107)."""
+
+    def __init__(self, pad_index: int, smoothing: float = 0.0):
+        super().__init__()
+        self.smoothing = smoothing
+        self.pad_index = pad_index
+        self.require_ctc_layer = False
+        self.takes_logits = True  # Model.forward hands us logits, not log-probs
+
+    def xent(self, logits: Tensor, trg: Tensor) -> Tuple[Tensor, Tensor]:
+        """(summed loss, n_correct) for logits [B,L,V] against trg [B,L]."""
+        return _XentFn.apply(logits, trg, int(self.pad_index), float(max(self.smoothing, 0.0)))
+
+    def forward(self, logits: Tensor, **kwargs) -> Tuple[Tensor]:
+        assert "trg" in kwargs
+        loss, _ = self.xent(logits, kwargs["trg"])
+        return (loss, )
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(criterion=hip_ls_xent, smoothing={self.smoothing})"
+
+
+class XentCTCLoss(XentLoss):
+    """(1-w) * label-smoothed xent + w * CTC (reference loss.py:110-177); blank = BOS (model.py:84)."""
+
+    def __init__(self, pad_index: int, bos_index: int, smoothing: float = 0.0, zero_infinity: bool = True,
+                 ctc_weight: float = 0.3):
+        super().__init__(pad_index=pad_index, smoothing=smoothing)
+        self.require_ctc_layer = True
+        self.bos_index = bos_index
+        self.ctc_weight = ctc_weight
+        self.zero_infinity = zero_infinity
+
+    def ctc(self, ctc_logits: Tensor, trg: Tensor, input_lengths: Tensor, target_lengths: Tensor) -> Tensor:
+        return _CtcFn.apply(ctc_logits, trg, input_lengths, target_lengths, int(self.bos_index), bool(self.zero_infinity))
+
+    def forward(self, logits: Tensor, **kwargs) -> Tuple[Tensor, Tensor, Tensor]:
+        assert "trg" in kwargs and "trg_length" in kwargs and "src_mask" in kwargs and "ctc_logits" in kwargs
+        xent_loss, _ = self.xent(logits, kwargs["trg"])
+        in_len = kwargs.get("ctc_input_lengths")
+        if in_len is None:
+            in_len = kwargs["src_mask"].squeeze(1).sum(dim=1)
+        ctc_loss = self.ctc(kwargs["ctc_logits"], kwargs["trg"], in_len, kwargs["trg_length"])
+        # interpolation of two 0-d tensors (loss.py:164); the reference's NaN / sign asserts (:166-167) force a
+        # host sync per micro-batch and are left to the caller's logging cadence
+        total_loss = (1.0 - self.ctc_weight) * xent_loss + self.ctc_weight * ctc_loss
+        return total_loss, xent_loss, ctc_loss
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(criterion=hip_ls_xent, smoothing={self.smoothing}, "
+                f"ctc=hip_ctc, ctc_weight={self.ctc_weight})")

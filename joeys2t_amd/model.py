@@ -1,0 +1,228 @@
+"""Model container and builder with the reference's call surface (joeynmt/model.py): `Model.forward(return_type,
+**vars(batch))` -> 4-tuple (:95-168), `DataParallelWrapper` (:323-363), `build_model(cfg, src_vocab, trg_vocab)`
+(:366-506).  Only the S2T / Transformer path is provided (the reference asserts the same for S2T, :70-72).
+
+What differs from the reference, by design:
+  * `Model.finalize(device, compute_dtype)` moves all parameters into one flat HBM buffer (runtime.ParamStore)
+    and binds the HIP runtime; forward on a CPU tensor or without libjoeys2t_hip.so raises.
+  * log-softmax is fused into the loss kernels, so the loss modules receive logits (loss.py).
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from joeys2t_amd import ops
+from joeys2t_amd.builders import ConfigurationError
+from joeys2t_amd.decoders import Decoder, TransformerDecoder
+from joeys2t_amd.embeddings import Embeddings
+from joeys2t_amd.encoders import Encoder, TransformerEncoder
+from joeys2t_amd.initialization import initialize_model
+from joeys2t_amd.loss import XentCTCLoss, XentLoss
+from joeys2t_amd.runtime import ParamStore, Runtime, install_runtime
+
+
+class Model(nn.Module):
+    def __init__(self, encoder: Encoder, decoder: Decoder, src_embed: nn.Module, trg_embed: Embeddings, src_vocab,
+                 trg_vocab, task: str = "S2T") -> None:
+        super().__init__()
+        self.src_embed = src_embed  # nn.Identity() for S2T
+        self.trg_embed = trg_embed
+        self.encoder = encoder
+        self.decoder = decoder
+        self.src_vocab = src_vocab
+        self.trg_vocab = trg_vocab
+        self.pad_index = trg_vocab.pad_index
+        self.bos_index = trg_vocab.bos_index
+        self.eos_index = trg_vocab.eos_index
+        self.sep_index = trg_vocab.sep_index
+        self.unk_index = trg_vocab.unk_index
+        self.specials = [trg_vocab.lookup(t) for t in trg_vocab.specials]
+        self.lang_tags = [trg_vocab.lookup(t) for t in trg_vocab.lang_tags]
+        self._loss_function = None
+        self.task = task
+        if self.task == "S2T":
+            assert isinstance(self.encoder, TransformerEncoder)
+            assert isinstance(self.decoder, TransformerDecoder)
+        self._rt_obj: Optional[Runtime] = None
+
+    # ------------------------------------------------------------------ HIP runtime binding
+    def finalize(self, device, compute_dtype: torch.dtype = torch.float32, seed: int = 42) -> "Model":
+        """Place the model on `device`, flatten its parameters into one HBM buffer and bind the kernel runtime."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ops.Js2tError("Model.finalize: the HIP path needs a cuda (ROCm) device")
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ops.Js2tError(f"compute dtype must be float32 or bfloat16, got {compute_dtype}")
+        for name, buf in list(self.named_buffers()):
+            mod = self
+            *path, leaf = name.split(".")
+            for part in path:
+                mod = getattr(mod, part)
+            mod._buffers[leaf] = buf.to(device)
+        rt = Runtime(device, compute_dtype)
+        rt.store = ParamStore(self, device)
+        rt.rng.seed(seed)
+        install_runtime(self, rt)
+        object.__setattr__(self, "_rt_obj", rt)
+        if compute_dtype == torch.bfloat16:
+            rt.store.refresh(force=True)
+        return self
+
+    @property
+    def runtime(self) -> Runtime:
+        if self._rt_obj is None:
+            raise ops.Js2tError("Model.finalize(device, compute_dtype) must be called before use")
+        return self._rt_obj
+
+    def _prepare_step(self):
+        rt = self.runtime
+        if rt.compute_dtype == torch.bfloat16:
+            # the bf16 shadow follows the fp32 master: re-cast before every training forward unless the optimizer
+            # keeps it in sync itself (store.auto_refresh = False), and whenever the master was marked dirty
+            rt.store.refresh(force=self.training and rt.store.auto_refresh)
+
+    # ------------------------------------------------------------------ loss
+    @property
+    def loss_function(self):
+        return self._loss_function
+
+    @loss_function.setter
+    def loss_function(self, cfg: Tuple):
+        loss_type, label_smoothing, ctc_weight = cfg
+        if loss_type == "crossentropy-ctc":
+            loss_function = XentCTCLoss(pad_index=self.pad_index, bos_index=self.bos_index,  # bos -> blank
+                                        smoothing=label_smoothing, ctc_weight=ctc_weight)
+        elif loss_type == "crossentropy":
+            loss_function = XentLoss(pad_index=self.pad_index, smoothing=label_smoothing)
+            self.decoder.ctc_output_layer = None
+        else:
+            raise ConfigurationError(f"unknown loss type {loss_type}")
+        self._loss_function = loss_function
+
+    # ------------------------------------------------------------------ forward dispatch
+    def forward(self, return_type: str = None, **kwargs) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        if return_type is None:
+            raise ValueError("Please specify return_type: {`loss`, `loss_probs`, `encode`, `decode`, `decode_ctc`}.")
+        self._prepare_step()
+        if return_type.startswith("loss"):
+            assert self.loss_function is not None
+            assert "trg" in kwargs and "trg_mask" in kwargs
+            out, ctc_out, src_mask = self._encode_decode(**kwargs)
+            lf = self.loss_function
+            xent_loss, n_correct = lf.xent(out, kwargs["trg"])
+            ret = [None, None, None, None]
+            if lf.require_ctc_layer and isinstance(ctc_out, Tensor):
+                in_len = src_mask.squeeze(1).sum(dim=1)  # subsampled mask (model.py:125; loss.py:159)
+                ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+                ret[0] = (1.0 - lf.ctc_weight) * xent_loss + lf.ctc_weight * ctc_loss
+                ret[1], ret[2] = xent_loss, ctc_loss
+            else:
+                ret[0] = xent_loss
+            ret[3] = n_correct.long()
+            if return_type == "loss_probs":
+                ret[1] = ops.log_softmax(out.detach())
+                ret[2] = ops.log_softmax(ctc_out.detach()) if isinstance(ctc_out, Tensor) else None
+            return tuple(ret)
+        if return_type == "encode":
+            encoder_output, encoder_hidden, src_mask = self._encode(**kwargs)
+            return encoder_output, encoder_hidden, src_mask, None
+        if return_type == "decode":
+            kwargs.setdefault("compute_ctc", False)
+            outputs, hidden, att_probs, att_vectors, _ = self._decode(**kwargs)
+            return outputs, hidden, att_probs, att_vectors
+        if return_type == "decode_ctc":
+            outputs, hidden, att_probs, _, ctc_out = self._decode(**kwargs)
+            return outputs, hidden, att_probs, ctc_out
+        raise ValueError(f"unknown return_type {return_type}")
+
+    def _encode_decode(self, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
+                       **kwargs):
+        encoder_output, encoder_hidden, src_mask = self._encode(src=src, src_length=src_length, src_mask=src_mask, **kwargs)
+        decoder_output, _, _, _, ctc_output = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden,
+                                                           src_mask=src_mask, trg_input=trg_input,
+                                                           unroll_steps=trg_input.size(1), trg_mask=trg_mask, **kwargs)
+        return decoder_output, ctc_output, src_mask
+
+    def _encode(self, src: Tensor, src_length: Tensor, src_mask: Tensor, **_kwargs):
+        assert _kwargs.get("task", self.task) == self.task, (_kwargs.get("task"), self.task)
+        if _kwargs.get("src_prompt_mask", None) is not None and isinstance(self.src_embed, Embeddings):
+            _kwargs["src_prompt_mask"] = self.src_embed(_kwargs["src_prompt_mask"])
+        return self.encoder(self.src_embed(src), src_length, src_mask, **_kwargs)
+
+    def _decode(self, encoder_output: Tensor, encoder_hidden: Tensor, src_mask: Tensor, trg_input: Tensor,
+                unroll_steps: int, decoder_hidden: Tensor = None, att_vector: Tensor = None, trg_mask: Tensor = None,
+                **_kwargs):
+        if _kwargs.get("trg_prompt_mask", None) is not None:
+            assert self.sep_index is not None and self.sep_index in self.specials, "This model doesn't support prompting!"
+            _kwargs["trg_prompt_mask"] = self.trg_embed(_kwargs["trg_prompt_mask"])
+        return self.decoder(trg_embed=self.trg_embed(trg_input), encoder_output=encoder_output,
+                            encoder_hidden=encoder_hidden, src_mask=src_mask, unroll_steps=unroll_steps,
+                            hidden=decoder_hidden, prev_att_vector=att_vector, trg_mask=trg_mask, **_kwargs)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(task={self.task},\n\tencoder={self.encoder},\n\tdecoder={self.decoder},\n"
+                f"\tsrc_embed={self.src_embed},\n\ttrg_embed={self.trg_embed},\n\tloss_function={self.loss_function})")
+
+
+class DataParallelWrapper(nn.Module):
+    """Attribute pass-through for a (DDP-)wrapped model (reference model.py:323-363): `wrapper.module.module`
+    is the Model; state_dict()/load_state_dict() address the inner model so checkpoints carry no prefixes."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        assert hasattr(module, "module")
+        self.module = module
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            try:
+                return getattr(self.module, name)
+            except AttributeError:
+                return getattr(self.module.module, name)
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.module.load_state_dict(*args, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def build_model(cfg: Dict = None, src_vocab=None, trg_vocab=None) -> Model:
+    """Build and initialise the model from the `model` section of a JoeyNMT config (reference model.py:366-506)."""
+    enc_cfg, dec_cfg = dict(cfg["encoder"]), dict(cfg["decoder"])
+    task = "MT" if src_vocab is not None else "S2T"
+    if task != "S2T":
+        raise ConfigurationError("joeys2t_amd builds the speech-to-text path only (src_vocab must be None)")
+    trg_pad_index = trg_vocab.pad_index
+    src_pad_index = trg_pad_index
+    src_embed = nn.Identity()
+    if cfg.get("tied_embeddings", False):
+        raise ConfigurationError("Embedding cannot be tied since vocabularies differ.")
+    trg_embed = Embeddings(**dec_cfg["embeddings"], vocab_size=len(trg_vocab), padding_idx=trg_pad_index)
+
+    if enc_cfg.get("type", "transformer") != "transformer" or dec_cfg.get("type", "transformer") != "transformer":
+        raise ConfigurationError("RNN model not supported for s2t task. use transformer.")
+    enc_dropout = enc_cfg.get("dropout", 0.0)
+    enc_emb_dropout = enc_cfg["embeddings"].get("dropout", enc_dropout)
+    encoder = TransformerEncoder(**enc_cfg, emb_size=enc_cfg["embeddings"]["embedding_dim"], emb_dropout=enc_emb_dropout,
+                                 pad_index=src_pad_index)
+    dec_dropout = dec_cfg.get("dropout", 0.0)
+    dec_emb_dropout = dec_cfg["embeddings"].get("dropout", dec_dropout)
+    dec_cfg["encoder_output_size_for_ctc"] = encoder.output_size
+    decoder = TransformerDecoder(**dec_cfg, encoder=None, vocab_size=len(trg_vocab), emb_size=trg_embed.embedding_dim,
+                                 emb_dropout=dec_emb_dropout)
+    model = Model(encoder=encoder, decoder=decoder, src_embed=src_embed, trg_embed=trg_embed, src_vocab=src_vocab,
+                  trg_vocab=trg_vocab, task=task)
+    if cfg.get("tied_softmax", False):
+        if trg_embed.lut.weight.shape == model.decoder.output_layer.weight.shape:
+            model.decoder.output_layer.weight = trg_embed.lut.weight
+        else:
+            raise ConfigurationError("For tied_softmax, the decoder embedding_dim and decoder hidden_size must be the same.")
+    initialize_model(model, cfg, src_pad_index, trg_pad_index)
+    return model

@@ -1,0 +1,412 @@
+"""Thin Python launchers for the C ABI in include/joeys2t_hip.h.
+
+Each function allocates its outputs with torch (device memory / stream plumbing only), passes raw
+device pointers to libjoeys2t_hip.so and enqueues on torch's current HIP stream.  Nothing here computes
+on the host and nothing falls back to PyTorch math: a CPU tensor or a missing library raises.
+"""
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from joeys2t_amd._lib import ACT_CODES, BF16, F32, GemmDesc, Js2tError, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt_code(t_or_dtype) -> int:
+    dtype = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise Js2tError(f"unsupported dtype {dtype}: the HIP path computes in float32 or bfloat16") from None
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Js2tError(
+                "joeys2t_amd ops run on the GPU through libjoeys2t_hip.so only; got a CPU tensor "
+                "(there is no CPU fallback in the product path)"
+            )
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------- RNG state
+class DropoutRng:
+    """Device-resident {seed, offset} pair read by every dropout-bearing kernel, plus a host-side
+    call-site counter.  `advance()` bumps the offset with a device op so a captured hipGraph draws fresh
+    masks on every replay; call-site ids restart at every step so forward and backward agree."""
+
+    def __init__(self, device, seed: int = 42):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self._site = 0
+
+    def begin_step(self):
+        self._site = 0
+
+    def advance(self):
+        self.state[1:2].add_(1)
+
+    def next_site(self) -> int:
+        self._site += 1
+        return self._site
+
+    def seed(self, seed: int):
+        self.state[0] = seed
+        self.state[1] = 0
+
+
+_rngs = {}
+
+
+def dropout_rng(device) -> DropoutRng:
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _rngs:
+        _rngs[key] = DropoutRng(device)
+    return _rngs[key]
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, batch=1, batch_inner=1,
+         a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
+         alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
+         rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
+         conv=None):
+    """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements."""
+    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev)
+    if A.dtype != B.dtype:
+        raise Js2tError(f"gemm: A/B dtype mismatch {A.dtype} vs {B.dtype}")
+    d = GemmDesc()
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.batch, d.batch_inner = int(batch), int(batch_inner)
+    d.dtype_ab, d.dtype_c = dt_code(A), dt_code(C_out)
+    d.trans_a, d.trans_b = int(bool(trans_a)), int(bool(trans_b))
+    esa, esc = A.element_size(), C_out.element_size()
+    d.A = A.data_ptr() + a_off * esa
+    d.lda, d.a_stride_o, d.a_stride_i = int(lda), int(a_strides[0]), int(a_strides[1])
+    d.B = B.data_ptr() + b_off * esa
+    d.ldb, d.b_stride_o, d.b_stride_i = int(ldb), int(b_strides[0]), int(b_strides[1])
+    d.C = C_out.data_ptr() + c_off * esc
+    d.ldc, d.c_stride_o, d.c_stride_i = int(ldc), int(c_strides[0]), int(c_strides[1])
+    d.alpha = float(alpha)
+    d.alpha_dev = None if alpha_dev is None else alpha_dev.data_ptr()
+    if bias is not None:
+        if bias.dtype != torch.float32:
+            raise Js2tError("gemm: bias must be float32")
+        d.bias = bias.data_ptr()
+    d.act = ACT_CODES[act]
+    if preact is not None:
+        if preact.dtype != C_out.dtype:
+            raise Js2tError("gemm: preact dtype must match C")
+        d.preact = preact.data_ptr() + c_off * esc
+    d.dropout_p = float(dropout_p)
+    if dropout_p > 0.0:
+        if rng is None:
+            raise Js2tError("gemm: dropout needs a DropoutRng")
+        d.rng_state = rng.state.data_ptr()
+        d.rng_stream = int(rng_stream)
+    if residual is not None:
+        if residual.dtype != C_out.dtype:
+            raise Js2tError("gemm: residual dtype must match C")
+        d.residual, d.ldr, d.res_scale = residual.data_ptr(), int(ldr), float(res_scale)
+    if gate is not None:
+        if gate.dtype != C_out.dtype:
+            raise Js2tError("gemm: gate dtype must match C")
+        d.gate, d.ldg, d.gate_scale = gate.data_ptr(), int(ldg), float(gate_scale)
+    d.beta = float(beta)
+    if conv is not None:
+        d.conv = 1
+        d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
+    check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm")
+    return C_out
+
+
+# ----------------------------------------------------------------------------------------- element-wise
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(src, out)
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib().js2t_cast(_p(src), dt_code(src), _p(out), dt_code(out), C.c_int64(src.numel()), _stream()), "js2t_cast")
+    return out
+
+
+def axpby(x, a: float, y=None, b: float = 0.0):
+    _dev(x, y)
+    out = torch.empty_like(x)
+    check(lib().js2t_axpby(_p(x), C.c_float(a), _p(y), C.c_float(b), _p(out), C.c_int64(x.numel()), dt_code(x), _stream()),
+          "js2t_axpby")
+    return out
+
+
+def glu_fwd(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    rows, c2 = x.shape[0], x.shape[1]
+    y = torch.empty((rows, c2 // 2), dtype=x.dtype, device=x.device)
+    check(lib().js2t_glu_fwd(_p(x), _p(y), C.c_int64(rows), C.c_int64(c2 // 2), dt_code(x), _stream()), "js2t_glu_fwd")
+    return y
+
+
+def glu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _dev(x, dy)
+    dx = torch.empty_like(x)
+    check(lib().js2t_glu_bwd(_p(x), _p(dy), _p(dx), C.c_int64(x.shape[0]), C.c_int64(x.shape[1] // 2), dt_code(x),
+                             _stream()), "js2t_glu_bwd")
+    return dx
+
+
+def add_pe_dropout(x, pe, extra, p, rng: Optional[DropoutRng], site: int):
+    _dev(x, pe, extra)
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    check(lib().js2t_add_pe_dropout(_p(x), _p(pe), _p(extra), _p(y), C.c_int64(B), C.c_int64(T), C.c_int64(D), dt_code(x),
+                                    C.c_float(p), _p(rng.state) if p > 0 else None, C.c_uint32(site), _stream()),
+          "js2t_add_pe_dropout")
+    return y
+
+
+def dropout_bwd(dy, p, rng: DropoutRng, site: int):
+    _dev(dy)
+    dy = dy.contiguous()
+    cols = dy.shape[-1]
+    rows = dy.numel() // cols
+    dx = torch.empty_like(dy)
+    check(lib().js2t_dropout_bwd(_p(dy), _p(dx), C.c_int64(rows), C.c_int64(cols), dt_code(dy), C.c_float(p),
+                                 _p(rng.state), C.c_uint32(site), _stream()), "js2t_dropout_bwd")
+    return dx
+
+
+def act_bwd(dh, z, act: str, scale: float = 1.0):
+    _dev(dh, z)
+    dz = torch.empty_like(dh)
+    check(lib().js2t_act_bwd(_p(dh), _p(z), _p(dz), C.c_int64(dh.numel()), ACT_CODES[act], dt_code(dh), C.c_float(scale),
+                             _stream()), "js2t_act_bwd")
+    return dz
+
+
+def embed_fwd(ids, table, scale: float, out_dtype):
+    _dev(ids, table)
+    ids = ids.contiguous()
+    D, V = table.shape[1], table.shape[0]
+    out = torch.empty((*ids.shape, D), dtype=out_dtype, device=table.device)
+    check(lib().js2t_embed_fwd(_p(ids), _p(table), dt_code(table), _p(out), dt_code(out), C.c_int64(ids.numel()),
+                               C.c_int64(D), C.c_int64(V), C.c_float(scale), _stream()), "js2t_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, dout, vocab: int, scale: float, pad_idx: int):
+    _dev(ids, dout)
+    ids, dout = ids.contiguous(), dout.contiguous()
+    D = dout.shape[-1]
+    dtable = torch.zeros((vocab, D), dtype=torch.float32, device=dout.device)
+    check(lib().js2t_embed_bwd(_p(ids), _p(dout), dt_code(dout), _p(dtable), C.c_int64(ids.numel()), C.c_int64(D),
+                               C.c_int64(vocab), C.c_float(scale), C.c_int64(-1 if pad_idx is None else pad_idx), _stream()),
+          "js2t_embed_bwd")
+    return dtable
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    _dev(x2d)
+    rows, cols = x2d.shape
+    out = torch.empty((cols,), dtype=torch.float32, device=x2d.device)
+    nparts = lib().js2t_colsum_partial_rows(rows)
+    partial = torch.empty((max(nparts, 1) * cols,), dtype=torch.float32, device=x2d.device)
+    check(lib().js2t_colsum(_p(x2d), dt_code(x2d), _p(out), _p(partial), C.c_int64(rows), C.c_int64(cols), _stream()),
+          "js2t_colsum")
+    return out
+
+
+def conv_weight_pack(w: torch.Tensor, dtype) -> torch.Tensor:
+    _dev(w)
+    cout, cin, k = w.shape
+    wp = torch.empty((cout, k * cin), dtype=dtype, device=w.device)
+    check(lib().js2t_conv_weight_pack(_p(w.contiguous()), _p(wp), dt_code(wp), C.c_int64(cout), C.c_int64(cin), C.c_int64(k),
+                                      _stream()), "js2t_conv_weight_pack")
+    return wp
+
+
+def conv_weight_unpack_grad(dwp_t: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
+    _dev(dwp_t)
+    dw = torch.empty((cout, cin, k), dtype=torch.float32, device=dwp_t.device)
+    check(lib().js2t_conv_weight_unpack_grad(_p(dwp_t), _p(dw), C.c_int64(cout), C.c_int64(cin), C.c_int64(k), _stream()),
+          "js2t_conv_weight_unpack_grad")
+    return dw
+
+
+def col2im(dcol, B, tin, tout, Cc, K, stride, pad):
+    _dev(dcol)
+    dx = torch.empty((B, tin, Cc), dtype=dcol.dtype, device=dcol.device)
+    check(lib().js2t_col2im(_p(dcol), _p(dx), C.c_int64(B), C.c_int64(tin), C.c_int64(tout), C.c_int64(Cc), C.c_int64(K),
+                            C.c_int64(stride), C.c_int64(pad), dt_code(dcol), _stream()), "js2t_col2im")
+    return dx
+
+
+def subsample_lengths_mask(lengths: torch.Tensor, t_out: int, kernel_sizes: Sequence[int]):
+    _dev(lengths)
+    B = lengths.shape[0]
+    lengths = lengths.to(torch.int64).contiguous()
+    out_len = torch.empty((B,), dtype=torch.int64, device=lengths.device)
+    mask = torch.empty((B, 1, t_out), dtype=torch.bool, device=lengths.device)
+    ks = (C.c_int32 * len(kernel_sizes))(*kernel_sizes)
+    check(lib().js2t_subsample_lengths_mask(_p(lengths), _p(out_len), _p(mask), C.c_int64(B), C.c_int64(t_out), ks,
+                                            C.c_int32(len(kernel_sizes)), _stream()), "js2t_subsample_lengths_mask")
+    return out_len, mask
+
+
+# ----------------------------------------------------------------------------------------- layer norm
+def layernorm_fwd(x, gamma, beta, eps: float):
+    _dev(x, gamma, beta)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().js2t_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), C.c_int64(rows), C.c_int64(D),
+                                   C.c_float(eps), dt_code(x), _stream()), "js2t_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0):
+    _dev(dy, x, gamma, mean, rstd, add)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    dgamma = dbeta = partial = None
+    if need_param_grads:
+        dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+        nparts = lib().js2t_colsum_partial_rows(rows)
+        partial = torch.empty((2 * max(nparts, 1) * D,), dtype=torch.float32, device=x.device)
+    check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
+                                   _p(partial),
+                                   C.c_int64(rows), C.c_int64(D), dt_code(x), _stream()), "js2t_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------- softmax
+def softmax_fwd(S, mask, B, H, Tq, Tk, ld, p, rng: Optional[DropoutRng], site: int):
+    _dev(S, mask)
+    P = torch.empty_like(S)
+    Pd = torch.empty_like(S) if p > 0 else P
+    mask_sb = mask_sq = 0
+    if mask is not None:
+        if mask.dtype != torch.bool or mask.dim() != 3 or mask.shape[2] != Tk or not mask.is_contiguous():
+            raise Js2tError(f"softmax: mask must be contiguous bool [B, 1|Tq, Tk], got {tuple(mask.shape)} {mask.dtype}")
+        mask_sq = 0 if mask.shape[1] == 1 else Tk
+        if mask.shape[1] not in (1, Tq):
+            raise Js2tError(f"softmax: mask query dim {mask.shape[1]} != 1 or {Tq}")
+        mask_sb = 0 if mask.shape[0] == 1 else mask.shape[1] * Tk
+        if mask.shape[0] not in (1, B):
+            raise Js2tError(f"softmax: mask batch dim {mask.shape[0]} != 1 or {B}")
+    check(lib().js2t_softmax_fwd(_p(S), _p(mask), _p(P), _p(Pd), C.c_int64(B), C.c_int64(H), C.c_int64(Tq), C.c_int64(Tk),
+                                 C.c_int64(ld), C.c_int64(mask_sb), C.c_int64(mask_sq), dt_code(S), C.c_float(p),
+                                 _p(rng.state) if p > 0 else None, C.c_uint32(site), _stream()), "js2t_softmax_fwd")
+    return P, Pd
+
+
+def softmax_bwd(P, dPd, Z, Tq, Tk, ld, p, rng: Optional[DropoutRng], site: int):
+    _dev(P, dPd)
+    dS = torch.empty_like(P)
+    check(lib().js2t_softmax_bwd(_p(P), _p(dPd), _p(dS), C.c_int64(Z), C.c_int64(Tq), C.c_int64(Tk), C.c_int64(ld),
+                                 dt_code(P), C.c_float(p), _p(rng.state) if p > 0 else None, C.c_uint32(site), _stream()),
+          "js2t_softmax_bwd")
+    return dS
+
+
+def attn_head_mean(P, B, H, Tq, Tk, ld):
+    _dev(P)
+    out = torch.empty((B, Tq, Tk), dtype=torch.float32, device=P.device)
+    check(lib().js2t_attn_head_mean(_p(P), _p(out), C.c_int64(B), C.c_int64(H), C.c_int64(Tq), C.c_int64(Tk), C.c_int64(ld),
+                                    dt_code(P), _stream()), "js2t_attn_head_mean")
+    return out
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------- vocabulary rows / losses
+def row_lse(x2d: torch.Tensor, want_argmax: bool = False):
+    _dev(x2d)
+    rows, V = x2d.shape
+    lse = torch.empty((rows,), dtype=torch.float32, device=x2d.device)
+    am = torch.empty((rows,), dtype=torch.int64, device=x2d.device) if want_argmax else None
+    check(lib().js2t_row_lse(_p(x2d), _p(lse), _p(am), C.c_int64(rows), C.c_int64(V), dt_code(x2d), _stream()), "js2t_row_lse")
+    return lse, am
+
+
+def log_softmax(x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    _dev(x)
+    x = x.contiguous()
+    V = x.shape[-1]
+    rows = x.numel() // V
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib().js2t_log_softmax(_p(x), dt_code(x), _p(y), dt_code(y), C.c_int64(rows), C.c_int64(V), _stream()),
+          "js2t_log_softmax")
+    return y
+
+
+def sum_f32(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib().js2t_sum_f32(_p(x), C.c_int64(x.numel()), _p(out), _stream()), "js2t_sum_f32")
+    return out
+
+
+def xent_fwd(logits2d, trg1d, pad_idx: int, smoothing: float):
+    _dev(logits2d, trg1d)
+    rows, V = logits2d.shape
+    dev = logits2d.device
+    loss_rows = torch.empty((rows,), dtype=torch.float32, device=dev)
+    correct_rows = torch.empty((rows,), dtype=torch.float32, device=dev)
+    lse = torch.empty((rows,), dtype=torch.float32, device=dev)
+    check(lib().js2t_xent_fwd(_p(logits2d), dt_code(logits2d), _p(trg1d), _p(loss_rows), _p(correct_rows), _p(lse),
+                              C.c_int64(rows), C.c_int64(V), C.c_int64(pad_idx), C.c_float(smoothing), _stream()),
+          "js2t_xent_fwd")
+    return loss_rows, correct_rows, lse
+
+
+def xent_bwd(logits2d, trg1d, lse, g_dev, scale: float, pad_idx: int, smoothing: float):
+    _dev(logits2d, trg1d, lse, g_dev)
+    rows, V = logits2d.shape
+    d = torch.empty_like(logits2d)
+    check(lib().js2t_xent_bwd(_p(logits2d), dt_code(logits2d), _p(trg1d), _p(lse), _p(g_dev), C.c_float(scale), _p(d),
+                              C.c_int64(rows), C.c_int64(V), C.c_int64(pad_idx), C.c_float(smoothing), _stream()),
+          "js2t_xent_bwd")
+    return d
+
+
+def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity: bool):
+    _dev(logits3d, lse, targets, in_len, tgt_len)
+    B, T, V = logits3d.shape
+    Lmax = targets.shape[1]
+    dev = logits3d.device
+    alpha = torch.empty((B, T, 2 * Lmax + 1), dtype=torch.float32, device=dev)
+    nll = torch.empty((B,), dtype=torch.float32, device=dev)
+    loss_rows = torch.empty((B,), dtype=torch.float32, device=dev)
+    check(lib().js2t_ctc_alpha(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha),
+                               _p(nll), _p(loss_rows), C.c_int64(B), C.c_int64(T), C.c_int64(V), C.c_int64(Lmax),
+                               C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_alpha")
+    return alpha, nll, loss_rows
+
+
+def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: float, blank: int, zero_infinity: bool):
+    _dev(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev)
+    B, T, V = logits3d.shape
+    Lmax = targets.shape[1]
+    beta = torch.empty_like(alpha)
+    d = torch.empty_like(logits3d)
+    check(lib().js2t_ctc_bwd(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha),
+                             _p(beta), _p(nll), _p(g_dev), C.c_float(scale), _p(d), C.c_int64(B), C.c_int64(T), C.c_int64(V),
+                             C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_bwd")
+    return d

@@ -1,0 +1,177 @@
+"""Per-model runtime state for the HIP path: compute dtype, dropout RNG and the flat parameter store.
+
+MI355X-first design notes
+  * All parameters of a model live in ONE flat fp32 buffer (`ParamStore.flat`), their gradients in one flat
+    fp32 buffer (`flat_grad`) and — for bf16 compute — a flat bf16 shadow (`flat_lp`).  `param.data` and
+    `param.grad` are views into those buffers, so checkpoint names/shapes are unchanged
+    (reference contract: transformer_layers.py:235-236) while
+      - the DDP gradient exchange is a handful of large RCCL collectives on `flat_grad` (helpers_for_ddp),
+      - AdamW + the bf16 re-cast is one fused kernel over the flat buffers,
+      - q/k/v (and k/v) projection weights are adjacent, so a fused [3d,d] weight is a *view*.
+  * With 288 GB of HBM per GPU there is no reason to shard or recompute any of this.
+"""
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from joeys2t_amd import ops
+
+_ALIGN = 64  # elements; keeps every group start 128/256-byte aligned in bf16/f32
+
+
+class ParamStore:
+    """Flat storage for a module's parameters (+ grads, + bf16 shadow)."""
+
+    def __init__(self, module: nn.Module, device: torch.device):
+        self.device = torch.device(device)
+        groups: List[List[nn.Parameter]] = []
+        seen = set()
+        # 1. adjacency groups requested by sub-modules (fused projections)
+        for m in module.modules():
+            fg = getattr(m, "fuse_groups", None)
+            if fg is None:
+                continue
+            for grp in fg():
+                grp = [p for p in grp if p is not None]
+                if any(id(p) in seen for p in grp):
+                    continue
+                for p in grp:
+                    seen.add(id(p))
+                groups.append(grp)
+        # 2. everything else, in registration order
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                groups.append([p])
+        offsets: Dict[int, int] = {}
+        total = 0
+        for grp in groups:
+            total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
+            for p in grp:
+                offsets[id(p)] = total
+                total += p.numel()
+        total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = total
+        self.offsets = offsets
+        self.params: List[nn.Parameter] = [p for grp in groups for p in grp]
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.flat_lp: Optional[torch.Tensor] = None
+        self.dirty = True
+        self.auto_refresh = True
+        with torch.no_grad():
+            for p in self.params:
+                off, n = offsets[id(p)], p.numel()
+                view = self.flat[off:off + n].view(p.shape)
+                view.copy_(p.data.to(device=self.device, dtype=torch.float32))
+                p.data = view
+                p.grad = None
+        self._cache: Dict[Tuple, torch.Tensor] = {}
+
+    # ---- gradient views -------------------------------------------------------------------------
+    def attach_grads(self, zero: bool = True):
+        """Point every param.grad at its slice of flat_grad (autograd then accumulates in place)."""
+        if zero:
+            self.flat_grad.zero_()
+        for p in self.params:
+            if p.requires_grad:
+                off, n = self.offsets[id(p)], p.numel()
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+
+    # ---- compute-dtype views --------------------------------------------------------------------
+    def refresh(self, force: bool = False):
+        """Re-cast the bf16 shadow from the fp32 master (one kernel over the whole store)."""
+        if self.flat_lp is None:
+            self.flat_lp = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+            self._cache.clear()
+            force = True
+        if force or self.dirty:
+            ops.cast(self.flat, torch.bfloat16, out=self.flat_lp)
+            self.dirty = False
+
+    def mark_dirty(self):
+        self.dirty = True
+
+    def view(self, params: Sequence[nn.Parameter], dtype: torch.dtype) -> Optional[torch.Tensor]:
+        """A [sum rows, ...] tensor over adjacent parameters in `dtype`, or None if they are not adjacent."""
+        key = (tuple(id(p) for p in params), dtype)
+        hit = self._cache.get(key)
+        if hit is not None:
+            return hit
+        try:
+            offs = [self.offsets[id(p)] for p in params]
+        except KeyError:
+            return None
+        for i in range(1, len(params)):
+            if offs[i] != offs[i - 1] + params[i - 1].numel() or params[i].shape[1:] != params[0].shape[1:]:
+                return None
+        rows = sum(p.shape[0] for p in params)
+        n = sum(p.numel() for p in params)
+        if dtype == torch.float32:
+            base = self.flat
+        else:
+            if self.flat_lp is None:
+                self.refresh()
+            base = self.flat_lp
+        out = base[offs[0]:offs[0] + n].view(rows, *params[0].shape[1:])
+        self._cache[key] = out
+        return out
+
+
+class Runtime:
+    """What every HIP-backed module needs at call time."""
+
+    def __init__(self, device=None, compute_dtype: torch.dtype = torch.float32):
+        self.device = torch.device(device) if device is not None else None
+        self.compute_dtype = compute_dtype
+        self.store: Optional[ParamStore] = None
+        self._rng: Optional[ops.DropoutRng] = None
+
+    @property
+    def rng(self) -> ops.DropoutRng:
+        if self._rng is None:
+            if self.device is None or self.device.type != "cuda":
+                raise ops.Js2tError("dropout RNG needs a GPU runtime (model not finalized on a cuda device)")
+            self._rng = ops.DropoutRng(self.device)
+        return self._rng
+
+    # weights in compute dtype: fused view when the store has the params adjacent, else gathered by kernels
+    def weight(self, params: Sequence[nn.Parameter]) -> torch.Tensor:
+        dt = self.compute_dtype
+        if self.store is not None:
+            v = self.store.view(params, dt)
+            if v is not None:
+                return v
+        ws = []
+        for p in params:
+            ws.append(p.data if p.dtype == dt else ops.cast(p.data, dt))
+        return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+
+    def bias(self, params: Sequence[Optional[nn.Parameter]]) -> Optional[torch.Tensor]:
+        if any(p is None for p in params):
+            return None
+        if self.store is not None:
+            v = self.store.view(params, torch.float32)
+            if v is not None:
+                return v
+        bs = [p.data for p in params]
+        return bs[0] if len(bs) == 1 else torch.cat(bs, dim=0)
+
+    def act_in(self, x: torch.Tensor) -> torch.Tensor:
+        """Bring an activation into the compute dtype (autocast-style entry cast)."""
+        if x.dtype == self.compute_dtype:
+            return x
+        return ops.cast(x, self.compute_dtype)
+
+
+_DEFAULT = Runtime()
+
+
+def runtime_of(module: nn.Module) -> Runtime:
+    return getattr(module, "_rt", None) or _DEFAULT
+
+
+def install_runtime(root: nn.Module, rt: Runtime):
+    for m in root.modules():
+        object.__setattr__(m, "_rt", rt)

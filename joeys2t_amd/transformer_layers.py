@@ -1,0 +1,210 @@
+"""Transformer layers with the reference's module / parameter names, computed by HIP kernels.
+
+Mirrors joeynmt/transformer_layers.py (reference): MultiHeadedAttention (:17-115), PositionwiseFeedForward
+(:118-168), PositionalEncoding (:171-213), TransformerEncoderLayer (:216-289), TransformerDecoderLayer
+(:292-407).  The nn.Linear / nn.LayerNorm sub-modules are kept only as *parameter containers* so that
+`state_dict()` keys match the reference checkpoints (`...src_src_att.k_layer.weight`, `...pwff_layer.0.weight`,
+...); their torch forward is never called.  All math runs in joeys2t_amd.functional (libjoeys2t_hip.so).
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from joeys2t_amd import functional as Fn
+from joeys2t_amd.builders import build_activation
+from joeys2t_amd.runtime import runtime_of
+
+
+def _rng(rt, x: Tensor):
+    if rt.device is None:
+        from joeys2t_amd.ops import dropout_rng
+        return dropout_rng(x.device)
+    return rt.rng
+
+
+class MultiHeadedAttention(nn.Module):
+    """Multi-head attention; argument order of forward is (k, v, q, mask) as in the reference (:49-56)."""
+
+    def __init__(self, num_heads: int, size: int, dropout: float = 0.1) -> None:
+        super().__init__()
+        assert size % num_heads == 0
+        self.head_size = size // num_heads
+        self.model_size = size
+        self.num_heads = num_heads
+        self.k_layer = nn.Linear(size, num_heads * self.head_size)
+        self.v_layer = nn.Linear(size, num_heads * self.head_size)
+        self.q_layer = nn.Linear(size, num_heads * self.head_size)
+        self.output_layer = nn.Linear(size, size)
+        self.softmax = nn.Softmax(dim=-1)  # kept for repr/state parity; unused
+        self.dropout = nn.Dropout(dropout)
+
+    def fuse_groups(self):
+        return [[self.k_layer.weight, self.v_layer.weight, self.q_layer.weight],
+                [self.k_layer.bias, self.v_layer.bias, self.q_layer.bias]]
+
+    # parameters in functional.param_order("self"/"cross") order, without the layer-norm pair
+    def _attn_params(self):
+        return [self.k_layer.weight, self.v_layer.weight, self.q_layer.weight, self.k_layer.bias, self.v_layer.bias,
+                self.q_layer.bias, self.output_layer.weight, self.output_layer.bias]
+
+    def _weights(self, rt, kind: str) -> dict:
+        k, v, q, o = self.k_layer, self.v_layer, self.q_layer, self.output_layer
+        w = {"w_out": rt.weight([o.weight]), "b_out": rt.bias([o.bias])}
+        if kind == "self":
+            w["w_in"] = rt.weight([k.weight, v.weight, q.weight])
+            w["b_in"] = rt.bias([k.bias, v.bias, q.bias])
+        else:
+            w["w_kv"] = rt.weight([k.weight, v.weight])
+            w["b_kv"] = rt.bias([k.bias, v.bias])
+            w["w_q"] = rt.weight([q.weight])
+            w["b_q"] = rt.bias([q.bias])
+        return w
+
+    def run_block(self, x: Tensor, memory: Optional[Tensor], mask: Optional[Tensor], *, ln: Optional[nn.LayerNorm],
+                  ln_mode: str, alpha: float, out_dropout: float, need_weights: bool = False):
+        """[LN] -> attention -> output projection (+dropout) + alpha*x [-> LN] as one fused autograd node."""
+        rt = runtime_of(self)
+        kind = "self" if memory is None else "cross"
+        x = rt.act_in(x)
+        if memory is not None:
+            memory = rt.act_in(memory)
+        cfg = Fn.BlockCfg(kind=kind, num_heads=self.num_heads, alpha=alpha, ln_mode=ln_mode, training=self.training,
+                          attn_dropout=self.dropout.p, out_dropout=out_dropout, need_weights=need_weights)
+        wts = self._weights(rt, kind)
+        params = self._attn_params()
+        if ln is not None:
+            wts["ln_g"], wts["ln_b"] = ln.weight.data, ln.bias.data
+            params = params + [ln.weight, ln.bias]
+        rng = _rng(rt, x) if cfg.any_dropout else None
+        if mask is not None and not mask.is_contiguous():
+            mask = mask.contiguous()
+        out = Fn.ResidualBlockFn.apply(cfg, rng, x, memory, mask, wts, *params)
+        return out if kind == "cross" else (out, None)
+
+    def forward(self, k: Tensor, v: Tensor, q: Tensor, mask: Optional[Tensor] = None,
+                return_weights: Optional[bool] = None):
+        """Stand-alone attention (no residual, no norm) — reference :49-115.  `k` and `v` must be the same
+        tensor (every call site of the reference passes them so: :282, :383, :394-396)."""
+        if k is not v:
+            raise NotImplementedError("MultiHeadedAttention: k and v must be the same tensor on the HIP path")
+        memory = None if q is k else k
+        out, att = self.run_block(q, memory, mask, ln=None, ln_mode="none", alpha=0.0, out_dropout=0.0,
+                                  need_weights=bool(return_weights))
+        if return_weights and memory is None:
+            raise NotImplementedError("attention weights are only exported for cross-attention (decoders.py:606-615)")
+        return out, att
+
+
+class PositionwiseFeedForward(nn.Module):
+    """LN -> Linear -> act -> Dropout -> Linear -> Dropout -> + alpha*x (reference :118-168)."""
+
+    def __init__(self, input_size: int, ff_size: int, dropout: float = 0.1, alpha: float = 1.0,
+                 layer_norm: str = "post", activation: str = "relu") -> None:
+        super().__init__()
+        activation_fnc = build_activation(activation=activation)
+        self.layer_norm = nn.LayerNorm(input_size, eps=1e-6)
+        self.pwff_layer = nn.Sequential(
+            nn.Linear(input_size, ff_size),
+            activation_fnc(),
+            nn.Dropout(dropout),
+            nn.Linear(ff_size, input_size),
+            nn.Dropout(dropout),
+        )
+        self.alpha = alpha
+        self._layer_norm_position = layer_norm
+        self._activation = activation
+        assert self._layer_norm_position in {"pre", "post"}
+
+    def forward(self, x: Tensor) -> Tensor:
+        rt = runtime_of(self)
+        x = rt.act_in(x)
+        l1, l2 = self.pwff_layer[0], self.pwff_layer[3]
+        p = self.pwff_layer[2].p
+        cfg = Fn.BlockCfg(kind="ffn", alpha=self.alpha, ln_mode=self._layer_norm_position, act=self._activation,
+                          training=self.training, attn_dropout=p, out_dropout=p)
+        wts = {"w1": rt.weight([l1.weight]), "b1": rt.bias([l1.bias]), "w2": rt.weight([l2.weight]),
+               "b2": rt.bias([l2.bias]), "ln_g": self.layer_norm.weight.data, "ln_b": self.layer_norm.bias.data}
+        rng = _rng(rt, x) if cfg.any_dropout else None
+        return Fn.ResidualBlockFn.apply(cfg, rng, x, None, None, wts, l1.weight, l1.bias, l2.weight, l2.bias,
+                                        self.layer_norm.weight, self.layer_norm.bias)
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal position table (reference :171-213): pe[p,2i] = sin(p * exp(-2i ln(1e4)/d)), pe[p,2i+1] = cos."""
+
+    def __init__(self, size: int = 0, max_len: int = 5000) -> None:
+        if size % 2 != 0:
+            raise ValueError(f"Cannot use sin/cos positional encoding with odd dim (got dim={size})")
+        super().__init__()
+        position = torch.arange(0, max_len).unsqueeze(1).float()
+        div_term = torch.exp(torch.arange(0, size, 2, dtype=torch.float) * -(math.log(10000.0) / size))
+        pe = torch.zeros(max_len, size)
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))  # (1, max_len, size) as in the reference state_dict
+        self.dim = size
+
+    def forward(self, emb: Tensor, extra: Optional[Tensor] = None, dropout: float = 0.0, training: bool = False) -> Tensor:
+        """emb + pe[:, :T] (+ extra), then dropout — the add and the encoder/decoder emb_dropout are one kernel."""
+        rt = runtime_of(self)
+        emb = rt.act_in(emb)
+        if emb.size(1) > self.pe.size(1):
+            raise ValueError(f"sequence length {emb.size(1)} exceeds positional table {self.pe.size(1)}")
+        p = dropout if training else 0.0
+        rng = _rng(rt, emb) if p > 0 else None
+        if extra is not None:
+            extra = rt.act_in(extra)
+        return Fn.AddPeDropoutFn.apply(emb, self.pe[0], extra, p, rng)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Self-attention block + feed-forward block (reference :216-289)."""
+
+    def __init__(self, size: int = 0, ff_size: int = 0, num_heads: int = 0, dropout: float = 0.1, alpha: float = 1.0,
+                 layer_norm: str = "post", activation: str = "relu") -> None:
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(size, eps=1e-6)
+        self.src_src_att = MultiHeadedAttention(num_heads, size, dropout=dropout)
+        self.feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha,
+                                                    layer_norm=layer_norm, activation=activation)
+        self.dropout = nn.Dropout(dropout)
+        self.size = size
+        self.alpha = alpha
+        self._layer_norm_position = layer_norm
+        assert self._layer_norm_position in {"pre", "post"}
+
+    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+        h, _ = self.src_src_att.run_block(x, None, mask, ln=self.layer_norm, ln_mode=self._layer_norm_position,
+                                          alpha=self.alpha, out_dropout=self.dropout.p)
+        return self.feed_forward(h)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """Masked self-attention, encoder-decoder attention, feed-forward (reference :292-407)."""
+
+    def __init__(self, size: int = 0, ff_size: int = 0, num_heads: int = 0, dropout: float = 0.1, alpha: float = 1.0,
+                 layer_norm: str = "post", activation: str = "relu") -> None:
+        super().__init__()
+        self.size = size
+        self.trg_trg_att = MultiHeadedAttention(num_heads, size, dropout=dropout)
+        self.src_trg_att = MultiHeadedAttention(num_heads, size, dropout=dropout)
+        self.feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha,
+                                                    layer_norm=layer_norm, activation=activation)
+        self.x_layer_norm = nn.LayerNorm(size, eps=1e-6)
+        self.dec_layer_norm = nn.LayerNorm(size, eps=1e-6)
+        self.dropout = nn.Dropout(dropout)
+        self.alpha = alpha
+        self._layer_norm_position = layer_norm
+        assert self._layer_norm_position in {"pre", "post"}
+
+    def forward(self, x: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor, return_attention: bool = False,
+                **kwargs):
+        h1, _ = self.trg_trg_att.run_block(x, None, trg_mask, ln=self.x_layer_norm, ln_mode=self._layer_norm_position,
+                                           alpha=self.alpha, out_dropout=self.dropout.p)
+        h2, att = self.src_trg_att.run_block(h1, memory, src_mask, ln=self.dec_layer_norm,
+                                             ln_mode=self._layer_norm_position, alpha=self.alpha,
+                                             out_dropout=self.dropout.p, need_weights=return_attention)
+        out = self.feed_forward(h2)
+        return out, (att if return_attention else None)

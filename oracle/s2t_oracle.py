@@ -1,0 +1,484 @@
+"""CPU ORACLE for the JoeyS2T hot path — TEST INFRASTRUCTURE ONLY.
+
+A plain-PyTorch / NumPy fp32 restatement of what the reference computes on its CPU path, written as pure
+functions over a `state_dict` (no nn.Module).  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+leg of `bench.py` may import this file; the product package `joeys2t_amd` never does (it fails loudly without
+its HIP library instead).
+
+Pinning: every function is checked against golden vectors produced by the *real* reference imported in the
+build container (`oracle/make_golden.py` -> `tests/golden/*.npz`, `tests/test_oracle_golden.py`), which in turn
+contain the reference's own unit-test constants.  The Kaldi fbank has no in-tree reference (torchaudio is a
+third-party dependency that is not installed): it is restated from the published Kaldi/torchaudio algorithm and
+pinned by the reference's own known-answer test (test/unit/test_tokenizer.py:310-329) and frame counts
+(test/data/speech/test.tsv).
+
+Each function cites the reference file:line (relative to the reference repo) it follows.
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------------------
+# helpers (reference helpers.py)
+# --------------------------------------------------------------------------------------------------
+def subsequent_mask(size: int) -> Tensor:
+    """helpers.py:81-90"""
+    return torch.tril(torch.ones(size, size, dtype=torch.bool)).unsqueeze(0)
+
+
+def lengths_to_padding_mask(lengths: Tensor) -> Tensor:
+    """helpers.py:459-469"""
+    max_len = int(lengths.max().item())
+    return torch.arange(max_len).unsqueeze(0) < lengths.view(-1, 1)
+
+
+def subsample_lengths(lengths: Tensor, kernel_sizes: List[int]) -> Tensor:
+    """encoders.py:348-352 (float arithmetic then floor, as the reference does)"""
+    out = lengths.clone()
+    for k in kernel_sizes:
+        out = ((out.float() + 2 * (k // 2) - (k - 1) - 1) / 2 + 1).floor().long()
+    return out
+
+
+def positional_table(max_len: int, size: int) -> Tensor:
+    """transformer_layers.py:192-199"""
+    pe = torch.zeros(max_len, size)
+    position = torch.arange(0, max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, size, 2, dtype=torch.float) * -(math.log(10000.0) / size))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+def activation(name: str):
+    """builders.py:24-41"""
+    return {"relu": F.relu, "gelu": F.gelu, "tanh": torch.tanh, "swish": F.silu}[name]
+
+
+# --------------------------------------------------------------------------------------------------
+# layers (reference transformer_layers.py / encoders.py / decoders.py)
+# --------------------------------------------------------------------------------------------------
+def linear(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+
+
+def layer_norm(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    """nn.LayerNorm(eps=1e-6): transformer_layers.py:146,248,339-340"""
+    return F.layer_norm(x, (x.size(-1), ), sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-6)
+
+
+def mha(sd: SD, prefix: str, k: Tensor, v: Tensor, q: Tensor, mask: Optional[Tensor], num_heads: int,
+        return_weights: bool = False):
+    """MultiHeadedAttention.forward, transformer_layers.py:49-115 (eval mode: dropout is the identity)."""
+    B, d = k.size(0), q.size(-1)
+    dh = d // num_heads
+    k = linear(sd, prefix + ".k_layer", k).view(B, -1, num_heads, dh).transpose(1, 2)
+    v = linear(sd, prefix + ".v_layer", v).view(B, -1, num_heads, dh).transpose(1, 2)
+    q = linear(sd, prefix + ".q_layer", q).view(B, -1, num_heads, dh).transpose(1, 2)
+    q = q / math.sqrt(dh)  # scaled BEFORE the product (:86)
+    scores = torch.matmul(q, k.transpose(2, 3))
+    if mask is not None:
+        scores = scores.masked_fill(~mask.unsqueeze(1), float("-inf"))
+    weights = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(weights, v).transpose(1, 2).contiguous().view(B, -1, d)
+    out = linear(sd, prefix + ".output_layer", ctx)
+    if return_weights:
+        return out, weights.sum(dim=1) / num_heads
+    return out, None
+
+
+def feed_forward(sd: SD, prefix: str, x: Tensor, alpha: float, ln_pos: str, act: str) -> Tensor:
+    """PositionwiseFeedForward.forward, transformer_layers.py:159-168"""
+    residual = x
+    if ln_pos == "pre":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    x = linear(sd, prefix + ".pwff_layer.3", activation(act)(linear(sd, prefix + ".pwff_layer.0", x))) + alpha * residual
+    if ln_pos == "post":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    return x
+
+
+def encoder_layer(sd: SD, prefix: str, x: Tensor, mask: Tensor, cfg: dict) -> Tensor:
+    """TransformerEncoderLayer.forward, transformer_layers.py:267-289"""
+    alpha, ln_pos = cfg["alpha"], cfg["layer_norm"]
+    residual = x
+    if ln_pos == "pre":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    x, _ = mha(sd, prefix + ".src_src_att", x, x, x, mask, cfg["num_heads"])
+    x = x + alpha * residual
+    if ln_pos == "post":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    return feed_forward(sd, prefix + ".feed_forward", x, alpha, ln_pos, cfg["activation"])
+
+
+def decoder_layer(sd: SD, prefix: str, x: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor, cfg: dict,
+                  return_attention: bool = False):
+    """TransformerDecoderLayer.forward, transformer_layers.py:348-407"""
+    alpha, ln_pos, H = cfg["alpha"], cfg["layer_norm"], cfg["num_heads"]
+    residual = x
+    if ln_pos == "pre":
+        x = layer_norm(sd, prefix + ".x_layer_norm", x)
+    h1, _ = mha(sd, prefix + ".trg_trg_att", x, x, x, trg_mask, H)
+    h1 = h1 + alpha * residual
+    if ln_pos == "post":
+        h1 = layer_norm(sd, prefix + ".x_layer_norm", h1)
+    h1_residual = h1
+    if ln_pos == "pre":
+        h1 = layer_norm(sd, prefix + ".dec_layer_norm", h1)
+    h2, att = mha(sd, prefix + ".src_trg_att", memory, memory, h1, src_mask, H, return_weights=return_attention)
+    h2 = h2 + alpha * h1_residual
+    if ln_pos == "post":
+        h2 = layer_norm(sd, prefix + ".dec_layer_norm", h2)
+    return feed_forward(sd, prefix + ".feed_forward", h2, alpha, ln_pos, cfg["activation"]), att
+
+
+def conv_subsample(sd: SD, prefix: str, x: Tensor, lengths: Tensor, kernel_sizes: List[int]) -> Tuple[Tensor, Tensor]:
+    """Conv1dSubsampler.forward, encoders.py:354-373 (padded frames are convolved like any other)."""
+    max_len = int(lengths.max().item())
+    if x.size(1) != max_len:
+        x = x[:, :max_len, :]
+    x = x.transpose(1, 2).contiguous()
+    for i, k in enumerate(kernel_sizes):
+        x = F.conv1d(x, sd[f"{prefix}.conv_layers.{i}.weight"], sd[f"{prefix}.conv_layers.{i}.bias"], stride=2, padding=k // 2)
+        x = F.glu(x, dim=1)
+    return x.transpose(1, 2).contiguous(), subsample_lengths(lengths, kernel_sizes)
+
+
+def encoder_forward(sd: SD, cfg: dict, src: Tensor, src_length: Tensor, prefix: str = "encoder"):
+    """TransformerEncoder.forward, encoders.py:241-288 (eval mode) -> (x, mask [B,1,T'], lengths)."""
+    e = cfg["encoder"]
+    x, lengths = src, src_length
+    if e.get("subsample", False):
+        x, lengths = conv_subsample(sd, prefix + ".subsampler", x, lengths, e["conv_kernel_sizes"])
+    mask = lengths_to_padding_mask(lengths).unsqueeze(1)
+    x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
+    for i in range(e["num_layers"]):
+        x = encoder_layer(sd, f"{prefix}.layers.{i}", x, mask, e)
+    if e["layer_norm"] == "pre":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    return x, mask, lengths
+
+
+def embed(sd: SD, cfg: dict, ids: Tensor) -> Tensor:
+    """Embeddings.forward, embeddings.py:55-64"""
+    w = sd["trg_embed.lut.weight"]
+    x = F.embedding(ids, w)
+    return x * math.sqrt(w.size(1)) if cfg["decoder"]["embeddings"].get("scale", False) else x
+
+
+def decoder_forward(sd: SD, cfg: dict, trg_input: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor,
+                    return_attention: bool = False, prefix: str = "decoder"):
+    """TransformerDecoder.forward, decoders.py:567-625 (eval mode) -> (logits, hidden, att, ctc_logits|None)."""
+    dcfg = cfg["decoder"]
+    x = embed(sd, cfg, trg_input)
+    x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
+    tmask = trg_mask & subsequent_mask(trg_input.size(1))
+    att = None
+    n = dcfg["num_layers"]
+    for i in range(n):
+        x, att = decoder_layer(sd, f"{prefix}.layers.{i}", x, memory, src_mask, tmask, dcfg,
+                               return_attention=(return_attention and i == n - 1))
+    if dcfg["layer_norm"] == "pre":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    out = F.linear(x, sd[prefix + ".output_layer.weight"])
+    ctc = None
+    if prefix + ".ctc_output_layer.weight" in sd:
+        ctc = F.linear(memory, sd[prefix + ".ctc_output_layer.weight"])
+    return out, x, att, ctc
+
+
+# --------------------------------------------------------------------------------------------------
+# losses (reference loss.py, model.py:113-148)
+# --------------------------------------------------------------------------------------------------
+def smooth_targets(targets: Tensor, vocab_size: int, pad_index: int, smoothing: float) -> Tensor:
+    """XentLoss._smooth_targets, loss.py:35-58"""
+    dist = torch.full((targets.size(0), vocab_size), smoothing / (vocab_size - 2))
+    dist.scatter_(1, targets.unsqueeze(1), 1.0 - smoothing)
+    dist[:, pad_index] = 0
+    dist[targets == pad_index] = 0.0
+    return dist
+
+
+def xent_loss(log_probs: Tensor, trg: Tensor, pad_index: int, smoothing: float) -> Tensor:
+    """XentLoss.forward, loss.py:85-101"""
+    V = log_probs.size(-1)
+    lp = log_probs.contiguous().view(-1, V)
+    t = trg.contiguous().view(-1)
+    if smoothing > 0:
+        return F.kl_div(lp, smooth_targets(t, V, pad_index, smoothing), reduction="sum")
+    return F.nll_loss(lp, t, ignore_index=pad_index, reduction="sum")
+
+
+def ctc_loss(ctc_log_probs: Tensor, trg: Tensor, input_lengths: Tensor, target_lengths: Tensor, blank: int) -> Tensor:
+    """XentCTCLoss.forward, loss.py:156-161: nn.CTCLoss(blank=bos, reduction='sum', zero_infinity=True)"""
+    return F.ctc_loss(ctc_log_probs.transpose(0, 1).contiguous(), trg, input_lengths, target_lengths, blank=blank,
+                      reduction="sum", zero_infinity=True)
+
+
+def model_loss(sd: SD, cfg: dict, batch: dict, specials: dict, smoothing: float, ctc_weight: Optional[float]):
+    """Model.forward(return_type="loss"), model.py:113-148 -> (total, xent, ctc|None, n_correct, logits, ctc_logits)."""
+    enc, src_mask, _ = encoder_forward(sd, cfg, batch["src"], batch["src_length"])
+    out, _, _, ctc_out = decoder_forward(sd, cfg, batch["trg_input"], enc, src_mask, batch["trg_mask"])
+    log_probs = F.log_softmax(out, dim=-1)
+    xent = xent_loss(log_probs, batch["trg"], specials["pad"], smoothing)
+    ctc = None
+    total = xent
+    if ctc_weight is not None and ctc_out is not None:
+        ctc = ctc_loss(F.log_softmax(ctc_out, dim=-1), batch["trg"], src_mask.squeeze(1).sum(dim=1), batch["trg_length"],
+                       specials["bos"])
+        total = (1.0 - ctc_weight) * xent + ctc_weight * ctc
+    tmask = batch["trg_mask"].squeeze(1)
+    n_correct = torch.sum(log_probs.argmax(-1).masked_select(tmask).eq(batch["trg"].masked_select(tmask)))
+    return total, xent, ctc, n_correct, out, ctc_out
+
+
+# --------------------------------------------------------------------------------------------------
+# search (reference search.py)
+# --------------------------------------------------------------------------------------------------
+def _forbid(log_probs: Tensor, ids: List[Optional[int]]):
+    for i in ids:
+        if i is not None and i < log_probs.size(1):
+            log_probs[:, i] = float("-inf")
+
+
+def greedy(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor, max_output_length: int,
+           min_output_length: int = 1, generate_unk: bool = True, return_prob: bool = False):
+    """transformer_greedy, search.py:162-342 (no prompts / penalties) -> (ids [B,L], scores|None)"""
+    B = src_mask.size(0)
+    ys = torch.full((B, 1), specials["bos"], dtype=torch.long)
+    yv = torch.zeros((B, 1)) if return_prob else None
+    trg_mask = torch.ones(1, 1, 1, dtype=torch.bool)
+    finished = torch.zeros(B, 1, dtype=torch.uint8)
+    for step in range(max_output_length):
+        logits, _, _, _ = decoder_forward(sd, cfg, ys, enc, src_mask, trg_mask)
+        lp = logits[:, -1]
+        if return_prob:
+            lp = F.log_softmax(lp, dim=-1)
+        _forbid(lp, [specials["bos"], specials.get("sep")])
+        if not generate_unk:
+            lp[:, specials["unk"]] = float("-inf")
+        if step < min_output_length:
+            lp[:, specials["eos"]] = float("-inf")
+        prob, nxt = torch.max(lp, dim=1)
+        ys = torch.cat([ys, nxt.unsqueeze(-1)], dim=1)
+        if return_prob:
+            yv = torch.cat([yv, prob.unsqueeze(-1)], dim=1)
+        finished += nxt.unsqueeze(-1).eq(specials["eos"]).to(torch.uint8)
+        if (finished >= 1).sum() == B:
+            break
+    return ys[:, 1:], (yv[:, 1:] if return_prob else None)
+
+
+def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor, beam_size: int, max_output_length: int,
+                alpha: float, n_best: int = 1, min_output_length: int = 1, generate_unk: bool = True):
+    """beam_search, search.py:345-825 (Transformer branch, no prompts / penalties) -> (ids [B*n_best,L], scores [B*n_best,1])"""
+    bos, eos, pad, unk = specials["bos"], specials["eos"], specials["pad"], specials["unk"]
+    B = src_mask.size(0)
+    V = sd["decoder.output_layer.weight"].size(0)
+    enc = enc.repeat_interleave(beam_size, dim=0)
+    src_mask = src_mask.repeat_interleave(beam_size, dim=0)
+    trg_mask = torch.ones(1, 1, 1, dtype=torch.bool)
+    batch_offset = torch.arange(B)
+    beam_offset = torch.arange(0, B * beam_size, step=beam_size)
+    alive_seq = torch.full((B * beam_size, 1), bos, dtype=torch.long)
+    topk_log_probs = torch.zeros(B, beam_size)
+    topk_log_probs[:, 1:] = float("-inf")
+    hypotheses = [[] for _ in range(B)]
+    results = {"predictions": [[] for _ in range(B)], "scores": [[] for _ in range(B)]}
+    is_finished = torch.zeros(B, beam_size, dtype=torch.bool)
+    for step in range(max_output_length):
+        logits, _, _, _ = decoder_forward(sd, cfg, alive_seq, enc, src_mask, trg_mask)
+        log_probs = F.log_softmax(logits[:, -1], dim=-1)
+        _forbid(log_probs, [bos, pad, specials.get("sep")])
+        if not generate_unk:
+            log_probs[:, unk] = float("-inf")
+        if step < min_output_length:
+            log_probs[:, eos] = float("-inf")
+        log_probs += topk_log_probs.view(-1).unsqueeze(1)
+        curr_scores = log_probs.clone()
+        if alpha > 0:
+            length_penalty = ((5.0 + (step + 1)) / 6.0)**alpha
+            curr_scores /= length_penalty
+        curr_scores = curr_scores.reshape(-1, beam_size * V)
+        topk_scores, topk_ids = curr_scores.topk(beam_size, dim=-1)
+        topk_log_probs = topk_scores * length_penalty if alpha > 0 else topk_scores.clone()
+        topk_beam_index = topk_ids.div(V, rounding_mode="floor")
+        topk_ids = topk_ids.fmod(V)
+        batch_index = topk_beam_index + beam_offset[:topk_ids.size(0)].unsqueeze(1)
+        select_indices = batch_index.view(-1)
+        alive_seq = torch.cat([alive_seq.index_select(0, select_indices), topk_ids.view(-1, 1)], -1)
+        is_finished = topk_ids.eq(eos) | is_finished | topk_scores.eq(-np.inf)
+        if step + 1 == max_output_length:
+            is_finished.fill_(True)
+        end_condition = is_finished.all(-1)
+        if is_finished.any():
+            predictions = alive_seq.view(-1, beam_size, alive_seq.size(-1))
+            for i in range(is_finished.size(0)):
+                b = batch_offset[i].item()
+                if end_condition[i]:
+                    is_finished[i].fill_(True)
+                for j in is_finished[i].nonzero(as_tuple=False).view(-1):
+                    n_eos = (predictions[i, j, 1:] == eos).count_nonzero().item()
+                    if n_eos > 1:
+                        continue
+                    if (n_eos == 0 and step + 1 == max_output_length) or (n_eos == 1 and predictions[i, j, -1] == eos):
+                        hypotheses[b].append((topk_scores[i, j], predictions[i, j, 1:]))
+                if end_condition[i]:
+                    for n, (score, pred) in enumerate(sorted(hypotheses[b], key=lambda x: x[0], reverse=True)):
+                        if n >= n_best:
+                            break
+                        results["scores"][b].append(score)
+                        results["predictions"][b].append(pred)
+            unfinished = end_condition.eq(False).nonzero(as_tuple=False).view(-1)
+            if len(unfinished) == 0:
+                break
+            batch_index = batch_index.index_select(0, unfinished)
+            topk_log_probs = topk_log_probs.index_select(0, unfinished)
+            is_finished = is_finished.index_select(0, unfinished)
+            batch_offset = batch_offset.index_select(0, unfinished)
+            alive_seq = predictions.index_select(0, unfinished).view(-1, alive_seq.size(-1))
+        select_indices = batch_index.view(-1)
+        enc = enc.index_select(0, select_indices)
+        src_mask = src_mask.index_select(0, select_indices)
+    for b in range(B):
+        for _ in range(n_best - len(results["predictions"][b])):
+            results["predictions"][b].append(torch.tensor([unk]).long())
+            results["scores"][b].append(torch.tensor([-1]).float())
+    preds = [u for r in results["predictions"] for u in r]
+    max_len = max(p.shape[0] for p in preds)
+    out = torch.full((len(preds), max_len), pad, dtype=torch.int64)
+    for j, p in enumerate(preds):
+        out[j, :p.shape[0]] = p
+    scores = torch.tensor([[float(u)] for r in results["scores"] for u in r])
+    return out, scores
+
+
+# --------------------------------------------------------------------------------------------------
+# audio front-end (reference helpers_for_audio.py, data_augmentation.py; Kaldi fbank from the published spec)
+# --------------------------------------------------------------------------------------------------
+def get_n_frames(wave_length: int, sample_rate: int) -> int:
+    """helpers_for_audio.py:93-96"""
+    duration_ms = int(wave_length / sample_rate * 1000)
+    return int(1 + (duration_ms - 25) / 10)
+
+
+def mel_scale(f):
+    return 1127.0 * np.log(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+
+
+def mel_banks(num_bins: int = 80, n_fft: int = 512, sample_rate: float = 16000.0, low: float = 20.0, high: float = 0.0):
+    """Kaldi triangular mel filters (torchaudio.compliance.kaldi.get_mel_banks): returns [num_bins, n_fft/2]."""
+    nyquist = 0.5 * sample_rate
+    if high <= 0.0:
+        high += nyquist
+    mel_low, mel_high = mel_scale(low), mel_scale(high)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = np.arange(num_bins, dtype=np.float64)[:, None]
+    left, center, right = mel_low + b * delta, mel_low + (b + 1) * delta, mel_low + (b + 2) * delta
+    mel = mel_scale((sample_rate / n_fft) * np.arange(n_fft // 2, dtype=np.float64))[None, :]
+    up, down = (mel - left) / (center - left), (right - mel) / (right - center)
+    return np.maximum(0.0, np.minimum(up, down)).astype(np.float32)
+
+
+def povey_window(n: int = 400) -> np.ndarray:
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n, dtype=np.float64) / (n - 1)))**0.85
+
+
+def fbank(waveform: np.ndarray, sample_rate: int = 16000, n_bins: int = 80) -> np.ndarray:
+    """ta_kaldi.fbank(waveform * 2**15, num_mel_bins=80, sample_frequency=sr) with Kaldi defaults, as called at
+    helpers_for_audio.py:30-37,54: 25 ms / 10 ms frames (snip_edges), no dither, DC removal, pre-emphasis 0.97,
+    Povey window, 512-point power spectrum, 80 mel bins from 20 Hz to Nyquist, log with floor eps(float32).
+    waveform: float array [N] in [-1, 1] (first channel).  Returns float32 [T, n_bins]."""
+    x = np.asarray(waveform, dtype=np.float32) * np.float32(2**15)
+    win_len, shift = int(sample_rate * 0.025), int(sample_rate * 0.010)
+    n_fft = 1 << (win_len - 1).bit_length()
+    if x.shape[0] < win_len:
+        return np.zeros((0, n_bins), dtype=np.float32)
+    T = 1 + (x.shape[0] - win_len) // shift
+    idx = np.arange(win_len)[None, :] + shift * np.arange(T)[:, None]
+    frames = x[idx].astype(np.float32)
+    frames = frames - frames.mean(axis=1, keepdims=True, dtype=np.float32)
+    prev = np.concatenate([frames[:, :1], frames[:, :-1]], axis=1)
+    frames = frames - np.float32(0.97) * prev
+    frames = frames * povey_window(win_len).astype(np.float32)[None, :]
+    spec = np.fft.rfft(frames.astype(np.float32), n=n_fft, axis=1)
+    power = (spec.real.astype(np.float32)**2 + spec.imag.astype(np.float32)**2).astype(np.float32)
+    banks = mel_banks(n_bins, n_fft, float(sample_rate))  # [n_bins, n_fft/2]; Nyquist bin has zero weight
+    mel = power[:, : n_fft // 2] @ banks.T
+    return np.log(np.maximum(mel, np.finfo(np.float32).eps)).astype(np.float32)
+
+
+def cmvn(x: np.ndarray, norm_means: bool = True, norm_vars: bool = True) -> np.ndarray:
+    """CMVN.__call__, data_augmentation.py:96-109"""
+    mean = x.mean(axis=0)
+    square_sums = (x**2).sum(axis=0)
+    if norm_means:
+        x = np.subtract(x, mean)
+    if norm_vars:
+        var = square_sums / x.shape[0] - mean**2
+        x = np.divide(x, np.sqrt(np.maximum(var, 1e-10)))
+    return x
+
+
+def specaugment_params(num_frames: int, num_freqs: int, rng: np.random.RandomState, freq_mask_n=2, freq_mask_f=27,
+                       time_mask_n=2, time_mask_t=40, time_mask_p=1.0):
+    """RNG draw order of SpecAugment.__call__, data_augmentation.py:54-68 -> (freq masks [(f0,f)], time masks [(t0,t)])
+    or None when the reference returns its input unchanged (:48-52)."""
+    if num_frames == 0 or num_freqs < freq_mask_f:
+        return None
+    fm, tm = [], []
+    for _ in range(freq_mask_n):
+        f = rng.randint(0, freq_mask_f)
+        f0 = rng.randint(0, num_freqs - f)
+        fm.append((f0, f))
+    max_t = min(time_mask_t, math.floor(num_frames * time_mask_p))
+    if max_t >= 1:
+        for _ in range(time_mask_n):
+            t = rng.randint(0, max_t)
+            t0 = rng.randint(0, num_frames - t)
+            tm.append((t0, t))
+    return fm, tm
+
+
+def specaugment_apply(x: np.ndarray, params) -> np.ndarray:
+    """Mask fill = mean of the INPUT spectrogram (data_augmentation.py:45-46,57-68)."""
+    if params is None:
+        return x
+    out = x.copy()
+    fill = x.mean()
+    for f0, f in params[0]:
+        if f != 0:
+            out[:, f0:f0 + f] = fill
+    for t0, t in params[1]:
+        if t != 0:
+            out[t0:t0 + t, :] = fill
+    return out
+
+
+def pad_features(feat_list: List[np.ndarray], embed_size: int = 80, pad_index: int = 1):
+    """helpers_for_audio.py:130-170 (pads with float(pad_index) = 1.0)"""
+    max_len = max(int(f.shape[0]) for f in feat_list)
+    out = np.full((len(feat_list), max_len, embed_size), float(pad_index), dtype=np.float32)
+    lengths = []
+    for i, f in enumerate(feat_list):
+        n = min(int(f.shape[0]), max_len)
+        out[i, :n, :] = f[:n, :]
+        lengths.append(n)
+    return out, lengths, None
+
+
+# --------------------------------------------------------------------------------------------------
+# batch bookkeeping (reference batch.py:79-96)
+# --------------------------------------------------------------------------------------------------
+def make_batch(src: Tensor, src_length: Tensor, trg_full: Tensor, trg_length_full: Tensor, pad: int, eos: int) -> dict:
+    trg_input = torch.where(trg_full == eos, torch.full_like(trg_full, pad), trg_full)[:, :-1]
+    trg = trg_full[:, 1:]
+    return {"src": src, "src_length": src_length, "trg_input": trg_input, "trg": trg, "trg_length": trg_length_full - 1,
+            "trg_mask": (trg != pad).unsqueeze(1)}

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol that include/joeys2t_hip.h declares;
+the product path refuses CPU tensors instead of falling back."""
+import ctypes
+
+import pytest
+import torch
+
+from joeys2t_amd import _lib, ops
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.declared_symbols()
+    assert "js2t_gemm" in names and "js2t_ctc_bwd" in names and len(names) >= 25
+    handle = _lib.lib()
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert handle.js2t_abi_version() >= 1
+
+
+def test_gemm_desc_matches_header_layout():
+    # field order / count of the ctypes mirror follows the header text
+    import re
+    text = _lib.HEADER_PATH.read_text()
+    body = text[text.index("typedef struct js2t_gemm_desc {"):text.index("} js2t_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = re.sub(r"^(const\s+)?[a-z0-9_]+(\s*\*)?\s+", "", decl)
+        fields += [n.strip().lstrip("*") for n in names.split(",")]
+    assert fields == [f[0] for f in _lib.GemmDesc._fields_]
+
+
+def test_no_cpu_fallback():
+    x = torch.zeros(4, 8)
+    with pytest.raises(ops.Js2tError):
+        ops.glu_fwd(x)
+    with pytest.raises(ops.Js2tError):
+        ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-6)

@@ -1,0 +1,118 @@
+"""GPU: the HIP model (joeys2t_amd.Model, C-ABI kernels) against golden vectors captured from the real reference
+and against the CPU oracle.  fp32 compute: 1e-4 (north_star); bf16 compute: checked against fp32 with bf16 slack."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_sd, load_golden
+from golden_cfg import FIXTURES, SPECIALS, oracle_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def build(name, device, dtype=torch.float32, train=False):
+    import copy
+
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    g = load_golden(name)
+    fx = FIXTURES[name]
+    torch.manual_seed(0)
+    model = build_model(copy.deepcopy(fx["cfg"]), None, Vocabulary.synthetic(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, fx["ctc_weight"])
+    missing = model.load_state_dict(golden_sd(g), strict=True)
+    model.finalize(device, dtype)
+    model.train(train)
+    return model, g
+
+
+def batch_kwargs(g, device):
+    from joeys2t_amd.batch import Batch
+    b = Batch(src=torch.from_numpy(g["src"]), src_length=torch.from_numpy(g["src_length"]), src_prompt_mask=None,
+              trg=torch.from_numpy(g["trg_full"]), trg_length=torch.from_numpy(g["trg_length_full"]), trg_prompt_mask=None,
+              indices=torch.arange(g["src"].shape[0]), device=device, pad_index=1, eos_index=3, is_train=True, task="S2T",
+              n_gpu=1)
+    for k in ("trg_input", "trg", "trg_length", "trg_mask"):
+        assert np.array_equal(getattr(b, k).cpu().numpy(), g[k]), k  # bit-exact batch bookkeeping
+    assert b.ntokens == int(g["ntokens"])
+    return b
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_forward_matches_reference(device, name):
+    model, g = build(name, device)
+    b = batch_kwargs(g, device)
+    with torch.no_grad():
+        enc, _, src_mask, _ = model(return_type="encode", **vars(b))
+        logits, hidden, att, ctc = model(return_type="decode_ctc", encoder_output=enc, encoder_hidden=None, src_mask=src_mask,
+                                         trg_input=b.trg_input, unroll_steps=None, trg_mask=b.trg_mask, return_attention=True)
+    assert np.array_equal(src_mask.cpu().numpy(), g["src_mask"])  # bit-exact conv-subsample length mask
+    torch.testing.assert_close(enc.cpu(), torch.from_numpy(g["enc_out"]), **TOL)
+    torch.testing.assert_close(logits.cpu(), torch.from_numpy(g["logits"]), **TOL)
+    torch.testing.assert_close(hidden.cpu(), torch.from_numpy(g["dec_hidden"]), **TOL)
+    torch.testing.assert_close(att.cpu(), torch.from_numpy(g["att"]), **TOL)
+    torch.testing.assert_close(ctc.cpu(), torch.from_numpy(g["ctc_logits"]), **TOL)
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_loss_and_gradients_match_reference(device, name):
+    model, g = build(name, device)
+    b = batch_kwargs(g, device)
+    total, xent, ctc, ncor = model(return_type="loss", **vars(b))
+    total.backward()
+    assert abs(total.item() - g["loss_total"]) <= 1e-4 * abs(g["loss_total"])
+    assert abs(xent.item() - g["loss_xent"]) <= 1e-4 * abs(g["loss_xent"])
+    assert abs(ctc.item() - g["loss_ctc"]) <= 1e-4 * abs(g["loss_ctc"])
+    assert int(ncor.item()) == int(g["n_correct"])
+    worst = 0.0
+    for n, p in model.named_parameters():
+        ref = torch.from_numpy(g[f"grad.{n}"])
+        assert p.grad is not None, n
+        scale = ref.abs().max().item() + 1e-6
+        err = (p.grad.cpu() - ref).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 1e-4 * scale + 1e-5, (n, err, scale)
+    print("worst relative grad error", worst)
+
+
+@pytest.mark.parametrize("name", ["model_pre"])
+def test_bf16_compute_close_to_fp32(device, name):
+    model, g = build(name, device, torch.bfloat16)
+    b = batch_kwargs(g, device)
+    total, xent, ctc, _ = model(return_type="loss", **vars(b))
+    total.backward()
+    assert abs(total.item() - g["loss_total"]) <= 3e-2 * abs(g["loss_total"])
+    bad = []
+    for n, p in model.named_parameters():
+        ref = torch.from_numpy(g[f"grad.{n}"])
+        scale = ref.abs().max().item() + 1e-6
+        if (p.grad.cpu() - ref).abs().max().item() > 0.15 * scale:
+            bad.append(n)
+    assert not bad, bad
+
+
+def test_training_mode_dropout_runs_and_is_finite(device):
+    import copy
+
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    g = load_golden("model_pre")
+    cfg = copy.deepcopy(FIXTURES["model_pre"]["cfg"])
+    cfg["encoder"]["dropout"] = cfg["decoder"]["dropout"] = 0.1
+    cfg["decoder"]["embeddings"]["dropout"] = 0.1
+    model = build_model(cfg, None, Vocabulary.synthetic(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.load_state_dict(golden_sd(g))
+    model.finalize(device, torch.float32).train()
+    b = batch_kwargs(g, device)
+    losses = []
+    for _ in range(2):
+        model.zero_grad()
+        total, *_ = model(return_type="loss", **vars(b))
+        total.backward()
+        losses.append(total.item())
+        model.runtime.rng.advance()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    assert losses[0] != losses[1]  # fresh masks every step
+    assert abs(losses[0] - g["loss_total"]) < 0.5 * abs(g["loss_total"])

@@ -1,0 +1,374 @@
+"""GPU: every HIP kernel against plain fp32 CPU math (the oracle's primitives) on seeded inputs.
+fp32 kernels: rtol=atol=1e-4 (the reference's own test tolerance).  bf16 kernels: inputs are rounded to bf16 first,
+the comparison tolerance is 2e-2 of the output scale (bf16 has 8 significant bits)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from joeys2t_amd import functional as Fn
+from joeys2t_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def bf16_close(got, ref, scale_tol=2e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= scale_tol * scale, f"max err {err} vs scale {scale}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 100), (128, 256, 64), (300, 520, 136)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_layouts(device, M, N, K, ta, tb):
+    A = rnd(K, M, seed=1) if ta else rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)
+    ref = (A.t() if ta else A) @ (B if tb else B.t())
+    C = torch.empty(M, N, device=device)
+    ops.gemm(A.to(device), B.to(device), C, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, trans_a=ta, trans_b=tb)
+    torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 72), (375, 376, 128), (1000, 512, 2048),
+                                   (130, 1536, 512)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(device, M, N, K, ta, tb):
+    # leading dims must be multiples of 8 for the MFMA kernel: pad the storage, keep the logical shape
+    def mk(r, c, seed):
+        cp = ops.round_up(c, 8)
+        t = torch.zeros(r, cp)
+        t[:, :c] = rnd(r, c, seed=seed)
+        return t.bfloat16()
+    A = mk(K, M, 1) if ta else mk(M, K, 1)
+    B = mk(K, N, 2) if tb else mk(N, K, 2)
+    Al = A.float()[:, :M] if ta else A.float()[:, :K]
+    Bl = B.float()[:, :N] if tb else B.float()[:, :K]
+    ref = (Al.t() if ta else Al) @ (Bl if tb else Bl.t())
+    C = torch.empty(M, N, device=device)
+    ops.gemm(A.to(device), B.to(device), C, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, trans_a=ta, trans_b=tb)
+    torch.testing.assert_close(C.cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(K))
+
+
+def test_gemm_bf16_exact_integers(device):
+    """Asymmetric small-integer operands: any fragment / transpose mix-up shows as an exact mismatch."""
+    M, N, K = 192, 160, 128
+    g = torch.Generator().manual_seed(3)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            A = torch.randint(-3, 4, (K, M) if ta else (M, K), generator=g).float()
+            B = torch.randint(-3, 4, (K, N) if tb else (N, K), generator=g).float()
+            ref = (A.t() if ta else A) @ (B if tb else B.t())
+            C = torch.empty(M, N, device=device)
+            ops.gemm(A.bfloat16().to(device), B.bfloat16().to(device), C, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1],
+                     ldc=N, trans_a=ta, trans_b=tb)
+            assert torch.equal(C.cpu(), ref), (ta, tb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue(device, dtype):
+    M, N, K = 96, 72, 40
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    xq, wq, rq = x.to(dtype), w.to(dtype), res.to(dtype)
+    pre_ref = xq.float() @ wq.float().t() * 0.5 + b
+    ref = F.relu(pre_ref) + 1.7 * rq.float()
+    y = torch.empty(M, N, dtype=dtype, device=device)
+    pre = torch.empty(M, N, dtype=dtype, device=device)
+    ops.gemm(xq.to(device), wq.to(device), y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=b.to(device), act="relu",
+             preact=pre, residual=rq.to(device), ldr=N, res_scale=1.7)
+    if dtype == torch.float32:
+        torch.testing.assert_close(y.cpu(), ref, **TOL)
+        torch.testing.assert_close(pre.cpu(), pre_ref, **TOL)
+    else:
+        bf16_close(y, ref)
+        bf16_close(pre, pre_ref)
+    # gate + beta
+    gate = rnd(M, N, seed=5).to(dtype)
+    c0 = rnd(M, N, seed=6).to(dtype)
+    out = c0.clone().to(device)
+    ops.gemm(xq.to(device), wq.to(device), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, gate=gate.to(device), ldg=N,
+             gate_scale=2.0, beta=1.0)
+    ref2 = torch.where(gate.float() > 0, (xq.float() @ wq.float().t()) * 2.0, torch.zeros(())) + c0.float()
+    if dtype == torch.float32:
+        torch.testing.assert_close(out.cpu(), ref2, **TOL)
+    else:
+        bf16_close(out, ref2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_heads(device, dtype):
+    B, T, H, dh = 3, 37, 4, 16
+    d = H * dh
+    qkv = rnd(B * T, 3 * d, seed=1).to(dtype)
+    q, k = qkv.float()[:, 2 * d:].view(B, T, H, dh), qkv.float()[:, :d].view(B, T, H, dh)
+    ref = torch.einsum("bqhc,bkhc->bhqk", q, k) / math.sqrt(dh)
+    ld = ops.round_up(T, 8)
+    S = torch.zeros(B * H, T, ld, dtype=dtype, device=device)
+    dq = qkv.to(device)
+    ops.gemm(dq, dq, S, M=T, N=T, K=dh, lda=3 * d, ldb=3 * d, ldc=ld, batch=B * H, batch_inner=H,
+             a_strides=(T * 3 * d, dh), b_strides=(T * 3 * d, dh), c_strides=(H * T * ld, T * ld), a_off=2 * d, b_off=0,
+             alpha=1 / math.sqrt(dh))
+    got = S.float().cpu().view(B, H, T, ld)[..., :T]
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, ref, **TOL)
+    else:
+        bf16_close(got, ref)
+
+
+@pytest.mark.parametrize("dtype,cin", [(torch.float32, 10), (torch.float32, 80), (torch.bfloat16, 80), (torch.bfloat16, 16)])
+def test_conv1d_glu_fwd_bwd(device, dtype, cin):
+    B, T, cout, k = 3, 41, 24, 5
+    x = rnd(B, T, cin, seed=1).to(dtype).float()
+    w = rnd(cout, cin, k, seed=2, scale=0.2)
+    b = rnd(cout, seed=3, scale=0.1)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    wq = w.to(dtype).float() if dtype == torch.bfloat16 else w
+    yr = F.glu(F.conv1d(xr.transpose(1, 2), wr if dtype == torch.float32 else wq.requires_grad_(True), br, stride=2,
+                        padding=k // 2), dim=1).transpose(1, 2)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy)
+    xd = x.to(dtype).to(device).requires_grad_(True)
+    wd, bd = w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    y = Fn.Conv1dGluFn.apply(xd, wd, bd, dtype)
+    y.backward(gy.to(dtype).to(device))
+    if dtype == torch.float32:
+        torch.testing.assert_close(y.detach().cpu(), yr.detach(), **TOL)
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, **TOL)
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-3)
+    else:
+        bf16_close(y.detach(), yr.detach())
+        bf16_close(xd.grad, xr.grad, 4e-2)
+        bf16_close(wd.grad, wq.grad, 4e-2)
+        bf16_close(bd.grad, br.grad, 4e-2)
+
+
+# ------------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(7, 12), (300, 512), (5, 100)])
+def test_layernorm(device, dtype, rows, D):
+    x = rnd(rows, D, seed=1).to(dtype)
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D, ), gr, br, eps=1e-6)
+    gy = rnd(rows, D, seed=4).to(dtype)
+    add = rnd(rows, D, seed=5).to(dtype)
+    yr.backward(gy.float())
+    y, mean, rstd = ops.layernorm_fwd(x.to(device), g.to(device), b.to(device), 1e-6)
+    dx, dg, db = ops.layernorm_bwd(gy.to(device), x.to(device), g.to(device), mean, rstd, add=add.to(device), add_scale=0.5)
+    ref_dx = xr.grad + 0.5 * add.float()
+    if dtype == torch.float32:
+        torch.testing.assert_close(y.cpu(), yr.detach(), **TOL)
+        torch.testing.assert_close(dx.cpu(), ref_dx, **TOL)
+        torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-3)
+    else:
+        bf16_close(y, yr.detach())
+        bf16_close(dx, ref_dx)
+        bf16_close(dg, gr.grad)
+        bf16_close(db, br.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("maskq", [1, 0])
+def test_softmax_fwd_bwd(device, dtype, maskq):
+    B, H, Tq, Tk = 2, 3, 9, 13
+    ld = ops.round_up(Tk, 8)
+    S = torch.zeros(B * H, Tq, ld)
+    S[..., :Tk] = rnd(B * H, Tq, Tk, seed=1, scale=2.0)
+    S = S.to(dtype)
+    g = torch.Generator().manual_seed(2)
+    mask = torch.rand(B, Tq if maskq == 0 else 1, Tk, generator=g) > 0.3
+    mask[..., 0] = True
+    Sr = S.float()[..., :Tk].view(B, H, Tq, Tk).clone().requires_grad_(True)
+    Pr = torch.softmax(Sr.masked_fill(~mask.unsqueeze(1), float("-inf")), -1)
+    gy = rnd(B, H, Tq, Tk, seed=3).to(dtype)
+    Pr.backward(gy.float())
+    P, Pd = ops.softmax_fwd(S.to(device), mask.to(device), B, H, Tq, Tk, ld, 0.0, None, 0)
+    assert Pd is P
+    gpad = torch.zeros(B * H, Tq, ld, dtype=dtype)
+    gpad[..., :Tk] = gy.view(B * H, Tq, Tk)
+    dS = ops.softmax_bwd(P, gpad.to(device), B * H, Tq, Tk, ld, 0.0, None, 0)
+    got_p = P.float().cpu()[..., :Tk].view(B, H, Tq, Tk)
+    got_ds = dS.float().cpu()[..., :Tk].view(B, H, Tq, Tk)
+    assert torch.all(P.float().cpu()[..., Tk:] == 0)
+    if dtype == torch.float32:
+        torch.testing.assert_close(got_p, Pr.detach(), **TOL)
+        torch.testing.assert_close(got_ds, Sr.grad, **TOL)
+    else:
+        bf16_close(got_p, Pr.detach())
+        bf16_close(got_ds, Sr.grad, 3e-2)
+
+
+def test_dropout_consistency(device):
+    """Forward mask (GEMM epilogue / softmax) and backward mask (dropout_bwd / softmax_bwd) agree; keep rate ~ 1-p."""
+    rng = ops.DropoutRng(device, seed=7)
+    M, N, K, p = 256, 512, 8, 0.25
+    x = torch.ones(M, K, device=device)
+    w = torch.ones(N, K, device=device)
+    y = torch.empty(M, N, device=device)
+    ops.gemm(x, w, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dropout_p=p, rng=rng, rng_stream=11)
+    keep = (y != 0)
+    assert torch.allclose(y[keep], torch.full_like(y[keep], K / (1 - p)))
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01
+    dx = ops.dropout_bwd(torch.ones(M, N, device=device), p, rng, 11)
+    assert torch.equal(dx != 0, keep)
+    y2 = torch.empty(M, N, device=device)
+    ops.gemm(x, w, y2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dropout_p=p, rng=rng, rng_stream=12)
+    assert not torch.equal(y2 != 0, keep)  # another call site -> another mask
+    rng.advance()
+    y3 = torch.empty(M, N, device=device)
+    ops.gemm(x, w, y3, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dropout_p=p, rng=rng, rng_stream=11)
+    assert not torch.equal(y3 != 0, keep)  # next step -> another mask
+    # softmax dropout: P kept as is, Pd masked & rescaled, backward uses the same mask
+    B, H, Tq, Tk = 2, 2, 16, 40
+    S = torch.randn(B * H, Tq, Tk, device=device)
+    P, Pd = ops.softmax_fwd(S, None, B, H, Tq, Tk, Tk, p, rng, 5)
+    k2 = Pd != 0
+    torch.testing.assert_close(Pd[k2], P[k2] / (1 - p))
+    dS = ops.softmax_bwd(P, torch.ones_like(P), B * H, Tq, Tk, Tk, p, rng, 5)
+    ref = P * (k2.float() / (1 - p) - (P * k2.float() / (1 - p)).sum(-1, keepdim=True))
+    torch.testing.assert_close(dS, ref, **TOL)
+
+
+def test_elementwise(device):
+    x = rnd(6, 5, 16, seed=1)
+    pe = rnd(9, 16, seed=2)
+    y = ops.add_pe_dropout(x.to(device), pe.to(device), None, 0.0, None, 0)
+    torch.testing.assert_close(y.cpu(), x + pe[:5].unsqueeze(0))
+    xg = rnd(12, 20, seed=3)
+    torch.testing.assert_close(ops.glu_fwd(xg.to(device)).cpu(), F.glu(xg, dim=1), **TOL)
+    xr = xg.clone().requires_grad_(True)
+    gy = rnd(12, 10, seed=4)
+    F.glu(xr, dim=1).backward(gy)
+    torch.testing.assert_close(ops.glu_bwd(xg.to(device), gy.to(device)).cpu(), xr.grad, **TOL)
+    big = rnd(1000, 37, seed=5)
+    torch.testing.assert_close(ops.colsum(big.to(device)).cpu(), big.sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(ops.cast(big.to(device), torch.bfloat16).cpu(), big.bfloat16())
+    torch.testing.assert_close(ops.axpby(big.to(device), 2.0, big.to(device), -0.5).cpu(), 1.5 * big)
+    ids = torch.tensor([[2, 5, 1, 7], [3, 3, 1, 1]])
+    table = rnd(9, 8, seed=6)
+    out = ops.embed_fwd(ids.to(device), table.to(device), 2.0, torch.float32)
+    torch.testing.assert_close(out.cpu(), F.embedding(ids, table) * 2.0)
+    dout = rnd(2, 4, 8, seed=7)
+    dt = ops.embed_bwd(ids.to(device), dout.to(device), 9, 2.0, 1)
+    ref = torch.zeros(9, 8).index_add_(0, ids.view(-1), dout.view(-1, 8) * 2.0)
+    ref[1] = 0
+    torch.testing.assert_close(dt.cpu(), ref, **TOL)
+    for act in ("relu", "gelu", "swish", "tanh"):
+        z = rnd(50, 8, seed=8).requires_grad_(True)
+        f = {"relu": F.relu, "gelu": F.gelu, "swish": F.silu, "tanh": torch.tanh}[act]
+        f(z).backward(torch.ones(50, 8))
+        got = ops.act_bwd(torch.ones(50, 8, device=device), z.detach().to(device), act)
+        torch.testing.assert_close(got.cpu(), z.grad, **TOL)
+
+
+def test_lengths_and_mask_bit_exact(device):
+    from oracle import s2t_oracle as O
+    lens = torch.arange(1, 300)
+    for ks in ([5, 5], [3, 3], [5]):
+        ref = O.subsample_lengths(lens, ks)
+        tout = int(ref.max())
+        out_len, mask = ops.subsample_lengths_mask(lens.to(device), tout, ks)
+        assert torch.equal(out_len.cpu(), ref)
+        assert torch.equal(mask.cpu().squeeze(1), torch.arange(tout)[None, :] < ref[:, None])
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@pytest.mark.parametrize("smoothing", [0.1, 0.0])
+def test_xent_matches_oracle(device, smoothing):
+    from oracle import s2t_oracle as O
+    N, L, V = 5, 7, 53
+    logits = rnd(N, L, V, seed=1, scale=2.0)
+    g = torch.Generator().manual_seed(2)
+    trg = torch.randint(2, V, (N, L), generator=g)
+    trg[:, -2:] = 1
+    lr = logits.clone().requires_grad_(True)
+    ref = O.xent_loss(torch.log_softmax(lr, -1), trg, 1, smoothing)
+    (ref * 0.37).backward()
+    from joeys2t_amd.loss import XentLoss
+    crit = XentLoss(pad_index=1, smoothing=smoothing)
+    ld = logits.to(device).requires_grad_(True)
+    loss, ncor = crit.xent(ld, trg.to(device))
+    (loss * 0.37).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-4, atol=1e-5)
+    tm = trg != 1
+    assert int(ncor.item()) == int((logits.argmax(-1)[tm] == trg[tm]).sum())
+
+
+def test_xent_ctc_golden(device):
+    """XentCTCLoss against the capture from the real reference (tests/golden/units.npz)."""
+    from conftest import load_golden
+    from joeys2t_amd.loss import XentCTCLoss
+    g = load_golden("units")
+    crit = XentCTCLoss(pad_index=1, bos_index=2, smoothing=0.1, ctc_weight=0.3)
+    logits = torch.from_numpy(g["xc_logits"]).to(device).requires_grad_(True)
+    ctc_logits = torch.from_numpy(g["xc_ctc_logits"]).to(device).requires_grad_(True)
+    trg = torch.from_numpy(g["xc_trg"]).to(device)
+    T = ctc_logits.shape[1]
+    in_len = torch.from_numpy(g["xc_in_len"])
+    mask = (torch.arange(T)[None, :] < in_len[:, None]).unsqueeze(1).to(device)
+    tot, xe, ct = crit(logits, trg=trg, trg_length=torch.from_numpy(g["xc_trg_len"]).to(device), src_mask=mask,
+                       ctc_logits=ctc_logits)
+    tot.backward()
+    assert abs(tot.item() - g["xc_total"]) < 1e-4 * abs(g["xc_total"])
+    assert abs(xe.item() - g["xc_xent"]) < 1e-4 * abs(g["xc_xent"])
+    assert abs(ct.item() - g["xc_ctc"]) < 1e-4 * abs(g["xc_ctc"])
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g["xc_dlogits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ctc_logits.grad.cpu().numpy(), g["xc_dctc"], rtol=1e-4, atol=1e-5)
+    # infeasible utterance -> zero_infinity
+    l2 = torch.from_numpy(g["xc_ctc_logits"]).to(device).requires_grad_(True)
+    in2 = torch.from_numpy(g["xc_in_len_inf"])
+    ct2 = crit.ctc(l2, trg, in2.to(device), torch.from_numpy(g["xc_trg_len"]).to(device))
+    ct2.backward()
+    assert abs(ct2.item() - g["xc_ctc_inf"]) < 1e-4 * abs(g["xc_ctc_inf"])
+    np.testing.assert_allclose(l2.grad.cpu().numpy(), g["xc_dctc_inf"], rtol=1e-4, atol=1e-5)
+
+
+def test_ctc_larger_random(device):
+    """CTC at a realistic size (T'=375, L<=80, V=500) incl. repeated labels, against F.ctc_loss on CPU."""
+    g = torch.Generator().manual_seed(4)
+    B, T, V, L = 6, 375, 500, 80
+    logits = torch.randn(B, T, V, generator=g)
+    tl = torch.randint(30, L + 1, (B, ), generator=g)
+    trg = torch.full((B, L), 1, dtype=torch.long)
+    for b in range(B):
+        seq = torch.randint(4, 12, (int(tl[b]) - 1, ), generator=g)  # small alphabet -> many repeats
+        trg[b, : int(tl[b]) - 1] = seq
+        trg[b, int(tl[b]) - 1] = 3
+    in_len = torch.randint(200, T + 1, (B, ), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = F.ctc_loss(torch.log_softmax(lr, -1).transpose(0, 1), trg, in_len, tl, blank=2, reduction="sum", zero_infinity=True)
+    ref.backward()
+    from joeys2t_amd.loss import XentCTCLoss
+    crit = XentCTCLoss(pad_index=1, bos_index=2)
+    ld = logits.to(device).requires_grad_(True)
+    got = crit.ctc(ld, trg.to(device), in_len.to(device), tl.to(device))
+    got.backward()
+    assert abs(got.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-3, atol=2e-5)
+
+
+def test_log_softmax_and_lse(device):
+    x = rnd(33, 501, seed=1, scale=3.0)
+    torch.testing.assert_close(ops.log_softmax(x.to(device)).cpu(), torch.log_softmax(x, -1), **TOL)
+    lse, am = ops.row_lse(x.to(device), want_argmax=True)
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(x, -1), **TOL)
+    assert torch.equal(am.cpu(), x.argmax(-1))

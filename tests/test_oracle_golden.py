@@ -1,0 +1,144 @@
+"""CPU: the oracle restatement (oracle/s2t_oracle.py) against golden vectors captured from the real reference
+(oracle/make_golden.py) and against the constants the reference's own unit tests assert."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_sd, load_golden
+from golden_cfg import FIXTURES, SPECIALS, oracle_cfg
+from oracle import s2t_oracle as O
+
+TOL = dict(rtol=1e-4, atol=1e-4)  # the reference's own tolerance (test/unit/*: rtol=atol=1e-4)
+
+
+def _batch(g):
+    return {"src": torch.from_numpy(g["src"]), "src_length": torch.from_numpy(g["src_length"]),
+            "trg_input": torch.from_numpy(g["trg_input"]), "trg": torch.from_numpy(g["trg"]),
+            "trg_length": torch.from_numpy(g["trg_length"]), "trg_mask": torch.from_numpy(g["trg_mask"])}
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_model_forward_loss(name):
+    g = load_golden(name)
+    cfg = oracle_cfg(FIXTURES[name]["cfg"])
+    sd = golden_sd(g)
+    b = _batch(g)
+    enc, mask, lens = O.encoder_forward(sd, cfg, b["src"], b["src_length"])
+    torch.testing.assert_close(enc, torch.from_numpy(g["enc_out"]), **TOL)
+    assert np.array_equal(mask.numpy(), g["src_mask"])  # bit-exact length mask
+    logits, hidden, att, ctc = O.decoder_forward(sd, cfg, b["trg_input"], enc, mask, b["trg_mask"], return_attention=True)
+    torch.testing.assert_close(logits, torch.from_numpy(g["logits"]), **TOL)
+    torch.testing.assert_close(hidden, torch.from_numpy(g["dec_hidden"]), **TOL)
+    torch.testing.assert_close(att, torch.from_numpy(g["att"]), **TOL)
+    torch.testing.assert_close(ctc, torch.from_numpy(g["ctc_logits"]), **TOL)
+    total, xent, ctcl, ncor, _, _ = O.model_loss(sd, cfg, b, SPECIALS, 0.1, FIXTURES[name]["ctc_weight"])
+    assert abs(total.item() - g["loss_total"]) <= 1e-4 * abs(g["loss_total"])
+    assert abs(xent.item() - g["loss_xent"]) <= 1e-4 * abs(g["loss_xent"])
+    assert abs(ctcl.item() - g["loss_ctc"]) <= 1e-4 * abs(g["loss_ctc"])
+    assert int(ncor) == int(g["n_correct"])
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_batch_bookkeeping(name):
+    g = load_golden(name)
+    b = O.make_batch(torch.from_numpy(g["src"]), torch.from_numpy(g["src_length"]), torch.from_numpy(g["trg_full"]),
+                     torch.from_numpy(g["trg_length_full"]), SPECIALS["pad"], SPECIALS["eos"])
+    for k in ("trg_input", "trg", "trg_length", "trg_mask"):
+        assert np.array_equal(b[k].numpy(), g[k]), k
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_search(name):
+    g = load_golden(name)
+    cfg = oracle_cfg(FIXTURES[name]["cfg"])
+    sd = golden_sd(g)
+    b = _batch(g)
+    enc, mask, _ = O.encoder_forward(sd, cfg, b["src"], b["src_length"])
+    ids, scores = O.greedy(sd, cfg, SPECIALS, enc, mask, 12, return_prob=True)
+    assert np.array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(scores.numpy(), g["greedy_scores"], rtol=1e-4, atol=1e-4)
+    k = int(g["beam_size"])
+    ids, scores = O.beam_search(sd, cfg, SPECIALS, enc, mask, k, 12, float(g["beam_alpha"]), n_best=k)
+    assert np.array_equal(ids.numpy(), g["beam_ids"])  # bit-exact beam indices
+    np.testing.assert_allclose(scores.numpy(), g["beam_scores"], rtol=1e-4, atol=1e-4)
+    max_len = int(max(g["src_length"]) * 1.5)  # search.py:863-864: un-subsampled frame count
+    ids, scores = O.beam_search(sd, cfg, SPECIALS, enc, mask, k, max_len, 0.0, n_best=1)
+    assert np.array_equal(ids.numpy(), g["beam_ids_a0"])
+    np.testing.assert_allclose(scores.numpy(), g["beam_scores_a0"], rtol=1e-4, atol=1e-4)
+
+
+def test_units_subsampler_and_lengths():
+    g = load_golden("units")
+    sd = golden_sd(g, "sub.sd.")
+    y, yl = O.conv_subsample(sd, "", torch.from_numpy(g["sub_x"]), torch.tensor([9, 9]), [3, 3]) if False else (None, None)
+    sd2 = {"s." + k: v for k, v in sd.items()}
+    y, yl = O.conv_subsample(sd2, "s", torch.from_numpy(g["sub_x"]), torch.tensor([9, 9]), [3, 3])
+    torch.testing.assert_close(y, torch.from_numpy(g["sub_y"]), **TOL)
+    # constants hard-coded in the reference's test (test_transformer_encoder.py:134-136)
+    np.testing.assert_allclose(y[0, 0].numpy(), g["sub_y_ref_row0"], rtol=1e-4, atol=1e-4)
+    assert yl.tolist() == g["sub_len"].tolist() == [3, 3]
+    lens = torch.from_numpy(g["len_in"])
+    for ks in ([3, 3], [5, 5], [5], [3, 5, 3]):
+        assert np.array_equal(O.subsample_lengths(lens, ks).numpy(), g["len_" + "_".join(map(str, ks))])
+
+
+def test_units_losses():
+    g = load_golden("units")
+    predict, targets = torch.from_numpy(g["xent_predict"]), torch.from_numpy(g["xent_targets"])
+    v1 = O.xent_loss(predict.log(), targets, 0, 0.4).item()
+    v0 = O.xent_loss(predict.log(), targets, 0, 0.0).item()
+    assert abs(v1 - g["xent_s04"]) < 1e-5 and abs(v0 - g["xent_s00"]) < 1e-5
+    assert round(v1, 4) == float(g["xent_s04_ref"]) and round(v0, 4) == float(g["xent_s00_ref"])  # test_loss.py:52,95
+    # smoothed target rows of test_loss.py:35-46
+    st = O.smooth_targets(targets.view(-1), 5, 0, 0.4)
+    np.testing.assert_allclose(st[0].numpy(), [0.0, 0.1333, 0.6, 0.1333, 0.1333], atol=1e-4)
+    assert torch.all(st[3] == 0) and torch.all(st[5] == 0)
+    logits = torch.from_numpy(g["xc_logits"]).requires_grad_(True)
+    ctc_logits = torch.from_numpy(g["xc_ctc_logits"]).requires_grad_(True)
+    trg = torch.from_numpy(g["xc_trg"])
+    xe = O.xent_loss(torch.log_softmax(logits, -1), trg, 1, 0.1)
+    ct = O.ctc_loss(torch.log_softmax(ctc_logits, -1), trg, torch.from_numpy(g["xc_in_len"]),
+                    torch.from_numpy(g["xc_trg_len"]), 2)
+    tot = 0.7 * xe + 0.3 * ct
+    tot.backward()
+    assert abs(tot.item() - g["xc_total"]) < 1e-3 and abs(xe.item() - g["xc_xent"]) < 1e-3
+    assert abs(ct.item() - g["xc_ctc"]) < 1e-3
+    np.testing.assert_allclose(logits.grad.numpy(), g["xc_dlogits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ctc_logits.grad.numpy(), g["xc_dctc"], rtol=1e-4, atol=1e-5)
+    ct2 = O.ctc_loss(torch.log_softmax(torch.from_numpy(g["xc_ctc_logits"]), -1), trg,
+                     torch.from_numpy(g["xc_in_len_inf"]), torch.from_numpy(g["xc_trg_len"]), 2)
+    assert abs(ct2.item() - g["xc_ctc_inf"]) < 1e-3
+
+
+def test_units_frontend():
+    g = load_golden("units")
+    np.testing.assert_allclose(O.cmvn(g["cmvn_in"].copy()), g["cmvn_out"], rtol=1e-6, atol=1e-6)
+    rs = np.random.RandomState(42)
+    p = O.specaugment_params(57, 80, rs, time_mask_t=100)
+    np.testing.assert_array_equal(O.specaugment_apply(g["cmvn_in"], p), g["spec_out"])
+    rs = np.random.RandomState(42)
+    p = O.specaugment_params(7, 80, rs, time_mask_t=100)
+    np.testing.assert_array_equal(O.specaugment_apply(g["cmvn_in"][:7], p), g["spec_out_short"])
+    feat = g["cmvn_in"]
+    padded, lengths, _ = O.pad_features([feat, feat[:20], feat[:33]])
+    np.testing.assert_array_equal(padded, g["pad_out"])
+    assert lengths == g["pad_len"].tolist()
+    assert [O.get_n_frames(int(n), 16000) for n in g["n_frames_in"]] == g["n_frames"].tolist()
+    assert O.get_n_frames(240000, 16000) == 1498
+
+
+def test_fbank_known_answer():
+    """Reference pin: test/unit/test_tokenizer.py:318-325 (CMVN'd frame 0, bins 0-9, atol=rtol=1e-5) and the
+    n_frames column of test/data/speech/test.tsv."""
+    g = load_golden("audio")
+    pcm = g["pcm_260-123440-1"].astype(np.float32) / 32768.0
+    feat = O.fbank(pcm)
+    names = g["tsv_names"].tolist()
+    assert feat.shape == (int(g["tsv_n_frames"][names.index("260-123440-1")]), 80)
+    got = O.cmvn(feat)[0, :10]
+    np.testing.assert_allclose(got, g["fbank_cmvn_ref_260-123440-1_frame0_bins0_9"], rtol=1e-5, atol=1e-5)
+    for n, ns in zip(g["tsv_n_frames"], g["tsv_n_samples"]):
+        assert 1 + (int(ns) - 400) // 160 == int(n) == O.get_n_frames(int(ns), 16000)
+    for key in ("pcm_260-123440-0", "pcm_260-123440-6"):
+        f = O.fbank(g[key].astype(np.float32) / 32768.0)
+        assert f.shape[0] == int(g["tsv_n_frames"][names.index(key[4:])]) and np.isfinite(f).all()
