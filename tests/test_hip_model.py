@@ -83,12 +83,16 @@ def test_bf16_compute_close_to_fp32(device, name):
     total, xent, ctc, _ = model(return_type="loss", **vars(b))
     total.backward()
     assert abs(total.item() - g["loss_total"]) <= 3e-2 * abs(g["loss_total"])
+    # bf16 tolerance: direction of every non-negligible parameter gradient within cos >= 0.97 of the fp32 reference
+    gmax = max(float(np.abs(g[f"grad.{n}"]).max()) for n, _ in model.named_parameters())
     bad = []
     for n, p in model.named_parameters():
-        ref = torch.from_numpy(g[f"grad.{n}"])
-        scale = ref.abs().max().item() + 1e-6
-        if (p.grad.cpu() - ref).abs().max().item() > 0.15 * scale:
-            bad.append(n)
+        ref = torch.from_numpy(g[f"grad.{n}"]).flatten()
+        if ref.abs().max().item() < 1e-2 * gmax:
+            continue  # e.g. key-projection biases, whose true gradient is zero
+        cos = torch.nn.functional.cosine_similarity(p.grad.cpu().flatten(), ref, dim=0).item()
+        if cos < 0.97:
+            bad.append((n, cos))
     assert not bad, bad
 
 
