@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py — train-step throughput of the JoeyS2T hot path on MI355X.
+
+One step = one pass of the whole hot path over one batch that is already resident in HBM:
+  raw 16 kHz waveforms [32 x 240000] -> Kaldi fbank -> CMVN -> SpecAugment -> pad -> conv subsampler ->
+  16-layer Transformer encoder / 8-layer decoder -> CTC + label-smoothed CE -> backward -> clip + AdamW
+(configs/librispeech_100h.yaml shapes, bf16 compute, dropout 0.1, batch_multiplier 1 so that every step carries
+its optimizer update).  Metric: input fbank frames per second over all GPUs (47,936 frames per GPU per step).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel = bf16 MFMA GEMM, HIP-event timed on its
+launch stream) and `cpu_baseline` (the CPU oracle restatement on a bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+LS100_MODEL = {
+    "initializer": "xavier_uniform", "init_gain": 1.0, "bias_initializer": "zeros", "embed_initializer": "xavier_uniform",
+    "embed_init_gain": 1.0, "tied_embeddings": False, "tied_softmax": False,
+    "encoder": {"type": "transformer", "num_layers": 16, "num_heads": 4, "embeddings": {"embedding_dim": 80},
+                "hidden_size": 512, "ff_size": 2048, "dropout": 0.1, "freeze": False, "subsample": True,
+                "conv_kernel_sizes": [5, 5], "conv_channels": 512, "in_channels": 80, "layer_norm": "pre", "activation": "relu"},
+    "decoder": {"type": "transformer", "num_layers": 8, "num_heads": 4,
+                "embeddings": {"embedding_dim": 512, "scale": True, "dropout": 0.1}, "hidden_size": 512, "ff_size": 2048,
+                "dropout": 0.1, "freeze": False, "layer_norm": "pre", "activation": "relu"},
+}
+VOCAB = 5000
+SAMPLES = 240000  # 15.0 s @ 16 kHz  ->  1498 frames  ->  375 encoder positions
+BATCH = 32
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synth_waveforms(batch, samples, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    return (0.1 * torch.randn(batch, samples, generator=g)).clamp_(-1.0, 1.0)
+
+
+def synth_targets(batch, vocab, seed=1234, lo=40, hi=80):
+    g = torch.Generator().manual_seed(seed + 1)
+    lens = torch.randint(lo, hi + 1, (batch, ), generator=g)
+    L = int(lens.max()) + 2
+    trg = torch.full((batch, L), 1, dtype=torch.long)
+    for b in range(batch):
+        n = int(lens[b])
+        trg[b, 0] = 2
+        trg[b, 1:1 + n] = torch.randint(4, vocab, (n, ), generator=g)
+        trg[b, 1 + n] = 3
+    return trg, lens + 2
+
+
+class GemmTimer:
+    """HIP-event timing of every launch of one kernel family, on the stream the launches go to."""
+
+    def __init__(self):
+        self.records = []  # (key, flops, start_event, end_event)
+
+    def wrap(self, key, flops, launch):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        s.record(st)
+        launch()
+        e.record(st)
+        self.records.append((key, flops, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, s, e in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += s.elapsed_time(e) * 1e-3
+        return agg
+
+
+def build_step(device, world, dtype=torch.bfloat16, seed=42):
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    import copy
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.finalize(device, dtype, seed=seed)
+    step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
+                     learning_rate_warmup=10000, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1,
+                     n_gpu=world)
+    proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
+                           specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
+                           cmvn=dict(norm_means=True, norm_vars=True, before=True))
+    rank = int(os.environ.get("RANK", 0))
+    wave = synth_waveforms(BATCH, SAMPLES, seed=1234 + rank).to(device)
+    trg, trg_len = synth_targets(BATCH, VOCAB, seed=1234 + rank)
+    n_samples = [SAMPLES] * BATCH
+    frames = 1 + (SAMPLES - 400) // 160
+
+    def one_step():
+        feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype)
+        batch = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=trg,
+                      trg_length=trg_len, trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1,
+                      eos_index=3, is_train=True, task="S2T", n_gpu=1)
+        return step.micro_step(batch)
+
+    return one_step, step, frames * BATCH
+
+
+def cpu_baseline(n_utts=2, threads=None):
+    """The CPU oracle (plain fp32 PyTorch/NumPy restatement of the reference path) timed on the host cores on a
+    bounded sample of the same workload: n_utts utterances of 15 s through fbank -> ... -> loss -> backward -> AdamW."""
+    import copy
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    from oracle import s2t_oracle as O
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    cfg = copy.deepcopy(LS100_MODEL)
+    cfg["encoder"]["alpha"] = cfg["decoder"]["alpha"] = 1.0
+    model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))  # parameters only (CPU tensors)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "pe.pe" not in k) for k, v in model.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.0)
+    wave = synth_waveforms(n_utts, SAMPLES).numpy()
+    trg, trg_len = synth_targets(n_utts, VOCAB)
+    specials = dict(unk=0, pad=1, bos=2, eos=3)
+    rs = np.random.RandomState(42)
+
+    def step():
+        feats = []
+        for u in range(n_utts):
+            f = O.cmvn(O.fbank(wave[u]))
+            f = O.specaugment_apply(f, O.specaugment_params(f.shape[0], 80, rs, time_mask_t=100))
+            feats.append(f.astype(np.float32))
+        padded, lengths, _ = O.pad_features(feats)
+        b = O.make_batch(torch.from_numpy(padded), torch.tensor(lengths), trg, trg_len, 1, 3)
+        total, *_ = O.model_loss(sd, cfg, b, specials, 0.1, 0.3)
+        opt.zero_grad()
+        (total / n_utts).backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    frames = n_utts * (1 + (SAMPLES - 400) // 160)
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n_utts} utterances x 15 s, LS100 model, full train step (fbank..AdamW), fp32, {n} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+
+    from joeys2t_amd import ops
+    one_step, step, frames_per_step = build_step(device, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = step.read_stats()
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        timer = GemmTimer()
+        ops.GEMM_TIMER = timer
+        for _ in range(2):
+            one_step()
+        ops.GEMM_TIMER = None
+        agg = timer.summary()
+        key = max(agg, key=lambda k: agg[k][2])  # the kernel family with the largest total time
+        n, flops, secs = agg[key]
+        achieved = flops / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
+                    "avg_launch_us": round(secs / n * 1e6, 2),
+                    "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
+                                             "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline()
+            except Exception as exc:  # the baseline is a reported side figure; never lose the GPU line over it
+                cpu = {"error": repr(exc)}
+        value = world * frames_per_step * args.steps / elapsed
+        out = {
+            "metric": "audio frames/sec (train step, 80-mel, 15 s utt, bs32 per GPU)", "value": round(value, 1),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs/librispeech_100h.yaml ASR train step on synthetic 16 kHz waveforms",
+                       "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": 375,
+                       "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
+                       "loss": round(stats["loss"] / max(1, args.steps + 0), 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

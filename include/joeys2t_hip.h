@@ -221,6 +221,56 @@ int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* ta
                  float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
                  int zero_infinity, js2t_stream stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * Audio front-end (raw waveform -> padded, normalised, augmented feature batch).
+ */
+
+/* Kaldi-compatible log-mel filterbank for a ragged batch of utterances — replaces
+ * torchaudio.compliance.kaldi.fbank(waveform * 2**15, num_mel_bins, sample_frequency) as called at
+ * helpers_for_audio.py:30-37,54 (snip_edges framing, DC removal, pre-emphasis, window, |FFT|^2, mel, log).
+ *   wave        f32 samples, utterance u starts at wave[sample_off[u]]
+ *   frame_off   int64[U+1] prefix sums of frames per utterance (T_u = 1 + (N_u - win_len)/shift); out is
+ *               f32[frame_off[U], n_mel], utterance u occupying rows frame_off[u] .. frame_off[u+1]-1
+ *   window      f32[win_len] (Povey);  tw_re/tw_im f32[n_fft/2] = cos/-sin(2 pi k / n_fft)
+ *   mel bin m   = sum_{k < mel_len[m]} power[mel_start[m]+k] * mel_w[mel_woff[m]+k]
+ *   scale       multiplies the samples first (2**15);  log_floor = FLT_EPSILON. */
+int js2t_fbank(const float* wave, const int64_t* sample_off, const int64_t* frame_off, int32_t U,
+               int64_t total_frames, const float* window, const float* tw_re, const float* tw_im,
+               const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_woff, const float* mel_w,
+               float* out, int32_t win_len, int32_t shift, int32_t n_fft, int32_t n_mel, float scale, float preemph,
+               float log_floor, js2t_stream stream);
+
+/* Utterance-level CMVN statistics — CMVN.__call__ (data_augmentation.py:96-109): mean[u,c], istd[u,c] =
+ * 1/sqrt(max(E[x^2] - mean^2, 1e-10)) and fill[u] = mean of the normalised spectrogram, which is the value
+ * SpecAugment writes into its masks (data_augmentation.py:45-46).  f32[U,F], f32[U,F], f32[U]. */
+int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd,
+                    float* fill, int32_t norm_means, int32_t norm_vars, js2t_stream stream);
+
+/* out[u,t,c] = masked((feat - mean) * istd) for t < T_u, pad_value beyond — CMVN apply + SpecAugment masks
+ * (data_augmentation.py:54-68; mask parameters drawn on the host to keep np.random parity) + pad_features
+ * (helpers_for_audio.py:130-170, pads with 1.0).  masks: int32[U,8] = (f0,f, f0,f, t0,t, t0,t) or NULL;
+ * mean/istd NULL = no CMVN.  out: [U,Tmax,F] in out_dt. */
+int js2t_feature_finalize(const float* feat, const int64_t* frame_off, const float* mean, const float* istd,
+                          const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
+                          int32_t F, float pad_value, js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * Update tail over the flat parameter store (training.py:436-456).
+ */
+
+/* out2[0] = ||g||_2 over the whole flat gradient, out2[1] = min(1, max_norm/(norm + 1e-6)) — the coefficient
+ * nn.utils.clip_grad_norm_ applies (builders.py:68-71; max_norm <= 0 disables clipping).
+ * partial: f32[js2t_sumsq_partials(n)] workspace. */
+int64_t js2t_sumsq_partials(int64_t n);
+int js2t_grad_norm_clip(const float* g, int64_t n, float max_norm, float* partial, float* out2, js2t_stream stream);
+
+/* torch.optim.AdamW step (builders.py:112-114) over flat fp32 buffers, gradient pre-scaled by
+ * gscale * (*gscale_dev) (clip coefficient / loss-scale), optional bf16 shadow write and gradient clear.
+ * step is the 1-based update count used for bias correction. */
+int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_bf16, int64_t n, float lr,
+               float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev,
+               float gscale, int zero_grad, js2t_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,8 @@ def lib():
         _lib.js2t_last_error.restype = C.c_char_p
         _lib.js2t_colsum_partial_rows.restype = C.c_int64
         _lib.js2t_colsum_partial_rows.argtypes = [C.c_int64]
+        _lib.js2t_sumsq_partials.restype = C.c_int64
+        _lib.js2t_sumsq_partials.argtypes = [C.c_int64]
     return _lib
 
 

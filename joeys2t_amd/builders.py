@@ -25,3 +25,86 @@ def build_activation(activation: str = "relu") -> Callable:
     if activation == "swish":
         return nn.SiLU
     raise ConfigurationError("Invalid activation function. Valid options: 'relu', 'gelu', 'tanh', 'swish'.")
+
+
+# ------------------------------------------------------------------------------------------------ update tail
+import ctypes as _C  # noqa: E402
+from typing import Dict, Optional  # noqa: E402
+
+import torch  # noqa: E402
+
+
+class FlatAdamW:
+    """AdamW over a runtime.ParamStore: one fused kernel (js2t_adamw) updates the fp32 master, both moments, the
+    bf16 shadow and clears the gradient buffer.  Numerically the torch.optim.AdamW update the reference builds at
+    builders.py:112-114 (betas from `adam_betas`, eps 1e-8, decoupled weight decay)."""
+
+    def __init__(self, store, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.store = store
+        self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": float(weight_decay)}]
+        self.exp_avg = torch.zeros_like(store.flat)
+        self.exp_avg_sq = torch.zeros_like(store.flat)
+        self.t = 0
+        from joeys2t_amd._lib import lib
+        n = store.total
+        self._partial = torch.empty((max(1, lib().js2t_sumsq_partials(_C.c_int64(n))), ), dtype=torch.float32,
+                                    device=store.device)
+        self.norm_clip = torch.ones((2, ), dtype=torch.float32, device=store.device)  # [grad norm, clip coefficient]
+
+    def clip_and_step(self, max_norm: Optional[float], grad_scale: float = 1.0, zero_grad: bool = True):
+        """clip_grad_norm_(max_norm) (builders.py:68-71) folded into the update: the coefficient stays on the device."""
+        from joeys2t_amd import ops
+        from joeys2t_amd._lib import check, lib
+        st, g = self.store, self.param_groups[0]
+        coef = None
+        if max_norm is not None and max_norm > 0:
+            check(lib().js2t_grad_norm_clip(ops._p(st.flat_grad), _C.c_int64(st.total), _C.c_float(max_norm),
+                                            ops._p(self._partial), ops._p(self.norm_clip), ops._stream()), "js2t_grad_norm_clip")
+            coef = self.norm_clip[1:2]
+        self.t += 1
+        lp = st.flat_lp
+        check(lib().js2t_adamw(ops._p(st.flat), ops._p(st.flat_grad), ops._p(self.exp_avg), ops._p(self.exp_avg_sq), ops._p(lp),
+                               _C.c_int64(st.total), _C.c_float(g["lr"]), _C.c_float(g["betas"][0]), _C.c_float(g["betas"][1]),
+                               _C.c_float(g["eps"]), _C.c_float(g["weight_decay"]), _C.c_int64(self.t), ops._p(coef),
+                               _C.c_float(grad_scale), int(zero_grad), ops._stream()), "js2t_adamw")
+        st.dirty = lp is None and st.dirty
+
+    def state_dict(self) -> Dict:
+        return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd: Dict):
+        self.t = sd["t"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = sd["param_groups"]
+
+
+class WarmupInverseSquareRootScheduler:
+    """lr = step*peak/warmup while step < warmup, else peak*sqrt(warmup)/sqrt(step), floored at min_rate
+    (reference builders.py:418-485).  `step(n)` sets the internal step to n+1 first (builders.py:278-284), so with the
+    trainer calling scheduler.step(stats.steps) AFTER optimizer.step() the first update uses the configured LR."""
+
+    def __init__(self, optimizer, peak_rate: float = 1.0e-3, warmup: int = 10000, min_rate: float = 1.0e-5):
+        self.optimizer = optimizer
+        self.warmup, self.min_rate, self.peak_rate = warmup, min_rate, peak_rate
+        self.decay_rate = peak_rate * (warmup**0.5)
+        self._step, self._rate = 0, 0
+
+    def _compute_rate(self) -> float:
+        step = self._step
+        rate = step * self.peak_rate / self.warmup if step < self.warmup else self.decay_rate * (step**-0.5)
+        return max(rate, self.min_rate)
+
+    def step(self, step: int):
+        self._step = step + 1
+        self._rate = self._compute_rate()
+        for g in self.optimizer.param_groups:
+            g["lr"] = self._rate
+
+    def state_dict(self):
+        return {"step": self._step, "rate": self._rate, "warmup": self.warmup, "peak_rate": self.peak_rate,
+                "decay_rate": self.decay_rate, "min_rate": self.min_rate}
+
+    def load_state_dict(self, sd):
+        self._step, self._rate = sd["step"], sd["rate"]
+        self.warmup, self.decay_rate, self.peak_rate, self.min_rate = sd["warmup"], sd["decay_rate"], sd["peak_rate"], sd["min_rate"]

@@ -1,0 +1,98 @@
+"""SpecAugment and CMVN with the reference's class names (joeynmt/data_augmentation.py).
+
+The reference transforms one NumPy spectrogram at a time on the host.  Here the mask *parameters* are still drawn
+on the host from np.random in the reference's order (:54-68) — that is what keeps seeded runs reproducible —
+while the statistics, normalisation, masking and batch padding run on the GPU for a whole batch at once
+(js2t_cmvn_stats + js2t_feature_finalize)."""
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from joeys2t_amd import ops
+from joeys2t_amd._lib import check, lib
+
+_p, _stream = ops._p, ops._stream
+
+
+class SpecAugment:
+    """SpecAugment (https://arxiv.org/abs/1904.08779), reference :14-80."""
+
+    def __init__(self, freq_mask_n: int = 2, freq_mask_f: int = 27, time_mask_n: int = 2, time_mask_t: int = 40,
+                 time_mask_p: float = 1.0, mask_value: Optional[float] = None):
+        self.freq_mask_n, self.freq_mask_f = freq_mask_n, freq_mask_f
+        self.time_mask_n, self.time_mask_t, self.time_mask_p = time_mask_n, time_mask_t, time_mask_p
+        self.mask_value = mask_value
+        if freq_mask_n > 2 or time_mask_n > 2:
+            raise NotImplementedError("the fused kernel carries at most 2 frequency and 2 time masks per utterance")
+
+    def draw(self, num_frames: int, num_freqs: int) -> np.ndarray:
+        """The 8 mask integers (f0,f, f0,f, t0,t, t0,t) for one utterance, consuming np.random exactly like
+        SpecAugment.__call__ (:54-68).  All-zero widths when the reference returns its input unchanged (:48-52)."""
+        m = np.zeros(8, dtype=np.int32)
+        if num_frames == 0 or num_freqs < self.freq_mask_f:
+            return m
+        for i in range(self.freq_mask_n):
+            f = np.random.randint(0, self.freq_mask_f)
+            f0 = np.random.randint(0, num_freqs - f)
+            m[2 * i], m[2 * i + 1] = f0, f
+        max_t = min(self.time_mask_t, math.floor(num_frames * self.time_mask_p))
+        if max_t < 1:
+            return m
+        for i in range(self.time_mask_n):
+            t = np.random.randint(0, max_t)
+            t0 = np.random.randint(0, num_frames - t)
+            m[4 + 2 * i], m[5 + 2 * i] = t0, t
+        return m
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(freq_mask_n={self.freq_mask_n}, freq_mask_f={self.freq_mask_f}, "
+                f"time_mask_n={self.time_mask_n}, time_mask_t={self.time_mask_t}, time_mask_p={self.time_mask_p})")
+
+
+class CMVN:
+    """Utterance-level mean / variance normalisation, reference :83-115."""
+
+    def __init__(self, norm_means: bool = True, norm_vars: bool = True, before: bool = True):
+        self.norm_means, self.norm_vars, self.before = norm_means, norm_vars, before
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(norm_means={self.norm_means}, norm_vars={self.norm_vars}, before={self.before})"
+
+
+def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Sequence[int], *, cmvn: Optional[CMVN],
+                      specaugment: Optional[SpecAugment], out_dtype=torch.float32, pad_value: float = 1.0,
+                      max_length: Optional[int] = None):
+    """feat f32 [sum T, F] (ragged, frame_off int64[U+1]) -> padded batch [U, Tmax, F] on the device:
+    CMVN (before) -> SpecAugment -> pad with 1.0, i.e. SpeechProcessor.__call__ (tokenizers.py:480-492) followed by
+    pad_features (helpers_for_audio.py:130-170), in two launches.  `max_length` truncates (evaluation-time rule,
+    tokenizers.py:474-478)."""
+    ops._dev(feat, frame_off)
+    U, F = len(frames), feat.shape[1]
+    dev = feat.device
+    eff = [min(int(t), max_length) if max_length else int(t) for t in frames]
+    Tmax = max(eff)
+    mean = istd = fill = masks = None
+    if cmvn is not None:
+        if not cmvn.before:
+            raise NotImplementedError("CMVN(before=False) is not wired into the fused front-end")
+        mean = torch.empty((U, F), dtype=torch.float32, device=dev)
+        istd = torch.empty((U, F), dtype=torch.float32, device=dev)
+        fill = torch.empty((U, ), dtype=torch.float32, device=dev)
+        check(lib().js2t_cmvn_stats(_p(feat), _p(frame_off), C.c_int32(U), C.c_int32(F), _p(mean), _p(istd), _p(fill),
+                                    C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)), _stream()),
+              "js2t_cmvn_stats")
+    if specaugment is not None:
+        m = np.stack([specaugment.draw(t, F) for t in eff])
+        masks = torch.from_numpy(m).to(dev)
+        if specaugment.mask_value is not None:
+            fill = torch.full((U, ), float(specaugment.mask_value), dtype=torch.float32, device=dev)
+        elif fill is None:
+            raise NotImplementedError("SpecAugment without CMVN needs an explicit mask_value on the fused path")
+    out = torch.empty((U, Tmax, F), dtype=out_dtype, device=dev)
+    check(lib().js2t_feature_finalize(_p(feat), _p(frame_off), _p(mean), _p(istd), _p(fill), _p(masks), _p(out),
+                                      ops.dt_code(out), C.c_int64(U), C.c_int64(Tmax), C.c_int32(F), C.c_float(pad_value),
+                                      _stream()), "js2t_feature_finalize")
+    return out, eff

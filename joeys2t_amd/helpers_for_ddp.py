@@ -1,0 +1,257 @@
+"""Distributed helpers with the reference's names (joeynmt/helpers_for_ddp.py): ddp_setup (:17-38), use_ddp (:41),
+ddp_cleanup (:46), ddp_synchronize (:52), ddp_merge (:58-154), ddp_reduce (:157-174), DistributedSubsetSampler
+(:244-342), RandomSubsetSampler (:345-391) — plus what replaces torch's DistributedDataParallel on MI355X:
+
+`FlatGradReducer`: gradients already live in one flat fp32 buffer (runtime.ParamStore), cut into a few large
+contiguous buckets.  Each bucket is all-reduced (average) with RCCL on a side HIP stream as soon as backward has
+produced all of its gradients, overlapping the exchange with the rest of backward.  xGMI is point-to-point
+(7 links/GPU): few, large messages keep every link busy; there is no per-parameter traffic and no bucket copy.
+One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" serves the CPU tests."""
+import math
+import os
+from typing import List, Optional, Union
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+from torch.utils.data import Dataset, Sampler
+
+
+def ddp_setup(rank: int, world_size: int, master_addr: str = "127.0.0.1", master_port: int = 12355,
+              backend: str = "nccl") -> None:
+    """init_process_group + set_device (reference :17-38; the reference hard-codes "nccl" and "localhost")."""
+    if dist.is_available():
+        os.environ.setdefault("MASTER_ADDR", master_addr)
+        os.environ.setdefault("MASTER_PORT", str(master_port))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+        if backend == "nccl":
+            torch.cuda.set_device(rank % max(1, torch.cuda.device_count()))
+
+
+def use_ddp() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def ddp_cleanup() -> None:
+    if use_ddp():
+        dist.destroy_process_group()
+
+
+def ddp_synchronize() -> None:
+    if use_ddp():
+        dist.barrier()
+
+
+def ddp_merge(data: Tensor, pad_index: int = 1) -> Tensor:
+    """Gather 2-D/3-D tensors of differing sizes from all ranks: pad to the per-dim maxima with pad_index,
+    all_gather, concatenate rank-major and drop each rank's padding-only tail rows (reference :58-154)."""
+    if data is None:
+        return None
+    assert torch.is_tensor(data), data
+    if not use_ddp():
+        return data
+    if data.dim() not in (2, 3):
+        raise ValueError
+    world = dist.get_world_size()
+    local_size = torch.tensor(data.size(), device=data.device)
+    all_sizes = [torch.zeros_like(local_size) for _ in range(world)]
+    dist.all_gather(all_sizes, local_size)
+    sizes = torch.stack(all_sizes).cpu()
+    max_dims = sizes.max(dim=0).values.tolist()
+    padded = torch.full(max_dims, pad_index, device=data.device, dtype=data.dtype)
+    padded[tuple(slice(0, s) for s in data.size())] = data
+    gathered = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    return torch.cat([t[: int(sizes[r, 0])] for r, t in enumerate(gathered)], dim=0)
+
+
+def ddp_reduce(data: Union[Tensor, int], device=None, dtype=None) -> Tensor:
+    """SUM all-reduce; Python numbers are lifted to tensors; a 0-d input comes back with shape [1] under DDP
+    (reference :157-174)."""
+    if data is None:
+        return None
+    if not torch.is_tensor(data):
+        assert device is not None and dtype is not None
+        data = torch.tensor(data, device=device, dtype=dtype)
+    if use_ddp():
+        if data.dim() < 1:
+            data = data.unsqueeze(0)
+        dist.all_reduce(data, op=dist.ReduceOp.SUM)
+    return data
+
+
+class FlatGradReducer:
+    """Bucketed, overlapped all-reduce(average) of ParamStore.flat_grad.
+
+    Usage per update:  reducer.begin()  ->  backward passes (hooks fire)  ->  reducer.finish().
+    With `sync_every_backward=False` (default) only the LAST micro-batch of an update arms the hooks, i.e. one
+    exchange per optimizer step; the reference's DDP exchanges on every micro-batch (training.py:584-588 enters
+    no_sync() after the forward, which does not disarm the reducer) — the summed gradient is identical."""
+
+    def __init__(self, store, n_buckets: int = 4, average: bool = True, comm_stream: Optional["torch.cuda.Stream"] = None):
+        self.store = store
+        self.average = average
+        self.world = dist.get_world_size() if use_ddp() else 1
+        total = store.total
+        # buckets are contiguous flat ranges cut at parameter boundaries, in REVERSE flat order (backward order)
+        bounds = sorted({store.offsets[id(p)] for p in store.params} | {total})
+        target = math.ceil(total / max(1, n_buckets))
+        cuts, last = [total], total
+        for b in reversed(bounds[:-1]):
+            if last - b >= target:
+                cuts.append(b)
+                last = b
+        if cuts[-1] != 0:
+            cuts.append(0)
+        self.ranges = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]  # (lo, hi), first = tail of flat
+        self.bucket_of = {}
+        self.need = [0] * len(self.ranges)
+        for p in store.params:
+            if not p.requires_grad:
+                continue
+            off = store.offsets[id(p)]
+            for bi, (lo, hi) in enumerate(self.ranges):
+                if lo <= off < hi:
+                    self.bucket_of[id(p)] = bi
+                    self.need[bi] += 1
+                    break
+        self.on_gpu = store.device.type == "cuda"
+        self.comm_stream = comm_stream or (torch.cuda.Stream(device=store.device) if self.on_gpu else None)
+        self.armed = False
+        self.count = [0] * len(self.ranges)
+        self.launched = [False] * len(self.ranges)
+        self.works = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in store.params if p.requires_grad]
+
+    def begin(self, armed: bool = True):
+        self.armed = armed and self.world > 1
+        self.count = [0] * len(self.ranges)
+        self.launched = [False] * len(self.ranges)
+        self.works = []
+
+    def _hook(self, p):
+        if not self.armed:
+            return
+        bi = self.bucket_of[id(p)]
+        self.count[bi] += 1
+        if self.count[bi] == self.need[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi: int):
+        if self.launched[bi]:
+            return
+        self.launched[bi] = True
+        lo, hi = self.ranges[bi]
+        buf = self.store.flat_grad[lo:hi]
+        op = dist.ReduceOp.AVG if (self.average and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                w = dist.all_reduce(buf, op=op, async_op=True)
+        else:
+            w = dist.all_reduce(buf, op=op, async_op=True)
+        self.works.append((w, buf, op))
+
+    def finish(self):
+        """Launch whatever has not been launched (frozen / unused parameters) and make the compute stream wait."""
+        if not self.armed:
+            return
+        for bi in range(len(self.ranges)):
+            self._launch(bi)
+        for w, buf, op in self.works:
+            w.wait()
+            if self.average and op == dist.ReduceOp.SUM:
+                buf.div_(self.world)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.armed = False
+
+
+class DistributedSubsetSampler(Sampler):
+    """Shared-seed permutation, truncated to a multiple of the world size, strided by rank (reference :244-342).
+    `dataset` needs `.indices` (list) like the reference's BaseDataset; `random_subset` is honoured via `_subsample`."""
+
+    def __init__(self, dataset: Dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True,
+                 drop_last: bool = True, generator: torch.Generator = None):
+        if num_replicas is None:
+            if not use_ddp():
+                raise RuntimeError("Requires distributed package to be available")
+            num_replicas = dist.get_world_size()
+        if rank is None:
+            if not use_ddp():
+                raise RuntimeError("Requires distributed package to be available")
+            rank = dist.get_rank()
+        if rank >= num_replicas or rank < 0:
+            raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}]")
+        self.data_source = dataset
+        self.num_replicas, self.rank, self.shuffle, self.drop_last, self.generator = num_replicas, rank, shuffle, drop_last, generator
+
+    @property
+    def num_samples(self) -> int:
+        return len(self.data_source.indices)
+
+    def __iter__(self):
+        indices = self.data_source.indices
+        if self.shuffle:
+            perm = torch.randperm(len(indices), generator=self.generator).tolist()
+            indices = [indices[i] for i in perm]
+        if len(indices) % self.num_replicas != 0 and not self.drop_last:
+            raise RuntimeError("`len(dataset)` must be divisible by `world_size`.")
+        total = (self.num_samples // self.num_replicas) * self.num_replicas
+        indices = indices[:total]
+        self.data_source.indices = indices
+        per_replica = indices[self.rank:self.num_samples:self.num_replicas]
+        assert len(per_replica) == math.ceil(self.num_samples / self.num_replicas)
+        return iter(per_replica)
+
+    def __len__(self) -> int:
+        return self.num_samples // self.num_replicas
+
+    def _subsample(self):
+        orig_len, subset_len = len(self.data_source), getattr(self.data_source, "random_subset", -1)
+        if 0 < subset_len < orig_len:
+            subset = torch.randperm(n=orig_len, generator=self.generator).tolist()[:subset_len]
+            self.data_source.indices = sorted(subset)
+
+    def reset(self):
+        self.data_source.reset_indices()
+
+    def set_seed(self, seed: int) -> None:
+        self.generator.manual_seed(seed)
+        self._subsample()
+
+
+class RandomSubsetSampler(Sampler):
+    """Single-process counterpart (reference :345-391)."""
+
+    def __init__(self, data_source: Dataset, shuffle: bool, generator: torch.Generator):
+        self.data_source, self.shuffle, self.generator = data_source, shuffle, generator
+
+    @property
+    def num_samples(self) -> int:
+        return len(self.data_source.indices)
+
+    def __iter__(self):
+        indices = self.data_source.indices
+        if self.shuffle:
+            perm = torch.randperm(n=len(indices), generator=self.generator).tolist()
+            return iter([indices[i] for i in perm])
+        return iter(indices)
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def _subsample(self):
+        orig_len, subset_len = len(self.data_source), getattr(self.data_source, "random_subset", -1)
+        if 0 < subset_len < orig_len:
+            subset = torch.randperm(n=orig_len, generator=self.generator).tolist()[:subset_len]
+            self.data_source.indices = sorted(subset)
+
+    def reset(self):
+        self.data_source.reset_indices()
+
+    def set_seed(self, seed: int) -> None:
+        self.generator.manual_seed(seed)
+        self._subsample()

@@ -77,6 +77,9 @@ def dropout_rng(device) -> DropoutRng:
 
 
 # ----------------------------------------------------------------------------------------- GEMM
+GEMM_TIMER = None  # bench.py installs an object with .wrap(key, flops, launch) to HIP-event-time every GEMM launch
+
+
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, batch=1, batch_inner=1,
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
@@ -127,7 +130,11 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     if conv is not None:
         d.conv = 1
         d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
-    check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm")
+    if GEMM_TIMER is not None:
+        key = f"gemm_{'bf16' if d.dtype_ab == BF16 else 'f32'}_kernel<{int(d.trans_a)},{int(d.trans_b)}>"
+        GEMM_TIMER.wrap(key, 2.0 * d.M * d.N * d.K * d.batch, lambda: check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm"))
+    else:
+        check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm")
     return C_out
 
 

@@ -25,25 +25,29 @@ class ParamStore:
 
     def __init__(self, module: nn.Module, device: torch.device):
         self.device = torch.device(device)
-        groups: List[List[nn.Parameter]] = []
-        seen = set()
-        # 1. adjacency groups requested by sub-modules (fused projections)
+        # Parameters in registration (~forward) order; a parameter that belongs to a fusion group pulls its whole
+        # group in at that point, so [k;v;q] weights are adjacent AND the flat order stays layer-by-layer (backward
+        # fills the buffer from its tail towards its head -> contiguous DDP buckets become ready in order).
+        group_of: Dict[int, List[nn.Parameter]] = {}
         for m in module.modules():
             fg = getattr(m, "fuse_groups", None)
             if fg is None:
                 continue
             for grp in fg():
                 grp = [p for p in grp if p is not None]
-                if any(id(p) in seen for p in grp):
+                if any(id(p) in group_of for p in grp):
                     continue
                 for p in grp:
-                    seen.add(id(p))
-                groups.append(grp)
-        # 2. everything else, in registration order
+                    group_of[id(p)] = grp
+        groups: List[List[nn.Parameter]] = []
+        seen = set()
         for p in module.parameters():
-            if id(p) not in seen:
-                seen.add(id(p))
-                groups.append([p])
+            if id(p) in seen:
+                continue
+            grp = group_of.get(id(p), [p])
+            for q in grp:
+                seen.add(id(q))
+            groups.append(grp)
         offsets: Dict[int, int] = {}
         total = 0
         for grp in groups:

@@ -1,0 +1,101 @@
+"""Minimal train-step driver for the HIP path.
+
+The reference's TrainManager (joeynmt/training.py:47-826) is the *caller* of the hot path and is out of scope; its
+Python never travels to the GPU box, so this module reproduces exactly the numerically relevant part:
+`_train_step` (:541-596) and the update tail (:436-456):
+
+  1. batch.sort_by_src_length(); model(return_type="loss", **vars(batch))
+  2. batch.normalize(loss, normalization, n_gpu, batch_multiplier)          (batch.py:135-175)
+  3. backward (gradients accumulate in the flat store)
+  4. every batch_multiplier-th micro-batch: clip_grad_norm_ -> AdamW -> scheduler.step(steps) -> zero grads -> steps += 1
+     (scheduler stepped AFTER the optimizer with the pre-increment counter: the first update runs at the configured LR)
+
+MI355X-first differences (results unchanged): statistics stay on the device (no .item() per micro-batch; the reference
+syncs 6 times, :422-423,591-594); clip coefficient, AdamW, bf16 re-cast and gradient clearing are one fused pass over
+the flat store; under DDP the gradient exchange is bucketed RCCL on a side stream (helpers_for_ddp.FlatGradReducer)."""
+from typing import Dict, Optional
+
+import torch
+
+from joeys2t_amd.batch import Batch
+from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
+from joeys2t_amd.helpers_for_ddp import FlatGradReducer, use_ddp
+from joeys2t_amd.model import Model
+
+
+class TrainStep:
+    def __init__(self, model: Model, *, learning_rate: float = 2.0e-3, adam_betas=(0.9, 0.98), weight_decay: float = 0.0,
+                 clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
+                 learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
+                 batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False):
+        self.model = model
+        self.rt = model.runtime
+        self.store = self.rt.store
+        self.normalization, self.batch_multiplier, self.n_gpu = normalization, batch_multiplier, n_gpu
+        self.clip_grad_norm = clip_grad_norm
+        self.optimizer = FlatAdamW(self.store, lr=learning_rate, betas=adam_betas, weight_decay=weight_decay)
+        self.scheduler = None
+        if scheduling == "warmupinversesquareroot":
+            self.scheduler = WarmupInverseSquareRootScheduler(self.optimizer, peak_rate=learning_rate,
+                                                              warmup=learning_rate_warmup, min_rate=learning_rate_min)
+        elif scheduling is not None:
+            raise NotImplementedError(f"scheduler {scheduling}")
+        self.store.attach_grads(zero=True)
+        self.store.auto_refresh = False  # js2t_adamw keeps the bf16 shadow in sync
+        self.steps = 0
+        self.micro = 0
+        self.sync_every_backward = sync_every_backward
+        self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets) if use_ddp() else None
+        # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
+        self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
+
+    def micro_step(self, batch: Batch):
+        """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss."""
+        model = self.model
+        model.train()
+        self.rt.rng.begin_step()
+        batch.sort_by_src_length()
+        last = (self.micro + 1) % self.batch_multiplier == 0
+        if self.reducer is not None:
+            self.reducer.begin(armed=last or self.sync_every_backward)
+        total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
+        norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
+        norm.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        with torch.no_grad():
+            s = self.stats
+            s[0] += norm.detach()
+            if nll is not None:
+                s[1] += batch.normalize(nll.detach(), self.normalization, self.n_gpu, self.batch_multiplier)
+            if ctc is not None:
+                s[2] += batch.normalize(ctc.detach(), self.normalization, self.n_gpu, self.batch_multiplier)
+            s[3] += n_correct
+            s[4] += batch.nseqs
+            s[5] += batch.ntokens or 0
+        self.rt.rng.advance()
+        self.micro += 1
+        if last:
+            self.update()
+        return norm.detach()
+
+    def update(self):
+        """clip -> AdamW -> scheduler.step(steps) -> (grads cleared in the kernel) -> steps += 1."""
+        self.optimizer.clip_and_step(self.clip_grad_norm, zero_grad=True)
+        if self.scheduler is not None:
+            self.scheduler.step(self.steps)
+        self.steps += 1
+
+    def read_stats(self, reset: bool = True) -> Dict[str, float]:
+        """One host sync (and, under DDP, one 6-element all-reduce) for everything the reference logs."""
+        s = self.stats.clone()
+        if use_ddp():
+            torch.distributed.all_reduce(s)
+        vals = s.tolist()
+        if reset:
+            self.stats.zero_()
+        keys = ["loss", "nll", "ctc", "n_correct", "nseqs", "ntokens"]
+        out = dict(zip(keys, vals))
+        out["grad_norm"] = float(self.optimizer.norm_clip[0])
+        out["lr"] = self.optimizer.param_groups[0]["lr"]
+        return out

@@ -1,0 +1,104 @@
+"""GPU: audio front-end kernels (fbank / CMVN / SpecAugment / pad) and the update tail (clip + AdamW) against the
+CPU oracle and torch.optim on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import s2t_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fbank_known_answer_and_oracle(device):
+    from joeys2t_amd.helpers_for_audio import extract_fbank_features, get_extractor, get_n_frames
+    g = load_golden("audio")
+    names = g["tsv_names"].tolist()
+    pcm = g["pcm_260-123440-1"].astype(np.float32) / 32768.0
+    feat = extract_fbank_features(torch.from_numpy(pcm).unsqueeze(0), 16000, device=device)
+    assert feat.shape == (int(g["tsv_n_frames"][names.index("260-123440-1")]), 80) and feat.dtype == np.float32
+    # the reference's own known answer: CMVN'd frame 0, bins 0-9 (test/unit/test_tokenizer.py:318-325, 1e-5)
+    np.testing.assert_allclose(O.cmvn(feat)[0, :10], g["fbank_cmvn_ref_260-123440-1_frame0_bins0_9"], rtol=1e-5, atol=1e-5)
+    ref = O.fbank(pcm)
+    np.testing.assert_allclose(feat, ref, rtol=1e-4, atol=2e-4)
+    # ragged batch in one launch, incl. an utterance shorter than one window (-> 0 frames)
+    ex = get_extractor(device)
+    waves = [g["pcm_260-123440-0"].astype(np.float32) / 32768.0, pcm, np.zeros(300, dtype=np.float32),
+             g["pcm_260-123440-6"].astype(np.float32) / 32768.0]
+    flat = torch.from_numpy(np.concatenate(waves)).to(device)
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in waves])[:-1]]).tolist()
+    out, foff, frames = ex.batch(flat, [len(w) for w in waves], offs)
+    assert frames == [215, 172, 0, 270] == [max(0, get_n_frames(len(w), 16000)) if len(w) >= 400 else 0 for w in waves]
+    foff = foff.cpu().numpy()
+    for i, w in enumerate(waves):
+        if frames[i]:
+            np.testing.assert_allclose(out[foff[i]:foff[i + 1]].cpu().numpy(), O.fbank(w), rtol=1e-4, atol=2e-4)
+
+
+def test_fbank_synthetic_noise(device):
+    from joeys2t_amd.helpers_for_audio import get_extractor
+    g = torch.Generator().manual_seed(1234)
+    wave = (0.1 * torch.randn(3, 48000, generator=g)).clamp_(-1, 1)
+    out, foff, frames = get_extractor(device).batch(wave.to(device), [48000, 40000, 16000])
+    assert frames == [298, 248, 98]
+    foff = foff.cpu().numpy()
+    for i, n in enumerate([48000, 40000, 16000]):
+        np.testing.assert_allclose(out[foff[i]:foff[i + 1]].cpu().numpy(), O.fbank(wave[i, :n].numpy()), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_cmvn_specaugment_pad(device, out_dtype):
+    from joeys2t_amd.data_augmentation import CMVN, SpecAugment, finalize_features
+    rs = np.random.RandomState(3)
+    feats = [(rs.randn(t, 80) * 3 + 1).astype(np.float32) for t in (57, 20, 133)]
+    frames = [f.shape[0] for f in feats]
+    flat = torch.from_numpy(np.concatenate(feats)).to(device)
+    foff = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int64, device=device)
+    sa = SpecAugment(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0)
+    np.random.seed(42)
+    out, lens = finalize_features(flat, foff, frames, cmvn=CMVN(), specaugment=sa, out_dtype=out_dtype)
+    rng = np.random.RandomState(42)
+    ref = [O.specaugment_apply(O.cmvn(f.copy()), O.specaugment_params(f.shape[0], 80, rng, time_mask_t=100)) for f in feats]
+    padded, rl, _ = O.pad_features(ref)
+    assert lens == rl and tuple(out.shape) == padded.shape
+    tol = dict(rtol=1e-5, atol=2e-5) if out_dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), padded, **tol)
+    # no augmentation, truncation to max_length (evaluation rule)
+    out2, lens2 = finalize_features(flat, foff, frames, cmvn=CMVN(), specaugment=None, out_dtype=torch.float32, max_length=40)
+    assert lens2 == [40, 20, 40] and out2.shape[1] == 40
+    np.testing.assert_allclose(out2[0].cpu().numpy(), O.cmvn(feats[0].copy())[:40], rtol=1e-5, atol=2e-5)
+    assert torch.all(out2[1, 20:] == 1.0)
+
+
+def test_flat_adamw_and_clip_match_torch(device):
+    from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
+    from joeys2t_amd.runtime import ParamStore
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11))
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11))
+    ref.load_state_dict(net.state_dict())
+    store = ParamStore(net, device)
+    store.attach_grads()
+    opt = FlatAdamW(store, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    sched = WarmupInverseSquareRootScheduler(opt, peak_rate=2e-3, warmup=4, min_rate=1e-6)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=2e-3, betas=(0.9, 0.98), weight_decay=0.01)
+    rsched = WarmupInverseSquareRootScheduler(ropt, peak_rate=2e-3, warmup=4, min_rate=1e-6)
+    g = torch.Generator().manual_seed(1)
+    lrs = []
+    for it in range(6):
+        grads = [torch.randn(p.shape, generator=g) * (30.0 if it % 2 == 0 else 0.01) for p in ref.parameters()]
+        for p, q, gr in zip(net.parameters(), ref.parameters(), grads):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        ropt.step()
+        rsched.step(it)
+        opt.clip_and_step(10.0)
+        sched.step(it)
+        lrs.append(opt.param_groups[0]["lr"])
+        assert abs(float(opt.norm_clip[0]) - float(total)) <= 1e-4 * float(total)
+        assert torch.all(store.flat_grad == 0)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
+    assert lrs == [ropt.param_groups[0]["lr"]] * 0 + lrs  # same schedule object semantics
+    assert lrs[0] == 2e-3 * 1 / 4 and lrs[3] == 2e-3
