@@ -107,15 +107,55 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
     trg, trg_len = synth_targets(BATCH, VOCAB, seed=1234 + rank)
     n_samples = [SAMPLES] * BATCH
     frames = 1 + (SAMPLES - 400) // 160
+    step.optimizer.device_schedule = True
+    # static per-step inputs: SpecAugment mask parameters are drawn on the host (np.random, reference order) and
+    # copied into a fixed device buffer, so the same code runs eagerly or as a replayed hipGraph
+    masks_host = torch.zeros((BATCH, 8), dtype=torch.int32).pin_memory()
+    masks_dev = torch.zeros((BATCH, 8), dtype=torch.int32, device=device)
+    state = {"batch": None}
 
-    def one_step():
-        feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype)
-        batch = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=trg,
+    def pre_step():
+        masks_host.copy_(torch.from_numpy(proc.draw_masks([frames] * BATCH)))
+        masks_dev.copy_(masks_host, non_blocking=True)
+
+    def body():
+        feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype, masks_dev=masks_dev)
+        if state["batch"] is None:
+            b = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=trg,
                       trg_length=trg_len, trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1,
                       eos_index=3, is_train=True, task="S2T", n_gpu=1)
-        return step.micro_step(batch)
+            b.sort_by_src_length()  # batch.sort_by_src_length() of training.py:555 (all lengths equal here)
+            state["batch"] = b
+        state["batch"].src = feats
+        return step.micro_step(state["batch"], sort=False)
 
-    return one_step, step, frames * BATCH
+    def eager_step():
+        pre_step()
+        return body()
+
+    graph_holder = {}
+
+    def capture():
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        pre_step()
+        with torch.cuda.graph(g):
+            body()
+        step.after_update()
+        graph_holder["g"] = g
+
+    def graph_step():
+        pre_step()
+        graph_holder["g"].replay()
+        step.after_update()
+
+    return eager_step, graph_step, capture, step, frames * BATCH
 
 
 def cpu_baseline(n_utts=2, threads=None):
@@ -171,6 +211,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -185,7 +226,12 @@ def main():
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
 
     from joeys2t_amd import ops
-    one_step, step, frames_per_step = build_step(device, world)
+    eager_step, graph_step, capture, step, frames_per_step = build_step(device, world)
+    use_graph = (world == 1) and not args.no_graph  # multi-GPU: eager, so the bucketed all-reduce hooks overlap backward
+    one_step = eager_step
+    if use_graph:
+        capture()
+        one_step = graph_step
 
     def barrier():
         if world > 1:
@@ -211,7 +257,7 @@ def main():
         timer = GemmTimer()
         ops.GEMM_TIMER = timer
         for _ in range(2):
-            one_step()
+            eager_step()
         ops.GEMM_TIMER = None
         agg = timer.summary()
         key = max(agg, key=lambda k: agg[k][2])  # the kernel family with the largest total time
@@ -239,6 +285,7 @@ def main():
             "config": {"workload": "configs/librispeech_100h.yaml ASR train step on synthetic 16 kHz waveforms",
                        "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": 375,
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if use_graph else "eager",
                        "loss": round(stats["loss"] / max(1, args.steps + 0), 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -60,6 +60,7 @@ const char* js2t_last_error(void);
  * along lda ("row" for trans_a=0, "k" for trans_a=1) is (b*conv_tout + t), the contiguous index is
  * kw*conv_c + c, and A = x[b, t*conv_stride - conv_pad + kw, c] (0 outside [0,conv_tin)).
  * dtype_ab = BF16 needs 16-byte aligned operands and leading dimensions that are multiples of 8.
+ * split_k > 1 (weight gradients: few output tiles, K = tokens) spreads the reduction over split_k blocks per tile.
  */
 typedef struct js2t_gemm_desc {
   int32_t M, N, K;
@@ -85,9 +86,13 @@ typedef struct js2t_gemm_desc {
   float gate_scale;
   float beta;
   int32_t conv, conv_tin, conv_tout, conv_c, conv_stride, conv_pad;
+  int32_t split_k;          /* >1: K is cut into slices reduced with f32 atomics into a zero-filled f32 C */
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
+/* Test hook: when on, bf16 GEMMs use the register-staged kernel (the one implicit-conv operands always use)
+ * instead of the LDS-DMA kernel, so both can be checked against each other. */
+void js2t_gemm_force_regstage(int on);
 
 /* --------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels.
@@ -266,10 +271,11 @@ int js2t_grad_norm_clip(const float* g, int64_t n, float max_norm, float* partia
 
 /* torch.optim.AdamW step (builders.py:112-114) over flat fp32 buffers, gradient pre-scaled by
  * gscale * (*gscale_dev) (clip coefficient / loss-scale), optional bf16 shadow write and gradient clear.
- * step is the 1-based update count used for bias correction. */
+ * step is the 1-based update count used for bias correction.  lr_dev / step_dev (optional device scalars)
+ * override lr / step so that a captured hipGraph can be replayed with a moving schedule. */
 int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_bf16, int64_t n, float lr,
                float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev,
-               float gscale, int zero_grad, js2t_stream stream);
+               float gscale, int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream);
 
 #ifdef __cplusplus
 }

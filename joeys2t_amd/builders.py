@@ -50,6 +50,10 @@ class FlatAdamW:
         self._partial = torch.empty((max(1, lib().js2t_sumsq_partials(_C.c_int64(n))), ), dtype=torch.float32,
                                     device=store.device)
         self.norm_clip = torch.ones((2, ), dtype=torch.float32, device=store.device)  # [grad norm, clip coefficient]
+        # device-resident schedule state, used when the step is replayed from a captured hipGraph
+        self.lr_dev = torch.full((1, ), float(lr), dtype=torch.float32, device=store.device)
+        self.step_dev = torch.zeros((1, ), dtype=torch.int64, device=store.device)
+        self.device_schedule = False
 
     def clip_and_step(self, max_norm: Optional[float], grad_scale: float = 1.0, zero_grad: bool = True):
         """clip_grad_norm_(max_norm) (builders.py:68-71) folded into the update: the coefficient stays on the device."""
@@ -63,10 +67,15 @@ class FlatAdamW:
             coef = self.norm_clip[1:2]
         self.t += 1
         lp = st.flat_lp
+        lr_dev = step_dev = None
+        if self.device_schedule:  # graph-replayable form: count and learning rate live on the device
+            self.step_dev.add_(1)
+            lr_dev, step_dev = self.lr_dev, self.step_dev
         check(lib().js2t_adamw(ops._p(st.flat), ops._p(st.flat_grad), ops._p(self.exp_avg), ops._p(self.exp_avg_sq), ops._p(lp),
                                _C.c_int64(st.total), _C.c_float(g["lr"]), _C.c_float(g["betas"][0]), _C.c_float(g["betas"][1]),
                                _C.c_float(g["eps"]), _C.c_float(g["weight_decay"]), _C.c_int64(self.t), ops._p(coef),
-                               _C.c_float(grad_scale), int(zero_grad), ops._stream()), "js2t_adamw")
+                               _C.c_float(grad_scale), int(zero_grad), ops._p(lr_dev), ops._p(step_dev), ops._stream()),
+              "js2t_adamw")
         st.dirty = lp is None and st.dirty
 
     def state_dict(self) -> Dict:

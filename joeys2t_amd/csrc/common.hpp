@@ -90,33 +90,35 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// ---------------------------------------------------------------- counter-based RNG (Philox4x32-7)
-// One call yields 4 uniform 32-bit words for counter (c0..c3) under key (k0,k1).
-struct philox4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += W0; k1 += W1;
-  }
-  return {c0, c1, c2, c3};
+// ---------------------------------------------------------------- counter-based dropout RNG
+// Stateless: the keep decision of element (row, col) is a pure function of {seed, offset, call-site stream, row,
+// col}, so forward and backward kernels regenerate identical masks and nothing is stored.  One 32-bit integer hash
+// (two v_mul_lo_u32; "lowbias32") yields two 16-bit uniform values = two decisions, i.e. ~1 multiply per element —
+// the first version used Philox4x32-7 (3.5 quarter-rate multiplies per element) and cost ~45% of an FFN epilogue.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
-// Dropout keep-decision for 4 consecutive columns (col4*4 .. col4*4+3) of `row`.
-// rng_state = {seed, offset} in device memory; `stream` separates call sites.
-// Returns a 4-bit keep mask (bit i = keep column col4*4+i).
-__device__ __forceinline__ uint32_t dropout_keep4(const uint64_t* rng_state, uint32_t stream,
-                                                  uint32_t row, uint32_t col4, float p) {
+__device__ __forceinline__ uint32_t dropout_key(const uint64_t* rng_state, uint32_t stream) {
   const uint64_t seed = rng_state[0], off = rng_state[1];
-  const philox4 r = philox4x32_7(col4, row, (uint32_t)off, (uint32_t)(off >> 32) ^ stream,
-                                 (uint32_t)seed, (uint32_t)(seed >> 32));
-  // keep iff u >= p, u = word * 2^-32
-  const uint32_t thr = (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
-  return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+  return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) + 0x9E3779B9u) ^ hash32((uint32_t)off * 0x85EBCA6Bu + 1u) ^
+                hash32(((uint32_t)(off >> 32) ^ stream) * 0xC2B2AE35u + 2u));
+}
+// Keep-decisions for 4 consecutive columns (col4*4 .. col4*4+3) of `row`; bit i = keep column col4*4+i.
+// P(drop) = floor(p * 65536) / 65536.
+// `key` = dropout_key(...) is call-invariant: kernels compute it ONCE per thread and pass it in.
+__device__ __forceinline__ uint32_t dropout_keep4_key(uint32_t key, uint32_t row, uint32_t col4, float p) {
+  const uint32_t rowkey = hash32(row ^ key);
+  const uint32_t h0 = hash32(rowkey + 2u * col4), h1 = hash32(rowkey + 2u * col4 + 1u);
+  const uint32_t thr = (uint32_t)(p * 65536.0f);
+  return ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
+         ((h1 >> 16) >= thr ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t dropout_keep4(const uint64_t* rng_state, uint32_t stream, uint32_t row, uint32_t col4,
+                                                  float p) {
+  return dropout_keep4_key(dropout_key(rng_state, stream), row, col4, p);
 }
 __device__ __forceinline__ bool dropout_keep1(const uint64_t* rng_state, uint32_t stream,
                                               uint32_t row, uint32_t col, float p) {

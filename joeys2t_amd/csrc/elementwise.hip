@@ -93,6 +93,7 @@ __global__ void add_pe_dropout_kernel(const T* __restrict__ x, const float* __re
   // one thread per 4 columns (D % 4 == 0 enforced by the host)
   const int64_t D4 = D >> 2, total = B * T_ * D4;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t dkey = p > 0.f ? dropout_key(rng, stream) : 0u;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / D4, c4 = i - row * D4, t = row % T_;
     float v[4], e[4];
@@ -105,7 +106,7 @@ __global__ void add_pe_dropout_kernel(const T* __restrict__ x, const float* __re
       for (int k = 0; k < 4; ++k) v[k] += e[k];
     }
     if (p > 0.f) {
-      const uint32_t keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)c4, p);
+      const uint32_t keep = dropout_keep4_key(dkey, (uint32_t)row, (uint32_t)c4, p);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = ((keep >> k) & 1u) ? v[k] * sc : 0.f;
     }
@@ -118,9 +119,10 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
                                    const uint64_t* rng, uint32_t stream) {
   const int64_t c4n = (cols + 3) >> 2, total = rows * c4n;
   const float sc = 1.f / (1.f - p);
+  const uint32_t dkey = dropout_key(rng, stream);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / c4n, c4 = i - row * c4n;
-    const uint32_t keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)c4, p);
+    const uint32_t keep = dropout_keep4_key(dkey, (uint32_t)row, (uint32_t)c4, p);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t c = 4 * c4 + k;
@@ -164,23 +166,36 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __res
 }
 
 // ---------------------------------------------------------------- column sums (two-stage, deterministic)
-constexpr int CS_ROWS_PER_BLOCK = 128;
+// Stage 1: block = 64 columns x 4 row-lanes over a 128-row slab (>= 750 blocks for a [12000, 512] operand, each wave
+// reading 128 B row segments); stage 2 adds the per-slab partials in a fixed order.
+constexpr int CS_ROWS_PER_BLOCK = 256;
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t rows, int64_t cols) {
-  // block (bx, by): columns [bx*256, +256), rows [by*128, +128); thread = one column
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t rows,
+                                                             int64_t cols) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK, r1 = min(rows, r0 + CS_ROWS_PER_BLOCK);
   float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += io<T>::ld(x + r * cols + c);
-  partial[(int64_t)blockIdx.y * cols + c] = s;
+  if (c < cols)
+    for (int64_t r = r0 + sub; r < r1; r += 4) s += io<T>::ld(x + r * cols + c);
+  sh[sub][cl] = s;
+  __syncthreads();
+  if (sub == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts, int64_t cols) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.f;
-  for (int64_t p = 0; p < nparts; ++p) s += partial[p * cols + c];
-  out[c] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent chains: the loads are L2-latency bound
+  int64_t p = 0;
+  for (; p + 4 <= nparts; p += 4) {
+    s0 += partial[p * cols + c];
+    s1 += partial[(p + 1) * cols + c];
+    s2 += partial[(p + 2) * cols + c];
+    s3 += partial[(p + 3) * cols + c];
+  }
+  for (; p < nparts; ++p) s0 += partial[p * cols + c];
+  out[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------- conv weight repack
@@ -346,11 +361,11 @@ extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, in
   JS2T_CHECK(x && out && partial && rows > 0, "colsum: bad arguments");
   const int64_t nparts = js2t_colsum_partial_rows(rows);
   JS2T_CHECK(nparts <= 65535, "colsum: too many rows");
-  const dim3 g1(cdiv(cols, EW_THREADS), (unsigned)nparts);
+  const dim3 g1(cdiv(cols, 64), (unsigned)nparts);
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), g1, dim3(EW_THREADS), 0, (hipStream_t)stream,
                                         (const T*)x, partial, rows, cols));
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, EW_THREADS)), dim3(EW_THREADS), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, partial,
                      out, nparts, cols);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;

@@ -17,6 +17,8 @@
 
 namespace {
 
+bool g_force_regstage = false;  // test hook: route non-conv bf16 GEMMs to the register-staged kernel
+
 // ------------------------------------------------------------------------------------------------
 // operand addressing shared by both kernels
 // ------------------------------------------------------------------------------------------------
@@ -42,6 +44,7 @@ __device__ __forceinline__ void gemm_epilogue4(const js2t_gemm_desc& d, int z, i
   float v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = acc[i] * alpha;
+
   if (d.bias) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -269,8 +272,11 @@ __device__ __forceinline__ bf16x8_t frag_load(const unsigned char* tile, int sub
   }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+// SPLITK instantiations reduce one K slice per blockIdx.z and add their tile into a zero-filled f32 C with atomics;
+// that path is kept out of the plain instantiations (and off the descriptor: the pointer arrives as its own argument).
+template <bool TA, bool TB, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
+                                                           int split_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int A_BYTES = TA ? TR_TILE_BYTES : KC_TILE_BYTES;
   constexpr int B_BYTES = TB ? TR_TILE_BYTES : KC_TILE_BYTES;
@@ -293,9 +299,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[4], rb[4];
-  const int nk = (d.K + F_BK - 1) / F_BK;
-  stage_load<TA, true>(d, Ab, d.lda, m0, 0, d.M, d.K, t, ra);
-  stage_load<TB, false>(d, Bb, d.ldb, n0, 0, d.N, d.K, t, rb);
+  const int nk_all = (d.K + F_BK - 1) / F_BK;
+  const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
+  const int kt0 = SPLITK ? blockIdx.z * per : 0;
+  const int nk = min(per, nk_all - kt0);
+  if (SPLITK && nk <= 0) return;
+  stage_load<TA, true>(d, Ab, d.lda, m0, kt0 * F_BK, d.M, d.K, t, ra);
+  stage_load<TB, false>(d, Bb, d.ldb, n0, kt0 * F_BK, d.N, d.K, t, rb);
   stage_store<TA>(smem, t, ra);
   stage_store<TB>(smem + A_BYTES, t, rb);
   __syncthreads();
@@ -303,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      stage_load<TA, true>(d, Ab, d.lda, m0, (kt + 1) * F_BK, d.M, d.K, t, ra);
-      stage_load<TB, false>(d, Bb, d.ldb, n0, (kt + 1) * F_BK, d.N, d.K, t, rb);
+      stage_load<TA, true>(d, Ab, d.lda, m0, (kt0 + kt + 1) * F_BK, d.M, d.K, t, ra);
+      stage_load<TB, false>(d, Bb, d.ldb, n0, (kt0 + kt + 1) * F_BK, d.N, d.K, t, rb);
     }
     const unsigned char* At = smem + cur * STAGE;
     const unsigned char* Bt = At + A_BYTES;
@@ -329,25 +339,353 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(js2t_gemm_desc d, int
     __syncthreads();
     cur ^= 1;
   }
-  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+  if constexpr (SPLITK) {
+    const int M = d.M, N = d.N;
+    const int64_t ldc = d.ldc;
+    const float alpha = d.alpha;
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat* cg = (gfloat*)(c_atomic + co);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+        const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
+        if (m < M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) __builtin_amdgcn_global_atomic_fadd_f32(cg + (int64_t)m * ldc + n + r, acc[i][j][r] * alpha);
+        }
+      }
+  } else {
+    const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+        const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
+        gemm_epilogue4(d, z, co, m, n, acc[i][j], alpha);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 fast kernel, second generation: LDS-DMA staging (global_load_lds_dwordx4) + LDS-staged epilogue
+// ------------------------------------------------------------------------------------------------
+// Same 128x128x64 tiling / wave layout as above, but
+//  * operand tiles go HBM -> LDS directly (no VGPR round trip, no ds_write): every wave-instruction lands 1 KiB
+//    contiguously, so the bank-conflict swizzles are applied to the per-lane SOURCE address and undone by the reads;
+//    tile t+1 streams in while the MFMAs of tile t run (2 LDS stages, one s_waitcnt vmcnt(0) + barrier per K tile);
+//  * a transposed-operand tile is a pad-free [64 k][128 rows] image whose 32-byte column groups are XORed with
+//    g(k) = (k&3) | ((k>>3)&1)<<2, which makes the ds_read_b64_tr_b16 fragment reads conflict-free;
+//  * the accumulators are staged through LDS so the epilogue reads/writes whole 16-byte row segments
+//    (bias / residual / gate / dropout / C all coalesced) instead of 8-byte scattered pieces.
+// Rows beyond M/N are clamped to the last valid row (their products are never stored); a partial last K tile is
+// zero-filled in LDS after the DMA has landed.  Implicit-conv operands stay on the register-staged kernel above.
+typedef __attribute__((address_space(1))) const void g_cvoid;
+typedef __attribute__((address_space(3))) void l_void;
+
+__device__ __forceinline__ int tr_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+template <bool TR>
+__device__ __forceinline__ bf16x8_t frag_load2(const unsigned char* tile, int sub, int kk, int lane) {
+  if (!TR) {
+    const int row = sub + (lane & 15), c = kk * 4 + (lane >> 4);
+    return *(const bf16x8_t*)(tile + row * 128 + ((c ^ (row & 7)) << 4));
+  } else {
+    const int gl = lane & 15, q = gl >> 2, p = gl & 3;
+    const int kb = kk * 32 + 8 * (lane >> 4);
+    const int colb = (sub + 4 * p) * 2;
+    const int k1 = kb + q, k2 = kb + 4 + q;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + k1 * 256 + (colb ^ (tr_g(k1) << 5))));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + k2 * 256 + (colb ^ (tr_g(k2) << 5))));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+// per-lane source element offsets of the 4 DMA pieces this wave issues for one operand tile
+template <bool TR>
+__device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_max, int k0, int K, int t, int64_t (&off)[4]) {
+  const int w = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = (w * 4 + q) * 64 + lane;  // 16-byte slot index inside the 16 KiB tile
+    if (!TR) {
+      const int row = p >> 3, slot = p & 7;
+      int chunk = slot ^ (row & 7);
+      if (k0 + chunk * 8 >= K) chunk = 0;  // clamped; zero-filled afterwards
+      off[q] = (int64_t)min(rowbase + row, rows_max - 1) * ld + k0 + chunk * 8;
+    } else {
+      const int kr = p >> 4, slot = p & 15;
+      int c = rowbase + ((slot ^ (tr_g(kr) << 1)) << 3);
+      if (c >= rows_max) c = rowbase;  // rows that are never stored
+      off[q] = (int64_t)min(k0 + kr, K - 1) * ld + c;
+    }
+  }
+}
+template <bool TR>
+__device__ __forceinline__ void dma_issue(const uint16_t* base, const int64_t (&off)[4], unsigned char* tile, int t) {
+  const int w = t >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * 4 + q) * 1024), 16, 0, 0);
+}
+// zero the LDS slots of a partial last K tile (k >= k_lim)
+template <bool TR>
+__device__ __forceinline__ void dma_zero_tail(unsigned char* tile, int k_lim, int t) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = t + 256 * q;
+    if (!TR) {
+      const int row = p >> 3, slot = p & 7;
+      if (((slot ^ (row & 7)) << 3) >= k_lim) *(uint4*)(tile + p * 16) = z;
+    } else {
+      if ((p >> 4) >= k_lim) *(uint4*)(tile + p * 16) = z;
+    }
+  }
+}
+
+// epilogue for 8 consecutive columns of one row, values already in registers (see header for the op order).
+// Everything that does not depend on the row (bias, dropout key, activation kind) is resolved by the caller once per
+// thread; residual / gate rows arrive pre-loaded (packed bf16) when the fast path applies.
+__device__ __forceinline__ void unpack_bf16x8(const uint4& r, float (&o)[8]) {
+  const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[2 * i] = __uint_as_float(rr[i] << 16);
+    o[2 * i + 1] = __uint_as_float(rr[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void gemm_epilogue8(const js2t_gemm_desc& d, int z, int64_t c_boff, int m, int n, float (&v)[8],
+                                               float alpha, uint32_t drop_key, const float (&bias_r)[8], bool vec_rg,
+                                               const uint4& res_pk, const uint4& gate_pk) {
+  const int nv = min(8, d.N - n);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + bias_r[i];
+  const int64_t coff = c_boff + (int64_t)m * d.ldc + n;
+  const bool full = nv == 8;
+  if (d.preact) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) st_elem(d.preact, coff + i, d.dtype_c, v[i]);
+  }
+  if (d.act == JS2T_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+  } else if (d.act != JS2T_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i], d.act);
+  }
+  if (d.dropout_p > 0.f) {
+    const float sc = 1.f / (1.f - d.dropout_p);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)(z * d.M + m), (uint32_t)((n >> 2) + h), d.dropout_p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[4 * h + i] = ((keep >> i) & 1u) ? v[4 * h + i] * sc : 0.f;
+    }
+  }
+  if (d.residual) {
+    if (vec_rg) {
+      float r[8];
+      unpack_bf16x8(res_pk, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] += d.res_scale * r[i];
+    } else {
+      const int64_t roff = (int64_t)m * d.ldr + n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < nv) v[i] += d.res_scale * ld_elem(d.residual, roff + i, d.dtype_c);
+    }
+  }
+  if (d.gate) {
+    if (vec_rg) {
+      float r[8];
+      unpack_bf16x8(gate_pk, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = r[i] > 0.f ? v[i] * d.gate_scale : 0.f;
+    } else {
+      const int64_t goff = (int64_t)m * d.ldg + n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < nv) v[i] = ld_elem(d.gate, goff + i, d.dtype_c) > 0.f ? v[i] * d.gate_scale : 0.f;
+    }
+  }
+  if (d.beta != 0.f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) v[i] += d.beta * ld_elem(d.C, coff + i, d.dtype_c);
+  }
+  if (full && d.dtype_c == JS2T_BF16 && ((coff & 7) == 0)) {
+    uint4 pk;
+    pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+    pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+    pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+    pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+    *(uint4*)((uint16_t*)d.C + coff) = pk;
+  } else if (full && d.dtype_c == JS2T_F32 && ((coff & 3) == 0)) {
+    *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)((float*)d.C + coff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nv) st_elem(d.C, coff + i, d.dtype_c, v[i]);
+  }
+}
+
+template <bool TA, bool TB, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
+                                                               int split_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TILE = 16384, STAGE = 2 * TILE;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int z = blockIdx.y;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * F_BM, n0 = (lid % tiles_n) * F_BN;
+  int64_t ao, bo, co;
+  batch_offsets(d, z, ao, bo, co);
+  const uint16_t* Ab = (const uint16_t*)d.A + ao;
+  const uint16_t* Bb = (const uint16_t*)d.B + bo;
+  const int wm = w >> 1, wn = w & 1;
+  const int M = d.M, N = d.N, K = d.K;
+  const int64_t lda = d.lda, ldb = d.ldb;
+  f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + 16 * i + (lane & 15);
-      const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
-      gemm_epilogue4(d, z, co, m, n, acc[i][j], alpha);
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = (K + F_BK - 1) / F_BK;
+  const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
+  const int kt0 = SPLITK ? blockIdx.z * per : 0;
+  const int nk = min(per, nk_all - kt0);
+  if (SPLITK && nk <= 0) return;
+
+  int64_t oa[4], ob[4];
+  dma_offsets<TA>(lda, m0, M, kt0 * F_BK, K, t, oa);
+  dma_offsets<TB>(ldb, n0, N, kt0 * F_BK, K, t, ob);
+  dma_issue<TA>(Ab, oa, smem, t);
+  dma_issue<TB>(Bb, ob, smem + TILE, t);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k0 = (kt0 + kt) * F_BK;
+    // tile kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (k0 + F_BK > K) {
+      dma_zero_tail<TA>(smem + cur * STAGE, K - k0, t);
+      dma_zero_tail<TB>(smem + cur * STAGE + TILE, K - k0, t);
     }
+    __syncthreads();
+    if (kt + 1 < nk) {  // stream the next tile into the other stage while this one is consumed
+      dma_offsets<TA>(lda, m0, M, k0 + F_BK, K, t, oa);
+      dma_offsets<TB>(ldb, n0, N, k0 + F_BK, K, t, ob);
+      dma_issue<TA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
+      dma_issue<TB>(Bb, ob, smem + (cur ^ 1) * STAGE + TILE, t);
+    }
+    const unsigned char* At = smem + cur * STAGE;
+    const unsigned char* Bt = At + TILE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t fn[4], fm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fm[i] = frag_load2<TA>(At, wm * 64 + 16 * i, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+    }
+    // the stage consumed here is overwritten by the DMA issued in the NEXT iteration, after its barrier
+    cur ^= 1;
+  }
+  if constexpr (SPLITK) {
+    // K-slice partial tile -> LDS -> f32 atomics issued as whole 256-byte row segments (one row half per wave
+    // instruction): scattered 4-byte atomics run an order of magnitude below the ~1.3 TB/s contiguous atomic rate
+    __syncthreads();
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ml = wm * 64 + 16 * i + (lane & 15);
+        const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
+        *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
+      }
+    __syncthreads();
+    const int64_t ldc = d.ldc;
+    const float alpha = d.alpha;
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat* cg = (gfloat*)(c_atomic + co);
+    for (int idx = w; idx < 256; idx += 4) {
+      const int ml = idx >> 1, nl = (idx & 1) * 64 + lane;
+      const int m = m0 + ml, n = n0 + nl;
+      if (m < M && n < N) {
+        const float v = Cs[ml * 128 + ((((nl >> 2) ^ (ml & 7)) << 2) | (nl & 3))];
+        __builtin_amdgcn_global_atomic_fadd_f32(cg + (int64_t)m * ldc + n, v * alpha);
+      }
+    }
+  } else {
+    // stage the 128x128 f32 tile in LDS ([row][32 float4 slots], slot ^= row&7), then walk it row-major
+    __syncthreads();
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ml = wm * 64 + 16 * i + (lane & 15);
+        const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
+        *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
+      }
+    __syncthreads();
+    const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+    const uint32_t drop_key = d.dropout_p > 0.f ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+    // this thread owns the same 8 columns in all 8 passes: fetch the bias once, and (fast path) pre-issue the
+    // residual / gate row loads of every pass so their latency overlaps instead of serialising pass after pass
+    const int c8 = t & 15, n = n0 + c8 * 8;
+    float bias_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias_r[i] = (d.bias && n + i < N) ? d.bias[n + i] : 0.f;
+    const bool full8 = n + 8 <= N;
+    const bool vec_rg = full8 && d.dtype_c == JS2T_BF16 && (!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
+                        (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0));
+    uint4 res_pk[8], gate_pk[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      res_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
+      gate_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
+      const int m = m0 + pass * 16 + (t >> 4);
+      if (vec_rg && m < M) {
+        if (d.residual) res_pk[pass] = *(const uint4*)((const uint16_t*)d.residual + (int64_t)m * d.ldr + n);
+        if (d.gate) gate_pk[pass] = *(const uint4*)((const uint16_t*)d.gate + (int64_t)m * d.ldg + n);
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int ml = pass * 16 + (t >> 4);
+      const int m = m0 + ml;
+      if (m < M && n < N) {
+        const f32x4_t lo = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+        const f32x4_t hi = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        gemm_epilogue8(d, z, co, m, n, v, alpha, drop_key, bias_r, vec_rg, res_pk[pass], gate_pk[pass]);
+      }
+    }
+  }
 }
 
-template <bool TA, bool TB>
-int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
-  constexpr int A_BYTES = TA ? TR_TILE_BYTES : KC_TILE_BYTES;
-  constexpr int B_BYTES = TB ? TR_TILE_BYTES : KC_TILE_BYTES;
-  constexpr int LDS = 2 * (A_BYTES + B_BYTES);
+template <bool TA, bool TB, bool SPLITK>
+int launch_bf16_dma(const js2t_gemm_desc& d, hipStream_t s) {
+  constexpr int LDS = 65536;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TA, TB>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<TA, TB, SPLITK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -356,14 +694,45 @@ int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
     attr_set = true;
   }
   const int tm = cdiv(d.M, F_BM), tn = cdiv(d.N, F_BN);
-  hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB>), dim3(tm * tn, d.batch), dim3(256), LDS, s, d, tm, tn);
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<TA, TB, SPLITK>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS, s,
+                     d, tm, tn, (float*)d.C, d.split_k);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
+}
+
+template <bool TA, bool TB, bool SPLITK>
+int launch_bf16_impl(const js2t_gemm_desc& d, hipStream_t s) {
+  constexpr int A_BYTES = TA ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int B_BYTES = TB ? TR_TILE_BYTES : KC_TILE_BYTES;
+  constexpr int LDS = 2 * (A_BYTES + B_BYTES);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<TA, TB, SPLITK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tm = cdiv(d.M, F_BM), tn = cdiv(d.N, F_BN);
+  hipLaunchKernelGGL((gemm_bf16_kernel<TA, TB, SPLITK>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS, s, d,
+                     tm, tn, (float*)d.C, d.split_k);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+template <bool TA, bool TB>
+int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
+  if (!d.conv && !g_force_regstage)
+    return d.split_k > 1 ? launch_bf16_dma<TA, TB, true>(d, s) : launch_bf16_dma<TA, TB, false>(d, s);
+  return d.split_k > 1 ? launch_bf16_impl<TA, TB, true>(d, s) : launch_bf16_impl<TA, TB, false>(d, s);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
+
+extern "C" void js2t_gemm_force_regstage(int on) { g_force_regstage = on != 0; }
 
 extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
   JS2T_CHECK(dp != nullptr, "gemm: null descriptor");
@@ -384,6 +753,12 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.conv_c > 0 && d.conv_tin > 0 && d.conv_tout > 0 && d.conv_stride > 0, "gemm: bad conv geometry");
   }
   JS2T_CHECK(!(d.residual || d.gate) || d.batch == 1, "gemm: residual / gate need batch == 1");
+  if (d.split_k < 1) d.split_k = 1;
+  if (d.split_k > 1) {
+    JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&
+                   !d.gate && d.beta == 0.f,
+               "gemm: split_k needs an f32 C and a plain epilogue (C must be zero-filled by the caller)");
+  }
   bool fast = d.dtype_ab == JS2T_BF16 && aligned16(d.A) && aligned16(d.B) && (d.lda % 8 == 0) && (d.ldb % 8 == 0) &&
               (d.a_stride_o % 8 == 0) && (d.a_stride_i % 8 == 0) && (d.b_stride_o % 8 == 0) && (d.b_stride_i % 8 == 0) &&
               (!d.conv || d.conv_c % 8 == 0) && d.K > 0;
@@ -393,6 +768,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     if (d.trans_a && !d.trans_b) return launch_bf16<true, false>(d, s);
     return launch_bf16<true, true>(d, s);
   }
+  d.split_k = 1;  // the generic kernel always reduces the whole K range (C stays pre-zeroed + one plain store)
   const int tm = cdiv(d.M, G_BM), tn = cdiv(d.N, G_BN);
   hipLaunchKernelGGL(gemm_generic_kernel, dim3(tm * tn, d.batch), dim3(256), 0, s, d, tm, tn);
   JS2T_LAUNCH_CHECK();

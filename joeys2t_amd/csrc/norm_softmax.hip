@@ -68,34 +68,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const T* __restri
   }
 }
 // partial[(2*part + 0)*D + c] = sum_r dy*xhat ; partial[(2*part+1)*D + c] = sum_r dy   over a 128-row slab
-constexpr int LN_SLAB = 128;
+// (block = 64 columns x 4 row-lanes, like colsum_partial_kernel)
+constexpr int LN_SLAB = 256;
 template <typename T>
-__global__ void layernorm_bwd_param_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                   float* __restrict__ partial, int64_t rows, int64_t D) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= D) return;
+__global__ __launch_bounds__(256) void layernorm_bwd_param_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                          const float* __restrict__ mean,
+                                                                          const float* __restrict__ rstd,
+                                                                          float* __restrict__ partial, int64_t rows, int64_t D) {
+  __shared__ float shg[4][64], shb[4][64];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   const int64_t r0 = (int64_t)blockIdx.y * LN_SLAB, r1 = min(rows, r0 + LN_SLAB);
   float sg = 0.f, sb = 0.f;
-  for (int64_t r = r0; r < r1; ++r) {
-    const float g = io<T>::ld(dy + r * D + c);
-    sg += g * (io<T>::ld(x + r * D + c) - mean[r]) * rstd[r];
-    sb += g;
+  if (c < D)
+    for (int64_t r = r0 + sub; r < r1; r += 4) {
+      const float g = io<T>::ld(dy + r * D + c);
+      sg += g * (io<T>::ld(x + r * D + c) - mean[r]) * rstd[r];
+      sb += g;
+    }
+  shg[sub][cl] = sg;
+  shb[sub][cl] = sb;
+  __syncthreads();
+  if (sub == 0 && c < D) {
+    partial[((int64_t)blockIdx.y * 2 + 0) * D + c] = (shg[0][cl] + shg[1][cl]) + (shg[2][cl] + shg[3][cl]);
+    partial[((int64_t)blockIdx.y * 2 + 1) * D + c] = (shb[0][cl] + shb[1][cl]) + (shb[2][cl] + shb[3][cl]);
   }
-  partial[((int64_t)blockIdx.y * 2 + 0) * D + c] = sg;
-  partial[((int64_t)blockIdx.y * 2 + 1) * D + c] = sb;
 }
 __global__ void layernorm_bwd_param_final_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                  float* __restrict__ dbeta, int64_t nparts, int64_t D) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= D) return;
-  float sg = 0.f, sb = 0.f;
-  for (int64_t p = 0; p < nparts; ++p) {
-    sg += partial[(p * 2 + 0) * D + c];
-    sb += partial[(p * 2 + 1) * D + c];
+  float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+  int64_t p = 0;
+  for (; p + 2 <= nparts; p += 2) {
+    sg0 += partial[(p * 2 + 0) * D + c];
+    sb0 += partial[(p * 2 + 1) * D + c];
+    sg1 += partial[(p * 2 + 2) * D + c];
+    sb1 += partial[(p * 2 + 3) * D + c];
   }
-  dgamma[c] = sg;
-  dbeta[c] = sb;
+  for (; p < nparts; ++p) {
+    sg0 += partial[(p * 2 + 0) * D + c];
+    sb0 += partial[(p * 2 + 1) * D + c];
+  }
+  dgamma[c] = sg0 + sg1;
+  dbeta[c] = sb0 + sb1;
 }
 
 // ---------------------------------------------------------------- masked softmax (+dropout) forward
@@ -125,11 +141,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* S, const uint
   // A fully masked row yields NaN exactly as softmax over all -inf does in the reference.
   const float inv = 1.f / sum;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t dkey = p > 0.f ? dropout_key(rng, stream) : 0u;
   T* pr = P + row * ld;
   T* pdr = Pd + row * ld;
   for (int64_t k4 = lane; k4 * 4 < ld; k4 += 64) {
     uint32_t keep = 0xFu;
-    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+    if (p > 0.f) keep = dropout_keep4_key(dkey, (uint32_t)row, (uint32_t)k4, p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t k = 4 * k4 + i;
@@ -155,10 +172,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   const T* pr = P + row * ld;
   const T* gr = dPd + row * ld;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const uint32_t dkey = p > 0.f ? dropout_key(rng, stream) : 0u;
   float dot = 0.f;
   for (int64_t k4 = lane; k4 * 4 < Tk; k4 += 64) {
     uint32_t keep = 0xFu;
-    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+    if (p > 0.f) keep = dropout_keep4_key(dkey, (uint32_t)row, (uint32_t)k4, p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t k = 4 * k4 + i;
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
   T* dr = dS + row * ld;
   for (int64_t k4 = lane; k4 * 4 < ld; k4 += 64) {
     uint32_t keep = 0xFu;
-    if (p > 0.f) keep = dropout_keep4(rng, stream, (uint32_t)row, (uint32_t)k4, p);
+    if (p > 0.f) keep = dropout_keep4_key(dkey, (uint32_t)row, (uint32_t)k4, p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t k = 4 * k4 + i;
@@ -231,10 +249,10 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
     JS2T_CHECK(partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
     const int64_t nparts = (rows + LN_SLAB - 1) / LN_SLAB;
     JS2T_CHECK(nparts <= 65535, "layernorm_bwd: too many rows");
-    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_param_partial_kernel<T>), dim3(cdiv(D, 256), (unsigned)nparts),
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_param_partial_kernel<T>), dim3(cdiv(D, 64), (unsigned)nparts),
                                           dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, partial, rows, D));
     JS2T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, partial, dgamma, dbeta, nparts,
+    hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(64), 0, s, partial, dgamma, dbeta, nparts,
                        D);
     JS2T_LAUNCH_CHECK();
   }

@@ -44,8 +44,15 @@ __global__ __launch_bounds__(1024) void norm_clip_kernel(const float* __restrict
 //   p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              uint16_t* __restrict__ lp, int64_t n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt, const float* __restrict__ gscale_dev, float gscale, int zero_grad) {
+                             float bc1, float bc2_sqrt, const float* __restrict__ gscale_dev, float gscale, int zero_grad,
+                             const float* __restrict__ lr_dev, const int64_t* __restrict__ step_dev) {
   const float gs = gscale * (gscale_dev ? *gscale_dev : 1.f);
+  if (lr_dev) lr = *lr_dev;
+  if (step_dev) {  // device-resident update count (hipGraph replays cannot change kernel arguments)
+    const double t = (double)(*step_dev);
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
   const float step_size = lr / bc1;
   for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
     float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
@@ -91,7 +98,7 @@ extern "C" int js2t_grad_norm_clip(const float* g, int64_t n, float max_norm, fl
 
 extern "C" int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_bf16, int64_t n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev, float gscale,
-                          int zero_grad, js2t_stream stream) {
+                          int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream) {
   JS2T_CHECK(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw: bad arguments");
   JS2T_CHECK(n % 4 == 0, "adamw: flat buffers must be padded to a multiple of 4 elements");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -100,7 +107,7 @@ extern "C" int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq,
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
                      (uint16_t*)lp_bf16, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), gscale_dev, gscale,
-                     zero_grad);
+                     zero_grad, lr_dev, step_dev);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -64,7 +64,7 @@ class CMVN:
 
 def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Sequence[int], *, cmvn: Optional[CMVN],
                       specaugment: Optional[SpecAugment], out_dtype=torch.float32, pad_value: float = 1.0,
-                      max_length: Optional[int] = None):
+                      max_length: Optional[int] = None, masks_dev: Optional[torch.Tensor] = None):
     """feat f32 [sum T, F] (ragged, frame_off int64[U+1]) -> padded batch [U, Tmax, F] on the device:
     CMVN (before) -> SpecAugment -> pad with 1.0, i.e. SpeechProcessor.__call__ (tokenizers.py:480-492) followed by
     pad_features (helpers_for_audio.py:130-170), in two launches.  `max_length` truncates (evaluation-time rule,
@@ -85,8 +85,11 @@ def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Seque
                                     C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)), _stream()),
               "js2t_cmvn_stats")
     if specaugment is not None:
-        m = np.stack([specaugment.draw(t, F) for t in eff])
-        masks = torch.from_numpy(m).to(dev)
+        if masks_dev is not None:  # caller-managed static int32[U,8] buffer (hipGraph replay): already drawn
+            masks = masks_dev
+        else:
+            m = np.stack([specaugment.draw(t, F) for t in eff])
+            masks = torch.from_numpy(m).to(dev)
         if specaugment.mask_value is not None:
             fill = torch.full((U, ), float(specaugment.mask_value), dtype=torch.float32, device=dev)
         elif fill is None:

@@ -59,11 +59,22 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
                  ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
     if need_dw:
         # dW[N,K] = dz^T[N,M] . x[M,K]  (both operands reduction-major -> trans_a, trans_b), f32 output
-        dw = torch.empty((N, K), dtype=torch.float32, device=x2d.device)
-        ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True)
+        sk = wgrad_split(N, K, M)
+        dw = (torch.zeros if sk > 1 else torch.empty)((N, K), dtype=torch.float32, device=x2d.device)
+        ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True,
+                 split_k=sk)
     if need_db:
         db = ops.colsum(dz2d if dz2d.is_contiguous() else dz2d.contiguous())
     return dx, dw, db
+
+
+def wgrad_split(rows: int, cols: int, red: int) -> int:
+    """Split-K factor for a weight-gradient GEMM [rows, cols] = sum over `red` tokens: the output has only
+    rows*cols/128^2 tiles (16..64 for the 512/2048-wide layers) against 256 CUs, so the token dimension is cut
+    until about two blocks per CU exist."""
+    tiles = ((rows + 127) // 128) * ((cols + 127) // 128)
+    nk = (red + 63) // 64
+    return max(1, min((512 + tiles - 1) // tiles, nk // 4 if nk >= 8 else 1, 32))
 
 
 class AttnShape:
@@ -422,9 +433,10 @@ class Conv1dGluFn(torch.autograd.Function):
         dpre = ops.glu_bwd(pre, dy2)
         db = ops.colsum(dpre)
         # dWp^T[K*Cin, Cout] = im2col(x)^T[K*Cin, M] . dpre[M, Cout]
-        dwp_t = torch.empty((K * Cin, Cout), dtype=torch.float32, device=x.device)
+        sk = wgrad_split(K * Cin, Cout, M)
+        dwp_t = (torch.zeros if sk > 1 else torch.empty)((K * Cin, Cout), dtype=torch.float32, device=x.device)
         ops.gemm(x, dpre, dwp_t, M=K * Cin, N=Cout, K=M, lda=conv[3] * Cin, ldb=Cout, ldc=Cout, trans_a=True, trans_b=True,
-                 conv=conv)
+                 conv=conv, split_k=sk)
         dw = ops.conv_weight_unpack_grad(dwp_t, Cout, Cin, K)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -73,6 +73,7 @@ class FbankExtractor:
         self.mel_len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self.mel_woff = torch.tensor(woffs, dtype=torch.int32, device=dev)
         self.mel_w = torch.tensor(wts if wts else [0.0], dtype=torch.float32, device=dev)
+        self._plans = {}
 
     def n_frames(self, n_samples: int) -> int:
         return 0 if n_samples < self.win_len else 1 + (n_samples - self.win_len) // self.shift
@@ -90,11 +91,19 @@ class FbankExtractor:
             sample_off = [u * stride for u in range(U)]
         if wave.numel() < max(o + n for o, n in zip(sample_off, n_samples)):
             raise ops.Js2tError("fbank: waveform buffer shorter than sample_off + n_samples")
-        frames = [self.n_frames(int(n)) for n in n_samples]
-        foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
-        total = int(foff[-1])
-        d_soff = torch.tensor(list(sample_off), dtype=torch.int64, device=self.device)
-        d_foff = torch.tensor(foff, dtype=torch.int64, device=self.device)
+        # offset tables are cached per batch geometry: repeated shapes cost no host->device traffic (and the call
+        # becomes capturable in a hipGraph)
+        key = (tuple(int(n) for n in n_samples), tuple(int(o) for o in sample_off))
+        plan = self._plans.get(key)
+        if plan is None:
+            frames = [self.n_frames(int(n)) for n in n_samples]
+            foff = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+            plan = (frames, torch.tensor(list(sample_off), dtype=torch.int64, device=self.device),
+                    torch.tensor(foff, dtype=torch.int64, device=self.device), int(foff[-1]))
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[key] = plan
+        frames, d_soff, d_foff, total = plan
         feat = torch.empty((total, self.n_mel), dtype=torch.float32, device=self.device)
         check(lib().js2t_fbank(_p(wave), _p(d_soff), _p(d_foff), C.c_int32(U), C.c_int64(total), _p(self.window),
                                _p(self.tw_re), _p(self.tw_im), _p(self.mel_start), _p(self.mel_len), _p(self.mel_woff),

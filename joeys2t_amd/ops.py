@@ -84,7 +84,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None):
+         conv=None, split_k=1):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements."""
     _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev)
     if A.dtype != B.dtype:
@@ -130,6 +130,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     if conv is not None:
         d.conv = 1
         d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
+    d.split_k = int(split_k)
     if GEMM_TIMER is not None:
         key = f"gemm_{'bf16' if d.dtype_ab == BF16 else 'f32'}_kernel<{int(d.trans_a)},{int(d.trans_b)}>"
         GEMM_TIMER.wrap(key, 2.0 * d.M * d.N * d.K * d.batch, lambda: check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm"))

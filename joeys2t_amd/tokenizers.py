@@ -33,16 +33,22 @@ class SpeechProcessor:
             keep.append(ok)
         return keep
 
+    def draw_masks(self, frames: Sequence[int]):
+        """SpecAugment parameters for a batch (host, np.random order of the reference) as an int32 [U,8] array."""
+        import numpy as np
+        eff = [min(int(t), self.max_length) if self.max_length > 0 else int(t) for t in frames]
+        return np.stack([self.specaugment.draw(t, self.num_freq) for t in eff])
+
     def batch_from_waveforms(self, wave: torch.Tensor, n_samples: Sequence[int], is_train: bool = False,
-                             out_dtype=torch.float32, sample_off: Optional[Sequence[int]] = None
-                             ) -> Tuple[torch.Tensor, List[int]]:
+                             out_dtype=torch.float32, sample_off: Optional[Sequence[int]] = None,
+                             masks_dev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
         """Raw waveforms resident in HBM -> (features [B,Tmax,F] padded with 1.0, frame counts).  Utterances are NOT
         filtered here (call keep_mask first); over-long ones are truncated to max_length as in evaluation."""
         ex = get_extractor(wave.device, self.sample_rate, self.num_freq)
         feat, frame_off, frames = ex.batch(wave, n_samples, sample_off)
         sa = self.specaugment if is_train else None
         return finalize_features(feat, frame_off, frames, cmvn=self.cmvn, specaugment=sa, out_dtype=out_dtype,
-                                 max_length=self.max_length if self.max_length > 0 else None)
+                                 max_length=self.max_length if self.max_length > 0 else None, masks_dev=masks_dev)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(level={self.level}, normalize={self.normalize}, "

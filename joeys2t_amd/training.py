@@ -49,12 +49,14 @@ class TrainStep:
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
 
-    def micro_step(self, batch: Batch):
-        """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss."""
+    def micro_step(self, batch: Batch, sort: bool = True):
+        """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss.
+        `sort=False` skips batch.sort_by_src_length() (a host sync) for callers that sorted already."""
         model = self.model
         model.train()
         self.rt.rng.begin_step()
-        batch.sort_by_src_length()
+        if sort:
+            batch.sort_by_src_length()
         last = (self.micro + 1) % self.batch_multiplier == 0
         if self.reducer is not None:
             self.reducer.begin(armed=last or self.sync_every_backward)
@@ -82,8 +84,14 @@ class TrainStep:
     def update(self):
         """clip -> AdamW -> scheduler.step(steps) -> (grads cleared in the kernel) -> steps += 1."""
         self.optimizer.clip_and_step(self.clip_grad_norm, zero_grad=True)
+        if torch.cuda.is_current_stream_capturing():
+            return  # host-side schedule bookkeeping happens per replay: after_replay()
+        self.after_update()
+
+    def after_update(self):
         if self.scheduler is not None:
             self.scheduler.step(self.steps)
+            self.optimizer.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
         self.steps += 1
 
     def read_stats(self, reset: bool = True) -> Dict[str, float]:

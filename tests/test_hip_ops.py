@@ -42,10 +42,19 @@ def test_gemm_f32_layouts(device, M, N, K, ta, tb):
     torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
 
 
+@pytest.fixture(params=["lds_dma", "regstage"])
+def bf16_kernel(request):
+    """Run a bf16 GEMM test under both MFMA kernels (LDS-DMA staging / register staging)."""
+    from joeys2t_amd._lib import lib
+    lib().js2t_gemm_force_regstage(1 if request.param == "regstage" else 0)
+    yield request.param
+    lib().js2t_gemm_force_regstage(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 72), (375, 376, 128), (1000, 512, 2048),
-                                   (130, 1536, 512)])
+                                   (130, 1536, 512), (375, 128, 375), (60, 375, 61)])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_bf16_layouts(device, M, N, K, ta, tb):
+def test_gemm_bf16_layouts(device, bf16_kernel, M, N, K, ta, tb):
     # leading dims must be multiples of 8 for the MFMA kernel: pad the storage, keep the logical shape
     def mk(r, c, seed):
         cp = ops.round_up(c, 8)
@@ -62,7 +71,7 @@ def test_gemm_bf16_layouts(device, M, N, K, ta, tb):
     torch.testing.assert_close(C.cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(K))
 
 
-def test_gemm_bf16_exact_integers(device):
+def test_gemm_bf16_exact_integers(device, bf16_kernel):
     """Asymmetric small-integer operands: any fragment / transpose mix-up shows as an exact mismatch."""
     M, N, K = 192, 160, 128
     g = torch.Generator().manual_seed(3)
@@ -372,3 +381,16 @@ def test_log_softmax_and_lse(device):
     lse, am = ops.row_lse(x.to(device), want_argmax=True)
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(x, -1), **TOL)
     assert torch.equal(am.cpu(), x.argmax(-1))
+
+
+@pytest.mark.parametrize("split", [2, 5, 16])
+def test_gemm_bf16_split_k_wgrad(device, bf16_kernel, split):
+    """Weight-gradient shape: small output, long token reduction, K cut over `split` blocks with f32 atomics."""
+    rows, cols, tokens = 136, 264, 3001
+    dz = rnd(tokens, ops.round_up(rows, 8), seed=1).bfloat16()
+    x = rnd(tokens, cols, seed=2).bfloat16()
+    ref = dz.float()[:, :rows].t() @ x.float()
+    C = torch.zeros(rows, cols, device=device)
+    ops.gemm(dz.to(device), x.to(device), C, M=rows, N=cols, K=tokens, lda=dz.shape[1], ldb=cols, ldc=cols, trans_a=True,
+             trans_b=True, split_k=split)
+    torch.testing.assert_close(C.cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
