@@ -277,6 +277,17 @@ int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_b
                float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev,
                float gscale, int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * Beam-search step (search.py:562-646): per live batch element, over its `beam` hypotheses:
+ *   log_softmax(logits[row,:]) ; forbidden ids := -inf (search.py:590-601; forbid_ids is a HOST array) ;
+ *   += beam_log_probs[row] (:622) ; *= 1/length_penalty when length_penalty > 0 (:626-628) ;
+ *   top-`beam` of the beam*V flattened scores (:632-636), ordered by score descending then flat index ascending.
+ * logits f32[n_batch*beam, V]; beam_log_probs f32[n_batch*beam]; out_scores f32[n_batch, beam] (penalised);
+ * out_ids int64[n_batch, beam] (flat index = beam_index*V + token); out_lse f32[n_batch*beam] (row log-sum-exp). */
+int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
+                   float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
+                   int32_t n_forbid, float length_penalty, js2t_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

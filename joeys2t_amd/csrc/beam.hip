@@ -1,0 +1,110 @@
+// Beam-search scoring kernel (search.py:562-646): for every live batch element, fuse
+//   log_softmax(logits[row]) -> forbid ids (BOS/PAD/SEP/tags, UNK, EOS below the minimum length) -> + beam log-prob
+//   -> / length penalty -> top-k over the k*V flattened candidates -> (score, flat index)
+// into one launch.  HBM-bound: one pass over the [k, V] logits of the element per selection round (they stay in
+// L2: k*V*4 B = 100-400 KB).  One 256-thread block per batch element; wavefront shuffles for every reduction.
+// Selection is by total order (score descending, flat index ascending), one block-wide arg-max per rank, so the
+// result does not depend on thread scheduling: beam indices are reproducible bit for bit.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BS_THREADS = 256;
+constexpr int BS_MAX_BEAM = 64;
+constexpr int BS_MAX_FORBID = 16;
+
+struct ForbidList { int32_t n; int32_t ids[BS_MAX_FORBID]; };
+
+__device__ __forceinline__ bool better(float s, int i, float bs, int bi) { return s > bs || (s == bs && i < bi); }
+
+__global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(const float* __restrict__ logits, const float* __restrict__ beam_lp,
+                                                              float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+                                                              float* __restrict__ out_lse, int k, int64_t V, ForbidList fb,
+                                                              float len_pen, int use_pen) {
+  __shared__ float red[BS_THREADS / 64];
+  __shared__ int redi[BS_THREADS / 64];
+  __shared__ float lse_s[BS_MAX_BEAM];
+  __shared__ float pick_s;
+  __shared__ int pick_i;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* lg = logits + (int64_t)b * k * V;
+  // 1. row log-sum-exp for the k hypotheses of this element
+  for (int r = 0; r < k; ++r) {
+    const float* row = lg + (int64_t)r * V;
+    float mx = -INFINITY;
+    for (int64_t v = t; v < V; v += BS_THREADS) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int64_t v = t; v < V; v += BS_THREADS) s += __expf(row[v] - mx);
+    s = block_sum(s, red);
+    if (t == 0) {
+      lse_s[r] = mx + __logf(s);
+      out_lse[(int64_t)b * k + r] = lse_s[r];
+    }
+  }
+  __syncthreads();
+  // 2. k rounds of arg-max under the (score desc, index asc) order, each bounded by the previous pick
+  float prev_s = INFINITY;
+  int prev_i = -1;
+  const int64_t total = (int64_t)k * V;
+  for (int rank = 0; rank < k; ++rank) {
+    float bs = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t c = t; c < total; c += BS_THREADS) {
+      const int r = (int)(c / V);
+      const int v = (int)(c - (int64_t)r * V);
+      float s = lg[c] - lse_s[r];
+      for (int f = 0; f < fb.n; ++f)
+        if (v == fb.ids[f]) s = -INFINITY;
+      s += beam_lp[(int64_t)b * k + r];
+      if (use_pen) s = s / len_pen;  // true division, as curr_scores /= length_penalty (search.py:628)
+      // candidate must come strictly after the previous pick in the total order
+      const bool after = s < prev_s || (s == prev_s && (int)c > prev_i);
+      if (after && better(s, (int)c, bs, bi)) { bs = s; bi = (int)c; }
+    }
+    // block arg-max
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (better(os, oi, bs, bi)) { bs = os; bi = oi; }
+    }
+    if ((t & 63) == 0) { red[t >> 6] = bs; redi[t >> 6] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      float fs = red[0];
+      int fi = redi[0];
+      for (int w = 1; w < BS_THREADS / 64; ++w)
+        if (better(red[w], redi[w], fs, fi)) { fs = red[w]; fi = redi[w]; }
+      pick_s = fs;
+      pick_i = fi;
+      out_scores[(int64_t)b * k + rank] = fs;
+      out_ids[(int64_t)b * k + rank] = fi == 0x7fffffff ? 0 : fi;
+    }
+    __syncthreads();
+    prev_s = pick_s;
+    prev_i = pick_i;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
+                              float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
+                              int32_t n_forbid, float length_penalty, js2t_stream stream) {
+  if (n_batch == 0) return JS2T_OK;
+  JS2T_CHECK(logits && beam_log_probs && out_scores && out_ids && out_lse, "beam_step: null pointer");
+  JS2T_CHECK(beam >= 1 && beam <= BS_MAX_BEAM, "beam_step: beam size 1..%d", BS_MAX_BEAM);
+  JS2T_CHECK(n_forbid >= 0 && n_forbid <= BS_MAX_FORBID && (n_forbid == 0 || forbid_ids), "beam_step: at most %d forbidden ids",
+             BS_MAX_FORBID);
+  JS2T_CHECK((int64_t)beam * V < 0x7fffffff, "beam_step: beam * vocab too large");
+  ForbidList fb;
+  fb.n = n_forbid;
+  for (int i = 0; i < BS_MAX_FORBID; ++i) fb.ids[i] = i < n_forbid ? forbid_ids[i] : -1;
+  const int use_pen = length_penalty > 0.f ? 1 : 0;
+  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
+                     out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

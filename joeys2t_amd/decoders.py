@@ -63,7 +63,8 @@ class TransformerDecoder(Decoder):
                            return_attention=(return_attention and i == last_layer))
         if self.layer_norm is not None:
             x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias)
-        out = self.project(self.output_layer, x, torch.float32)
+        # decoding only scores the newest position (search.py:534 `logits[:, -1]`): project just that row
+        out = self.project(self.output_layer, x[:, -1:].contiguous() if kwargs.get("last_only", False) else x, torch.float32)
         ctc_output = None
         if self.ctc_output_layer is not None and kwargs.get("compute_ctc", True):
             ctc_output = self.project(self.ctc_output_layer, encoder_output, rt.compute_dtype)

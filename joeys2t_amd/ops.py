@@ -418,3 +418,23 @@ def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: f
                              _p(beta), _p(nll), _p(g_dev), C.c_float(scale), _p(d), C.c_int64(B), C.c_int64(T), C.c_int64(V),
                              C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_bwd")
     return d
+
+
+# ----------------------------------------------------------------------------------------- beam search
+def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int, beam: int, forbid_ids, length_penalty: float):
+    """Fused log-softmax + masks + beam score + length penalty + top-k (js2t_beam_step).  Returns
+    (scores [n_batch, beam], flat ids [n_batch, beam] int64, row lse [n_batch*beam])."""
+    _dev(logits2d, beam_log_probs)
+    if logits2d.dtype != torch.float32 or not logits2d.is_contiguous():
+        raise Js2tError("beam_step: logits must be contiguous float32")
+    V = logits2d.shape[1]
+    dev = logits2d.device
+    scores = torch.empty((n_batch, beam), dtype=torch.float32, device=dev)
+    ids = torch.empty((n_batch, beam), dtype=torch.int64, device=dev)
+    lse = torch.empty((n_batch * beam, ), dtype=torch.float32, device=dev)
+    fb = (C.c_int32 * max(1, len(forbid_ids)))(*forbid_ids)
+    blp = beam_log_probs.contiguous().float()
+    check(lib().js2t_beam_step(_p(logits2d), _p(blp), _p(scores), _p(ids), _p(lse), C.c_int64(n_batch), C.c_int32(beam),
+                               C.c_int64(V), fb, C.c_int32(len(forbid_ids)), C.c_float(length_penalty), _stream()),
+          "js2t_beam_step")
+    return scores, ids, lse
