@@ -158,7 +158,7 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
     return eager_step, graph_step, capture, step, frames * BATCH
 
 
-def cpu_baseline(n_utts=2, threads=None):
+def cpu_baseline(n_utts=8, threads=None):
     """The CPU oracle (plain fp32 PyTorch/NumPy restatement of the reference path) timed on the host cores on a
     bounded sample of the same workload: n_utts utterances of 15 s through fbank -> ... -> loss -> backward -> AdamW."""
     import copy
@@ -195,7 +195,7 @@ def cpu_baseline(n_utts=2, threads=None):
 
     step()  # warm-up
     t0 = time.perf_counter()
-    n = 2
+    n = 4
     for _ in range(n):
         step()
     dt = (time.perf_counter() - t0) / n
@@ -260,9 +260,14 @@ def main():
             eager_step()
         ops.GEMM_TIMER = None
         agg = timer.summary()
-        key = max(agg, key=lambda k: agg[k][2])  # the kernel family with the largest total time
-        n, flops, secs = agg[key]
+        # dominant kernel = the bf16 LDS-DMA MFMA GEMM (all <trans_a,trans_b,split_k> instantiations of
+        # gemm_bf16_dma_kernel: forward, dgrad and wgrad products); per-instantiation figures are listed beside it
+        fam = {k: v for k, v in agg.items() if k.startswith("gemm_bf16_dma_kernel")}
+        n = sum(v[0] for v in fam.values())
+        flops = sum(v[1] for v in fam.values())
+        secs = sum(v[2] for v in fam.values())
         achieved = flops / secs / 1e12
+        key = "gemm_bf16_dma_kernel<*>"
         roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
                     "avg_launch_us": round(secs / n * 1e6, 2),

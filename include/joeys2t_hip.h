@@ -137,14 +137,14 @@ int js2t_embed_bwd(const int64_t* ids, const void* dout, int dout_dt, float* dta
 /* out[c] = sum_r x[r,c] (f32) — bias gradients of every nn.Linear / nn.Conv1d on the path.
  * partial is a caller-provided f32[colsum_partial_rows(rows) * cols] workspace. */
 int64_t js2t_colsum_partial_rows(int64_t rows);
-int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols,
-                js2t_stream stream);
+int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, int accumulate,
+                js2t_stream stream); /* accumulate != 0: out[c] += sum (gradient accumulation in place) */
 
 /* Conv1d weight repack: w[Cout,Cin,K] (torch layout, encoders.py:339-345) <-> wp[Cout, K*Cin] (GEMM layout). */
 int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_t cout, int64_t cin, int64_t k,
                           js2t_stream stream);
 int js2t_conv_weight_unpack_grad(const float* dwp_t, float* dw, int64_t cout, int64_t cin, int64_t k,
-                                 js2t_stream stream); /* dwp_t is [K*Cin, Cout] (transposed wgrad) */
+                                 int accumulate, js2t_stream stream); /* dwp_t is [K*Cin, Cout] (transposed wgrad) */
 /* dx[b,tau,c] = sum over taps of dcol[(b*tout+t), kw*C+c] with t*stride-pad+kw == tau (conv dgrad gather). */
 int js2t_col2im(const void* dcol, void* dx, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
                 int64_t stride, int64_t pad, int dt, js2t_stream stream);
@@ -166,7 +166,8 @@ int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
  * dgamma/dbeta f32[D] (may both be NULL); partial = f32[2 * js2t_colsum_partial_rows(rows) * D] workspace. */
 int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, void* dx, const void* add, float add_scale, float* dgamma,
-                       float* dbeta, float* partial, int64_t rows, int64_t D, int dt, js2t_stream stream);
+                       float* dbeta, float* partial, int accumulate, int64_t rows, int64_t D, int dt,
+                       js2t_stream stream); /* accumulate != 0: dgamma/dbeta += (in-place gradient accumulation) */
 
 /* --------------------------------------------------------------------------------------------------
  * Masked softmax (+ dropout) over attention scores — transformer_layers.py:93-98.

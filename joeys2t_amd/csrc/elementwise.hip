@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   __syncthreads();
   if (sub == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts, int64_t cols) {
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts, int64_t cols,
+                                    int accumulate) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent chains: the loads are L2-latency bound
@@ -195,7 +196,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
     s3 += partial[(p + 3) * cols + c];
   }
   for (; p < nparts; ++p) s0 += partial[p * cols + c];
-  out[c] = (s0 + s1) + (s2 + s3);
+  const float tot = (s0 + s1) + (s2 + s3);
+  out[c] = accumulate ? out[c] + tot : tot;
 }
 
 // ---------------------------------------------------------------- conv weight repack
@@ -209,12 +211,13 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, D* __restrict__ wp
   }
 }
 __global__ void conv_unpack_grad_kernel(const float* __restrict__ dwp_t, float* __restrict__ dw, int64_t cout, int64_t cin,
-                                        int64_t k) {
+                                        int64_t k, int accumulate) {
   const int64_t total = cout * cin * k;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     // destination index i = (o, c, kw) in torch layout; source [(kw*cin + c), o]
     const int64_t o = i / (cin * k), rem = i - o * cin * k, c = rem / k, kw = rem - c * k;
-    dw[i] = dwp_t[(kw * cin + c) * cout + o];
+    const float v = dwp_t[(kw * cin + c) * cout + o];
+    dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
@@ -356,7 +359,8 @@ extern "C" int js2t_embed_bwd(const int64_t* ids, const void* dout, int dout_dt,
 
 extern "C" int64_t js2t_colsum_partial_rows(int64_t rows) { return (rows + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK; }
 
-extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, js2t_stream stream) {
+extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, int accumulate,
+                           js2t_stream stream) {
   if (cols == 0) return JS2T_OK;
   JS2T_CHECK(x && out && partial && rows > 0, "colsum: bad arguments");
   const int64_t nparts = js2t_colsum_partial_rows(rows);
@@ -366,7 +370,7 @@ extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, in
                                         (const T*)x, partial, rows, cols));
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, partial,
-                     out, nparts, cols);
+                     out, nparts, cols, accumulate);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -380,10 +384,10 @@ extern "C" int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_
   return JS2T_OK;
 }
 extern "C" int js2t_conv_weight_unpack_grad(const float* dwp_t, float* dw, int64_t cout, int64_t cin, int64_t k,
-                                            js2t_stream stream) {
+                                            int accumulate, js2t_stream stream) {
   JS2T_CHECK(dwp_t && dw && cout > 0 && cin > 0 && k > 0, "conv_weight_unpack_grad: bad arguments");
   hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3(ew_grid(cout * cin * k)), dim3(EW_THREADS), 0, (hipStream_t)stream, dwp_t,
-                     dw, cout, cin, k);
+                     dw, cout, cin, k, accumulate);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_partial_kernel(const 
   }
 }
 __global__ void layernorm_bwd_param_final_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, int64_t nparts, int64_t D) {
+                                                 float* __restrict__ dbeta, int64_t nparts, int64_t D, int accumulate) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= D) return;
   float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
@@ -110,8 +110,8 @@ __global__ void layernorm_bwd_param_final_kernel(const float* __restrict__ parti
     sg0 += partial[(p * 2 + 0) * D + c];
     sb0 += partial[(p * 2 + 1) * D + c];
   }
-  dgamma[c] = sg0 + sg1;
-  dbeta[c] = sb0 + sb1;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (sg0 + sg1);
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (sb0 + sb1);
 }
 
 // ---------------------------------------------------------------- masked softmax (+dropout) forward
@@ -237,7 +237,7 @@ extern "C" int js2t_layernorm_fwd(const void* x, const float* gamma, const float
 
 extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, const void* add, float add_scale, float* dgamma, float* dbeta, float* partial,
-                                  int64_t rows, int64_t D, int dt, js2t_stream stream) {
+                                  int accumulate, int64_t rows, int64_t D, int dt, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0, "layernorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -253,7 +253,7 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
                                           dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, partial, rows, D));
     JS2T_LAUNCH_CHECK();
     hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(64), 0, s, partial, dgamma, dbeta, nparts,
-                       D);
+                       D, accumulate);
     JS2T_LAUNCH_CHECK();
   }
   return JS2T_OK;

@@ -43,7 +43,10 @@ class TransformerDecoder(Decoder):
         rt = runtime_of(self)
         x = rt.act_in(x)
         bias = None if layer.bias is None else layer.bias
-        return Fn.LinearFn.apply(x, rt.weight([layer.weight]), layer.weight, bias, out_dtype)
+        smap = {"w": [layer.weight]}
+        if bias is not None:
+            smap["b"] = [bias]
+        return Fn.LinearFn.apply(x, rt.weight([layer.weight]), layer.weight, bias, out_dtype, rt.sinks(smap), rt.grads_ready)
 
     def forward(self, trg_embed: Tensor, encoder_output: Tensor, encoder_hidden: Tensor, src_mask: Tensor,
                 unroll_steps: int, hidden: Tensor, trg_mask: Tensor, **kwargs):
@@ -62,7 +65,9 @@ class TransformerDecoder(Decoder):
             x, att = layer(x=x, memory=encoder_output, src_mask=src_mask, trg_mask=trg_mask,
                            return_attention=(return_attention and i == last_layer))
         if self.layer_norm is not None:
-            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias)
+            sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"]),
+                                     rt.grads_ready)
         # decoding only scores the newest position (search.py:534 `logits[:, -1]`): project just that row
         out = self.project(self.output_layer, x[:, -1:].contiguous() if kwargs.get("last_only", False) else x, torch.float32)
         ctc_output = None

@@ -2,6 +2,7 @@
 nn.Embedding parameter (checkpoint key `trg_embed.lut.weight`); the gather * sqrt(d) runs in js2t_embed_fwd."""
 import math
 
+import torch
 from torch import Tensor, nn
 
 from joeys2t_amd import functional as Fn
@@ -23,7 +24,8 @@ class Embeddings(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         rt = runtime_of(self)
         factor = math.sqrt(self.embedding_dim) if self.scale else 1.0
-        return Fn.EmbedFn.apply(x, self.lut.weight, factor, self.lut.padding_idx, rt.compute_dtype)
+        return Fn.EmbedFn.apply(x, self.lut.weight, factor, self.lut.padding_idx, rt.compute_dtype,
+                                rt.grad_sink([self.lut.weight]) if torch.is_grad_enabled() else None, rt.grads_ready)
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(embedding_dim={self.embedding_dim}, vocab_size={self.vocab_size})"

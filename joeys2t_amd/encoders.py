@@ -62,7 +62,8 @@ class Conv1dSubsampler(nn.Module):
             src_lengths = src_lengths.to(src_tokens.device)
         x = rt.act_in(src_tokens.contiguous())
         for conv in self.conv_layers:
-            x = Fn.Conv1dGluFn.apply(x, conv.weight, conv.bias, rt.compute_dtype)
+            x = Fn.Conv1dGluFn.apply(x, conv.weight, conv.bias, rt.compute_dtype,
+                                     rt.sinks({"w": [conv.weight], "b": [conv.bias]}), rt.grads_ready)
         out_lens, mask = ops.subsample_lengths_mask(src_lengths, x.size(1), self.kernel_sizes)
         return x, out_lens, mask
 
@@ -106,7 +107,10 @@ class TransformerEncoder(Encoder):
         for layer in self.layers:
             x = layer(x, mask)
         if self.layer_norm is not None:
-            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias)
+            rt = runtime_of(self)
+            sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"]),
+                                     rt.grads_ready)
         if kwargs.get("repad", False) and "src_max_len" in kwargs and self.subsample:
             x, mask = self._repad(x, mask, kwargs["src_max_len"])
         assert src_length.size() == (x.size(0), ), (src_length.size(), x.size())

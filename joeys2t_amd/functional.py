@@ -46,8 +46,11 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
     return y
 
 
-def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None):
-    """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32)."""
+def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None,
+               dw_out=None, db_out=None):
+    """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32).
+    dw_out / db_out: fp32 gradient buffers (views of the flat gradient store) to ACCUMULATE into; the corresponding
+    return value is then None (nothing left for autograd to add)."""
     _row_major_2d(dz2d), _row_major_2d(x2d), _row_major_2d(w)
     M, N = dz2d.shape
     K = x2d.shape[1]
@@ -60,11 +63,20 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
     if need_dw:
         # dW[N,K] = dz^T[N,M] . x[M,K]  (both operands reduction-major -> trans_a, trans_b), f32 output
         sk = wgrad_split(N, K, M)
-        dw = (torch.zeros if sk > 1 else torch.empty)((N, K), dtype=torch.float32, device=x2d.device)
-        ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True,
-                 split_k=sk)
+        if dw_out is not None:
+            # split-K atomics add onto whatever is there; a single-slice GEMM accumulates through beta = 1
+            ops.gemm(dz2d, x2d, dw_out, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True,
+                     trans_b=True, split_k=sk, beta=0.0 if sk > 1 else 1.0)
+        else:
+            dw = (torch.zeros if sk > 1 else torch.empty)((N, K), dtype=torch.float32, device=x2d.device)
+            ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True,
+                     split_k=sk)
     if need_db:
-        db = ops.colsum(dz2d if dz2d.is_contiguous() else dz2d.contiguous())
+        dzc = dz2d if dz2d.is_contiguous() else dz2d.contiguous()
+        if db_out is not None:
+            ops.colsum(dzc, out=db_out, accumulate=True)
+        else:
+            db = ops.colsum(dzc)
     return dx, dw, db
 
 
@@ -226,6 +238,7 @@ class ResidualBlockFn(torch.autograd.Function):
             y, mean, rstd = _ln_fwd(u, wts["ln_g"], wts["ln_b"])
             saved.update(mean=mean, rstd=rstd, u=u)
         ctx.cfg, ctx.rng, ctx.sites, ctx.wts, ctx.saved = cfg, rng, sites, wts, saved
+        ctx.params = params
         ctx.x2, ctx.n, ctx.c = x2, n, c
         ctx.shape = (B, T, d)
         ctx.mem_shape = None if memory is None else tuple(memory.shape)
@@ -247,17 +260,23 @@ class ResidualBlockFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         g = {}
+        sink = wts.get("sink") or {}
+        ln_sink = (sink["ln_g"], sink["ln_b"]) if "ln_g" in sink else None
+
+        def sk(name):
+            return sink.get(name)
+
         if cfg.ln_mode != "post":
             du = dy2
         else:
-            du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"])
+            du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"], grad_out=ln_sink)
         dz_o = ops.dropout_bwd(du, p_out, rng, sites[1]) if p_out > 0 else du
         dmem = None
         if cfg.kind == "ffn":
             relu = cfg.act == "relu"
             # dh = dz_o . W2, gated by the saved post-dropout activations for ReLU (sign carries both masks)
             dh, g["w2"], g["b2"] = linear_bwd(dz_o, c, wts["w2"], gate=c if relu else None,
-                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0)
+                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0, dw_out=sk("w2"), db_out=sk("b2"))
             if relu or cfg.act is None:
                 dz1 = dh
                 if cfg.act is None and p > 0:
@@ -265,30 +284,38 @@ class ResidualBlockFn(torch.autograd.Function):
             else:
                 dz1 = ops.dropout_bwd(dh, p, rng, sites[0]) if p > 0 else dh
                 dz1 = ops.act_bwd(dz1, sv["pre"], cfg.act)
-            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"])
+            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"))
         elif cfg.kind == "self":
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"])
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"))
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
                      sites[0])
-            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"])
+            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"))
         else:  # cross
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"])
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"))
             q, kv = sv["q"], sv["kv"]
             dq, dkv = torch.empty_like(q), torch.empty_like(kv)
             attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0])
-            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"])
-            dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3])
+            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"))
+            dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
+                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"))
             dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
         if cfg.ln_mode == "pre":
             dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
-                                                          add_scale=cfg.alpha)
+                                                          add_scale=cfg.alpha, grad_out=ln_sink)
         elif cfg.alpha != 0.0:
             dx2 = ops.axpby(dn, 1.0, du, cfg.alpha)
         else:
             dx2 = dn
-        grads = _route_param_grads(cfg.kind, g, d, cfg.ln_mode != "none")
+        if sink:
+            # every parameter gradient of this block was accumulated in place: nothing goes back through autograd
+            notify = wts.get("notify")
+            if notify is not None:
+                notify(ctx.params)
+            grads = [None] * ctx.nparams
+        else:
+            grads = _route_param_grads(cfg.kind, g, d, cfg.ln_mode != "none")
         assert len(grads) == ctx.nparams
         return (None, None, dx2.view(B, T, d), dmem, None, None, *grads)
 
@@ -322,12 +349,12 @@ class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm(d, eps=1e-6) — final encoder/decoder norm (encoders.py:281-282, decoders.py:617-618)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, sink=None, notify=None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         y, mean, rstd = ops.layernorm_fwd(x2, gamma, beta, LN_EPS)
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.shape = shape
+        ctx.shape, ctx.sink, ctx.notify, ctx.leaves = shape, sink, notify, (gamma, beta)
         return y.view(shape)
 
     @staticmethod
@@ -336,21 +363,26 @@ class LayerNormFn(torch.autograd.Function):
         dy2 = dy.reshape(x2.shape)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd)
-        return dx.view(ctx.shape), dg, db
+        dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, grad_out=ctx.sink)
+        if ctx.sink is not None:
+            if ctx.notify is not None:
+                ctx.notify(ctx.leaves)
+            dg = db = None
+        return dx.view(ctx.shape), dg, db, None, None
 
 
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) — vocabulary / CTC projections (decoders.py:620-623), Conformer input linear."""
 
     @staticmethod
-    def forward(ctx, x, w_compute, weight, bias, out_dtype):
+    def forward(ctx, x, w_compute, weight, bias, out_dtype, sink=None, notify=None):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         y = linear_fwd(x2, w_compute, bias, out_dtype=out_dtype)
         ctx.x2, ctx.w = x2, w_compute
         ctx.has_bias = bias is not None
         ctx.shape = shape
+        ctx.sink, ctx.notify, ctx.leaves = sink, notify, (weight, bias)
         return y.view(*shape[:-1], w_compute.shape[0])
 
     @staticmethod
@@ -361,9 +393,12 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         if dy2.dtype != x2.dtype:
             dy2 = ops.cast(dy2, x2.dtype)
+        sink = ctx.sink or {}
         dx, dw, db = linear_bwd(dy2, x2, w, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[2],
-                                need_db=ctx.has_bias and ctx.needs_input_grad[3])
-        return (None if dx is None else dx.view(ctx.shape)), None, dw, db, None
+                                need_db=ctx.has_bias and ctx.needs_input_grad[3], dw_out=sink.get("w"), db_out=sink.get("b"))
+        if sink and ctx.notify is not None:
+            ctx.notify(ctx.leaves)
+        return (None if dx is None else dx.view(ctx.shape)), None, dw, db, None, None, None
 
 
 class AddPeDropoutFn(torch.autograd.Function):
@@ -387,13 +422,19 @@ class EmbedFn(torch.autograd.Function):
     """lut(ids) * sqrt(d) — Embeddings.forward (embeddings.py:55-64)."""
 
     @staticmethod
-    def forward(ctx, ids, table, scale, pad_idx, out_dtype):
+    def forward(ctx, ids, table, scale, pad_idx, out_dtype, sink=None, notify=None):
         ctx.ids, ctx.scale, ctx.pad_idx, ctx.vocab = ids, scale, pad_idx, table.shape[0]
+        ctx.sink, ctx.notify, ctx.leaf = sink, notify, table
         return ops.embed_fwd(ids, table, scale, out_dtype)
 
     @staticmethod
     def backward(ctx, dout):
-        return None, ops.embed_bwd(ctx.ids, dout, ctx.vocab, ctx.scale, ctx.pad_idx), None, None, None
+        dt = ops.embed_bwd(ctx.ids, dout, ctx.vocab, ctx.scale, ctx.pad_idx, out=ctx.sink)
+        if ctx.sink is not None:
+            if ctx.notify is not None:
+                ctx.notify((ctx.leaf, ))
+            dt = None
+        return None, dt, None, None, None, None, None
 
 
 def conv_out_len(t_in: int, k: int, stride: int = 2) -> int:
@@ -406,7 +447,8 @@ class Conv1dGluFn(torch.autograd.Function):
     (encoders.py:362-368) as an implicit-im2col MFMA GEMM + GLU epilogue kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, compute_dtype):
+    def forward(ctx, x, weight, bias, compute_dtype, sink=None, notify=None):
+        ctx.sink, ctx.notify, ctx.leaves = sink, notify, (weight, bias)
         B, T, Cin = x.shape
         Cout, _, K = weight.shape
         stride, pad = 2, K // 2
@@ -431,16 +473,21 @@ class Conv1dGluFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dpre = ops.glu_bwd(pre, dy2)
-        db = ops.colsum(dpre)
+        sink = ctx.sink or {}
+        db = ops.colsum(dpre, out=sink.get("b"), accumulate=True) if sink else ops.colsum(dpre)
         # dWp^T[K*Cin, Cout] = im2col(x)^T[K*Cin, M] . dpre[M, Cout]
         sk = wgrad_split(K * Cin, Cout, M)
         dwp_t = (torch.zeros if sk > 1 else torch.empty)((K * Cin, Cout), dtype=torch.float32, device=x.device)
         ops.gemm(x, dpre, dwp_t, M=K * Cin, N=Cout, K=M, lda=conv[3] * Cin, ldb=Cout, ldc=Cout, trans_a=True, trans_b=True,
                  conv=conv, split_k=sk)
-        dw = ops.conv_weight_unpack_grad(dwp_t, Cout, Cin, K)
+        dw = ops.conv_weight_unpack_grad(dwp_t, Cout, Cin, K, out=sink.get("w"))
+        if sink:
+            if ctx.notify is not None:
+                ctx.notify(ctx.leaves)
+            dw = db = None
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = torch.empty((M, K * Cin), dtype=pre.dtype, device=x.device)
             ops.gemm(dpre, wp, dcol, M=M, N=K * Cin, K=Cout, lda=Cout, ldb=K * Cin, ldc=K * Cin, trans_b=True)
             dx = ops.col2im(dcol, B, T, Tout, Cin, K, conv[3], conv[4])
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None

@@ -129,6 +129,12 @@ class FlatGradReducer:
         self.launched = [False] * len(self.ranges)
         self.works = []
 
+    def params_ready(self, params):
+        """Gradients of `params` were accumulated in place by a kernel (no autograd hook fires for them)."""
+        for p in params:
+            if p is not None and id(p) in self.bucket_of:
+                self._hook(p)
+
     def _hook(self, p):
         if not self.armed:
             return

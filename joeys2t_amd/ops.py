@@ -132,7 +132,11 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
     d.split_k = int(split_k)
     if GEMM_TIMER is not None:
-        key = f"gemm_{'bf16' if d.dtype_ab == BF16 else 'f32'}_kernel<{int(d.trans_a)},{int(d.trans_b)}>"
+        if d.dtype_ab == BF16:
+            fam = "gemm_bf16_kernel" if d.conv else "gemm_bf16_dma_kernel"
+            key = f"{fam}<{int(d.trans_a)},{int(d.trans_b)},{int(d.split_k > 1)}>"
+        else:
+            key = "gemm_generic_kernel"
         GEMM_TIMER.wrap(key, 2.0 * d.M * d.N * d.K * d.batch, lambda: check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm"))
     else:
         check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm")
@@ -212,25 +216,27 @@ def embed_fwd(ids, table, scale: float, out_dtype):
     return out
 
 
-def embed_bwd(ids, dout, vocab: int, scale: float, pad_idx: int):
-    _dev(ids, dout)
+def embed_bwd(ids, dout, vocab: int, scale: float, pad_idx: int, out: Optional[torch.Tensor] = None):
+    _dev(ids, dout, out)
     ids, dout = ids.contiguous(), dout.contiguous()
     D = dout.shape[-1]
-    dtable = torch.zeros((vocab, D), dtype=torch.float32, device=dout.device)
+    dtable = out if out is not None else torch.zeros((vocab, D), dtype=torch.float32, device=dout.device)
     check(lib().js2t_embed_bwd(_p(ids), _p(dout), dt_code(dout), _p(dtable), C.c_int64(ids.numel()), C.c_int64(D),
                                C.c_int64(vocab), C.c_float(scale), C.c_int64(-1 if pad_idx is None else pad_idx), _stream()),
           "js2t_embed_bwd")
     return dtable
 
 
-def colsum(x2d: torch.Tensor) -> torch.Tensor:
-    _dev(x2d)
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    _dev(x2d, out)
     rows, cols = x2d.shape
-    out = torch.empty((cols,), dtype=torch.float32, device=x2d.device)
+    if out is None:
+        out = torch.empty((cols,), dtype=torch.float32, device=x2d.device)
+        accumulate = False
     nparts = lib().js2t_colsum_partial_rows(rows)
     partial = torch.empty((max(nparts, 1) * cols,), dtype=torch.float32, device=x2d.device)
-    check(lib().js2t_colsum(_p(x2d), dt_code(x2d), _p(out), _p(partial), C.c_int64(rows), C.c_int64(cols), _stream()),
-          "js2t_colsum")
+    check(lib().js2t_colsum(_p(x2d), dt_code(x2d), _p(out), _p(partial), C.c_int64(rows), C.c_int64(cols), int(accumulate),
+                            _stream()), "js2t_colsum")
     return out
 
 
@@ -243,11 +249,13 @@ def conv_weight_pack(w: torch.Tensor, dtype) -> torch.Tensor:
     return wp
 
 
-def conv_weight_unpack_grad(dwp_t: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
-    _dev(dwp_t)
-    dw = torch.empty((cout, cin, k), dtype=torch.float32, device=dwp_t.device)
-    check(lib().js2t_conv_weight_unpack_grad(_p(dwp_t), _p(dw), C.c_int64(cout), C.c_int64(cin), C.c_int64(k), _stream()),
-          "js2t_conv_weight_unpack_grad")
+def conv_weight_unpack_grad(dwp_t: torch.Tensor, cout: int, cin: int, k: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[K*Cin, Cout] wgrad -> torch Conv1d layout; `out` given = accumulate into it (in-place gradient accumulation)."""
+    _dev(dwp_t, out)
+    acc = out is not None
+    dw = out if acc else torch.empty((cout, cin, k), dtype=torch.float32, device=dwp_t.device)
+    check(lib().js2t_conv_weight_unpack_grad(_p(dwp_t), _p(dw), C.c_int64(cout), C.c_int64(cin), C.c_int64(k), int(acc),
+                                             _stream()), "js2t_conv_weight_unpack_grad")
     return dw
 
 
@@ -284,19 +292,23 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0):
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None):
+    """grad_out = (dgamma_buf, dbeta_buf): accumulate the parameter gradients into these buffers in place."""
     _dev(dy, x, gamma, mean, rstd, add)
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty_like(x)
     dgamma = dbeta = partial = None
     if need_param_grads:
-        dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
-        dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
+        if grad_out is not None:
+            dgamma, dbeta = grad_out
+        else:
+            dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
+            dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
         nparts = lib().js2t_colsum_partial_rows(rows)
         partial = torch.empty((2 * max(nparts, 1) * D,), dtype=torch.float32, device=x.device)
     check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
-                                   _p(partial),
+                                   _p(partial), int(grad_out is not None and need_param_grads),
                                    C.c_int64(rows), C.c_int64(D), dt_code(x), _stream()), "js2t_layernorm_bwd")
     return dx, dgamma, dbeta
 

@@ -83,6 +83,23 @@ class ParamStore:
                 off, n = self.offsets[id(p)], p.numel()
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
 
+    def grad_view(self, params: Sequence[nn.Parameter]) -> Optional[torch.Tensor]:
+        """fp32 view of flat_grad over adjacent parameters — the target kernels accumulate gradients into directly.
+        None unless every parameter requires grad and its .grad currently IS its slice of flat_grad."""
+        try:
+            offs = [self.offsets[id(p)] for p in params]
+        except KeyError:
+            return None
+        base_ptr = self.flat_grad.data_ptr()
+        for i, p in enumerate(params):
+            if not p.requires_grad or p.grad is None or p.grad.data_ptr() != base_ptr + 4 * offs[i]:
+                return None
+            if i and (offs[i] != offs[i - 1] + params[i - 1].numel() or p.shape[1:] != params[0].shape[1:]):
+                return None
+        rows = sum(p.shape[0] for p in params)
+        n = sum(p.numel() for p in params)
+        return self.flat_grad[offs[0]:offs[0] + n].view(rows, *params[0].shape[1:])
+
     # ---- compute-dtype views --------------------------------------------------------------------
     def refresh(self, force: bool = False):
         """Re-cast the bf16 shadow from the fp32 master (one kernel over the whole store)."""
@@ -131,6 +148,8 @@ class Runtime:
         self.compute_dtype = compute_dtype
         self.store: Optional[ParamStore] = None
         self._rng: Optional[ops.DropoutRng] = None
+        self.direct_grads = True  # kernels accumulate parameter gradients straight into the flat gradient buffer
+        self.on_grads_ready = None  # callable(list of params): DDP bucket bookkeeping for directly written gradients
 
     @property
     def rng(self) -> ops.DropoutRng:
@@ -161,6 +180,28 @@ class Runtime:
                 return v
         bs = [p.data for p in params]
         return bs[0] if len(bs) == 1 else torch.cat(bs, dim=0)
+
+    def grad_sink(self, params: Sequence[Optional[nn.Parameter]]) -> Optional[torch.Tensor]:
+        if self.store is None or not self.direct_grads or any(p is None for p in params):
+            return None
+        return self.store.grad_view(params)
+
+    def sinks(self, mapping) -> Optional[dict]:
+        """{name: [params]} -> {name: flat-gradient view}, all or nothing (None when autograd should carry the
+        parameter gradients instead: no flat store, grads not attached, frozen parameters, no_grad mode)."""
+        if not torch.is_grad_enabled():
+            return None
+        out = {}
+        for name, ps in mapping.items():
+            v = self.grad_sink(ps)
+            if v is None:
+                return None
+            out[name] = v
+        return out
+
+    def grads_ready(self, params):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready([p for p in params if p is not None])
 
     def act_in(self, x: torch.Tensor) -> torch.Tensor:
         """Bring an activation into the compute dtype (autocast-style entry cast)."""

@@ -46,6 +46,7 @@ class TrainStep:
         self.micro = 0
         self.sync_every_backward = sync_every_backward
         self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets) if use_ddp() else None
+        self.rt.on_grads_ready = self.reducer.params_ready if self.reducer is not None else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
 

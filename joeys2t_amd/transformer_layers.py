@@ -74,9 +74,17 @@ class MultiHeadedAttention(nn.Module):
                           attn_dropout=self.dropout.p, out_dropout=out_dropout, need_weights=need_weights)
         wts = self._weights(rt, kind)
         params = self._attn_params()
+        k_, v_, q_, o_ = self.k_layer, self.v_layer, self.q_layer, self.output_layer
+        smap = {"w_out": [o_.weight], "b_out": [o_.bias]}
+        if kind == "self":
+            smap.update(w_in=[k_.weight, v_.weight, q_.weight], b_in=[k_.bias, v_.bias, q_.bias])
+        else:
+            smap.update(w_kv=[k_.weight, v_.weight], b_kv=[k_.bias, v_.bias], w_q=[q_.weight], b_q=[q_.bias])
         if ln is not None:
             wts["ln_g"], wts["ln_b"] = ln.weight.data, ln.bias.data
             params = params + [ln.weight, ln.bias]
+            smap.update(ln_g=[ln.weight], ln_b=[ln.bias])
+        wts["sink"], wts["notify"] = rt.sinks(smap), rt.grads_ready
         rng = _rng(rt, x) if cfg.any_dropout else None
         if mask is not None and not mask.is_contiguous():
             mask = mask.contiguous()
@@ -125,7 +133,10 @@ class PositionwiseFeedForward(nn.Module):
         cfg = Fn.BlockCfg(kind="ffn", alpha=self.alpha, ln_mode=self._layer_norm_position, act=self._activation,
                           training=self.training, attn_dropout=p, out_dropout=p)
         wts = {"w1": rt.weight([l1.weight]), "b1": rt.bias([l1.bias]), "w2": rt.weight([l2.weight]),
-               "b2": rt.bias([l2.bias]), "ln_g": self.layer_norm.weight.data, "ln_b": self.layer_norm.bias.data}
+               "b2": rt.bias([l2.bias]), "ln_g": self.layer_norm.weight.data, "ln_b": self.layer_norm.bias.data,
+               "sink": rt.sinks({"w1": [l1.weight], "b1": [l1.bias], "w2": [l2.weight], "b2": [l2.bias],
+                                 "ln_g": [self.layer_norm.weight], "ln_b": [self.layer_norm.bias]}),
+               "notify": rt.grads_ready}
         rng = _rng(rt, x) if cfg.any_dropout else None
         return Fn.ResidualBlockFn.apply(cfg, rng, x, None, None, wts, l1.weight, l1.bias, l2.weight, l2.bias,
                                         self.layer_norm.weight, self.layer_norm.bias)

@@ -120,3 +120,22 @@ def test_training_mode_dropout_runs_and_is_finite(device):
         assert all(torch.isfinite(p.grad).all() for p in model.parameters())
     assert losses[0] != losses[1]  # fresh masks every step
     assert abs(losses[0] - g["loss_total"]) < 0.5 * abs(g["loss_total"])
+
+
+@pytest.mark.parametrize("name", ["model_pre", "model_post"])
+def test_direct_gradient_accumulation_into_flat_store(device, name):
+    """With param.grad attached to the flat store, kernels accumulate gradients in place (no autograd adds):
+    two identical micro-batches must leave exactly twice the reference gradient in the flat buffer."""
+    model, g = build(name, device)
+    store = model.runtime.store
+    store.attach_grads(zero=True)
+    b = batch_kwargs(g, device)
+    for _ in range(2):
+        total, *_ = model(return_type="loss", **vars(b))
+        total.backward()
+    for n, p in model.named_parameters():
+        ref = 2.0 * torch.from_numpy(g[f"grad.{n}"])
+        assert p.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * store.offsets[id(p)]
+        scale = ref.abs().max().item() + 1e-6
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 1e-4 * scale + 2e-5, (n, err, scale)
