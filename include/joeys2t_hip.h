@@ -289,6 +289,30 @@ int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_
                    float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
                    int32_t n_forbid, float length_penalty, js2t_stream stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * Fused multi-head attention (bf16, head size 128): softmax(mask(q k^T * scale)) [dropout] v without
+ * materialising the [B,H,Tq,Tk] scores — MultiHeadedAttention.forward, transformer_layers.py:86-105, and its
+ * backward.  Head h of token (b,t) lives at ptr[(b*T + t)*ld + h*128 ..]; pointers are pre-offset into fused
+ * k|v|q buffers.  mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k] (mask_sq = 0 for key padding),
+ * NULL = none.  lse: f32[B*H, Tq] row log-sum-exp (written by fwd, read by bwd); delta: f32[B*H, Tq] workspace.
+ * Dropout draws the same masks as js2t_softmax_fwd for equal (rng_state, rng_stream).
+ */
+typedef struct js2t_attn_desc {
+  const void* q; const void* k; const void* v;
+  void* o;            /* fwd: output [B*Tq, ldo]; bwd: the forward output (input) */
+  const void* d_o;    /* bwd: gradient of o */
+  void* dq; void* dk; void* dv; /* bwd outputs */
+  float* lse; float* delta;
+  const uint8_t* mask;
+  int64_t ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv, mask_sb, mask_sq;
+  int32_t B, H, Tq, Tk, head_dim;
+  float scale, dropout_p;
+  const uint64_t* rng_state;
+  uint32_t rng_stream;
+} js2t_attn_desc;
+int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
+int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

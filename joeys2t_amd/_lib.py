@@ -45,6 +45,20 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnDesc(C.Structure):
+    """Mirror of js2t_attn_desc (include/joeys2t_hip.h)."""
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("d_o", C.c_void_p),
+        ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("lse", C.c_void_p), ("delta", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64), ("ld_do", C.c_int64),
+        ("ld_dq", C.c_int64), ("ld_dk", C.c_int64), ("ld_dv", C.c_int64), ("mask_sb", C.c_int64), ("mask_sq", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("head_dim", C.c_int32),
+        ("scale", C.c_float), ("dropout_p", C.c_float),
+        ("rng_state", C.c_void_p), ("rng_stream", C.c_uint32),
+    ]
+
+
 def declared_symbols(header: Path = HEADER_PATH):
     """Names of every function declared in the public header."""
     text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)

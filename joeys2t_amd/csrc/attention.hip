@@ -1,0 +1,594 @@
+// Fused ("flash") multi-head attention for bf16, head size 128 — forward, dK/dV and dQ kernels.
+//
+// Replaces the materialised chain of MultiHeadedAttention.forward (transformer_layers.py:86-105):
+//   scores = (q/sqrt(dh)) k^T ; masked_fill(~mask, -inf) ; softmax ; dropout ; @ v
+// and its autograd backward.  Scores and probabilities never touch HBM (the [B,H,T,T] tensors were ~5 passes of
+// 72 MB per layer); K/V (forward, dQ) or Q/dO (dK/dV) tiles are staged in LDS by LDS-DMA, QK^T / PV / the three
+// backward products run on v_mfma_f32_16x16x32_bf16, the online softmax reduces with wavefront shuffles.
+//
+// Geometry (all three kernels): 256 threads = 4 waves; a wave owns 32 "own" rows (two 16-row MFMA column blocks) of
+// one (batch, head) and sweeps the other sequence in 64-row tiles held in LDS as [64][128] bf16 images (256 B rows,
+// 16-byte chunk c of row r stored at slot c ^ ((r&7)<<1): conflict-free for both ds_read_b128 row reads and
+// ds_read_b64_tr_b16 transposed reads, applied on the DMA source address).  MFMAs are issued "swapped"
+// (D rows = tile rows / head columns, D cols = own rows) so that each lane holds, for ONE own row, 4 consecutive
+// tile rows — the probability registers are then directly the B operand of the next product, with the k index
+// permuted as {sub-tile 2s rows 4g..4g+3, sub-tile 2s+1 rows 4g..4g+3}; the transposed LDS reads use the same order.
+//
+// Dropout uses the same counter hash and (row, col4) indexing as softmax_fwd_kernel, so fused and unfused paths
+// draw identical masks (tests compare them).  A row whose keys are all masked yields NaN like the reference.
+#include "common.hpp"
+
+namespace {
+
+constexpr int DH = 128;
+constexpr int IMG_BYTES = 64 * DH * 2;  // 16 KiB
+typedef __attribute__((address_space(1))) const void g_cvoid;
+typedef __attribute__((address_space(3))) void l_void;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+struct AttnArgs {
+  const uint16_t* q; const uint16_t* k; const uint16_t* v; const uint16_t* o; const uint16_t* d_o;
+  uint16_t* out;   // fwd: O ; bwd: unused
+  uint16_t* dq; uint16_t* dk; uint16_t* dv;
+  float* lse;      // [B*H, Tq]
+  float* delta;    // [B*H, Tq] rowsum(dO * O)
+  const uint8_t* mask;
+  int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, msb, msq;
+  int B, H, Tq, Tk;
+  float scale, p;
+  const uint64_t* rng;
+  uint32_t stream;
+};
+
+// HBM -> LDS image of 64 rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave
+__device__ __forceinline__ void img_dma(const uint16_t* base, int64_t ld, int row0, int rows_max, unsigned char* img, int t) {
+  const int w = t >> 6, lane = t & 63;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = (w * 4 + q) * 64 + lane;
+    const int row = p >> 4, slot = p & 15;
+    const int chunk = slot ^ ((row & 7) << 1);
+    const uint16_t* src = base + (int64_t)min(row0 + row, rows_max - 1) * ld + chunk * 8;
+    __builtin_amdgcn_global_load_lds((g_cvoid*)src, (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+  }
+}
+// row fragment: 8 consecutive head columns (32*ks + 8*(lane>>4) ..) of image row rb + (lane&15)
+__device__ __forceinline__ bf16x8_t img_row(const unsigned char* img, int rb, int ks, int lane) {
+  const int row = rb + (lane & 15), chunk = 4 * ks + (lane >> 4);
+  return *(const bf16x8_t*)(img + row * 256 + ((chunk ^ ((row & 7) << 1)) << 4));
+}
+// transposed fragment for k-step s and head-column tile ct: element j<4 = row 32s+4g+j, j>=4 = row 32s+16+4g+(j-4),
+// column 16*ct + (lane&15)
+__device__ __forceinline__ bf16x8_t img_tr(const unsigned char* img, int s, int ct, int lane) {
+  const int gl = lane & 15, qq = gl >> 2, p = gl & 3, g = lane >> 4;
+  const int r1 = 32 * s + 4 * g + qq, r2 = r1 + 16;
+  const int cc = 2 * ct + (p >> 1), off = 8 * (p & 1);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r1 * 256 + ((cc ^ ((r1 & 7) << 1)) << 4) + off));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r2 * 256 + ((cc ^ ((r2 & 7) << 1)) << 4) + off));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// own-row fragments straight from HBM: rows rb + (lane&15) (clamped), columns 32*ks + 8*(lane>>4) ..
+__device__ __forceinline__ void own_frags(const uint16_t* base, int64_t ld, int rb, int rows_max, int lane, bf16x8_t (&f)[4]) {
+  const int row = min(rb + (lane & 15), rows_max - 1);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8_t*)(base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
+}
+__device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
+  const s16x8_t v = {(short)f32_to_bf16_bits(a[0]), (short)f32_to_bf16_bits(a[1]), (short)f32_to_bf16_bits(a[2]),
+                     (short)f32_to_bf16_bits(a[3]), (short)f32_to_bf16_bits(b[0]), (short)f32_to_bf16_bits(b[1]),
+                     (short)f32_to_bf16_bits(b[2]), (short)f32_to_bf16_bits(b[3])};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ float quad_max(float v) {  // over the 4 lanes that share (lane & 15)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) {
+  uint2 pk;
+  pk.x = (uint32_t)f32_to_bf16_bits(v[0] * sc) | ((uint32_t)f32_to_bf16_bits(v[1] * sc) << 16);
+  pk.y = (uint32_t)f32_to_bf16_bits(v[2] * sc) | ((uint32_t)f32_to_bf16_bits(v[3] * sc) << 16);
+  *(uint2*)p = pk;
+}
+
+// Key validity for key-padding masks (mask_sq == 0) is staged ONCE per block in LDS as bytes; per tile a lane then
+// needs 4 ds_read_b32 instead of 16-32 dependent global byte loads in the inner loop.
+constexpr int KMASK_MAX = 8192;
+__device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, int b, int nkeys_padded, int t) {
+  for (int k = t; k < nkeys_padded; k += 256) {
+    bool on = k < a.Tk;
+    if (on && a.mask && a.msq == 0) on = a.mask[(int64_t)b * a.msb + k] != 0;
+    kmask[k] = on ? 1 : 0;
+  }
+}
+// 16 validity bits of this lane's keys in tile kt: bit (4*tt + r) <-> key 64kt + 16tt + 4g + r
+__device__ __forceinline__ uint32_t tile_kbits(const uint8_t* kmask, int kt, int g) {
+  uint32_t bits = 0;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const uint32_t w4 = *(const uint32_t*)(kmask + 64 * kt + 16 * tt + 4 * g);  // 4 bytes, each 0/1
+    bits |= ((w4 & 1u) | ((w4 >> 7) & 2u) | ((w4 >> 14) & 4u) | ((w4 >> 21) & 8u)) << (4 * tt);
+  }
+  return bits;
+}
+// per-query full mask (mask_sq != 0): AND the row's bytes into the key bits
+__device__ __forceinline__ uint32_t row_kbits(uint32_t bits, const uint8_t* mrow, int kt, int g, int Tk) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 64 * kt + 16 * tt + 4 * g + r;
+      if (key < Tk && !mrow[key]) bits &= ~(1u << (4 * tt + r));
+    }
+  return bits;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
+  __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  bf16x8_t qf[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
+  f32x4_t o[2][8];
+  float mi[2], li[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    mi[mt] = -INFINITY;
+    li[mt] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) o[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
+  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const int nkt = (a.Tk + 63) / 64;
+  const bool full_mask = a.mask && a.msq != 0;
+  uint32_t rowkey[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  const uint32_t thr = (uint32_t)(a.p * 65536.0f);
+  stage_kmask(kmask, a, b, nkt * 64, t);
+  img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
+  img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      img_dma(Kb, a.ldk, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma(Vb, a.ldv, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+    }
+    const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
+    const unsigned char* Vi = Ki + IMG_BYTES;
+    const uint32_t kbits = tile_kbits(kmask, kt, g);
+    // S^T = K Q^T : s[mt][tt][r] = score(query q0+16mt+m, key 64kt + 16tt + 4g + r)
+    f32x4_t s[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) s[mt][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = img_row(Ki, 16 * tt, ks, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) s[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], s[mt][tt], 0, 0, 0);
+      }
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int qrow = q0 + 16 * mt + m;
+      const int qc = min(qrow, a.Tq - 1);
+      uint32_t bits = kbits;
+      if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool on = (bits >> (4 * tt + r)) & 1u;
+          const float v = on ? s[mt][tt][r] * a.scale : -INFINITY;
+          s[mt][tt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = quad_max(mx);
+      const float mnew = fmaxf(mi[mt], mx);
+      const float msafe = mnew == -INFINITY ? 0.f : mnew;
+      const float corr = __expf(mi[mt] - msafe);  // exp(-inf) = 0 on the first live tile
+      float rs = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        uint32_t keep = 0xFu;
+        if (a.p > 0.f) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
+          const uint32_t c4 = (uint32_t)(16 * kt + 4 * tt + g);
+          const uint32_t h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
+          keep = ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
+                 ((h1 >> 16) >= thr ? 8u : 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(s[mt][tt][r] - msafe);
+          rs += pv;
+          s[mt][tt][r] = ((keep >> r) & 1u) ? pv * drop_sc : 0.f;
+        }
+      }
+      rs = quad_sum(rs);
+      li[mt] = li[mt] * corr + rs;
+      mi[mt] = mnew;
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[mt][ct][r] *= corr;
+      pf[mt][0] = pack8(s[mt][0], s[mt][1]);
+      pf[mt][1] = pack8(s[mt][2], s[mt][3]);
+    }
+    // O^T += V^T P^T
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8_t vf = img_tr(Vi, ss, ct, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) o[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][ss], o[mt][ct], 0, 0, 0);
+      }
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int qrow = q0 + 16 * mt + m;
+    if (qrow >= a.Tq) continue;
+    const float inv = li[mt] > 0.f ? 1.f / li[mt] : NAN;  // all keys masked -> NaN, as softmax over -inf
+    uint16_t* orow = a.out + ((int64_t)b * a.Tq + qrow) * a.ldo + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) store4(orow + 16 * ct + 4 * g, o[mt][ct], inv);
+    if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi[mt] + __logf(li[mt]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO*O)
+__global__ void attn_delta_kernel(AttnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Tq*H
+  if (row >= (int64_t)a.B * a.Tq * a.H) return;
+  const int64_t bt = row / a.H;
+  const int h = (int)(row - bt * a.H);
+  const int b = (int)(bt / a.Tq), q = (int)(bt - (int64_t)b * a.Tq);
+  const uint16_t* orow = a.o + bt * a.ldo + h * DH;
+  const uint16_t* grow = a.d_o + bt * a.lddo + h * DH;
+  float s = 0.f;
+  for (int c = lane; c < DH; c += 64) s += bf16_bits_to_f32(orow[c]) * bf16_bits_to_f32(grow[c]);
+  s = wave_sum(s);
+  if (lane == 0) a.delta[((int64_t)b * a.H + h) * a.Tq + q] = s;
+}
+
+// shared by both backward kernels: probability and dS for one (own row mt, tile rows) block
+// ------------------------------------------------------------------------------------------------ dQ
+// own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
+// 1 wave per SIMD: the 128 persistent accumulator/operand registers + tile temporaries need the wide register budget
+__global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
+  const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  bf16x8_t qf[2][4], gf[2][4];
+  float lse[2], dl[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
+    own_frags(Gb, a.lddo, q0 + 16 * mt, a.Tq, lane, gf[mt]);
+    const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
+    lse[mt] = a.lse[(int64_t)z * a.Tq + qc];
+    dl[mt] = a.delta[(int64_t)z * a.Tq + qc];
+  }
+  f32x4_t dq[2][8];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) dq[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
+  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const int nkt = (a.Tk + 63) / 64;
+  const bool full_mask = a.mask && a.msq != 0;
+  uint32_t rowkey[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  const uint32_t thr = (uint32_t)(a.p * 65536.0f);
+  stage_kmask(kmask, a, b, nkt * 64, t);
+  img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
+  img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      img_dma(Kb, a.ldk, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma(Vb, a.ldv, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+    }
+    const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
+    const unsigned char* Vi = Ki + IMG_BYTES;
+    const uint32_t kbits = tile_kbits(kmask, kt, g);
+    bf16x8_t dsf[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {  // one own-row block at a time keeps the S / dP accumulators at 32 VGPRs
+      f32x4_t s[4], dp[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ki, 16 * tt, ks, lane), qf[mt][ks], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Vi, 16 * tt, ks, lane), gf[mt][ks], dp[tt], 0, 0, 0);
+        }
+      const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
+      uint32_t bits = kbits;
+      if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        uint32_t keep = 0xFu;
+        if (a.p > 0.f) {
+          const uint32_t c4 = (uint32_t)(16 * kt + 4 * tt + g);
+          const uint32_t h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
+          keep = ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
+                 ((h1 >> 16) >= thr ? 8u : 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool on = (bits >> (4 * tt + r)) & 1u;
+          const float pv = on ? __expf(s[tt][r] * a.scale - lse[mt]) : 0.f;
+          const float dpv = ((keep >> r) & 1u) ? dp[tt][r] * drop_sc : 0.f;
+          s[tt][r] = pv * (dpv - dl[mt]) * a.scale;  // dS (scaled for dQ = dS K / sqrt(dh))
+        }
+      }
+      dsf[mt][0] = pack8(s[0], s[1]);
+      dsf[mt][1] = pack8(s[2], s[3]);
+    }
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8_t kt_f = img_tr(Ki, ss, ct, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) dq[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[mt][ss], dq[mt][ct], 0, 0, 0);
+      }
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int qrow = q0 + 16 * mt + m;
+    if (qrow >= a.Tq) continue;
+    uint16_t* drow = a.dq + ((int64_t)b * a.Tq + qrow) * a.lddq + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) store4(drow + 16 * ct + 4 * g, dq[mt][ct], 1.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK / dV
+// own rows = keys; sweeps query tiles; Q image (row + transposed reads) and dO image (row + transposed reads)
+__global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float lse_s[2][64], dl_s[2][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
+  const int k0 = blockIdx.x * 128 + w * 32;
+  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
+  const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  bf16x8_t kf[2][4], vf[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    own_frags(Kb, a.ldk, k0 + 16 * nt, a.Tk, lane, kf[nt]);
+    own_frags(Vb, a.ldv, k0 + 16 * nt, a.Tk, lane, vf[nt]);
+  }
+  f32x4_t dk[2][8], dv[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      dk[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dv[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
+  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const uint32_t thr = (uint32_t)(a.p * 65536.0f);
+  const bool full_mask = a.mask && a.msq != 0;
+  bool key_valid[2];  // key-padding masks depend on the own key only: resolved once, outside the query sweep
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int key = k0 + 16 * nt + m;
+    key_valid[nt] = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
+  }
+  const int nqt = (a.Tq + 63) / 64;
+  img_dma(Qb, a.ldq, 0, a.Tq, smem, t);
+  img_dma(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
+  int cur = 0;
+  for (int qt = 0; qt < nqt; ++qt) {
+    if (t < 64) {
+      const int qc = min(qt * 64 + t, a.Tq - 1);
+      lse_s[cur][t] = a.lse[(int64_t)z * a.Tq + qc];
+      dl_s[cur][t] = a.delta[(int64_t)z * a.Tq + qc];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (qt + 1 < nqt) {
+      img_dma(Qb, a.ldq, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma(Gb, a.lddo, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+    }
+    const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
+    const unsigned char* Gi = Qi + IMG_BYTES;
+    // S = Q K^T and dP = dO V^T with D rows = tile queries, D cols = own keys:
+    // s[nt][tt][r] <-> (query 64qt + 16tt + 4g + r, key k0 + 16nt + m)
+    bf16x8_t pf[2][2], dsf[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {  // one own-key block at a time (register budget)
+      f32x4_t s[4], dp[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Qi, 16 * tt, ks, lane), kf[nt][ks], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Gi, 16 * tt, ks, lane), vf[nt][ks], dp[tt], 0, 0, 0);
+        }
+      const int key = k0 + 16 * nt + m;
+      const bool key_ok = key_valid[nt];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * tt + 4 * g + r;
+          const int qrow = qt * 64 + ql;
+          bool on = key_ok && qrow < a.Tq;
+          if (on && full_mask) on = a.mask[(int64_t)b * a.msb + (int64_t)qrow * a.msq + key] != 0;
+          const float pv = on ? __expf(s[tt][r] * a.scale - lse_s[cur][ql]) : 0.f;
+          bool keep = true;
+          if (a.p > 0.f) {
+            // same decision as dropout_keep4_key(row = z*Tq + q, col4 = key/4) bit (key & 3)
+            const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(qrow, a.Tq - 1)) ^ dkey);
+            const uint32_t hh = hash32(rowkey + 2u * (uint32_t)(key >> 2) + (uint32_t)((key >> 1) & 1));
+            keep = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= thr;
+          }
+          const float dpv = keep ? dp[tt][r] * drop_sc : 0.f;
+          s[tt][r] = keep ? pv * drop_sc : 0.f;                 // dropped probability (for dV)
+          dp[tt][r] = pv * (dpv - dl_s[cur][ql]) * a.scale;      // dS (for dK)
+        }
+      pf[nt][0] = pack8(s[0], s[1]);
+      pf[nt][1] = pack8(s[2], s[3]);
+      dsf[nt][0] = pack8(dp[0], dp[1]);
+      dsf[nt][1] = pack8(dp[2], dp[3]);
+    }
+    // dV^T += dO^T Pd ; dK^T += Q^T dS   (contraction over the tile's queries)
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8_t gt = img_tr(Gi, ss, ct, lane);
+        const bf16x8_t qt_f = img_tr(Qi, ss, ct, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          dv[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf[nt][ss], dv[nt][ct], 0, 0, 0);
+          dk[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[nt][ss], dk[nt][ct], 0, 0, 0);
+        }
+      }
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int key = k0 + 16 * nt + m;
+    if (key >= a.Tk) continue;
+    uint16_t* krow = a.dk + ((int64_t)b * a.Tk + key) * a.lddk + h * DH;
+    uint16_t* vrow = a.dv + ((int64_t)b * a.Tk + key) * a.lddv + h * DH;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      store4(krow + 16 * ct + 4 * g, dk[nt][ct], 1.f);
+      store4(vrow + 16 * ct + 4 * g, dv[nt][ct], 1.f);
+    }
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return JS2T_ERR_LAUNCH;
+  }
+  return JS2T_OK;
+}
+
+int check_common(const js2t_attn_desc* d) {
+  JS2T_CHECK(d != nullptr, "flash_attn: null descriptor");
+  JS2T_CHECK(d->head_dim == DH, "flash_attn: head size %d not supported (128 only; use the unfused path)", d->head_dim);
+  JS2T_CHECK(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "flash_attn: bad sizes");
+  JS2T_CHECK(d->Tk <= KMASK_MAX - 64, "flash_attn: at most %d keys", KMASK_MAX - 64);
+  JS2T_CHECK((int64_t)d->B * d->H <= 65535, "flash_attn: B*H too large");
+  JS2T_CHECK(d->q && d->k && d->v && d->lse, "flash_attn: null pointer");
+  JS2T_CHECK((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "flash_attn: leading dims must be multiples of 8");
+  JS2T_CHECK(((((uintptr_t)d->q) | ((uintptr_t)d->k) | ((uintptr_t)d->v)) & 15) == 0, "flash_attn: q/k/v must be 16-byte aligned");
+  JS2T_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f && (d->dropout_p == 0.f || d->rng_state), "flash_attn: bad dropout args");
+  return JS2T_OK;
+}
+
+AttnArgs to_args(const js2t_attn_desc* d) {
+  AttnArgs a;
+  a.q = (const uint16_t*)d->q; a.k = (const uint16_t*)d->k; a.v = (const uint16_t*)d->v;
+  a.o = (const uint16_t*)d->o; a.d_o = (const uint16_t*)d->d_o; a.out = (uint16_t*)d->o;
+  a.dq = (uint16_t*)d->dq; a.dk = (uint16_t*)d->dk; a.dv = (uint16_t*)d->dv;
+  a.lse = d->lse; a.delta = d->delta; a.mask = d->mask;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo; a.lddo = d->ld_do; a.lddq = d->ld_dq; a.lddk = d->ld_dk;
+  a.lddv = d->ld_dv; a.msb = d->mask_sb; a.msq = d->mask_sq;
+  a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk;
+  a.scale = d->scale; a.p = d->dropout_p; a.rng = d->rng_state; a.stream = d->rng_stream;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) {
+  int rc = check_common(d);
+  if (rc) return rc;
+  JS2T_CHECK(d->o && (d->ldo % 4) == 0 && ((((uintptr_t)d->o)) & 7) == 0, "flash_attn_fwd: bad output");
+  static bool once = false;
+  if (!once) {
+    rc = set_lds(flash_fwd_kernel, 4 * IMG_BYTES);
+    if (rc) return rc;
+    once = true;
+  }
+  AttnArgs a = to_args(d);
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) {
+  int rc = check_common(d);
+  if (rc) return rc;
+  JS2T_CHECK(d->o && d->d_o && d->dq && d->dk && d->dv && d->delta, "flash_attn_bwd: null pointer");
+  JS2T_CHECK((d->ld_do % 8) == 0 && (d->ld_dq % 4) == 0 && (d->ld_dk % 4) == 0 && (d->ld_dv % 4) == 0 && (d->ldo % 1) == 0,
+             "flash_attn_bwd: bad leading dims");
+  JS2T_CHECK((((uintptr_t)d->d_o) & 15) == 0 && ((((uintptr_t)d->dq) | ((uintptr_t)d->dk) | ((uintptr_t)d->dv)) & 7) == 0,
+             "flash_attn_bwd: misaligned gradient buffers");
+  static bool once = false;
+  if (!once) {
+    rc = set_lds(flash_dq_kernel, 4 * IMG_BYTES);
+    if (rc) return rc;
+    rc = set_lds(flash_dkv_kernel, 4 * IMG_BYTES);
+    if (rc) return rc;
+    once = true;
+  }
+  AttnArgs a = to_args(d);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)d->B * d->Tq * d->H, 4)), dim3(256), 0, s, a);
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

@@ -97,12 +97,20 @@ class AttnShape:
         self.ld = ops.round_up(Tk, 8)  # score row stride: 16-byte rows for the bf16 GEMMs
 
 
-def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, site):
+USE_FLASH = True  # fused attention kernels when the shapes allow (bf16, head size 128); tests flip this to compare
+
+
+def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, site, need_probs=False):
     """softmax(mask(q k^T / sqrt(dh))) v for all heads; q_t/k_t/v_t are [B*T, ld*] row-major 2-D buffers whose
-    head h lives at column off + h*dh.  Returns (ctx[B*Tq, H*dh], P, Pd)."""
+    head h lives at column off + h*dh.  Returns (ctx[B*Tq, H*dh], P, Pd) on the materialised path and
+    (ctx, None, lse) on the fused path (P is None)."""
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
     dev, dt = q_t.device, q_t.dtype
     Z = B * H
+    if USE_FLASH and not need_probs and ops.flash_supported(q_t, k_t, v_t, dh):
+        # fused kernel: scores / probabilities stay on chip; the forward keeps (out, lse) for backward
+        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+        return out, None, lse
     S = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
     ops.gemm(q_t, k_t, S, M=Tq, N=Tk, K=dh, lda=q_t.stride(0), ldb=k_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
              a_strides=(Tq * q_t.stride(0), dh), b_strides=(Tk * k_t.stride(0), dh), c_strides=(H * Tq * ld, Tq * ld),
@@ -115,9 +123,14 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
 
 
 def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, shp: AttnShape, P, Pd, p,
-             rng, site):
-    """Writes dq/dk/dv into the given (row-major 2-D) gradient buffers at the given column offsets."""
+             rng, site, ctx_out=None, mask=None):
+    """Writes dq/dk/dv into the given (row-major 2-D) gradient buffers at the given column offsets.
+    Fused path: P is None, Pd carries the forward's row log-sum-exp and ctx_out its output."""
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
+    if P is None:
+        ops.flash_attn_bwd(dctx, ctx_out, Pd, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off,
+                           B, H, Tq, Tk, dh, mask, p, rng, site)
+        return
     Z = B * H
     dev, dt = dctx.device, dctx.dtype
     sP = (H * Tq * ld, Tq * ld)
@@ -219,7 +232,7 @@ class ResidualBlockFn(torch.autograd.Function):
             q = linear_fwd(n, wts["w_q"], wts["b_q"])
             kv = linear_fwd(m2, wts["w_kv"], wts["b_kv"])  # columns: [k | v]
             shp = AttnShape(B, T, S, H, dh)
-            c, P, Pd = attn_fwd(q, 0, kv, 0, kv, d, shp, mask, p_in, rng, sites[0])
+            c, P, Pd = attn_fwd(q, 0, kv, 0, kv, d, shp, mask, p_in, rng, sites[0], need_probs=cfg.need_weights)
             if cfg.need_weights:
                 att_w = ops.attn_head_mean(P, B, H, T, S, shp.ld)
             saved.update(q=q, kv=kv, m2=m2, P=P, Pd=Pd, shp=shp)
@@ -240,6 +253,7 @@ class ResidualBlockFn(torch.autograd.Function):
         ctx.cfg, ctx.rng, ctx.sites, ctx.wts, ctx.saved = cfg, rng, sites, wts, saved
         ctx.params = params
         ctx.x2, ctx.n, ctx.c = x2, n, c
+        ctx.mask = mask
         ctx.shape = (B, T, d)
         ctx.mem_shape = None if memory is None else tuple(memory.shape)
         ctx.nparams = len(params)
@@ -290,13 +304,14 @@ class ResidualBlockFn(torch.autograd.Function):
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
-                     sites[0])
+                     sites[0], ctx_out=c, mask=ctx.mask)
             dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"))
         else:  # cross
             dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"))
             q, kv = sv["q"], sv["kv"]
             dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-            attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0])
+            attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
+                     ctx_out=c, mask=ctx.mask)
             dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"))
             dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
                                                      dw_out=sk("w_kv"), db_out=sk("b_kv"))

@@ -10,7 +10,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from joeys2t_amd._lib import ACT_CODES, BF16, F32, GemmDesc, Js2tError, check, lib
+from joeys2t_amd._lib import ACT_CODES, BF16, F32, AttnDesc, GemmDesc, Js2tError, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -450,3 +450,61 @@ def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int
                                C.c_int64(V), fb, C.c_int32(len(forbid_ids)), C.c_float(length_penalty), _stream()),
           "js2t_beam_step")
     return scores, ids, lse
+
+
+# ----------------------------------------------------------------------------------------- fused attention
+def _mask_strides(mask, B, Tq, Tk):
+    if mask is None:
+        return 0, 0
+    if mask.dtype != torch.bool or mask.dim() != 3 or mask.shape[2] != Tk or not mask.is_contiguous():
+        raise Js2tError(f"attention mask must be contiguous bool [B|1, 1|Tq, Tk], got {tuple(mask.shape)} {mask.dtype}")
+    if mask.shape[1] not in (1, Tq) or mask.shape[0] not in (1, B):
+        raise Js2tError(f"attention mask shape {tuple(mask.shape)} does not broadcast to [{B},{Tq},{Tk}]")
+    return (0 if mask.shape[0] == 1 else mask.shape[1] * Tk), (0 if mask.shape[1] == 1 else Tk)
+
+
+def flash_supported(q_t, k_t, v_t, dh: int) -> bool:
+    """Fused attention kernel constraints: bf16, head size 128, 16-byte aligned rows."""
+    ok = q_t.dtype == torch.bfloat16 and dh == 128 and k_t.shape[0] >= 1
+    for t in (q_t, k_t, v_t):
+        ok = ok and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+    return ok
+
+
+def _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site):
+    d = AttnDesc()
+    es = q_t.element_size()
+    d.q, d.k, d.v = q_t.data_ptr() + q_off * es, k_t.data_ptr() + k_off * es, v_t.data_ptr() + v_off * es
+    d.ldq, d.ldk, d.ldv = q_t.stride(0), k_t.stride(0), v_t.stride(0)
+    d.B, d.H, d.Tq, d.Tk, d.head_dim = B, H, Tq, Tk, dh
+    d.scale, d.dropout_p = 1.0 / math.sqrt(dh), float(p)
+    if mask is not None:
+        d.mask = mask.data_ptr()
+        d.mask_sb, d.mask_sq = _mask_strides(mask, B, Tq, Tk)
+    if p > 0:
+        d.rng_state, d.rng_stream = rng.state.data_ptr(), int(site)
+    return d
+
+
+def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site):
+    _dev(q_t, k_t, v_t, mask)
+    out = torch.empty((B * Tq, H * dh), dtype=q_t.dtype, device=q_t.device)
+    lse = torch.empty((B * H, Tq), dtype=torch.float32, device=q_t.device)
+    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+    d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
+    check(lib().js2t_flash_attn_fwd(C.byref(d), _stream()), "js2t_flash_attn_fwd")
+    return out, lse
+
+
+def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
+                   dh, mask, p, rng, site):
+    _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask)
+    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+    delta = torch.empty_like(lse)
+    es = q_t.element_size()
+    d.o, d.ldo, d.lse, d.delta = out.data_ptr(), out.stride(0), lse.data_ptr(), delta.data_ptr()
+    d.d_o, d.ld_do = dout.data_ptr(), dout.stride(0)
+    d.dq, d.ld_dq = dq_t.data_ptr() + dq_off * es, dq_t.stride(0)
+    d.dk, d.ld_dk = dk_t.data_ptr() + dk_off * es, dk_t.stride(0)
+    d.dv, d.ld_dv = dv_t.data_ptr() + dv_off * es, dv_t.stride(0)
+    check(lib().js2t_flash_attn_bwd(C.byref(d), _stream()), "js2t_flash_attn_bwd")

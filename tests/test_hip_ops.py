@@ -394,3 +394,76 @@ def test_gemm_bf16_split_k_wgrad(device, bf16_kernel, split):
     ops.gemm(dz.to(device), x.to(device), C, M=rows, N=cols, K=tokens, lda=dz.shape[1], ldb=cols, ldc=cols, trans_a=True,
              trans_b=True, split_k=split)
     torch.testing.assert_close(C.cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
+
+
+# ------------------------------------------------------------------------------------------------ fused attention
+def _attn_ref(q, k, v, mask, H):
+    B, Tq, d = q.shape
+    dh = d // H
+    qh = q.view(B, Tq, H, dh).transpose(1, 2) / math.sqrt(dh)
+    kh = k.view(B, -1, H, dh).transpose(1, 2)
+    vh = v.view(B, -1, H, dh).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3)
+    if mask is not None:
+        s = s.masked_fill(~mask.unsqueeze(1), float("-inf"))
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, d)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,mask_kind", [(2, 2, 75, 75, "pad"), (1, 4, 200, 333, "pad"), (2, 1, 40, 40, "full"),
+                                                 (1, 2, 130, 64, None)])
+def test_flash_attention_matches_reference(device, B, H, Tq, Tk, mask_kind):
+    """Fused bf16 attention (fwd + bwd) against fp32 math on the bf16-rounded inputs."""
+    dh = 128
+    d = H * dh
+    q = rnd(B, Tq, d, seed=1).bfloat16()
+    kv = rnd(B, Tk, 2 * d, seed=2).bfloat16()
+    g = torch.Generator().manual_seed(3)
+    mask = None
+    if mask_kind == "pad":
+        lens = torch.randint(Tk // 2, Tk + 1, (B, ), generator=g)
+        mask = (torch.arange(Tk)[None, :] < lens[:, None]).unsqueeze(1)
+    elif mask_kind == "full":
+        mask = torch.tril(torch.ones(Tq, Tk, dtype=torch.bool)).unsqueeze(0).expand(B, -1, -1).contiguous()
+    qr = q.float().requires_grad_(True)
+    kr = kv.float()[..., :d].clone().requires_grad_(True)
+    vr = kv.float()[..., d:].clone().requires_grad_(True)
+    ref = _attn_ref(qr, kr, vr, mask, H)
+    gy = rnd(B, Tq, d, seed=4).bfloat16()
+    ref.backward(gy.float())
+    shp = Fn.AttnShape(B, Tq, Tk, H, dh)
+    qd, kvd = q.view(B * Tq, d).to(device), kv.view(B * Tk, 2 * d).to(device)
+    md = None if mask is None else mask.to(device)
+    assert ops.flash_supported(qd, kvd, kvd, dh)
+    out, P, lse = Fn.attn_fwd(qd, 0, kvd, 0, kvd, d, shp, md, 0.0, None, 0)
+    assert P is None  # fused path taken
+    bf16_close(out.view(B, Tq, d), ref.detach(), 2e-2)
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    Fn.attn_bwd(gy.view(B * Tq, d).to(device), qd, 0, kvd, 0, kvd, d, dq, 0, dkv, 0, dkv, d, shp, None, lse, 0.0, None, 0,
+                ctx_out=out, mask=md)
+    bf16_close(dq.view(B, Tq, d), qr.grad, 3e-2)
+    bf16_close(dkv.view(B, Tk, 2 * d)[..., :d], kr.grad, 3e-2)
+    bf16_close(dkv.view(B, Tk, 2 * d)[..., d:], vr.grad, 3e-2)
+
+
+def test_flash_attention_dropout_matches_unfused(device):
+    """Same RNG state and call site: the fused kernels must draw exactly the masks of the unfused softmax path."""
+    B, H, Tq, Tk, dh, p = 2, 2, 96, 150, 128, 0.2
+    d = H * dh
+    rng = ops.DropoutRng(device, seed=11)
+    qkv = rnd(B * Tq, 3 * d, seed=1).bfloat16().to(device)
+    mem = rnd(B * Tk, 2 * d, seed=2).bfloat16().to(device)
+    shp = Fn.AttnShape(B, Tq, Tk, H, dh)
+    gy = rnd(B * Tq, d, seed=3).bfloat16().to(device)
+    res = {}
+    for flash in (True, False):
+        Fn.USE_FLASH = flash
+        try:
+            out, P, aux = Fn.attn_fwd(qkv, 2 * d, mem, 0, mem, d, shp, None, p, rng, 7)
+            dq, dkv = torch.zeros_like(qkv), torch.zeros_like(mem)
+            Fn.attn_bwd(gy, qkv, 2 * d, mem, 0, mem, d, dq, 2 * d, dkv, 0, dkv, d, shp, P, aux, p, rng, 7, ctx_out=out)
+            res[flash] = (out.float().cpu(), dq.float().cpu(), dkv.float().cpu())
+        finally:
+            Fn.USE_FLASH = True
+    for a, b in zip(res[True], res[False]):
+        bf16_close(a, b, 3e-2)
