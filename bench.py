@@ -127,11 +127,22 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
             b.sort_by_src_length()  # batch.sort_by_src_length() of training.py:555 (all lengths equal here)
             state["batch"] = b
         state["batch"].src = feats
-        return step.micro_step(state["batch"], sort=False)
+        # single GPU: the update is part of the captured step.  Multi-GPU: forward+backward only; the gradient
+        # exchange (RCCL, bucketed) and the fused update follow the replay.
+        return step.micro_step(state["batch"], sort=False, update=(world == 1), overlap=False)
+
+    def post_body(capturing=False):
+        if world > 1:
+            step.reducer.reduce_all()
+            step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+        if world > 1 or capturing:
+            step.after_update()
 
     def eager_step():
         pre_step()
-        return body()
+        out = body()
+        post_body()
+        return out
 
     graph_holder = {}
 
@@ -147,13 +158,13 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
         pre_step()
         with torch.cuda.graph(g):
             body()
-        step.after_update()
+        post_body(capturing=True)
         graph_holder["g"] = g
 
     def graph_step():
         pre_step()
         graph_holder["g"].replay()
-        step.after_update()
+        post_body(capturing=True)
 
     return eager_step, graph_step, capture, step, frames * BATCH
 
@@ -227,7 +238,7 @@ def main():
 
     from joeys2t_amd import ops
     eager_step, graph_step, capture, step, frames_per_step = build_step(device, world)
-    use_graph = (world == 1) and not args.no_graph  # multi-GPU: eager, so the bucketed all-reduce hooks overlap backward
+    use_graph = not args.no_graph
     one_step = eager_step
     if use_graph:
         capture()

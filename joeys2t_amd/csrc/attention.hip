@@ -441,6 +441,14 @@ __global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
     // S = Q K^T and dP = dO V^T with D rows = tile queries, D cols = own keys:
     // s[nt][tt][r] <-> (query 64qt + 16tt + 4g + r, key k0 + 16nt + m)
     bf16x8_t pf[2][2], dsf[2][2];
+    uint32_t rk[4][4];  // dropout row hashes of this lane's 16 tile queries, shared by both own-key blocks
+    if (a.p > 0.f) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          rk[tt][r] = hash32((uint32_t)(z * a.Tq + min(qt * 64 + 16 * tt + 4 * g + r, a.Tq - 1)) ^ dkey);
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {  // one own-key block at a time (register budget)
       f32x4_t s[4], dp[4];
@@ -470,8 +478,7 @@ __global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
           bool keep = true;
           if (a.p > 0.f) {
             // same decision as dropout_keep4_key(row = z*Tq + q, col4 = key/4) bit (key & 3)
-            const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(qrow, a.Tq - 1)) ^ dkey);
-            const uint32_t hh = hash32(rowkey + 2u * (uint32_t)(key >> 2) + (uint32_t)((key >> 1) & 1));
+            const uint32_t hh = hash32(rk[tt][r] + 2u * (uint32_t)(key >> 2) + (uint32_t)((key >> 1) & 1));
             keep = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= thr;
           }
           const float dpv = keep ? dp[tt][r] * drop_sc : 0.f;

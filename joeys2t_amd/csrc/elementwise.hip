@@ -166,9 +166,10 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __res
 }
 
 // ---------------------------------------------------------------- column sums (two-stage, deterministic)
-// Stage 1: block = 64 columns x 4 row-lanes over a 128-row slab (>= 750 blocks for a [12000, 512] operand, each wave
-// reading 128 B row segments); stage 2 adds the per-slab partials in a fixed order.
-constexpr int CS_ROWS_PER_BLOCK = 256;
+// Stage 1: block = 64 column-chunks x 4 row-lanes over a 64-row slab; a thread owns 8 consecutive columns (16-byte
+// bf16 loads) when the row length allows, else one column.  Stage 2 adds the per-slab partials in a fixed order with
+// 4 partial-lanes per column.
+constexpr int CS_ROWS_PER_BLOCK = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t rows,
                                                              int64_t cols) {
@@ -183,21 +184,53 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   __syncthreads();
   if (sub == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts, int64_t cols,
-                                    int accumulate) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent chains: the loads are L2-latency bound
-  int64_t p = 0;
-  for (; p + 4 <= nparts; p += 4) {
-    s0 += partial[p * cols + c];
-    s1 += partial[(p + 1) * cols + c];
-    s2 += partial[(p + 2) * cols + c];
-    s3 += partial[(p + 3) * cols + c];
+// 8 columns per thread (cols % 8 == 0, 16-byte aligned rows): block covers 512 columns
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial,
+                                                                 int64_t rows, int64_t cols) {
+  __shared__ float sh[4][64][9];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + cl) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK, r1 = min(rows, r0 + CS_ROWS_PER_BLOCK);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < cols)
+    for (int64_t r = r0 + sub; r < r1; r += 4) {
+      const uint4 v = *(const uint4*)(x + r * cols + c);
+      const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[2 * i] += __uint_as_float(vv[i] << 16);
+        s[2 * i + 1] += __uint_as_float(vv[i] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sh[sub][cl][i] = s[i];
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      partial[(int64_t)blockIdx.y * cols + c + i] = (sh[0][cl][i] + sh[1][cl][i]) + (sh[2][cl][i] + sh[3][cl][i]);
   }
-  for (; p < nparts; ++p) s0 += partial[p * cols + c];
-  const float tot = (s0 + s1) + (s2 + s3);
-  out[c] = accumulate ? out[c] + tot : tot;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t nparts,
+                                                           int64_t cols, int accumulate) {
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int64_t p = sub;
+    for (; p + 4 < nparts; p += 8) {
+      s0 += partial[p * cols + c];
+      s1 += partial[(p + 4) * cols + c];
+    }
+    for (; p < nparts; p += 4) s0 += partial[p * cols + c];
+  }
+  sh[sub][cl] = s0 + s1;
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+    const float tot = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    out[c] = accumulate ? out[c] + tot : tot;
+  }
 }
 
 // ---------------------------------------------------------------- conv weight repack
@@ -365,12 +398,16 @@ extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, in
   JS2T_CHECK(x && out && partial && rows > 0, "colsum: bad arguments");
   const int64_t nparts = js2t_colsum_partial_rows(rows);
   JS2T_CHECK(nparts <= 65535, "colsum: too many rows");
-  const dim3 g1(cdiv(cols, 64), (unsigned)nparts);
-  DISPATCH_DT(dt, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), g1, dim3(EW_THREADS), 0, (hipStream_t)stream,
-                                        (const T*)x, partial, rows, cols));
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == JS2T_BF16 && cols % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+    hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(cdiv(cols, 512), (unsigned)nparts), dim3(256), 0, s, (const uint16_t*)x,
+                       partial, rows, cols);
+  } else {
+    const dim3 g1(cdiv(cols, 64), (unsigned)nparts);
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((colsum_partial_kernel<T>), g1, dim3(256), 0, s, (const T*)x, partial, rows, cols));
+  }
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, partial,
-                     out, nparts, cols, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, partial, out, nparts, cols, accumulate);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

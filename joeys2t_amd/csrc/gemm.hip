@@ -407,13 +407,14 @@ __device__ __forceinline__ bf16x8_t frag_load2(const unsigned char* tile, int su
   }
 }
 
-// per-lane source element offsets of the 4 DMA pieces this wave issues for one operand tile
-template <bool TR>
-__device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_max, int k0, int K, int t, int64_t (&off)[4]) {
+// per-lane source element offsets of the NP DMA pieces this wave issues for one operand tile of ROWS rows
+// (kc image: ROWS x 64 k, NP = ROWS/32; tr image: 64 k x 128 rows, NP = 4)
+template <bool TR, int NP>
+__device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_max, int k0, int K, int t, int64_t (&off)[NP]) {
   const int w = t >> 6, lane = t & 63;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int p = (w * 4 + q) * 64 + lane;  // 16-byte slot index inside the 16 KiB tile
+  for (int q = 0; q < NP; ++q) {
+    const int p = (w * NP + q) * 64 + lane;  // 16-byte slot index inside the tile
     if (!TR) {
       const int row = p >> 3, slot = p & 7;
       int chunk = slot ^ (row & 7);
@@ -427,19 +428,19 @@ __device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_ma
     }
   }
 }
-template <bool TR>
-__device__ __forceinline__ void dma_issue(const uint16_t* base, const int64_t (&off)[4], unsigned char* tile, int t) {
+template <int NP>
+__device__ __forceinline__ void dma_issue(const uint16_t* base, const int64_t (&off)[NP], unsigned char* tile, int t) {
   const int w = t >> 6;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * 4 + q) * 1024), 16, 0, 0);
+  for (int q = 0; q < NP; ++q)
+    __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * NP + q) * 1024), 16, 0, 0);
 }
 // zero the LDS slots of a partial last K tile (k >= k_lim)
-template <bool TR>
+template <bool TR, int NP>
 __device__ __forceinline__ void dma_zero_tail(unsigned char* tile, int k_lim, int t) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NP; ++q) {
     const int p = t + 256 * q;
     if (!TR) {
       const int row = p >> 3, slot = p & 7;
@@ -538,15 +539,19 @@ __device__ __forceinline__ void gemm_epilogue8(const js2t_gemm_desc& d, int z, i
   }
 }
 
-template <bool TA, bool TB, bool SPLITK>
+// BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
+// decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
+template <int BM, bool TA, bool TB, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
                                                                int split_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TILE = 16384, STAGE = 2 * TILE;
+  static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
+  constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
+  constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int z = blockIdx.y;
   const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (lid / tiles_n) * F_BM, n0 = (lid % tiles_n) * F_BN;
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
   int64_t ao, bo, co;
   batch_offsets(d, z, ao, bo, co);
   const uint16_t* Ab = (const uint16_t*)d.A + ao;
@@ -554,9 +559,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
   const int wm = w >> 1, wn = w & 1;
   const int M = d.M, N = d.N, K = d.K;
   const int64_t lda = d.lda, ldb = d.ldb;
-  f32x4_t acc[4][4];
+  f32x4_t acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -566,38 +571,38 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
   const int nk = min(per, nk_all - kt0);
   if (SPLITK && nk <= 0) return;
 
-  int64_t oa[4], ob[4];
-  dma_offsets<TA>(lda, m0, M, kt0 * F_BK, K, t, oa);
-  dma_offsets<TB>(ldb, n0, N, kt0 * F_BK, K, t, ob);
-  dma_issue<TA>(Ab, oa, smem, t);
-  dma_issue<TB>(Bb, ob, smem + TILE, t);
+  int64_t oa[NPA], ob[4];
+  dma_offsets<TA, NPA>(lda, m0, M, kt0 * F_BK, K, t, oa);
+  dma_offsets<TB, 4>(ldb, n0, N, kt0 * F_BK, K, t, ob);
+  dma_issue<NPA>(Ab, oa, smem, t);
+  dma_issue<4>(Bb, ob, smem + A_TILE, t);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int k0 = (kt0 + kt) * F_BK;
     // tile kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (k0 + F_BK > K) {
-      dma_zero_tail<TA>(smem + cur * STAGE, K - k0, t);
-      dma_zero_tail<TB>(smem + cur * STAGE + TILE, K - k0, t);
+      dma_zero_tail<TA, NPA>(smem + cur * STAGE, K - k0, t);
+      dma_zero_tail<TB, 4>(smem + cur * STAGE + A_TILE, K - k0, t);
     }
     __syncthreads();
     if (kt + 1 < nk) {  // stream the next tile into the other stage while this one is consumed
-      dma_offsets<TA>(lda, m0, M, k0 + F_BK, K, t, oa);
-      dma_offsets<TB>(ldb, n0, N, k0 + F_BK, K, t, ob);
-      dma_issue<TA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
-      dma_issue<TB>(Bb, ob, smem + (cur ^ 1) * STAGE + TILE, t);
+      dma_offsets<TA, NPA>(lda, m0, M, k0 + F_BK, K, t, oa);
+      dma_offsets<TB, 4>(ldb, n0, N, k0 + F_BK, K, t, ob);
+      dma_issue<NPA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
+      dma_issue<4>(Bb, ob, smem + (cur ^ 1) * STAGE + A_TILE, t);
     }
     const unsigned char* At = smem + cur * STAGE;
-    const unsigned char* Bt = At + TILE;
+    const unsigned char* Bt = At + A_TILE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t fn[4], fm[4];
+      bf16x8_t fn[4], fm[MI];
 #pragma unroll
       for (int j = 0; j < 4; ++j) fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fm[i] = frag_load2<TA>(At, wm * 64 + 16 * i, kk, lane);
+      for (int i = 0; i < MI; ++i) fm[i] = frag_load2<TA>(At, wm * (BM / 2) + 16 * i, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
@@ -611,10 +616,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     __syncthreads();
     float* Cs = (float*)smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ml = wm * 64 + 16 * i + (lane & 15);
+        const int ml = wm * (BM / 2) + 16 * i + (lane & 15);
         const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
         *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
       }
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     const float alpha = d.alpha;
     typedef __attribute__((address_space(1))) float gfloat;
     gfloat* cg = (gfloat*)(c_atomic + co);
-    for (int idx = w; idx < 256; idx += 4) {
+    for (int idx = w; idx < 2 * BM; idx += 4) {
       const int ml = idx >> 1, nl = (idx & 1) * 64 + lane;
       const int m = m0 + ml, n = n0 + nl;
       if (m < M && n < N) {
@@ -636,10 +641,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     __syncthreads();
     float* Cs = (float*)smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ml = wm * 64 + 16 * i + (lane & 15);
+        const int ml = wm * (BM / 2) + 16 * i + (lane & 15);
         const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
         *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
       }
@@ -655,9 +660,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     const bool full8 = n + 8 <= N;
     const bool vec_rg = full8 && d.dtype_c == JS2T_BF16 && (!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
                         (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0));
-    uint4 res_pk[8], gate_pk[8];
+    constexpr int NPASS = BM / 16;
+    uint4 res_pk[NPASS], gate_pk[NPASS];
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       res_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
       gate_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
       const int m = m0 + pass * 16 + (t >> 4);
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
       }
     }
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       const int ml = pass * 16 + (t >> 4);
       const int m = m0 + ml;
       if (m < M && n < N) {
@@ -680,12 +686,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
   }
 }
 
-template <bool TA, bool TB, bool SPLITK>
-int launch_bf16_dma(const js2t_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = 65536;
+template <int BM, bool TA, bool TB, bool SPLITK>
+int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
+  constexpr int LDS = (BM == 128 || TA) ? 65536 : 2 * (BM * 128 + 16384) > BM * 128 * 4 ? 2 * (BM * 128 + 16384) : BM * 128 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<TA, TB, SPLITK>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, TA, TB, SPLITK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -693,11 +699,20 @@ int launch_bf16_dma(const js2t_gemm_desc& d, hipStream_t s) {
     }
     attr_set = true;
   }
-  const int tm = cdiv(d.M, F_BM), tn = cdiv(d.N, F_BN);
-  hipLaunchKernelGGL((gemm_bf16_dma_kernel<TA, TB, SPLITK>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS, s,
+  const int tm = cdiv(d.M, BM), tn = cdiv(d.N, F_BN);
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, TA, TB, SPLITK>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS, s,
                      d, tm, tn, (float*)d.C, d.split_k);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
+}
+template <bool TA, bool TB, bool SPLITK>
+int launch_bf16_dma(const js2t_gemm_desc& d, hipStream_t s) {
+  if constexpr (!TA && !SPLITK) {
+    // few 128x128 tiles (N = 512 layers, decoder-sized M): halve the row tile to put ~2x more blocks on the 256 CUs
+    const int64_t tiles = (int64_t)cdiv(d.M, 128) * cdiv(d.N, F_BN) * d.batch;
+    if (tiles < 512 && d.M > 64) return launch_bf16_dma_bm<64, TA, TB, SPLITK>(d, s);
+  }
+  return launch_bf16_dma_bm<128, TA, TB, SPLITK>(d, s);
 }
 
 template <bool TA, bool TB, bool SPLITK>

@@ -94,24 +94,198 @@ __global__ __launch_bounds__(256) void layernorm_bwd_param_partial_kernel(const 
     partial[((int64_t)blockIdx.y * 2 + 1) * D + c] = (shb[0][cl] + shb[1][cl]) + (shb[2][cl] + shb[3][cl]);
   }
 }
-__global__ void layernorm_bwd_param_final_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, int64_t nparts, int64_t D, int accumulate) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= D) return;
+__global__ __launch_bounds__(256) void layernorm_bwd_param_final_kernel(const float* __restrict__ partial,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                        int64_t nparts, int64_t D, int accumulate) {
+  // block = 64 columns x 4 partial-lanes; fixed summation order -> bit-reproducible
+  __shared__ float shg[4][64], shb[4][64];
+  const int cl = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
   float sg0 = 0.f, sg1 = 0.f, sb0 = 0.f, sb1 = 0.f;
-  int64_t p = 0;
-  for (; p + 2 <= nparts; p += 2) {
-    sg0 += partial[(p * 2 + 0) * D + c];
-    sb0 += partial[(p * 2 + 1) * D + c];
-    sg1 += partial[(p * 2 + 2) * D + c];
-    sb1 += partial[(p * 2 + 3) * D + c];
+  if (c < D) {
+    int64_t p = sub;
+    for (; p + 4 < nparts; p += 8) {
+      sg0 += partial[(p * 2 + 0) * D + c];
+      sb0 += partial[(p * 2 + 1) * D + c];
+      sg1 += partial[((p + 4) * 2 + 0) * D + c];
+      sb1 += partial[((p + 4) * 2 + 1) * D + c];
+    }
+    for (; p < nparts; p += 4) {
+      sg0 += partial[(p * 2 + 0) * D + c];
+      sb0 += partial[(p * 2 + 1) * D + c];
+    }
   }
-  for (; p < nparts; ++p) {
-    sg0 += partial[(p * 2 + 0) * D + c];
-    sb0 += partial[(p * 2 + 1) * D + c];
+  shg[sub][cl] = sg0 + sg1;
+  shb[sub][cl] = sb0 + sb1;
+  __syncthreads();
+  if (sub == 0 && c < D) {
+    const float tg = (shg[0][cl] + shg[1][cl]) + (shg[2][cl] + shg[3][cl]);
+    const float tb = (shb[0][cl] + shb[1][cl]) + (shb[2][cl] + shb[3][cl]);
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + tg;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + tb;
   }
-  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (sg0 + sg1);
-  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (sb0 + sb1);
+}
+
+// ---------------------------------------------------------------- vectorised LayerNorm (D % 8 == 0, D <= 2048)
+// One wave per row, every lane owns 8-column chunks (16-byte bf16 / 2 x 16-byte f32 accesses).  The backward kernel
+// also accumulates this block's dgamma/dbeta partial sums in registers while it streams dy and x for dx, so the
+// parameter gradients cost no extra pass over the activations.
+template <typename T> struct ld8;
+template <> struct ld8<uint16_t> {
+  static __device__ __forceinline__ void ld(const uint16_t* p, float (&v)[8]) {
+    const uint4 r = *(const uint4*)p;
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(rr[i] << 16); v[2 * i + 1] = __uint_as_float(rr[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(uint16_t* p, const float (&v)[8]) {
+    uint4 r;
+    r.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+    r.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+    r.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+    r.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+    *(uint4*)p = r;
+  }
+};
+template <> struct ld8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+constexpr int LNV_MAXCH = 4;        // chunks of 8 columns per lane -> D <= 2048
+constexpr int LNV_ROWS = 32;        // rows per 256-thread block in the backward kernel (8 per wave)
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                                int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = D >> 3;
+  float v[LNV_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LNV_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      ld8<T>::ld(x + row * D + 8 * c, v[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[j][i];
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LNV_MAXCH; ++j)
+    if (lane + 64 * j < nch) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float dlt = v[j][i] - mu; q += dlt * dlt; }
+    }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < LNV_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nch) {
+      float gm[8], bt[8], o[8];
+      ld8<float>::ld(gamma + 8 * c, gm);
+      ld8<float>::ld(beta + 8 * c, bt);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mu) * rs * gm[i] + bt[i];
+      ld8<T>::st(y + row * D + 8 * c, o);
+    }
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx (+ add) and per-block partial sums of dgamma / dbeta: partial[(2*blk + 0)*D + c], partial[(2*blk + 1)*D + c]
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, T* __restrict__ dx,
+                                                                const T* __restrict__ add, float add_scale,
+                                                                float* __restrict__ partial, int64_t rows, int D) {
+  extern __shared__ float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  float gm[LNV_MAXCH][8], ag[LNV_MAXCH][8], ab[LNV_MAXCH][8];
+#pragma unroll
+  for (int j = 0; j < LNV_MAXCH; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; gm[j][i] = 0.f; }
+    if (c < nch) ld8<float>::ld(gamma + 8 * c, gm[j]);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * LNV_ROWS + w * (LNV_ROWS / 4);
+  for (int rr = 0; rr < LNV_ROWS / 4; ++rr) {
+    const int64_t row = r0 + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float g[LNV_MAXCH][8], xh[LNV_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNV_MAXCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float dyv[8], xv[8];
+        ld8<T>::ld(dy + row * D + 8 * c, dyv);
+        ld8<T>::ld(x + row * D + 8 * c, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          xh[j][i] = (xv[i] - mu) * rs;
+          ag[j][i] += dyv[i] * xh[j][i];
+          ab[j][i] += dyv[i];
+          g[j][i] = dyv[i] * gm[j][i];
+          s1 += g[j][i];
+          s2 += g[j][i] * xh[j][i];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int j = 0; j < LNV_MAXCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (g[j][i] - s1 - xh[j][i] * s2);
+        if (add) {
+          float av[8];
+          ld8<T>::ld(add + row * D + 8 * c, av);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += add_scale * av[i];
+        }
+        ld8<T>::st(dx + row * D + 8 * c, o);
+      }
+    }
+  }
+  if (partial) {
+#pragma unroll
+    for (int j = 0; j < LNV_MAXCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          red[(w * 2 + 0) * D + 8 * c + i] = ag[j][i];
+          red[(w * 2 + 1) * D + 8 * c + i] = ab[j][i];
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+      const int which = i / D, c = i - which * D;
+      const float tot = (red[(0 * 2 + which) * D + c] + red[(1 * 2 + which) * D + c]) +
+                        (red[(2 * 2 + which) * D + c] + red[(3 * 2 + which) * D + c]);
+      partial[((int64_t)blockIdx.x * 2 + which) * D + c] = tot;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- masked softmax (+dropout) forward
@@ -229,6 +403,14 @@ extern "C" int js2t_layernorm_fwd(const void* x, const float* gamma, const float
                                   int64_t rows, int64_t D, float eps, int dt, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(x && gamma && beta && y && mean && rstd && rows > 0 && D > 0, "layernorm_fwd: bad arguments");
+  const bool vec = (D % 8 == 0) && D <= 64 * 8 * LNV_MAXCH &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+  if (vec) {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_fwd_vec_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, (int)D, eps));
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, D, eps));
   JS2T_LAUNCH_CHECK();
@@ -241,6 +423,24 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0, "layernorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  const bool vec = (D % 8 == 0) && D <= 64 * 8 * LNV_MAXCH &&
+                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)add) & 15) == 0;
+  if (vec) {
+    const bool want_p = dgamma && dbeta;
+    JS2T_CHECK(!want_p || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
+    const int64_t nblk = (rows + LNV_ROWS - 1) / LNV_ROWS;
+    const size_t lds = sizeof(float) * 8 * D;
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, s, (const T*)dy,
+                                          (const T*)x, gamma, mean, rstd, (T*)dx, (const T*)add, add_scale,
+                                          want_p ? partial : (float*)nullptr, rows, (int)D));
+    JS2T_LAUNCH_CHECK();
+    if (want_p) {
+      hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D,
+                         accumulate);
+      JS2T_LAUNCH_CHECK();
+    }
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, s,
                                         (const T*)dy, (const T*)x, gamma, mean, rstd, (T*)dx, (const T*)add, add_scale,
                                         rows, D));
@@ -252,7 +452,7 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_param_partial_kernel<T>), dim3(cdiv(D, 64), (unsigned)nparts),
                                           dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, partial, rows, D));
     JS2T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(64), 0, s, partial, dgamma, dbeta, nparts,
+    hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, partial, dgamma, dbeta, nparts,
                        D, accumulate);
     JS2T_LAUNCH_CHECK();
   }

@@ -160,6 +160,14 @@ class FlatGradReducer:
             w = dist.all_reduce(buf, op=op, async_op=True)
         self.works.append((w, buf, op))
 
+    def reduce_all(self):
+        """Exchange the whole flat gradient now (all buckets back to back on the side stream), e.g. after a
+        hipGraph replay of forward+backward where no per-parameter hooks fire; blocks the compute stream until done."""
+        if self.world <= 1:
+            return
+        self.begin(armed=True)
+        self.finish()
+
     def finish(self):
         """Launch whatever has not been launched (frozen / unused parameters) and make the compute stream wait."""
         if not self.armed:

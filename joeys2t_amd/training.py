@@ -50,21 +50,24 @@ class TrainStep:
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
 
-    def micro_step(self, batch: Batch, sort: bool = True):
+    def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True):
         """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss.
-        `sort=False` skips batch.sort_by_src_length() (a host sync) for callers that sorted already."""
+        `sort=False` skips batch.sort_by_src_length() (a host sync) for callers that sorted already;
+        `update=False` leaves the optimizer step to the caller (hipGraph capture of forward+backward only);
+        `overlap=False` disables the hook-driven bucket exchange (the caller runs reducer.reduce_all())."""
         model = self.model
         model.train()
         self.rt.rng.begin_step()
         if sort:
             batch.sort_by_src_length()
         last = (self.micro + 1) % self.batch_multiplier == 0
-        if self.reducer is not None:
+        use_hooks = self.reducer is not None and overlap
+        if use_hooks:
             self.reducer.begin(armed=last or self.sync_every_backward)
         total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
         norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
         norm.backward()
-        if self.reducer is not None:
+        if use_hooks:
             self.reducer.finish()
         with torch.no_grad():
             s = self.stats
@@ -78,7 +81,7 @@ class TrainStep:
             s[5] += batch.ntokens or 0
         self.rt.rng.advance()
         self.micro += 1
-        if last:
+        if last and update:
             self.update()
         return norm.detach()
 
