@@ -215,6 +215,54 @@ def cpu_baseline(n_utts=8, threads=None):
             "sample": f"{n_utts} utterances x 15 s, LS100 model, full train step (fbank..AdamW), fp32, {n} timed steps"}
 
 
+MUSTC_MODEL = {
+    "initializer": "xavier_normal", "init_gain": 1.0, "bias_initializer": "zeros", "embed_initializer": "xavier_normal",
+    "embed_init_gain": 1.0, "tied_embeddings": False, "tied_softmax": False,
+    "encoder": {"type": "transformer", "num_layers": 12, "num_heads": 8, "embeddings": {"embedding_dim": 80},
+                "hidden_size": 512, "ff_size": 2048, "dropout": 0.1, "freeze": False, "subsample": True,
+                "conv_kernel_sizes": [5, 5], "conv_channels": 512, "in_channels": 80, "layer_norm": "pre", "activation": "relu"},
+    "decoder": {"type": "transformer", "num_layers": 6, "num_heads": 8,
+                "embeddings": {"embedding_dim": 512, "scale": True, "dropout": 0.0, "freeze": False}, "hidden_size": 512,
+                "ff_size": 2048, "dropout": 0.1, "freeze": False, "layer_norm": "pre", "activation": "relu"},
+}
+
+
+def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100):
+    """Second half of BASELINE.json's metric: beam-5 decode real-time factor on configs/mustc_st.yaml shapes
+    (12+6 layers, H=8, beam 5, alpha 1.0, max_output_length 100), 32 synthetic 15 s utterances resident in HBM.
+    RTF = wall time of front-end + encode + beam search / seconds of audio."""
+    import copy
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.search import search
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    from joeys2t_amd.vocabulary import Vocabulary
+    torch.manual_seed(42)
+    model = build_model(copy.deepcopy(MUSTC_MODEL), None, Vocabulary.synthetic(VOCAB))
+    model.finalize(device, dtype).eval()
+    proc = SpeechProcessor(num_freq=80, min_length=10, max_length=5000, cmvn=dict(norm_means=True, norm_vars=True, before=True))
+    wave = synth_waveforms(BATCH, SAMPLES).to(device)
+
+    def run():
+        feats, lengths = proc.batch_from_waveforms(wave, [SAMPLES] * BATCH, is_train=False, out_dtype=dtype)
+        b = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=None, trg_length=None,
+                  trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1, eos_index=3, is_train=False,
+                  task="S2T", n_gpu=1)
+        b.sort_by_src_length()
+        ids, _, _ = search(model, b, max_output_length=max_len, beam_size=beam, beam_alpha=alpha, n_best=1)
+        return ids
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    audio_s = BATCH * SAMPLES / 16000.0
+    return {"rtf": round(dt / audio_s, 6), "wall_s": round(dt, 3), "audio_s": audio_s, "beam": beam, "alpha": alpha,
+            "steps": int(ids.shape[1]), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +271,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--no-decode", action="store_true", help="skip the beam-5 decode RTF measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -285,6 +334,12 @@ def main():
                     "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
                                              "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
 
+    decode = None
+    if rank == 0 and not args.no_decode:
+        try:
+            decode = decode_rtf(device)
+        except Exception as exc:
+            decode = {"error": repr(exc)}
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
@@ -303,7 +358,7 @@ def main():
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "loss": round(stats["loss"] / max(1, args.steps + 0), 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -71,7 +71,7 @@ def import_reference():
 
 
 def np_sd(sd):
-    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}  # copy: optimizers update in place
 
 
 SPECIALS = dict(unk=0, pad=1, bos=2, eos=3)
@@ -277,6 +277,55 @@ def golden_audio():
     print("audio fixture:", {k: getattr(v, 'shape', None) for k, v in out.items()})
 
 
+def golden_train_steps(name="train_steps", n_updates=3, batch_multiplier=2):
+    """The reference's own _train_step + update tail (training.py:541-596,436-456) replayed with its builders: tiny
+    pre-LN model, 6 micro-batches = 3 updates (batch_multiplier 2, normalization 'batch'), clip 1.0, AdamW,
+    warmupinversesquareroot (warmup 2).  Captures per-micro-batch losses, per-update grad norms and learning rates, and
+    the final parameters."""
+    from joeynmt.batch import Batch
+    from joeynmt.builders import build_gradient_clipper, build_optimizer, build_scheduler
+    from joeynmt.model import build_model
+    torch.manual_seed(42)
+    cfg = tiny_cfg("pre")
+    model = build_model(cfg, src_vocab=None, trg_vocab=make_vocab(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    tcfg = {"optimizer": "adamw", "learning_rate": 2.0e-3, "weight_decay": 0.0, "adam_betas": [0.9, 0.98],
+            "scheduling": "warmupinversesquareroot", "learning_rate_warmup": 2, "learning_rate_min": 1.0e-6,
+            "clip_grad_norm": 1.0, "clip_grad_val": None}
+    clipper = build_gradient_clipper(tcfg)
+    opt = build_optimizer(tcfg, model.parameters())
+    sched, step_at = build_scheduler(tcfg, optimizer=opt, scheduler_mode="min", hidden_size=16)
+    assert step_at == "step"
+    out = {f"sd0.{k}": v for k, v in np_sd(model.state_dict()).items()}
+    steps, losses, norms, lrs = 0, [], [], []
+    model.train()  # dropout is 0 in tiny_cfg, so train mode is deterministic
+    for i in range(n_updates * batch_multiplier):
+        src, lengths, trg, trg_len = synth_batch(3, 37, 8, 20, 3, 6, seed=100 + i)
+        out.update({f"mb{i}.src": src.numpy(), f"mb{i}.src_length": lengths.numpy(), f"mb{i}.trg": trg.numpy(),
+                    f"mb{i}.trg_length": trg_len.numpy()})
+        batch = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=trg, trg_length=trg_len, trg_prompt_mask=None,
+                      indices=torch.arange(3), device=torch.device("cpu"), pad_index=1, eos_index=3, is_train=True, task="S2T")
+        batch.sort_by_src_length()
+        kw = dict(vars(batch))
+        kw["repad"] = False
+        total, nll, ctc, ncor = model(return_type="loss", **kw)
+        norm = batch.normalize(total, "batch", 1, batch_multiplier)
+        norm.backward()
+        losses.append([norm.item(), batch.normalize(nll, "batch", 1, batch_multiplier).item(),
+                       batch.normalize(ctc, "batch", 1, batch_multiplier).item(), ncor.item()])
+        if (i + 1) % batch_multiplier == 0:
+            norms.append(float(clipper(parameters=model.parameters())))
+            lrs.append(opt.param_groups[0]["lr"])  # the rate this update is taken with
+            opt.step()
+            sched.step(steps)
+            model.zero_grad(set_to_none=True)
+            steps += 1
+    out.update({f"sd1.{k}": v for k, v in np_sd(model.state_dict()).items()})
+    out.update(losses=np.array(losses), grad_norms=np.array(norms), lrs=np.array(lrs), lr_next=np.float64(opt.param_groups[0]["lr"]))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(name, "losses", np.array(losses)[:, 0], "norms", norms, "lrs", lrs)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -286,6 +335,7 @@ def main():
     golden_model("model_pre", tiny_cfg("pre"))
     golden_model("model_post", tiny_cfg("post", act="gelu"))
     golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1)
+    golden_train_steps()
 
 
 if __name__ == "__main__":

@@ -139,3 +139,70 @@ def test_direct_gradient_accumulation_into_flat_store(device, name):
         scale = ref.abs().max().item() + 1e-6
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err <= 1e-4 * scale + 2e-5, (n, err, scale)
+
+
+def _ls100_cfg(layers_enc=2, layers_dec=1):
+    return {
+        "initializer": "xavier_uniform", "bias_initializer": "zeros", "embed_initializer": "xavier_uniform",
+        "tied_embeddings": False, "tied_softmax": False,
+        "encoder": {"type": "transformer", "num_layers": layers_enc, "num_heads": 4, "embeddings": {"embedding_dim": 80},
+                    "hidden_size": 512, "ff_size": 2048, "dropout": 0.0, "freeze": False, "subsample": True,
+                    "conv_kernel_sizes": [5, 5], "conv_channels": 512, "in_channels": 80, "layer_norm": "pre",
+                    "activation": "relu"},
+        "decoder": {"type": "transformer", "num_layers": layers_dec, "num_heads": 4,
+                    "embeddings": {"embedding_dim": 512, "scale": True, "dropout": 0.0}, "hidden_size": 512, "ff_size": 2048,
+                    "dropout": 0.0, "freeze": False, "layer_norm": "pre", "activation": "relu"},
+    }
+
+
+def test_full_width_model_matches_oracle(device):
+    """LibriSpeech-100h layer shapes (d=512, H=4/dh=128, ff=2048, V=5000, 15 s utterances -> T=1498, T'=375) with a
+    reduced depth so the CPU oracle finishes in seconds: fp32 HIP loss == oracle loss to 1e-4, bf16 HIP (MFMA bf16 GEMMs,
+    fused attention) within bf16 tolerance, and the subsampled length mask bit-exact."""
+    import copy
+
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    from oracle import s2t_oracle as O
+    cfg = _ls100_cfg()
+    torch.manual_seed(3)
+    V, B, T = 5000, 3, 1498
+    base = build_model(copy.deepcopy(cfg), None, Vocabulary.synthetic(V))
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.tensor([1498, 1200, 901])
+    src = torch.randn(B, T, 80, generator=g)
+    for b in range(B):
+        src[b, lengths[b]:] = 1.0
+    tl = torch.tensor([60, 45, 70])
+    L = int(tl.max()) + 2
+    trg = torch.full((B, L), 1, dtype=torch.long)
+    for b in range(B):
+        trg[b, 0] = 2
+        trg[b, 1:1 + tl[b]] = torch.randint(4, V, (int(tl[b]), ), generator=g)
+        trg[b, 1 + tl[b]] = 3
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"] = ocfg["decoder"]["alpha"] = 1.0
+    ob = O.make_batch(src, lengths, trg, tl + 2, 1, 3)
+    with torch.no_grad():
+        rt, rx, rc, rn, _, _ = O.model_loss(sd, ocfg, ob, SPECIALS, 0.1, 0.3)
+        _, omask, olens = O.encoder_forward(sd, ocfg, src[:, :, :], lengths)
+    results = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        model = build_model(copy.deepcopy(cfg), None, Vocabulary.synthetic(V))
+        model.load_state_dict(sd)
+        model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+        model.finalize(device, dtype).eval()
+        b = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=trg, trg_length=tl + 2, trg_prompt_mask=None,
+                  indices=torch.arange(B), device=device, pad_index=1, eos_index=3, is_train=True, task="S2T", n_gpu=1)
+        with torch.no_grad():
+            total, xent, ctc, ncor = model(return_type="loss", **vars(b))
+            _, _, mask, _ = model(return_type="encode", **vars(b))
+        results[dtype] = (total.item(), xent.item(), ctc.item(), int(ncor))
+        assert torch.equal(mask.cpu(), omask)
+    f32, bf = results[torch.float32], results[torch.bfloat16]
+    assert abs(f32[0] - rt.item()) <= 1e-4 * abs(rt.item()), (f32, rt.item())
+    assert abs(f32[1] - rx.item()) <= 1e-4 * abs(rx.item()) and abs(f32[2] - rc.item()) <= 1e-4 * abs(rc.item())
+    assert f32[3] == int(rn)
+    assert abs(bf[0] - rt.item()) <= 2e-2 * abs(rt.item()), (bf, rt.item())
