@@ -61,6 +61,9 @@ const char* js2t_last_error(void);
  * kw*conv_c + c, and A = x[b, t*conv_stride - conv_pad + kw, c] (0 outside [0,conv_tin)).
  * dtype_ab = BF16 needs 16-byte aligned operands and leading dimensions that are multiples of 8.
  * split_k > 1 (weight gradients: few output tiles, K = tokens) spreads the reduction over split_k blocks per tile.
+ * a_rowsum != NULL: additionally a_rowsum[m] += sum_k op(A)[m,k] (f32 atomics onto whatever is there).  For a weight
+ * gradient dW = dY^T X this is the bias gradient (autograd of nn.Linear, transformer_layers.py:75-107), taken from the
+ * dY tiles the product already holds in LDS.  bf16 LDS-DMA path only (batch == 1, no implicit conv).
  */
 typedef struct js2t_gemm_desc {
   int32_t M, N, K;
@@ -87,6 +90,7 @@ typedef struct js2t_gemm_desc {
   float beta;
   int32_t conv, conv_tin, conv_tout, conv_c, conv_stride, conv_pad;
   int32_t split_k;          /* >1: K is cut into slices reduced with f32 atomics into a zero-filled f32 C */
+  float* a_rowsum;          /* optional f32[M]: += row sums of op(A) */
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);

@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("conv", C.c_int32), ("conv_tin", C.c_int32), ("conv_tout", C.c_int32), ("conv_c", C.c_int32),
         ("conv_stride", C.c_int32), ("conv_pad", C.c_int32),
         ("split_k", C.c_int32),
+        ("a_rowsum", C.c_void_p),
     ]
 
 

@@ -441,7 +441,7 @@ __device__ __forceinline__ void dma_zero_tail(unsigned char* tile, int k_lim, in
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    const int p = t + 256 * q;
+    const int p = ((t >> 6) * NP + q) * 64 + (t & 63);  // the slots this wave's own DMA instructions filled
     if (!TR) {
       const int row = p >> 3, slot = p & 7;
       if (((slot ^ (row & 7)) << 3) >= k_lim) *(uint4*)(tile + p * 16) = z;
@@ -539,77 +539,16 @@ __device__ __forceinline__ void gemm_epilogue8(const js2t_gemm_desc& d, int z, i
   }
 }
 
-// BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
-// decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
-template <int BM, bool TA, bool TB, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
-                                                               int split_k) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
-  constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
-  constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
+// Tile epilogue shared by the LDS-DMA kernels: accumulators -> LDS -> row-major walk (fused epilogue / split-K atomics).
+// The caller guarantees that no DMA into `smem` is outstanding and that every wave is done reading operand tiles
+// (the function starts with a barrier).
+template <int BM, bool SPLITK>
+__device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4_t (&acc)[BM / 32][4], unsigned char* smem, int z,
+                                                  int64_t co, int m0, int n0, float* c_atomic) {
+  constexpr int MI = BM / 32;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int z = blockIdx.y;
-  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
-  int64_t ao, bo, co;
-  batch_offsets(d, z, ao, bo, co);
-  const uint16_t* Ab = (const uint16_t*)d.A + ao;
-  const uint16_t* Bb = (const uint16_t*)d.B + bo;
   const int wm = w >> 1, wn = w & 1;
-  const int M = d.M, N = d.N, K = d.K;
-  const int64_t lda = d.lda, ldb = d.ldb;
-  f32x4_t acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nk_all = (K + F_BK - 1) / F_BK;
-  const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
-  const int kt0 = SPLITK ? blockIdx.z * per : 0;
-  const int nk = min(per, nk_all - kt0);
-  if (SPLITK && nk <= 0) return;
-
-  int64_t oa[NPA], ob[4];
-  dma_offsets<TA, NPA>(lda, m0, M, kt0 * F_BK, K, t, oa);
-  dma_offsets<TB, 4>(ldb, n0, N, kt0 * F_BK, K, t, ob);
-  dma_issue<NPA>(Ab, oa, smem, t);
-  dma_issue<4>(Bb, ob, smem + A_TILE, t);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int k0 = (kt0 + kt) * F_BK;
-    // tile kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (k0 + F_BK > K) {
-      dma_zero_tail<TA, NPA>(smem + cur * STAGE, K - k0, t);
-      dma_zero_tail<TB, 4>(smem + cur * STAGE + A_TILE, K - k0, t);
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {  // stream the next tile into the other stage while this one is consumed
-      dma_offsets<TA, NPA>(lda, m0, M, k0 + F_BK, K, t, oa);
-      dma_offsets<TB, 4>(ldb, n0, N, k0 + F_BK, K, t, ob);
-      dma_issue<NPA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
-      dma_issue<4>(Bb, ob, smem + (cur ^ 1) * STAGE + A_TILE, t);
-    }
-    const unsigned char* At = smem + cur * STAGE;
-    const unsigned char* Bt = At + A_TILE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t fn[4], fm[MI];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fm[i] = frag_load2<TA>(At, wm * (BM / 2) + 16 * i, kk, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
-    }
-    // the stage consumed here is overwritten by the DMA issued in the NEXT iteration, after its barrier
-    cur ^= 1;
-  }
+  const int M = d.M, N = d.N;
   if constexpr (SPLITK) {
     // K-slice partial tile -> LDS -> f32 atomics issued as whole 256-byte row segments (one row half per wave
     // instruction): scattered 4-byte atomics run an order of magnitude below the ~1.3 TB/s contiguous atomic rate
@@ -651,39 +590,198 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     __syncthreads();
     const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
     const uint32_t drop_key = d.dropout_p > 0.f ? dropout_key(d.rng_state, d.rng_stream) : 0u;
-    // this thread owns the same 8 columns in all 8 passes: fetch the bias once, and (fast path) pre-issue the
-    // residual / gate row loads of every pass so their latency overlaps instead of serialising pass after pass
-    const int c8 = t & 15, n = n0 + c8 * 8;
+    // this thread owns the same 8 columns in all passes (16 rows per pass): the bias is fetched once
+    const int c8 = t & 15, r16 = t >> 4, n = n0 + c8 * 8;
     float bias_r[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bias_r[i] = (d.bias && n + i < N) ? d.bias[n + i] : 0.f;
-    const bool full8 = n + 8 <= N;
-    const bool vec_rg = full8 && d.dtype_c == JS2T_BF16 && (!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
-                        (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0));
     constexpr int NPASS = BM / 16;
-    uint4 res_pk[NPASS], gate_pk[NPASS];
+    // Fast path (block-uniform): whole tile inside N, 16-byte row segments, and only the terms the train step
+    // uses (alpha, bias, none/ReLU, dropout, bf16 residual, bf16 gate).  It is kept small on purpose - 4 passes
+    // unrolled, not 16 - because the fully unrolled general epilogue made the kernel larger than the
+    // instruction cache and cost more time than the global stores it feeds.
+    const bool bf16_out = d.dtype_c == JS2T_BF16;
+    const int esh = bf16_out ? 1 : 2;
+    const bool fast = n0 + 128 <= N && !d.preact && d.beta == 0.f && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
+                      ((((uintptr_t)d.C + ((uintptr_t)co << esh)) & 15) == 0) && ((((uintptr_t)d.ldc << esh) & 15) == 0) &&
+                      (bf16_out ? ((!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
+                                   (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0)))
+                                : (!d.residual && !d.gate));
+    if (fast) {
+      const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
+      const bool has_drop = d.dropout_p > 0.f;
+      const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+      const uint16_t* resp = (const uint16_t*)d.residual + n;
+      const uint16_t* gatep = (const uint16_t*)d.gate + n;
+#pragma unroll 1
+      for (int g = 0; g < NPASS; g += 4) {
+        uint4 res_pk[4], gate_pk[4];
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      res_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
-      gate_pk[pass] = make_uint4(0u, 0u, 0u, 0u);
-      const int m = m0 + pass * 16 + (t >> 4);
-      if (vec_rg && m < M) {
-        if (d.residual) res_pk[pass] = *(const uint4*)((const uint16_t*)d.residual + (int64_t)m * d.ldr + n);
-        if (d.gate) gate_pk[pass] = *(const uint4*)((const uint16_t*)d.gate + (int64_t)m * d.ldg + n);
+        for (int u = 0; u < 4; ++u) {
+          const int m = m0 + (g + u) * 16 + r16;
+          res_pk[u] = gate_pk[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (m < M) {
+            if (has_res) res_pk[u] = *(const uint4*)(resp + (int64_t)m * d.ldr);
+            if (has_gate) gate_pk[u] = *(const uint4*)(gatep + (int64_t)m * d.ldg);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ml = (g + u) * 16 + r16, m = m0 + ml;
+          if (m >= M) continue;
+          const f32x4_t lo = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+          const f32x4_t hi = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = v[i] * alpha + bias_r[i];
+          if (relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          if (has_drop) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)(z * M + m), (uint32_t)((n >> 2) + h), d.dropout_p);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[4 * h + i] = ((keep >> i) & 1u) ? v[4 * h + i] * keep_scale : 0.f;
+            }
+          }
+          if (has_res) {
+            float rr[8];
+            unpack_bf16x8(res_pk[u], rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += res_scale * rr[i];
+          }
+          if (has_gate) {
+            float rr[8];
+            unpack_bf16x8(gate_pk[u], rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = rr[i] > 0.f ? v[i] * gate_scale : 0.f;
+          }
+          const int64_t coff = co + (int64_t)m * d.ldc + n;
+          if (bf16_out) {
+            uint4 pk;
+            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+            *(uint4*)((uint16_t*)d.C + coff) = pk;
+          } else {
+            *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)d.C + coff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
       }
-    }
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      const int ml = pass * 16 + (t >> 4);
-      const int m = m0 + ml;
-      if (m < M && n < N) {
-        const f32x4_t lo = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
-        const f32x4_t hi = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        gemm_epilogue8(d, z, co, m, n, v, alpha, drop_key, bias_r, vec_rg, res_pk[pass], gate_pk[pass]);
+    } else {
+      const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int ml = pass * 16 + r16;
+        const int m = m0 + ml;
+        if (m < M && n < N) {
+          const f32x4_t lo = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8) ^ (ml & 7)) << 2));
+          const f32x4_t hi = *(const f32x4_t*)(Cs + ml * 128 + (((2 * c8 + 1) ^ (ml & 7)) << 2));
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          gemm_epilogue8(d, z, co, m, n, v, alpha, drop_key, bias_r, false, none, none);
+        }
       }
     }
   }
+}
+
+// BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
+// decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
+template <int BM, bool TA, bool TB, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
+                                                               int split_k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
+  constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
+  constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int z = blockIdx.y;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
+  int64_t ao, bo, co;
+  batch_offsets(d, z, ao, bo, co);
+  const uint16_t* Ab = (const uint16_t*)d.A + ao;
+  const uint16_t* Bb = (const uint16_t*)d.B + bo;
+  const int wm = w >> 1, wn = w & 1;
+  const int M = d.M, N = d.N, K = d.K;
+  const int64_t lda = d.lda, ldb = d.ldb;
+  f32x4_t acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = (K + F_BK - 1) / F_BK;
+  const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
+  const int kt0 = SPLITK ? blockIdx.z * per : 0;
+  const int nk = min(per, nk_all - kt0);
+  if (SPLITK && nk <= 0) return;
+
+  // optional row sums of op(A) (bias gradient of a weight-gradient product): the first tile column's wn == 0 waves
+  // multiply their A fragments with an all-ones fragment, 4 extra MFMAs per 32 k
+  const bool do_rs = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
+  f32x4_t racc[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) racc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8_ones_t;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, s16x8_ones_t{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+
+  int64_t oa[NPA], ob[4];
+  dma_offsets<TA, NPA>(lda, m0, M, kt0 * F_BK, K, t, oa);
+  dma_offsets<TB, 4>(ldb, n0, N, kt0 * F_BK, K, t, ob);
+  dma_issue<NPA>(Ab, oa, smem, t);
+  dma_issue<4>(Bb, ob, smem + A_TILE, t);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k0 = (kt0 + kt) * F_BK;
+    // tile kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (k0 + F_BK > K) {
+      dma_zero_tail<TA, NPA>(smem + cur * STAGE, K - k0, t);
+      dma_zero_tail<TB, 4>(smem + cur * STAGE + A_TILE, K - k0, t);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {  // stream the next tile into the other stage while this one is consumed
+      dma_offsets<TA, NPA>(lda, m0, M, k0 + F_BK, K, t, oa);
+      dma_offsets<TB, 4>(ldb, n0, N, k0 + F_BK, K, t, ob);
+      dma_issue<NPA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
+      dma_issue<4>(Bb, ob, smem + (cur ^ 1) * STAGE + A_TILE, t);
+    }
+    const unsigned char* At = smem + cur * STAGE;
+    const unsigned char* Bt = At + A_TILE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t fn[4], fm[MI];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fm[i] = frag_load2<TA>(At, wm * (BM / 2) + 16 * i, kk, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[j], fm[i], acc[i][j], 0, 0, 0);
+      if (do_rs) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[i], racc[i], 0, 0, 0);
+      }
+    }
+    // the stage consumed here is overwritten by the DMA issued in the NEXT iteration, after its barrier
+    cur ^= 1;
+  }
+  if (do_rs && (lane >> 4) == 0) {  // every output row of the ones-product holds the same sums: take row 0
+    typedef __attribute__((address_space(1))) float gfloat;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * (BM / 2) + 16 * i + lane;
+      if (m < M) __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)d.a_rowsum + m, racc[i][0]);
+    }
+  }
+  dma_tile_epilogue<BM, SPLITK>(d, acc, smem, z, co, m0, n0, c_atomic);
 }
 
 template <int BM, bool TA, bool TB, bool SPLITK>
@@ -768,6 +866,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.conv_c > 0 && d.conv_tin > 0 && d.conv_tout > 0 && d.conv_stride > 0, "gemm: bad conv geometry");
   }
   JS2T_CHECK(!(d.residual || d.gate) || d.batch == 1, "gemm: residual / gate need batch == 1");
+  JS2T_CHECK(!d.a_rowsum || (d.batch == 1 && !d.conv && !g_force_regstage), "gemm: a_rowsum needs batch == 1 and the LDS-DMA kernel");
   if (d.split_k < 1) d.split_k = 1;
   if (d.split_k > 1) {
     JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&
@@ -783,6 +882,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     if (d.trans_a && !d.trans_b) return launch_bf16<true, false>(d, s);
     return launch_bf16<true, true>(d, s);
   }
+  JS2T_CHECK(!d.a_rowsum, "gemm: a_rowsum needs bf16 operands on the LDS-DMA path (16-byte aligned, ld % 8 == 0)");
   d.split_k = 1;  // the generic kernel always reduces the whole K range (C stays pre-zeroed + one plain store)
   const int tm = cdiv(d.M, G_BM), tn = cdiv(d.N, G_BN);
   hipLaunchKernelGGL(gemm_generic_kernel, dim3(tm * tn, d.batch), dim3(256), 0, s, d, tm, tn);

@@ -60,24 +60,37 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
         dx = torch.empty((M, K), dtype=dx_dtype or x2d.dtype, device=x2d.device)
         ops.gemm(dz2d, w, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w.stride(0), ldc=K, trans_b=True, gate=gate,
                  ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+    # the bias gradient (column sums of dz) rides on the weight-gradient product when that runs on the bf16 LDS-DMA
+    # kernel: its dz tiles are already in LDS, so no separate pass over dz is needed
+    fuse_db = need_dw and need_db and _mfma_operand(dz2d) and _mfma_operand(x2d)
+    if need_db and db_out is None:
+        db = torch.zeros((N, ), dtype=torch.float32, device=x2d.device) if fuse_db else None
+    rs = (db_out if db_out is not None else db) if fuse_db else None
     if need_dw:
         # dW[N,K] = dz^T[N,M] . x[M,K]  (both operands reduction-major -> trans_a, trans_b), f32 output
         sk = wgrad_split(N, K, M)
         if dw_out is not None:
             # split-K atomics add onto whatever is there; a single-slice GEMM accumulates through beta = 1
             ops.gemm(dz2d, x2d, dw_out, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True,
-                     trans_b=True, split_k=sk, beta=0.0 if sk > 1 else 1.0)
+                     trans_b=True, split_k=sk, beta=0.0 if sk > 1 else 1.0, a_rowsum=rs)
         else:
             dw = (torch.zeros if sk > 1 else torch.empty)((N, K), dtype=torch.float32, device=x2d.device)
             ops.gemm(dz2d, x2d, dw, M=N, N=K, K=M, lda=dz2d.stride(0), ldb=x2d.stride(0), ldc=K, trans_a=True, trans_b=True,
-                     split_k=sk)
-    if need_db:
+                     split_k=sk, a_rowsum=rs)
+    if need_db and not fuse_db:
         dzc = dz2d if dz2d.is_contiguous() else dz2d.contiguous()
         if db_out is not None:
             ops.colsum(dzc, out=db_out, accumulate=True)
         else:
             db = ops.colsum(dzc)
+    if db_out is not None:
+        db = None
     return dx, dw, db
+
+
+def _mfma_operand(t: torch.Tensor) -> bool:
+    """True when js2t_gemm takes `t` on the bf16 LDS-DMA path (16-byte aligned rows)."""
+    return t.dtype == torch.bfloat16 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0
 
 
 def wgrad_split(rows: int, cols: int, red: int) -> int:

@@ -84,9 +84,9 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1):
+         conv=None, split_k=1, a_rowsum=None):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements."""
-    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev)
+    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum)
     if A.dtype != B.dtype:
         raise Js2tError(f"gemm: A/B dtype mismatch {A.dtype} vs {B.dtype}")
     d = GemmDesc()
@@ -131,6 +131,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.conv = 1
         d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
     d.split_k = int(split_k)
+    d.a_rowsum = None if a_rowsum is None else a_rowsum.data_ptr()
     if GEMM_TIMER is not None:
         if d.dtype_ab == BF16:
             fam = "gemm_bf16_kernel" if d.conv else "gemm_bf16_dma_kernel"

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from joeys2t_amd import functional as Fn
 from joeys2t_amd import ops
+from joeys2t_amd._lib import Js2tError
 
 pytestmark = pytest.mark.gpu
 TOL = dict(rtol=1e-4, atol=1e-4)
@@ -467,3 +468,28 @@ def test_flash_attention_dropout_matches_unfused(device):
             Fn.USE_FLASH = True
     for a, b in zip(res[True], res[False]):
         bf16_close(a, b, 3e-2)
+
+
+@pytest.mark.parametrize("split", [1, 4])
+def test_gemm_a_rowsum_bias_grad(device, split):
+    """a_rowsum: the bias gradient taken inside the weight-gradient product equals the column sums of dz (added onto
+    the existing contents), for a ragged shape and with / without split-K."""
+    rows, cols, tokens = 200, 136, 1003
+    dz = rnd(tokens, rows, seed=1).bfloat16()
+    x = rnd(tokens, cols, seed=2).bfloat16()
+    C = torch.zeros(rows, cols, device=device)
+    base = rnd(rows, seed=3)
+    db = base.clone().to(device)
+    ops.gemm(dz.to(device), x.to(device), C, M=rows, N=cols, K=tokens, lda=rows, ldb=cols, ldc=cols, trans_a=True, trans_b=True,
+             split_k=split, a_rowsum=db)
+    torch.testing.assert_close(db.cpu(), base + dz.float().sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(C.cpu(), dz.float().t() @ x.float(), rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
+    # k-contiguous A as well (row sums of A itself)
+    a = rnd(300, 264, seed=4).bfloat16()
+    b = rnd(130, 264, seed=5).bfloat16()
+    out = torch.empty(300, 130, device=device)
+    rs = torch.zeros(300, device=device)
+    ops.gemm(a.to(device), b.to(device), out, M=300, N=130, K=264, lda=264, ldb=264, ldc=130, a_rowsum=rs)
+    torch.testing.assert_close(rs.cpu(), a.float().sum(1), rtol=1e-4, atol=1e-3)
+    with pytest.raises(Js2tError):  # fp32 operands run on the generic kernel, which has no row-sum path
+        ops.gemm(a.float().to(device), b.float().to(device), out, M=300, N=130, K=264, lda=264, ldb=264, ldc=130, a_rowsum=rs)
