@@ -171,7 +171,8 @@ int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
 int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, void* dx, const void* add, float add_scale, float* dgamma,
                        float* dbeta, float* partial, int accumulate, int64_t rows, int64_t D, int dt,
-                       js2t_stream stream); /* accumulate != 0: dgamma/dbeta += (in-place gradient accumulation) */
+                       js2t_stream stream); /* accumulate != 0: dgamma/dbeta += (in-place gradient accumulation; the vectorised
+                                              * kernel adds its block totals with f32 atomics, `partial` is unused) */
 
 /* --------------------------------------------------------------------------------------------------
  * Masked softmax (+ dropout) over attention scores — transformer_layers.py:93-98.

@@ -542,7 +542,9 @@ __device__ __forceinline__ void gemm_epilogue8(const js2t_gemm_desc& d, int z, i
 // Tile epilogue shared by the LDS-DMA kernels: accumulators -> LDS -> row-major walk (fused epilogue / split-K atomics).
 // The caller guarantees that no DMA into `smem` is outstanding and that every wave is done reading operand tiles
 // (the function starts with a barrier).
-template <int BM, bool SPLITK>
+// PERM: accumulator j, register r of lane group g = lane>>4 is tile column 16g + 4j + r (see the kernel) instead of
+// 16j + 4g + r.
+template <int BM, bool SPLITK, bool PERM>
 __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4_t (&acc)[BM / 32][4], unsigned char* smem, int z,
                                                   int64_t co, int m0, int n0, float* c_atomic) {
   constexpr int MI = BM / 32;
@@ -559,7 +561,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ml = wm * (BM / 2) + 16 * i + (lane & 15);
-        const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
+        const int n4 = PERM ? wn * 16 + 4 * (lane >> 4) + j : wn * 16 + 4 * j + (lane >> 4);
         *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
       }
     __syncthreads();
@@ -584,7 +586,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ml = wm * (BM / 2) + 16 * i + (lane & 15);
-        const int n4 = (wn * 64 + 16 * j + 4 * (lane >> 4)) >> 2;
+        const int n4 = PERM ? wn * 16 + 4 * (lane >> 4) + j : wn * 16 + 4 * j + (lane >> 4);
         *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
       }
     __syncthreads();
@@ -689,6 +691,115 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
   }
 }
 
+// Register-direct epilogue for the permuted accumulator layout (k-contiguous B operand): lane (g = lane>>4, r = lane&15)
+// holds, for each of its MI row blocks, the 16 consecutive columns n0 + 64*wn + 16g .. +15 of row 16i + r.  Returns false
+// (nothing done) when the tile needs the general path: partial N tile, unaligned rows, pre-activation output, beta,
+// activations other than ReLU, f32 residual / gate.
+template <int BM>
+__device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f32x4_t (&acc)[BM / 32][4], int z, int64_t co, int m0,
+                                                     int n0) {
+  constexpr int MI = BM / 32;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int M = d.M, N = d.N;
+  const bool bf16_out = d.dtype_c == JS2T_BF16;
+  const int esh = 1;
+  const bool fast = bf16_out && n0 + 128 <= N && !d.preact && d.beta == 0.f && !(d.residual && d.gate) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
+                    ((((uintptr_t)d.C + ((uintptr_t)co << esh)) & 15) == 0) && ((((uintptr_t)d.ldc << esh) & 15) == 0) &&
+                    (bf16_out ? ((!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
+                                 (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0)))
+                              : (!d.residual && !d.gate));
+  if (!fast) return false;
+  const int n = n0 + wn * 64 + 16 * (lane >> 4);
+  const int mrow = m0 + wm * (BM / 2) + (lane & 15);
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+  const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
+  const bool has_drop = d.dropout_p > 0.f;
+  const uint32_t drop_key = has_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+  // residual / gate rows first: their latency overlaps the bias fetch and the arithmetic of the earlier rows
+  uint4 rg[MI][2];
+  if (has_res || has_gate) {
+    const uint16_t* src = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
+    const int64_t ld = has_res ? d.ldr : d.ldg;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = min(mrow + 16 * i, M - 1);
+      rg[i][0] = *(const uint4*)(src + (int64_t)m * ld);
+      rg[i][1] = *(const uint4*)(src + (int64_t)m * ld + 8);
+    }
+  }
+  float bias_r[16];
+  if (d.bias && (((uintptr_t)d.bias) & 15) == 0) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float4 b4 = *(const float4*)(d.bias + n + 4 * h);
+      bias_r[4 * h] = b4.x, bias_r[4 * h + 1] = b4.y, bias_r[4 * h + 2] = b4.z, bias_r[4 * h + 3] = b4.w;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) bias_r[c] = d.bias ? d.bias[n + c] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mrow + 16 * i;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * alpha + bias_r[4 * j + r];
+    if (relu) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    if (has_drop) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)(z * M + m), (uint32_t)((n >> 2) + h), d.dropout_p);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[4 * h + c] = ((keep >> c) & 1u) ? v[4 * h + c] * keep_scale : 0.f;
+      }
+    }
+    if (has_res) {
+      float rr[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unpack_bf16x8(rg[i][h], rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[8 * h + c] += res_scale * rr[c];
+      }
+    }
+    if (has_gate) {
+      float rr[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unpack_bf16x8(rg[i][h], rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[8 * h + c] = rr[c] > 0.f ? v[8 * h + c] * gate_scale : 0.f;
+      }
+    }
+    if (m < M) {
+      const int64_t coff = co + (int64_t)m * d.ldc + n;
+      if (bf16_out) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint4 pk;
+          pk.x = (uint32_t)f32_to_bf16_bits(v[8 * h + 0]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16_bits(v[8 * h + 2]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 3]) << 16);
+          pk.z = (uint32_t)f32_to_bf16_bits(v[8 * h + 4]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 5]) << 16);
+          pk.w = (uint32_t)f32_to_bf16_bits(v[8 * h + 6]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 7]) << 16);
+          *(uint4*)((uint16_t*)d.C + coff + 8 * h) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          *(float4*)((float*)d.C + coff + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+      }
+    }
+  }
+  return true;
+}
+
 // BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
 // decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
 template <int BM, bool TA, bool TB, bool SPLITK>
@@ -757,7 +868,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8_t fn[4], fm[MI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (!TB) {
+          // fragment row rho of accumulator j is tile row 16*(rho>>2) + 4j + (rho&3): a lane (group g) then owns the 16
+          // CONSECUTIVE output columns 16g .. 16g+15 of its rows, i.e. 32-byte bf16 runs it can store straight
+          // from registers (no LDS round trip, no barriers in the epilogue)
+          const int row = wn * 64 + ((lane & 15) >> 2) * 16 + j * 4 + (lane & 3), c = kk * 4 + (lane >> 4);
+          fn[j] = *(const bf16x8_t*)(Bt + row * 128 + ((c ^ (row & 7)) << 4));
+        } else {
+          // reduction-major B image: the same column ownership costs a 2-way bank conflict on the transposing reads
+          // (the 8-byte offset inside a 32-byte group would be the same for all lanes) - measured slower, so these
+          // variants keep the natural fragment order and the LDS-staged epilogue
+          fn[j] = frag_load2<TB>(Bt, wn * 64 + 16 * j, kk, lane);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) fm[i] = frag_load2<TA>(At, wm * (BM / 2) + 16 * i, kk, lane);
 #pragma unroll
@@ -781,7 +905,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
       if (m < M) __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)d.a_rowsum + m, racc[i][0]);
     }
   }
-  dma_tile_epilogue<BM, SPLITK>(d, acc, smem, z, co, m0, n0, c_atomic);
+  if constexpr (!SPLITK && !TB) {
+    if (direct_tile_epilogue<BM>(d, acc, z, co, m0, n0)) return;
+  }
+  dma_tile_epilogue<BM, SPLITK, !TB>(d, acc, smem, z, co, m0, n0, c_atomic);
 }
 
 template <int BM, bool TA, bool TB, bool SPLITK>

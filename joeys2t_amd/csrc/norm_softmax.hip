@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd, T* __restrict__ dx,
                                                                 const T* __restrict__ add, float add_scale,
-                                                                float* __restrict__ partial, int64_t rows, int D) {
+                                                                float* __restrict__ partial, float* dgamma_acc,
+                                                                float* dbeta_acc, int64_t rows, int D) {
   extern __shared__ float red[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = D >> 3;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
       }
     }
   }
-  if (partial) {
+  if (partial || dgamma_acc) {
 #pragma unroll
     for (int j = 0; j < LNV_MAXCH; ++j) {
       const int c = lane + 64 * j;
@@ -279,11 +280,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
       }
     }
     __syncthreads();
+    typedef __attribute__((address_space(1))) float gfloat;
     for (int i = threadIdx.x; i < 2 * D; i += 256) {
       const int which = i / D, c = i - which * D;
       const float tot = (red[(0 * 2 + which) * D + c] + red[(1 * 2 + which) * D + c]) +
                         (red[(2 * 2 + which) * D + c] + red[(3 * 2 + which) * D + c]);
-      partial[((int64_t)blockIdx.x * 2 + which) * D + c] = tot;
+      if (dgamma_acc) {
+        // accumulate mode: the block totals go straight onto the gradient (contiguous 1 KB atomic segments per
+        // wave-instruction), no partial slab and no second kernel
+        __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)(which ? dbeta_acc : dgamma_acc) + c, tot);
+      } else {
+        partial[((int64_t)blockIdx.x * 2 + which) * D + c] = tot;
+      }
     }
   }
 }
@@ -427,14 +435,16 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
                    (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)add) & 15) == 0;
   if (vec) {
     const bool want_p = dgamma && dbeta;
-    JS2T_CHECK(!want_p || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
+    const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
+    JS2T_CHECK(!want_p || direct || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
     const int64_t nblk = (rows + LNV_ROWS - 1) / LNV_ROWS;
     const size_t lds = sizeof(float) * 8 * D;
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, s, (const T*)dy,
                                           (const T*)x, gamma, mean, rstd, (T*)dx, (const T*)add, add_scale,
-                                          want_p ? partial : (float*)nullptr, rows, (int)D));
+                                          (want_p && !direct) ? partial : (float*)nullptr, direct ? dgamma : (float*)nullptr,
+                                          direct ? dbeta : (float*)nullptr, rows, (int)D));
     JS2T_LAUNCH_CHECK();
-    if (want_p) {
+    if (want_p && !direct) {
       hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D,
                          accumulate);
       JS2T_LAUNCH_CHECK();
