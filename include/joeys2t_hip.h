@@ -94,6 +94,15 @@ typedef struct js2t_gemm_desc {
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
+/* `count` independent products of ONE shape (d: M, N, K, leading dimensions, alpha, beta, split_k, dtype_c) whose
+ * operands live at unrelated addresses A[i], B[i], C[i] (and optional a_rowsum[i]); d->A/B/C/a_rowsum are ignored.
+ * bf16 operands with trans_a = trans_b = 1 and a plain epilogue only: this is the weight-gradient product
+ * dW_i = dY_i^T X_i of the nn.Linear layers (autograd of transformer_layers.py:75-107,147-153), deferred to the end
+ * of the backward pass and run for all layers of one type in one launch - enough output tiles to fill the chip
+ * without cutting K into atomically reduced slices.  Host pointer tables; any count (launched in chunks). */
+#define JS2T_GEMM_GROUP_MAX 32
+int js2t_gemm_grouped(const js2t_gemm_desc* d, int32_t count, const void* const* A, const void* const* B, void* const* C,
+                      float* const* a_rowsum, js2t_stream stream);
 /* Test hook: when on, bf16 GEMMs use the register-staged kernel (the one implicit-conv operands always use)
  * instead of the LDS-DMA kernel, so both can be checked against each other. */
 void js2t_gemm_force_regstage(int on);

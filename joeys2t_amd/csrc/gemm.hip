@@ -604,7 +604,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
     // instruction cache and cost more time than the global stores it feeds.
     const bool bf16_out = d.dtype_c == JS2T_BF16;
     const int esh = bf16_out ? 1 : 2;
-    const bool fast = n0 + 128 <= N && !d.preact && d.beta == 0.f && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
+    const bool fast = n0 + 128 <= N && !d.preact && (d.beta == 0.f || !bf16_out) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
                       ((((uintptr_t)d.C + ((uintptr_t)co << esh)) & 15) == 0) && ((((uintptr_t)d.ldc << esh) & 15) == 0) &&
                       (bf16_out ? ((!d.residual || ((d.ldr & 7) == 0 && (((uintptr_t)d.residual) & 15) == 0)) &&
                                    (!d.gate || ((d.ldg & 7) == 0 && (((uintptr_t)d.gate) & 15) == 0)))
@@ -669,6 +669,11 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
             pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
             *(uint4*)((uint16_t*)d.C + coff) = pk;
           } else {
+            if (d.beta != 0.f) {  // in-place accumulation of an f32 gradient
+              const float4 o0 = *(const float4*)((const float*)d.C + coff), o1 = *(const float4*)((const float*)d.C + coff + 4);
+              v[0] += d.beta * o0.x, v[1] += d.beta * o0.y, v[2] += d.beta * o0.z, v[3] += d.beta * o0.w;
+              v[4] += d.beta * o1.x, v[5] += d.beta * o1.y, v[6] += d.beta * o1.z, v[7] += d.beta * o1.w;
+            }
             *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)((float*)d.C + coff + 4) = make_float4(v[4], v[5], v[6], v[7]);
           }
@@ -803,14 +808,13 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 // BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
 // decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
 template <int BM, bool TA, bool TB, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
-                                                               int split_k) {
+__device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tiles_m, int tiles_n, float* c_atomic, int split_k,
+                                               int z) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
   constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
   constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int z = blockIdx.y;
   const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
   int64_t ao, bo, co;
@@ -912,6 +916,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d,
 }
 
 template <int BM, bool TA, bool TB, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
+                                                               int split_k) {
+  dma_gemm_block<BM, TA, TB, SPLITK>(d, tiles_m, tiles_n, c_atomic, split_k, blockIdx.y);
+}
+
+// Grouped launch: blockIdx.y selects one of up to JS2T_GEMM_GROUP_MAX independent products of identical shape whose
+// operands live at unrelated addresses (the deferred weight gradients of one layer type: see js2t_gemm_grouped).
+struct GemmGroup {
+  const void* A[JS2T_GEMM_GROUP_MAX];
+  const void* B[JS2T_GEMM_GROUP_MAX];
+  void* C[JS2T_GEMM_GROUP_MAX];
+  float* rowsum[JS2T_GEMM_GROUP_MAX];
+};
+template <int BM, bool TA, bool TB, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_grouped_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n,
+                                                                       int split_k) {
+  const int g = blockIdx.y;
+  js2t_gemm_desc dd = d;
+  dd.A = grp.A[g];
+  dd.B = grp.B[g];
+  dd.C = grp.C[g];
+  dd.a_rowsum = grp.rowsum[g];
+  dma_gemm_block<BM, TA, TB, SPLITK>(dd, tiles_m, tiles_n, (float*)dd.C, split_k, 0);
+}
+
+template <int BM, bool TA, bool TB, bool SPLITK>
 int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
   constexpr int LDS = (BM == 128 || TA) ? 65536 : 2 * (BM * 128 + 16384) > BM * 128 * 4 ? 2 * (BM * 128 + 16384) : BM * 128 * 4;
   static bool attr_set = false;
@@ -973,6 +1003,58 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 extern "C" void js2t_gemm_force_regstage(int on) { g_force_regstage = on != 0; }
+
+template <bool SPLITK>
+static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
+  constexpr int LDS = 65536;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_grouped_kernel<128, true, true, SPLITK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tm = cdiv(d.M, 128), tn = cdiv(d.N, F_BN);
+  hipLaunchKernelGGL((gemm_bf16_dma_grouped_kernel<128, true, true, SPLITK>), dim3(tm * tn, count, SPLITK ? d.split_k : 1), dim3(256),
+                     LDS, s, d, grp, tm, tn, d.split_k);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const void* const* A, const void* const* B, void* const* C,
+                                 float* const* a_rowsum, js2t_stream stream) {
+  JS2T_CHECK(dp != nullptr && count >= 0, "gemm_grouped: bad arguments");
+  if (count == 0) return JS2T_OK;
+  JS2T_CHECK(A && B && C, "gemm_grouped: null pointer tables");
+  js2t_gemm_desc d = *dp;
+  JS2T_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "gemm_grouped: empty product");
+  JS2T_CHECK(d.dtype_ab == JS2T_BF16 && d.trans_a && d.trans_b && !d.conv && d.batch == 1,
+             "gemm_grouped: bf16 reduction-major operands only (trans_a = trans_b = 1, batch = 1)");
+  JS2T_CHECK((d.lda % 8 == 0) && (d.ldb % 8 == 0), "gemm_grouped: leading dimensions must be multiples of 8");
+  JS2T_CHECK(d.dtype_c == JS2T_F32 || d.dtype_c == JS2T_BF16, "gemm_grouped: bad dtype_c");
+  JS2T_CHECK(!d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual && !d.gate && !d.alpha_dev,
+             "gemm_grouped: plain epilogue only (alpha, beta)");
+  if (d.split_k < 1) d.split_k = 1;
+  JS2T_CHECK(d.split_k == 1 || (d.dtype_c == JS2T_F32 && d.beta == 0.f), "gemm_grouped: split_k needs f32 C and beta = 0");
+  for (int base = 0; base < count; base += JS2T_GEMM_GROUP_MAX) {
+    const int n = count - base < JS2T_GEMM_GROUP_MAX ? count - base : JS2T_GEMM_GROUP_MAX;
+    GemmGroup grp;
+    for (int i = 0; i < JS2T_GEMM_GROUP_MAX; ++i) {
+      const int j = base + (i < n ? i : 0);
+      JS2T_CHECK(A[j] && B[j] && C[j] && aligned16(A[j]) && aligned16(B[j]), "gemm_grouped: operands must be non-null, 16-byte aligned");
+      grp.A[i] = A[j], grp.B[i] = B[j], grp.C[i] = C[j];
+      grp.rowsum[i] = a_rowsum ? a_rowsum[j] : nullptr;
+    }
+    d.A = grp.A[0], d.B = grp.B[0], d.C = grp.C[0];
+    const int rc = d.split_k > 1 ? launch_grouped_tt<true>(d, grp, n, (hipStream_t)stream)
+                                 : launch_grouped_tt<false>(d, grp, n, (hipStream_t)stream);
+    if (rc != JS2T_OK) return rc;
+  }
+  return JS2T_OK;
+}
 
 extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
   JS2T_CHECK(dp != nullptr, "gemm: null descriptor");

@@ -47,7 +47,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
 
 
 def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None,
-               dw_out=None, db_out=None):
+               dw_out=None, db_out=None, queue=None):
     """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32).
     dw_out / db_out: fp32 gradient buffers (views of the flat gradient store) to ACCUMULATE into; the corresponding
     return value is then None (nothing left for autograd to add)."""
@@ -63,6 +63,11 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
     # the bias gradient (column sums of dz) rides on the weight-gradient product when that runs on the bf16 LDS-DMA
     # kernel: its dz tiles are already in LDS, so no separate pass over dz is needed
     fuse_db = need_dw and need_db and _mfma_operand(dz2d) and _mfma_operand(x2d)
+    if (queue is not None and need_dw and dw_out is not None and (not need_db or (fuse_db and db_out is not None))
+            and _mfma_operand(dz2d) and _mfma_operand(x2d)):
+        # deferred: runs with the same product of the other layers as one grouped launch (runtime.WgradQueue)
+        queue.add(dz2d, x2d, dw_out, db_out if need_db else None)
+        need_dw = need_db = False
     if need_db and db_out is None:
         db = torch.zeros((N, ), dtype=torch.float32, device=x2d.device) if fuse_db else None
     rs = (db_out if db_out is not None else db) if fuse_db else None
@@ -93,11 +98,11 @@ def _mfma_operand(t: torch.Tensor) -> bool:
     return t.dtype == torch.bfloat16 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0
 
 
-def wgrad_split(rows: int, cols: int, red: int) -> int:
-    """Split-K factor for a weight-gradient GEMM [rows, cols] = sum over `red` tokens: the output has only
-    rows*cols/128^2 tiles (16..64 for the 512/2048-wide layers) against 256 CUs, so the token dimension is cut
-    until about two blocks per CU exist."""
-    tiles = ((rows + 127) // 128) * ((cols + 127) // 128)
+def wgrad_split(rows: int, cols: int, red: int, count: int = 1) -> int:
+    """Split-K factor for `count` weight-gradient GEMMs [rows, cols] = sum over `red` tokens launched together: one
+    output has only rows*cols/128^2 tiles (16..64 for the 512/2048-wide layers) against 256 CUs, so the token
+    dimension is cut until about two blocks per CU exist."""
+    tiles = ((rows + 127) // 128) * ((cols + 127) // 128) * count
     nk = (red + 63) // 64
     return max(1, min((512 + tiles - 1) // tiles, nk // 4 if nk >= 8 else 1, 32))
 
@@ -290,6 +295,8 @@ class ResidualBlockFn(torch.autograd.Function):
         sink = wts.get("sink") or {}
         ln_sink = (sink["ln_g"], sink["ln_b"]) if "ln_g" in sink else None
 
+        wq = sink.get("_wq")
+
         def sk(name):
             return sink.get(name)
 
@@ -303,7 +310,7 @@ class ResidualBlockFn(torch.autograd.Function):
             relu = cfg.act == "relu"
             # dh = dz_o . W2, gated by the saved post-dropout activations for ReLU (sign carries both masks)
             dh, g["w2"], g["b2"] = linear_bwd(dz_o, c, wts["w2"], gate=c if relu else None,
-                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0, dw_out=sk("w2"), db_out=sk("b2"))
+                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0, dw_out=sk("w2"), db_out=sk("b2"), queue=wq)
             if relu or cfg.act is None:
                 dz1 = dh
                 if cfg.act is None and p > 0:
@@ -311,23 +318,23 @@ class ResidualBlockFn(torch.autograd.Function):
             else:
                 dz1 = ops.dropout_bwd(dh, p, rng, sites[0]) if p > 0 else dh
                 dz1 = ops.act_bwd(dz1, sv["pre"], cfg.act)
-            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"))
+            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"), queue=wq)
         elif cfg.kind == "self":
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"))
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq)
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
                      sites[0], ctx_out=c, mask=ctx.mask)
-            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"))
+            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"), queue=wq)
         else:  # cross
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"))
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq)
             q, kv = sv["q"], sv["kv"]
             dq, dkv = torch.empty_like(q), torch.empty_like(kv)
             attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
                      ctx_out=c, mask=ctx.mask)
-            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"))
+            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"), queue=wq)
             dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
-                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"))
+                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq)
             dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
         if cfg.ln_mode == "pre":
             dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
@@ -423,7 +430,8 @@ class LinearFn(torch.autograd.Function):
             dy2 = ops.cast(dy2, x2.dtype)
         sink = ctx.sink or {}
         dx, dw, db = linear_bwd(dy2, x2, w, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[2],
-                                need_db=ctx.has_bias and ctx.needs_input_grad[3], dw_out=sink.get("w"), db_out=sink.get("b"))
+                                need_db=ctx.has_bias and ctx.needs_input_grad[3], dw_out=sink.get("w"), db_out=sink.get("b"),
+                                queue=sink.get("_wq"))
         if sink and ctx.notify is not None:
             ctx.notify(ctx.leaves)
         return (None if dx is None else dx.view(ctx.shape)), None, dw, db, None, None, None

@@ -144,6 +144,35 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     return C_out
 
 
+def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alpha=1.0, a_rowsums=None):
+    """len(As) independent products C_i = alpha * A_i^T B_i (+ beta C_i) of one shape in one launch (js2t_gemm_grouped):
+    bf16 [K, M] / [K, N] operands (trans_a = trans_b = 1), f32 or bf16 C_i, optional f32[M] row-sum targets."""
+    n = len(As)
+    if not (n == len(Bs) == len(Cs)) or (a_rowsums is not None and len(a_rowsums) != n):
+        raise Js2tError("gemm_grouped: list lengths differ")
+    if n == 0:
+        return
+    _dev(*As, *Bs, *Cs, *(a_rowsums or ()))
+    if any(t.dtype != torch.bfloat16 for t in (*As, *Bs)) or any(c.dtype != Cs[0].dtype for c in Cs):
+        raise Js2tError("gemm_grouped: bf16 operands and one output dtype required")
+    d = GemmDesc()
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.batch, d.batch_inner = 1, 1
+    d.dtype_ab, d.dtype_c = BF16, dt_code(Cs[0])
+    d.trans_a, d.trans_b = 1, 1
+    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
+    d.alpha, d.beta, d.split_k = float(alpha), float(beta), int(split_k)
+    d.res_scale = d.gate_scale = 1.0
+    arr = C.c_void_p * n
+    pa, pb, pc = arr(*[t.data_ptr() for t in As]), arr(*[t.data_ptr() for t in Bs]), arr(*[t.data_ptr() for t in Cs])
+    pr = None if a_rowsums is None else arr(*[t.data_ptr() for t in a_rowsums])
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.wrap(f"gemm_bf16_dma_grouped_kernel<1,1,{int(d.split_k > 1)}>", 2.0 * d.M * d.N * d.K * n,
+                        lambda: check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped"))
+    else:
+        check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped")
+
+
 # ----------------------------------------------------------------------------------------- element-wise
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(src, out)

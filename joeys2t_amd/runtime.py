@@ -140,6 +140,44 @@ class ParamStore:
         return out
 
 
+class WgradQueue:
+    """Weight-gradient products put off until the backward pass is over (or `flush_every` of them are waiting).
+
+    A single dW = dY^T X of a 512/2048-wide layer has 16..64 output tiles for 256 CUs, so on its own it has to cut the
+    token dimension into slices that are summed with f32 atomics - the atomics cost as much as the product.  All layers
+    of one type together have enough tiles: queued products of one shape run as ONE grouped launch
+    (ops.gemm_grouped) with no, or a much smaller, split.  The operands (dY, X) are kept alive by the queue; 288 GB of
+    HBM make the extra ~2 GB irrelevant.  The bias gradient rides along (a_rowsum)."""
+
+    def __init__(self, flush_every: Optional[int] = None):
+        self.groups = {}
+        self.pending = 0
+        self.flush_every = flush_every
+        self.after_flush = []  # callables run once the queued gradients are complete (DDP bucket bookkeeping)
+
+    def add(self, dz2d: torch.Tensor, x2d: torch.Tensor, dw_out: torch.Tensor, db_out: Optional[torch.Tensor]):
+        N, K, M = dz2d.shape[1], x2d.shape[1], dz2d.shape[0]
+        key = (N, K, M, dz2d.stride(0), x2d.stride(0), db_out is not None)
+        self.groups.setdefault(key, []).append((dz2d, x2d, dw_out, db_out))
+        self.pending += 1
+        if self.flush_every is not None and self.pending >= self.flush_every:
+            self.flush()
+
+    def flush(self):
+        from joeys2t_amd.functional import wgrad_split
+        for (N, K, M, lda, ldb, has_db), items in self.groups.items():
+            n = len(items)
+            sk = wgrad_split(N, K, M, count=n)
+            ops.gemm_grouped([it[0] for it in items], [it[1] for it in items], [it[2] for it in items], M=N, N=K, K=M, lda=lda,
+                             ldb=ldb, ldc=K, split_k=sk, beta=0.0 if sk > 1 else 1.0,
+                             a_rowsums=[it[3] for it in items] if has_db else None)
+        self.groups.clear()
+        self.pending = 0
+        cbs, self.after_flush = self.after_flush, []
+        for cb in cbs:
+            cb()
+
+
 class Runtime:
     """What every HIP-backed module needs at call time."""
 
@@ -150,6 +188,7 @@ class Runtime:
         self._rng: Optional[ops.DropoutRng] = None
         self.direct_grads = True  # kernels accumulate parameter gradients straight into the flat gradient buffer
         self.on_grads_ready = None  # callable(list of params): DDP bucket bookkeeping for directly written gradients
+        self.wgrad_queue: Optional[WgradQueue] = None  # set (TrainStep) to defer + group the weight-gradient products
 
     @property
     def rng(self) -> ops.DropoutRng:
@@ -197,11 +236,23 @@ class Runtime:
             if v is None:
                 return None
             out[name] = v
+        if self.wgrad_queue is not None:
+            out["_wq"] = self.wgrad_queue
         return out
+
+    def flush_wgrads(self):
+        """Run the deferred weight-gradient products (call after backward, before anything reads the gradients)."""
+        if self.wgrad_queue is not None:
+            self.wgrad_queue.flush()
 
     def grads_ready(self, params):
         if self.on_grads_ready is not None:
-            self.on_grads_ready([p for p in params if p is not None])
+            ps = [p for p in params if p is not None]
+            q = self.wgrad_queue
+            if q is not None and q.pending:
+                q.after_flush.append(lambda: self.on_grads_ready(ps))  # their weight gradients are still queued
+            else:
+                self.on_grads_ready(ps)
 
     def act_in(self, x: torch.Tensor) -> torch.Tensor:
         """Bring an activation into the compute dtype (autocast-style entry cast)."""

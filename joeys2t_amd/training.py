@@ -21,13 +21,15 @@ from joeys2t_amd.batch import Batch
 from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
 from joeys2t_amd.helpers_for_ddp import FlatGradReducer, use_ddp
 from joeys2t_amd.model import Model
+from joeys2t_amd.runtime import WgradQueue
 
 
 class TrainStep:
     def __init__(self, model: Model, *, learning_rate: float = 2.0e-3, adam_betas=(0.9, 0.98), weight_decay: float = 0.0,
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
                  learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
-                 batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False):
+                 batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False,
+                 defer_wgrads: bool = True):
         self.model = model
         self.rt = model.runtime
         self.store = self.rt.store
@@ -47,6 +49,8 @@ class TrainStep:
         self.sync_every_backward = sync_every_backward
         self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets) if use_ddp() else None
         self.rt.on_grads_ready = self.reducer.params_ready if self.reducer is not None else None
+        # weight-gradient products are queued during backward and run grouped by layer type afterwards
+        self.rt.wgrad_queue = WgradQueue() if defer_wgrads else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
 
@@ -67,6 +71,7 @@ class TrainStep:
         total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
         norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
         norm.backward()
+        self.rt.flush_wgrads()
         if use_hooks:
             self.reducer.finish()
         with torch.no_grad():

@@ -493,3 +493,23 @@ def test_gemm_a_rowsum_bias_grad(device, split):
     torch.testing.assert_close(rs.cpu(), a.float().sum(1), rtol=1e-4, atol=1e-3)
     with pytest.raises(Js2tError):  # fp32 operands run on the generic kernel, which has no row-sum path
         ops.gemm(a.float().to(device), b.float().to(device), out, M=300, N=130, K=264, lda=264, ldb=264, ldc=130, a_rowsum=rs)
+
+
+@pytest.mark.parametrize("split", [1, 3])
+def test_gemm_grouped_matches_single_products(device, split):
+    """js2t_gemm_grouped: several dW_i = dY_i^T X_i of one shape at unrelated addresses in one launch, accumulating onto
+    the existing gradient (beta = 1 / atomics) with the bias gradient alongside; more products than one chunk holds."""
+    rows, cols, tokens, n = 136, 264, 777, 35
+    g = torch.Generator().manual_seed(5)
+    dzs = [torch.randn(tokens, rows, generator=g).bfloat16().to(device) for _ in range(n)]
+    xs = [torch.randn(tokens, cols, generator=g).bfloat16().to(device) for _ in range(n)]
+    base_w = [torch.randn(rows, cols, generator=g) for _ in range(n)]
+    base_b = [torch.randn(rows, generator=g) for _ in range(n)]
+    Cs = [b.clone().to(device) for b in base_w]
+    rs = [b.clone().to(device) for b in base_b]
+    ops.gemm_grouped(dzs, xs, Cs, M=rows, N=cols, K=tokens, lda=rows, ldb=cols, ldc=cols, split_k=split,
+                     beta=0.0 if split > 1 else 1.0, a_rowsums=rs)
+    for i in (0, 1, 17, 33, 34):
+        ref = base_w[i] + dzs[i].float().cpu().t() @ xs[i].float().cpu()
+        torch.testing.assert_close(Cs[i].cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
+        torch.testing.assert_close(rs[i].cpu(), base_b[i] + dzs[i].float().cpu().sum(0), rtol=1e-4, atol=2e-3)
