@@ -65,22 +65,24 @@ class GemmTimer:
     def __init__(self):
         self.records = []  # (key, flops, start_event, end_event)
 
-    def wrap(self, key, flops, launch):
+    def wrap(self, key, flops, launch, nbytes=0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = torch.cuda.current_stream()
         s.record(st)
         launch()
         e.record(st)
-        self.records.append((key, flops, s, e))
+        self.records.append((key, flops, s, e, nbytes))
 
     def summary(self):
+        """{kernel: [launches, flops, seconds, algorithmic operand + result bytes]}"""
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, s, e in self.records:
-            a = agg.setdefault(key, [0, 0.0, 0.0])
+        for key, flops, s, e, nbytes in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += flops
             a[2] += s.elapsed_time(e) * 1e-3
+            a[3] += nbytes
         return agg
 
 
@@ -315,23 +317,49 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         timer = GemmTimer()
+        # The eager pass is launch-bound on the host (~40 us of Python per kernel): an event pair around a launch
+        # would also time the GPU waiting for the next packet.  A spin kernel in front of each step holds the GPU
+        # while the host enqueues the whole step, so the timed kernels then run back to back from a full queue.
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        torch.cuda._sleep(10_000_000)
+        s1.record()
+        torch.cuda.synchronize()
+        cycles_per_ms = 10_000_000 / max(s0.elapsed_time(s1), 1e-3)
         ops.GEMM_TIMER = timer
         for _ in range(2):
+            torch.cuda._sleep(int(80 * cycles_per_ms))
             eager_step()
+            torch.cuda.synchronize()
         ops.GEMM_TIMER = None
+        # an event pair with nothing between its records still reads a few microseconds (the two timestamp packets):
+        # measured here the same way and taken off every timed launch
+        torch.cuda._sleep(int(20 * cycles_per_ms))
+        empty = GemmTimer()
+        for _ in range(256):
+            empty.wrap("empty", 0.0, lambda: None)
+        pair_overhead = empty.summary()["empty"][2] / 256
         agg = timer.summary()
+        for v in agg.values():
+            v[2] = max(v[2] - v[0] * pair_overhead, 1e-9)
         # dominant kernel = the bf16 LDS-DMA MFMA GEMM (all <trans_a,trans_b,split_k> instantiations of
         # gemm_bf16_dma_kernel and its grouped launch form: forward, dgrad and the deferred wgrad products);
         # per-instantiation figures are listed beside it
-        fam = {k: v for k, v in agg.items() if k.startswith("gemm_bf16_dma_kernel")}
+        fam = {k: v for k, v in agg.items() if k.startswith("gemm_bf16_dma_")}
         n = sum(v[0] for v in fam.values())
         flops = sum(v[1] for v in fam.values())
         secs = sum(v[2] for v in fam.values())
         achieved = flops / secs / 1e12
+        algo_bytes = sum(v[3] for v in fam.values()) / n
+        traffic = None  # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE)
+        tfile = ROOT / "profiles" / "gemm_traffic.json"
+        if tfile.exists():
+            traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
         key = "gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
         roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // 2,
-                    "avg_launch_us": round(secs / n * 1e6, 2),
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo_bytes),
+                    "flop_per_launch": round(flops / n), "launches_per_step": n // 2,
+                    "avg_launch_us": round(secs / n * 1e6, 2), "event_pair_overhead_us": round(pair_overhead * 1e6, 2),
                     "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
                                              "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
 

@@ -138,7 +138,8 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
             key = f"{fam}<{int(d.trans_a)},{int(d.trans_b)},{int(d.split_k > 1)}>"
         else:
             key = "gemm_generic_kernel"
-        GEMM_TIMER.wrap(key, 2.0 * d.M * d.N * d.K * d.batch, lambda: check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm"))
+        GEMM_TIMER.wrap(key, 2.0 * d.M * d.N * d.K * d.batch, lambda: check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm"),
+                        nbytes=d.batch * (esa * (d.M * d.K + d.N * d.K) + esc * d.M * d.N))
     else:
         check(lib().js2t_gemm(C.byref(d), _stream()), "js2t_gemm")
     return C_out
@@ -168,7 +169,8 @@ def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alp
     pr = None if a_rowsums is None else arr(*[t.data_ptr() for t in a_rowsums])
     if GEMM_TIMER is not None:
         GEMM_TIMER.wrap(f"gemm_bf16_dma_grouped_kernel<1,1,{int(d.split_k > 1)}>", 2.0 * d.M * d.N * d.K * n,
-                        lambda: check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped"))
+                        lambda: check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped"),
+                        nbytes=n * (2 * (d.M * d.K + d.N * d.K) + Cs[0].element_size() * d.M * d.N * (2 if d.beta else 1)))
     else:
         check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped")
 

@@ -1,0 +1,53 @@
+"""Micro-benchmark of the fused attention kernels on the LS100 train-step shapes (run on the GPU box).
+usage: python tools/attn_bench.py [reps]   (profile with rocprofv3 --kernel-trace --stats for the per-kernel split)"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from joeys2t_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+
+
+def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
+    dh = 128
+    d = H * dh
+    qkv = torch.randn(B * Tq, 3 * d, device=dev).bfloat16()
+    kv = qkv if Tk == Tq else torch.randn(B * Tk, 3 * d, device=dev).bfloat16()
+    dout = torch.randn(B * Tq, d, device=dev).bfloat16()
+    dqkv = torch.empty_like(qkv)
+    dkv = dqkv if Tk == Tq else torch.empty_like(kv)
+    mask = torch.ones(B, Tq if causal else 1, Tk, dtype=torch.bool, device=dev)
+    if causal:
+        mask = torch.tril(mask)
+    rng = ops.dropout_rng(dev)
+
+    def fwd():
+        return ops.flash_attn_fwd(qkv, 2 * d, kv, 0, kv, d, B, H, Tq, Tk, dh, mask, p, rng, 5)
+
+    out, lse = fwd()
+
+    def bwd():
+        ops.flash_attn_bwd(dout, out, lse, qkv, 2 * d, kv, 0, kv, d, dqkv, 2 * d, dkv, 0, dkv, d, B, H, Tq, Tk, dh, mask, p, rng, 5)
+
+    for fn, nm, gemms in ((fwd, "fwd", 2), (bwd, "bwd", 7)):
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 1e3 / reps
+        fl = gemms * 2.0 * B * H * Tq * Tk * dh
+        print(f"{name:24s} {nm} B={B} H={H} Tq={Tq} Tk={Tk} {us:8.1f} us {fl / us / 1e6:7.1f} TF", flush=True)
+
+
+bench("encoder self", 32, 4, 375, 375)
+bench("decoder self (causal)", 32, 4, 81, 81, causal=True)
+bench("decoder cross", 32, 4, 81, 375)

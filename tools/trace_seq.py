@@ -1,0 +1,14 @@
+"""Print the kernel launch sequence of the last eager train step in a rocprofv3 kernel trace (name, grid, us)."""
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+f = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+# last step = from the last fbank_kernel on
+idx = max(i for i, r in enumerate(rows) if "fbank_kernel" in r["Kernel_Name"])
+t0 = int(rows[idx]["Start_Timestamp"])
+for r in rows[idx:]:
+    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
+    print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} {name:60s} grid={r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}")
