@@ -281,11 +281,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # JS2T_BENCH_BACKEND=gloo + several ranks on one card rehearses the N > 1 code path on a single-GPU box
+    # (gradient exchange through gloo instead of RCCL); never set by the driver
+    backend = os.environ.get("JS2T_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from joeys2t_amd import ops
     eager_step, graph_step, capture, step, frames_per_step = build_step(device, world)
