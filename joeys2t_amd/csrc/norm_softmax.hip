@@ -158,7 +158,7 @@ template <> struct ld8<float> {
   }
 };
 constexpr int LNV_MAXCH = 4;        // chunks of 8 columns per lane -> D <= 2048
-constexpr int LNV_ROWS = 32;        // rows per 256-thread block in the backward kernel (8 per wave)
+constexpr int LNV_ROWS = 32;        // rows per block in the backward kernel (shared by its 4..16 waves)
 
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -204,34 +204,38 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restr
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// dx (+ add) and per-block partial sums of dgamma / dbeta: partial[(2*blk + 0)*D + c], partial[(2*blk + 1)*D + c]
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                const float* __restrict__ rstd, T* __restrict__ dx,
-                                                                const T* __restrict__ add, float add_scale,
-                                                                float* __restrict__ partial, float* dgamma_acc,
-                                                                float* dbeta_acc, int64_t rows, int D) {
-  extern __shared__ float red[];  // [4 waves][2][D]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// dx (+ add) and per-block partial sums of dgamma / dbeta: partial[(2*blk + 0)*D + c], partial[(2*blk + 1)*D + c].
+// NCH = chunks of 8 columns per lane (compile-time so the per-lane arrays are no larger than the row needs); the block
+// has blockDim/64 waves sharing LNV_ROWS rows - many short waves, because one row is a load -> two wave reductions ->
+// store latency chain and only other waves can hide it.
+template <typename T, int NCH>
+__global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, T* __restrict__ dx,
+                                                                 const T* __restrict__ add, float add_scale,
+                                                                 float* __restrict__ partial, float* dgamma_acc,
+                                                                 float* dbeta_acc, int64_t rows, int D) {
+  extern __shared__ float red[];  // [waves][2][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int nch = D >> 3;
-  float gm[LNV_MAXCH][8], ag[LNV_MAXCH][8], ab[LNV_MAXCH][8];
+  const int rpw = LNV_ROWS / nw;
+  float gm[NCH][8], ag[NCH][8], ab[NCH][8];
 #pragma unroll
-  for (int j = 0; j < LNV_MAXCH; ++j) {
+  for (int j = 0; j < NCH; ++j) {
     const int c = lane + 64 * j;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; gm[j][i] = 0.f; }
     if (c < nch) ld8<float>::ld(gamma + 8 * c, gm[j]);
   }
-  const int64_t r0 = (int64_t)blockIdx.x * LNV_ROWS + w * (LNV_ROWS / 4);
-  for (int rr = 0; rr < LNV_ROWS / 4; ++rr) {
+  const int64_t r0 = (int64_t)blockIdx.x * LNV_ROWS + w * rpw;
+  for (int rr = 0; rr < rpw; ++rr) {
     const int64_t row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
-    float g[LNV_MAXCH][8], xh[LNV_MAXCH][8];
+    float g[NCH][8], xh[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LNV_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
         float dyv[8], xv[8];
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int j = 0; j < LNV_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
         float o[8];
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
   }
   if (partial || dgamma_acc) {
 #pragma unroll
-    for (int j = 0; j < LNV_MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
 #pragma unroll
@@ -281,10 +285,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const T* __restr
     }
     __syncthreads();
     typedef __attribute__((address_space(1))) float gfloat;
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
       const int which = i / D, c = i - which * D;
-      const float tot = (red[(0 * 2 + which) * D + c] + red[(1 * 2 + which) * D + c]) +
-                        (red[(2 * 2 + which) * D + c] + red[(3 * 2 + which) * D + c]);
+      float tot = 0.f;
+      for (int ww = 0; ww < nw; ++ww) tot += red[(ww * 2 + which) * D + c];
       if (dgamma_acc) {
         // accumulate mode: the block totals go straight onto the gradient (contiguous 1 KB atomic segments per
         // wave-instruction), no partial slab and no second kernel
@@ -398,6 +402,24 @@ __global__ void attn_head_mean_kernel(const T* __restrict__ P, float* __restrict
 
 }  // namespace
 
+template <typename T, int NCH>
+static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                             const void* add, float add_scale, float* part, float* dga, float* dba, int64_t rows, int D,
+                             int64_t nblk, int nw, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_vec_kernel<T, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T, NCH>), dim3((unsigned)nblk), dim3(64 * nw), lds, s, (const T*)dy, (const T*)x, gamma,
+                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D);
+  return JS2T_OK;
+}
+
 #define DISPATCH_DT(dt, T, ...)                                  \
   do {                                                           \
     if ((dt) == JS2T_F32) { typedef float T; __VA_ARGS__; }      \
@@ -438,11 +460,24 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
     const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
     JS2T_CHECK(!want_p || direct || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
     const int64_t nblk = (rows + LNV_ROWS - 1) / LNV_ROWS;
-    const size_t lds = sizeof(float) * 8 * D;
-    DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, s, (const T*)dy,
-                                          (const T*)x, gamma, mean, rstd, (T*)dx, (const T*)add, add_scale,
-                                          (want_p && !direct) ? partial : (float*)nullptr, direct ? dgamma : (float*)nullptr,
-                                          direct ? dbeta : (float*)nullptr, rows, (int)D));
+    // waves per block: as many as a 64 KB cross-wave reduction buffer allows (16 for D <= 512)
+    int nw = 16;
+    while (nw > 4 && (size_t)nw * 2 * D * sizeof(float) > 65536) nw >>= 1;
+    const size_t lds = sizeof(float) * 2 * nw * D;
+    float* part = (want_p && !direct) ? partial : (float*)nullptr;
+    float* dga = direct ? dgamma : (float*)nullptr;
+    float* dba = direct ? dbeta : (float*)nullptr;
+    int rc;
+    if (dt == JS2T_F32) {
+      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
+         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
+                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s);
+    } else {
+      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
+         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
+                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s);
+    }
+    if (rc != JS2T_OK) return rc;
     JS2T_LAUNCH_CHECK();
     if (want_p && !direct) {
       hipLaunchKernelGGL(layernorm_bwd_param_final_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, partial, dgamma, dbeta, nblk, D,
