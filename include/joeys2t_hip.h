@@ -63,7 +63,7 @@ const char* js2t_last_error(void);
  * split_k > 1 (weight gradients: few output tiles, K = tokens) spreads the reduction over split_k blocks per tile.
  * a_rowsum != NULL: additionally a_rowsum[m] += sum_k op(A)[m,k] (f32 atomics onto whatever is there).  For a weight
  * gradient dW = dY^T X this is the bias gradient (autograd of nn.Linear, transformer_layers.py:75-107), taken from the
- * dY tiles the product already holds in LDS.  bf16 LDS-DMA path only (batch == 1, no implicit conv).
+ * dY tiles the product already holds in LDS.  bf16 LDS-DMA path with trans_a = trans_b = 1 only (batch == 1, no conv).
  */
 typedef struct js2t_gemm_desc {
   int32_t M, N, K;

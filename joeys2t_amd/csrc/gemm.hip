@@ -814,6 +814,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
   static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
   constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
   constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
+  constexpr int NST = 2;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
@@ -838,34 +839,48 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
 
   // optional row sums of op(A) (bias gradient of a weight-gradient product): the first tile column's wn == 0 waves
   // multiply their A fragments with an all-ones fragment, 4 extra MFMAs per 32 k
-  const bool do_rs = d.a_rowsum != nullptr && n0 == 0 && wn == 0;
+  const bool do_rs = TA && TB && d.a_rowsum != nullptr && n0 == 0 && wn == 0;
   f32x4_t racc[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) racc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((ext_vector_type(8))) short s16x8_ones_t;
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, s16x8_ones_t{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
 
+  // Two stages of 64 k.  A third stage with counted vmcnt + raw s_barrier (NST = 3, kept below) was measured on the
+  // 64-row tile: 72 KB of LDS leave two blocks per CU instead of three and the products got 25-60 % slower - what
+  // hides the DMA latency here is the third resident block, not a deeper ring.
+  constexpr int PER = NPA + 4;  // DMA instructions per wave and stage
   int64_t oa[NPA], ob[4];
-  dma_offsets<TA, NPA>(lda, m0, M, kt0 * F_BK, K, t, oa);
-  dma_offsets<TB, 4>(ldb, n0, N, kt0 * F_BK, K, t, ob);
-  dma_issue<NPA>(Ab, oa, smem, t);
-  dma_issue<4>(Bb, ob, smem + A_TILE, t);
+  auto issue_stage = [&](int s, int slot) {
+    dma_offsets<TA, NPA>(lda, m0, M, (kt0 + s) * F_BK, K, t, oa);
+    dma_offsets<TB, 4>(ldb, n0, N, (kt0 + s) * F_BK, K, t, ob);
+    dma_issue<NPA>(Ab, oa, smem + slot * STAGE, t);
+    dma_issue<4>(Bb, ob, smem + slot * STAGE + A_TILE, t);
+  };
+  issue_stage(0, 0);
+  if (NST == 3 && nk > 1) issue_stage(1, 1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int k0 = (kt0 + kt) * F_BK;
-    // tile kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
+    if (NST == 3 && kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (k0 + F_BK > K) {
       dma_zero_tail<TA, NPA>(smem + cur * STAGE, K - k0, t);
       dma_zero_tail<TB, 4>(smem + cur * STAGE + A_TILE, K - k0, t);
     }
-    __syncthreads();
-    if (kt + 1 < nk) {  // stream the next tile into the other stage while this one is consumed
-      dma_offsets<TA, NPA>(lda, m0, M, k0 + F_BK, K, t, oa);
-      dma_offsets<TB, 4>(ldb, n0, N, k0 + F_BK, K, t, ob);
-      dma_issue<NPA>(Ab, oa, smem + (cur ^ 1) * STAGE, t);
-      dma_issue<4>(Bb, ob, smem + (cur ^ 1) * STAGE + A_TILE, t);
+    if (NST == 2) {
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    // the slot requested now was consumed in iteration kt-1, which every wave has left (barrier above)
+    if (kt + NST - 1 < nk) issue_stage(kt + NST - 1, NST == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
     const unsigned char* At = smem + cur * STAGE;
     const unsigned char* Bt = At + A_TILE;
 #pragma unroll
@@ -898,8 +913,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
         for (int i = 0; i < MI; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm[i], racc[i], 0, 0, 0);
       }
     }
-    // the stage consumed here is overwritten by the DMA issued in the NEXT iteration, after its barrier
-    cur ^= 1;
+    cur = cur + 1 == NST ? 0 : cur + 1;
   }
   if (do_rs && (lane >> 4) == 0) {  // every output row of the ones-product holds the same sums: take row 0
     typedef __attribute__((address_space(1))) float gfloat;
@@ -943,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_grouped_kernel(js2t_gemm
 
 template <int BM, bool TA, bool TB, bool SPLITK>
 int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = (BM == 128 || TA) ? 65536 : 2 * (BM * 128 + 16384) > BM * 128 * 4 ? 2 * (BM * 128 + 16384) : BM * 128 * 4;
+  constexpr int LDS = (BM == 128 || TA) ? 65536 : 2 * (BM * 128 + 16384);  // stages (the epilogue staging aliases them)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, TA, TB, SPLITK>,
@@ -1075,7 +1089,8 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.conv_c > 0 && d.conv_tin > 0 && d.conv_tout > 0 && d.conv_stride > 0, "gemm: bad conv geometry");
   }
   JS2T_CHECK(!(d.residual || d.gate) || d.batch == 1, "gemm: residual / gate need batch == 1");
-  JS2T_CHECK(!d.a_rowsum || (d.batch == 1 && !d.conv && !g_force_regstage), "gemm: a_rowsum needs batch == 1 and the LDS-DMA kernel");
+  JS2T_CHECK(!d.a_rowsum || (d.batch == 1 && !d.conv && !g_force_regstage && d.trans_a && d.trans_b),
+             "gemm: a_rowsum needs trans_a = trans_b = 1, batch == 1 and the LDS-DMA kernel");
   if (d.split_k < 1) d.split_k = 1;
   if (d.split_k > 1) {
     JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&

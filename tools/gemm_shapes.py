@@ -31,8 +31,9 @@ def main():
         return orig(A, B, C_out, **kw)
 
     class T:
-        def wrap(self, key, flops, launch):
-            timer.wrap(timer.tag, flops, launch)
+        def wrap(self, key, flops, launch, nbytes=0):
+            tag = timer.tag if "grouped" not in key else (1, 1, 0, 0, 0, 0, 0, "-", "grp", "-", "-", "-", key[-12:])
+            timer.wrap(tag, flops, launch)
 
     ops.gemm = gemm
     import joeys2t_amd.functional as F
@@ -45,7 +46,7 @@ def main():
     tot = 0.0
     rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
     print(f"{'ta tb sk     M     N     K  bat epi':44s} {'n/step':>6s} {'us':>8s} {'TF':>7s} {'ms/step':>8s} {'hbm_us':>7s}")
-    for tag, (cnt, flops, secs) in rows:
+    for tag, (cnt, flops, secs, _) in rows:
         ta, tb, sk, M, N, K, bat, b, act, d, r, c, cd = tag
         es = 4 if cd == "float32" else 2
         byts = bat * (M * K * 2 + N * K * 2 + M * N * es)
