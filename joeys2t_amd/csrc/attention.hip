@@ -386,71 +386,127 @@ __global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ dK / dV
 // own rows = keys; sweeps query tiles; Q image (row + transposed reads) and dO image (row + transposed reads)
-__global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
+// One (query tile, own-key block) of the dK/dV pass: probabilities and dS from the S / dP accumulators.
+//   pv  = exp2(s * scale*log2e - lse*log2e)        (lse_s holds lse*log2e, +inf for rows past Tq -> pv = 0)
+//   pd  = keep ? pv : 0                             (dV gets the 1/(1-p) factor once, at the end)
+//   ds' = pv * ((keep ? dp : 0) - delta*(1-p))      (dK gets scale/(1-p) once, at the end)
+// Dropout: the decision of (query row, key) is the half (key & 1) of hash32(rowhash + (key >> 1)) - the same value for
+// the two neighbouring lanes of a key pair, so each lane hashes two of the four rows and swaps with its neighbour (DPP).
+template <bool KEYCHECK, bool FULLMASK>
+__device__ __forceinline__ void dkv_elements(f32x4_t (&s)[4], f32x4_t (&dp)[4], const float* lse2, const float* dl2, const uint32_t* rkp,
+                                             float scale2, bool key_ok, int key, uint32_t thr, bool drop, int g, int par,
+                                             const uint8_t* mcol, int64_t msq, int qbase, int Tq) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const f32x4_t l4 = *(const f32x4_t*)(lse2 + 16 * tt + 4 * g);
+    const f32x4_t d4 = *(const f32x4_t*)(dl2 + 16 * tt + 4 * g);
+    uint32_t h[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (drop) {
+      const uint2 rk2 = *(const uint2*)(rkp + 16 * tt + 4 * g + 2 * par);  // row hashes of this lane's two rows
+      const uint32_t c2 = (uint32_t)(key >> 1);
+      const uint32_t ha = hash32(rk2.x + c2), hb = hash32(rk2.y + c2);
+      const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)ha, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+      const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)hb, 0xB1, 0xf, 0xf, true);
+      h[0] = par ? na : ha, h[1] = par ? nb : hb, h[2] = par ? ha : na, h[3] = par ? hb : nb;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -l4[r]));
+      if (KEYCHECK) pv = key_ok ? pv : 0.f;
+      if (FULLMASK) {
+        const int qrow = min(qbase + 16 * tt + 4 * g + r, Tq - 1);
+        pv = mcol[(int64_t)qrow * msq] ? pv : 0.f;
+      }
+      const bool keep = ((h[r] >> (16 * (key & 1))) & 0xffffu) >= thr;
+      const float tdp = keep ? dp[tt][r] : 0.f;
+      s[tt][r] = keep ? pv : 0.f;
+      dp[tt][r] = pv * (tdp - d4[r]);
+    }
+  }
+}
+
+// DKV_NT own-key blocks of 16 per wave: with two (32 keys per wave) the dK / dV accumulators, the own K / V fragments and the
+// S / dP tiles need > 400 registers - one wave per SIMD, nothing to overlap the MFMA, exp / dropout VALU work and LDS
+// latency with.  One block per wave fits 256 registers, i.e. two waves per SIMD.
+constexpr int DKV_NT = 1;
+__global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float lse_s[2][64], dl_s[2][64];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
+  __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int k0 = blockIdx.x * 128 + w * 32;
+  const int k0 = blockIdx.x * (64 * DKV_NT) + w * (16 * DKV_NT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  bf16x8_t kf[2][4], vf[2][4];
+  bf16x8_t kf[DKV_NT][4], vf[DKV_NT][4];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < DKV_NT; ++nt) {
     own_frags(Kb, a.ldk, k0 + 16 * nt, a.Tk, lane, kf[nt]);
     own_frags(Vb, a.ldv, k0 + 16 * nt, a.Tk, lane, vf[nt]);
   }
-  f32x4_t dk[2][8], dv[2][8];
+  f32x4_t dk[DKV_NT][8], dv[DKV_NT][8];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int nt = 0; nt < DKV_NT; ++nt)
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
       dk[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       dv[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
-  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const bool drop = a.p > 0.f;
+  const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
+  const float keep_p = 1.f - a.p;  // delta is pre-multiplied by it so that dS carries a common 1/(1-p)
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
+  const float scale2 = a.scale * 1.4426950408889634f;
   const bool full_mask = a.mask && a.msq != 0;
-  bool key_valid[2];  // key-padding masks depend on the own key only: resolved once, outside the query sweep
+  bool key_valid[DKV_NT];  // key-padding masks depend on the own key only: resolved once, outside the query sweep
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < DKV_NT; ++nt) {
     const int key = k0 + 16 * nt + m;
     key_valid[nt] = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
   }
+  bool kv_all = true;
+#pragma unroll
+  for (int nt = 0; nt < DKV_NT; ++nt) kv_all = kv_all && key_valid[nt];
+  const bool all_keys = __all(kv_all) != 0;  // wave-uniform: no per-element key test needed
   const int nqt = (a.Tq + 63) / 64;
   img_dma(Qb, a.ldq, 0, a.Tq, smem, t);
   img_dma(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
+  // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in wave 0's registers: fetching
+  // them at the top of the iteration they are used in put a global-load round trip in front of every tile
+  float lse_r = 0.f, dl_r = 0.f;
+  if (t < 64) {
+    const int qc = min(t, a.Tq - 1);
+    lse_r = a.lse[(int64_t)z * a.Tq + qc];
+    dl_r = a.delta[(int64_t)z * a.Tq + qc];
+  }
   int cur = 0;
   for (int qt = 0; qt < nqt; ++qt) {
     if (t < 64) {
-      const int qc = min(qt * 64 + t, a.Tq - 1);
-      lse_s[cur][t] = a.lse[(int64_t)z * a.Tq + qc];
-      dl_s[cur][t] = a.delta[(int64_t)z * a.Tq + qc];
+      const bool live = qt * 64 + t < a.Tq;
+      lse_s[cur][t] = live ? lse_r * 1.4426950408889634f : INFINITY;  // rows past Tq: exp2(-inf) = 0
+      dl_s[cur][t] = dl_r * keep_p;
+      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * 64 + t, a.Tq - 1)) ^ dkey);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) {
       img_dma(Qb, a.ldq, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
       img_dma(Gb, a.lddo, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      if (t < 64) {
+        const int qc = min((qt + 1) * 64 + t, a.Tq - 1);
+        lse_r = a.lse[(int64_t)z * a.Tq + qc];
+        dl_r = a.delta[(int64_t)z * a.Tq + qc];
+      }
     }
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Gi = Qi + IMG_BYTES;
     // S = Q K^T and dP = dO V^T with D rows = tile queries, D cols = own keys:
     // s[nt][tt][r] <-> (query 64qt + 16tt + 4g + r, key k0 + 16nt + m)
-    bf16x8_t pf[2][2], dsf[2][2];
-    uint32_t rk[4][4];  // dropout row hashes of this lane's 16 tile queries, shared by both own-key blocks
-    if (a.p > 0.f) {
+    bf16x8_t pf[DKV_NT][2], dsf[DKV_NT][2];
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          rk[tt][r] = hash32((uint32_t)(z * a.Tq + min(qt * 64 + 16 * tt + 4 * g + r, a.Tq - 1)) ^ dkey);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {  // one own-key block at a time (register budget)
+    for (int nt = 0; nt < DKV_NT; ++nt) {  // one own-key block at a time (register budget)
       f32x4_t s[4], dp[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -465,26 +521,16 @@ __global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
           dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Gi, 16 * tt, ks, lane), vf[nt][ks], dp[tt], 0, 0, 0);
         }
       const int key = k0 + 16 * nt + m;
-      const bool key_ok = key_valid[nt];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ql = 16 * tt + 4 * g + r;
-          const int qrow = qt * 64 + ql;
-          bool on = key_ok && qrow < a.Tq;
-          if (on && full_mask) on = a.mask[(int64_t)b * a.msb + (int64_t)qrow * a.msq + key] != 0;
-          const float pv = on ? __expf(s[tt][r] * a.scale - lse_s[cur][ql]) : 0.f;
-          bool keep = true;
-          if (a.p > 0.f) {
-            // same decision as dropout_keep4_key(row = z*Tq + q, col4 = key/4) bit (key & 3)
-            const uint32_t hh = hash32(rk[tt][r] + 2u * (uint32_t)(key >> 2) + (uint32_t)((key >> 1) & 1));
-            keep = ((key & 1) ? (hh >> 16) : (hh & 0xffffu)) >= thr;
-          }
-          const float dpv = keep ? dp[tt][r] * drop_sc : 0.f;
-          s[tt][r] = keep ? pv * drop_sc : 0.f;                 // dropped probability (for dV)
-          dp[tt][r] = pv * (dpv - dl_s[cur][ql]) * a.scale;      // dS (for dK)
-        }
+      const uint8_t* mcol = full_mask ? a.mask + (int64_t)b * a.msb + min(key, a.Tk - 1) : nullptr;
+      if (full_mask)
+        dkv_elements<true, true>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, key_valid[nt], key, thr, drop, g, m & 1, mcol, a.msq,
+                                 qt * 64, a.Tq);
+      else if (!all_keys)
+        dkv_elements<true, false>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, key_valid[nt], key, thr, drop, g, m & 1, nullptr, 0,
+                                  qt * 64, a.Tq);
+      else
+        dkv_elements<false, false>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, true, key, thr, drop, g, m & 1, nullptr, 0,
+                                   qt * 64, a.Tq);
       pf[nt][0] = pack8(s[0], s[1]);
       pf[nt][1] = pack8(s[2], s[3]);
       dsf[nt][0] = pack8(dp[0], dp[1]);
@@ -498,23 +544,24 @@ __global__ __launch_bounds__(256, 1) void flash_dkv_kernel(AttnArgs a) {
         const bf16x8_t gt = img_tr(Gi, ss, ct, lane);
         const bf16x8_t qt_f = img_tr(Qi, ss, ct, lane);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < DKV_NT; ++nt) {
           dv[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf[nt][ss], dv[nt][ct], 0, 0, 0);
           dk[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[nt][ss], dk[nt][ct], 0, 0, 0);
         }
       }
     cur ^= 1;
   }
+  const float dv_sc = drop ? 1.f / keep_p : 1.f, dk_sc = a.scale * dv_sc;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < DKV_NT; ++nt) {
     const int key = k0 + 16 * nt + m;
     if (key >= a.Tk) continue;
     uint16_t* krow = a.dk + ((int64_t)b * a.Tk + key) * a.lddk + h * DH;
     uint16_t* vrow = a.dv + ((int64_t)b * a.Tk + key) * a.lddv + h * DH;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-      store4(krow + 16 * ct + 4 * g, dk[nt][ct], 1.f);
-      store4(vrow + 16 * ct + 4 * g, dv[nt][ct], 1.f);
+      store4(krow + 16 * ct + 4 * g, dk[nt][ct], dk_sc);
+      store4(vrow + 16 * ct + 4 * g, dv[nt][ct], dv_sc);
     }
   }
 }
@@ -593,7 +640,7 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)d->B * d->Tq * d->H, 4)), dim3(256), 0, s, a);
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
