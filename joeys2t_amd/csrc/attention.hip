@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) o[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
-  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const bool drop = a.p > 0.f;
+  const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
+  const float drop_sc = drop ? 1.f / (1.f - a.p) : 1.f;
+  const float scale2 = a.scale * 1.4426950408889634f;
   const int nkt = (a.Tk + 63) / 64;
   const bool full_mask = a.mask && a.msq != 0;
   uint32_t rowkey[2];
@@ -186,51 +188,55 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) s[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], s[mt][tt], 0, 0, 0);
       }
+    // online softmax in base 2: mi = running max of s*scale*log2e, li = running sum of exp2(.. - mi); the dropped
+    // probabilities go to the PV product unscaled, 1/(1-p) is applied with 1/li at the end
+    const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int qrow = q0 + 16 * mt + m;
-      const int qc = min(qrow, a.Tq - 1);
       uint32_t bits = kbits;
-      if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+      if (!tile_clear) {
+        const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
+        if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[mt][tt][r] = ((bits >> (4 * tt + r)) & 1u) ? s[mt][tt][r] : -INFINITY;
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool on = (bits >> (4 * tt + r)) & 1u;
-          const float v = on ? s[mt][tt][r] * a.scale : -INFINITY;
-          s[mt][tt][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = quad_max(mx);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[mt][tt][r]);
+      mx = quad_max(mx) * scale2;  // scale > 0: the max commutes with it
       const float mnew = fmaxf(mi[mt], mx);
       const float msafe = mnew == -INFINITY ? 0.f : mnew;
-      const float corr = __expf(mi[mt] - msafe);  // exp(-inf) = 0 on the first live tile
+      const float corr = __builtin_amdgcn_exp2f(mi[mt] - msafe);  // exp2(-inf) = 0 on the first live tile
       float rs = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        uint32_t keep = 0xFu;
-        if (a.p > 0.f) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
+        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+        if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
           const uint32_t c4 = (uint32_t)(16 * kt + 4 * tt + g);
-          const uint32_t h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
-          keep = ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
-                 ((h1 >> 16) >= thr ? 8u : 0u);
+          h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
         }
+        const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(s[mt][tt][r] - msafe);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[mt][tt][r], scale2, -msafe));
           rs += pv;
-          s[mt][tt][r] = ((keep >> r) & 1u) ? pv * drop_sc : 0.f;
+          s[mt][tt][r] = hv[r] >= thr ? pv : 0.f;
         }
       }
       rs = quad_sum(rs);
       li[mt] = li[mt] * corr + rs;
       mi[mt] = mnew;
+      if (!__all(corr == 1.f)) {  // the running maximum moved for some row of this wave: rescale the accumulators
 #pragma unroll
-      for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[mt][ct][r] *= corr;
+          for (int r = 0; r < 4; ++r) o[mt][ct][r] *= corr;
+      }
       pf[mt][0] = pack8(s[mt][0], s[mt][1]);
       pf[mt][1] = pack8(s[mt][2], s[mt][3]);
     }
@@ -249,11 +255,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   for (int mt = 0; mt < 2; ++mt) {
     const int qrow = q0 + 16 * mt + m;
     if (qrow >= a.Tq) continue;
-    const float inv = li[mt] > 0.f ? 1.f / li[mt] : NAN;  // all keys masked -> NaN, as softmax over -inf
+    const float inv = li[mt] > 0.f ? drop_sc / li[mt] : NAN;  // all keys masked -> NaN, as softmax over -inf
     uint16_t* orow = a.out + ((int64_t)b * a.Tq + qrow) * a.ldo + h * DH;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) store4(orow + 16 * ct + 4 * g, o[mt][ct], inv);
-    if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi[mt] + __logf(li[mt]);
+    if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi[mt] * 0.6931471805599453f + __logf(li[mt]);  // natural-log units
   }
 }
 
@@ -277,38 +283,65 @@ __global__ void attn_delta_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------ dQ
 // own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
 // 1 wave per SIMD: the 128 persistent accumulator/operand registers + tile temporaries need the wide register budget
-__global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
+// dS' of one (own query block, key tile): pv * ((keep ? dp : 0) - delta*(1-p)); the common factor scale/(1-p) is applied to
+// dQ once at the end.  lse2 = lse*log2e, scale2 = scale*log2e.  MASKED = some key of the tile is padded / masked out.
+template <bool MASKED>
+__device__ __forceinline__ void dq_elements(f32x4_t (&s)[4], const f32x4_t (&dp)[4], float scale2, float lse2, float dl2, uint32_t bits,
+                                            uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop) {
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+    if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
+      const uint32_t c4 = c4base + 4u * tt;
+      h0 = hash32(rowkey + 2u * c4), h1 = hash32(rowkey + 2u * c4 + 1u);
+    }
+    const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -lse2));
+      if (MASKED) pv = ((bits >> (4 * tt + r)) & 1u) ? pv : 0.f;
+      const float tdp = hv[r] >= thr ? dp[tt][r] : 0.f;
+      s[tt][r] = pv * (tdp - dl2);
+    }
+  }
+}
+
+// DQ_MT own-query blocks of 16 per wave (see DKV_NT: two need 346 registers, one wave per SIMD)
+constexpr int DQ_MT = 1;
+__global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q0 = blockIdx.x * (64 * DQ_MT) + w * (16 * DQ_MT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  bf16x8_t qf[2][4], gf[2][4];
-  float lse[2], dl[2];
+  const bool drop = a.p > 0.f;
+  const float keep_p = 1.f - a.p;
+  bf16x8_t qf[DQ_MT][4], gf[DQ_MT][4];
+  float lse2[DQ_MT], dl2[DQ_MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < DQ_MT; ++mt) {
     own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
     own_frags(Gb, a.lddo, q0 + 16 * mt, a.Tq, lane, gf[mt]);
     const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
-    lse[mt] = a.lse[(int64_t)z * a.Tq + qc];
-    dl[mt] = a.delta[(int64_t)z * a.Tq + qc];
+    lse2[mt] = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
+    dl2[mt] = a.delta[(int64_t)z * a.Tq + qc] * keep_p;
   }
-  f32x4_t dq[2][8];
+  f32x4_t dq[DQ_MT][8];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < DQ_MT; ++mt)
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) dq[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const uint32_t dkey = a.p > 0.f ? dropout_key(a.rng, a.stream) : 0u;
-  const float drop_sc = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
+  const float scale2 = a.scale * 1.4426950408889634f;
   const int nkt = (a.Tk + 63) / 64;
   const bool full_mask = a.mask && a.msq != 0;
-  uint32_t rowkey[2];
+  uint32_t rowkey[DQ_MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  for (int mt = 0; mt < DQ_MT; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kmask(kmask, a, b, nkt * 64, t);
   img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
@@ -324,9 +357,10 @@ __global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
     const uint32_t kbits = tile_kbits(kmask, kt, g);
-    bf16x8_t dsf[2][2];
+    const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
+    bf16x8_t dsf[DQ_MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {  // one own-row block at a time keeps the S / dP accumulators at 32 VGPRs
+    for (int mt = 0; mt < DQ_MT; ++mt) {
       f32x4_t s[4], dp[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -340,25 +374,14 @@ __global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
           s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ki, 16 * tt, ks, lane), qf[mt][ks], s[tt], 0, 0, 0);
           dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Vi, 16 * tt, ks, lane), gf[mt][ks], dp[tt], 0, 0, 0);
         }
-      const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
-      uint32_t bits = kbits;
-      if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        uint32_t keep = 0xFu;
-        if (a.p > 0.f) {
-          const uint32_t c4 = (uint32_t)(16 * kt + 4 * tt + g);
-          const uint32_t h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
-          keep = ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
-                 ((h1 >> 16) >= thr ? 8u : 0u);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool on = (bits >> (4 * tt + r)) & 1u;
-          const float pv = on ? __expf(s[tt][r] * a.scale - lse[mt]) : 0.f;
-          const float dpv = ((keep >> r) & 1u) ? dp[tt][r] * drop_sc : 0.f;
-          s[tt][r] = pv * (dpv - dl[mt]) * a.scale;  // dS (scaled for dQ = dS K / sqrt(dh))
-        }
+      const uint32_t c4base = (uint32_t)(16 * kt + g);
+      if (tile_clear) {
+        dq_elements<false>(s, dp, scale2, lse2[mt], dl2[mt], 0xffffu, rowkey[mt], c4base, thr, drop);
+      } else {
+        const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
+        uint32_t bits = kbits;
+        if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+        dq_elements<true>(s, dp, scale2, lse2[mt], dl2[mt], bits, rowkey[mt], c4base, thr, drop);
       }
       dsf[mt][0] = pack8(s[0], s[1]);
       dsf[mt][1] = pack8(s[2], s[3]);
@@ -370,17 +393,18 @@ __global__ __launch_bounds__(256, 1) void flash_dq_kernel(AttnArgs a) {
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8_t kt_f = img_tr(Ki, ss, ct, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) dq[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[mt][ss], dq[mt][ct], 0, 0, 0);
+        for (int mt = 0; mt < DQ_MT; ++mt) dq[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[mt][ss], dq[mt][ct], 0, 0, 0);
       }
     cur ^= 1;
   }
+  const float dq_sc = a.scale * (drop ? 1.f / keep_p : 1.f);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < DQ_MT; ++mt) {
     const int qrow = q0 + 16 * mt + m;
     if (qrow >= a.Tq) continue;
     uint16_t* drow = a.dq + ((int64_t)b * a.Tq + qrow) * a.lddq + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) store4(drow + 16 * ct + 4 * g, dq[mt][ct], 1.f);
+    for (int ct = 0; ct < 8; ++ct) store4(drow + 16 * ct + 4 * g, dq[mt][ct], dq_sc);
   }
 }
 
@@ -642,7 +666,7 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
