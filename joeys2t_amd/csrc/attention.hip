@@ -129,22 +129,23 @@ __device__ __forceinline__ uint32_t row_kbits(uint32_t bits, const uint8_t* mrow
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+constexpr int FWD_MT = 1;  // own-query blocks of 16 per wave
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  const int q0 = blockIdx.x * (64 * FWD_MT) + w * (16 * FWD_MT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  bf16x8_t qf[2][4];
+  bf16x8_t qf[FWD_MT][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
-  f32x4_t o[2][8];
-  float mi[2], li[2];
+  for (int mt = 0; mt < FWD_MT; ++mt) own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
+  f32x4_t o[FWD_MT][8];
+  float mi[FWD_MT], li[FWD_MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < FWD_MT; ++mt) {
     mi[mt] = -INFINITY;
     li[mt] = 0.f;
 #pragma unroll
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   const float scale2 = a.scale * 1.4426950408889634f;
   const int nkt = (a.Tk + 63) / 64;
   const bool full_mask = a.mask && a.msq != 0;
-  uint32_t rowkey[2];
+  uint32_t rowkey[FWD_MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  for (int mt = 0; mt < FWD_MT; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kmask(kmask, a, b, nkt * 64, t);
   img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     const unsigned char* Vi = Ki + IMG_BYTES;
     const uint32_t kbits = tile_kbits(kmask, kt, g);
     // S^T = K Q^T : s[mt][tt][r] = score(query q0+16mt+m, key 64kt + 16tt + 4g + r)
-    f32x4_t s[2][4];
+    f32x4_t s[FWD_MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < FWD_MT; ++mt)
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) s[mt][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -186,14 +187,14 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8_t kf = img_row(Ki, 16 * tt, ks, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) s[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], s[mt][tt], 0, 0, 0);
+        for (int mt = 0; mt < FWD_MT; ++mt) s[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], s[mt][tt], 0, 0, 0);
       }
     // online softmax in base 2: mi = running max of s*scale*log2e, li = running sum of exp2(.. - mi); the dropped
     // probabilities go to the PV product unscaled, 1/(1-p) is applied with 1/li at the end
     const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
-    bf16x8_t pf[2][2];
+    bf16x8_t pf[FWD_MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < FWD_MT; ++mt) {
       uint32_t bits = kbits;
       if (!tile_clear) {
         const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
@@ -247,12 +248,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
       for (int ss = 0; ss < 2; ++ss) {
         const bf16x8_t vf = img_tr(Vi, ss, ct, lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) o[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][ss], o[mt][ct], 0, 0, 0);
+        for (int mt = 0; mt < FWD_MT; ++mt) o[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][ss], o[mt][ct], 0, 0, 0);
       }
     cur ^= 1;
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < FWD_MT; ++mt) {
     const int qrow = q0 + 16 * mt + m;
     if (qrow >= a.Tq) continue;
     const float inv = li[mt] > 0.f ? drop_sc / li[mt] : NAN;  // all keys masked -> NaN, as softmax over -inf
@@ -639,7 +640,7 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 128), d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 64 * FWD_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
