@@ -230,16 +230,19 @@ int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream);
 /* nn.CTCLoss(blank, reduction='sum', zero_infinity) of loss.py:128-130,156-161 on LOGITS [B,T,V]
  * (batch-major; the reference's transpose(0,1) and log_softmax are folded in through `lse` = js2t_row_lse).
  * targets int64[B,Lmax] (padded), in_len/tgt_len int64[B].  alpha: f32[B,T,2*Lmax+1] (kept for backward),
- * nll: f32[B] raw negative log-likelihoods (inf when infeasible), loss_rows: f32[B] after zero_infinity. */
+ * nll: f32[B] raw negative log-likelihoods (inf when infeasible), loss_rows: f32[B] after zero_infinity.
+ * beta (optional, f32[B,T,2*Lmax+1]): when given, the backward recursion runs in the same launch (it does not depend on
+ * alpha) so that js2t_ctc_bwd(beta_ready = 1) only has the gradient pass left. */
 int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
-                   const int64_t* tgt_len, float* alpha, float* nll, float* loss_rows, int64_t B, int64_t T,
+                   const int64_t* tgt_len, float* alpha, float* beta, float* nll, float* loss_rows, int64_t B, int64_t T,
                    int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream);
-/* beta recursion + dlogits[b,t,v] = scale*(*g_dev)*(softmax_t(v) - sum_{s:ext(s)=v} exp(alpha+beta-lp+nll)),
- * zero for t >= in_len[b] and for infeasible utterances when zero_infinity.  beta: f32[B,T,2*Lmax+1] workspace. */
+/* beta recursion (skipped when beta_ready != 0) + dlogits[b,t,v] = scale*(*g_dev)*(softmax_t(v) -
+ * sum_{s:ext(s)=v} exp(alpha+beta-lp+nll)), zero for t >= in_len[b] and for infeasible utterances when zero_infinity.
+ * beta: f32[B,T,2*Lmax+1] workspace, or the result of js2t_ctc_alpha. */
 int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                  const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
                  float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
-                 int zero_infinity, js2t_stream stream);
+                 int zero_infinity, int beta_ready, js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Audio front-end (raw waveform -> padded, normalised, augmented feature batch).

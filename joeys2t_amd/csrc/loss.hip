@@ -163,13 +163,11 @@ constexpr int CTC_MAX_S = 1024;
 constexpr int CTC_CHUNK_FLOATS = 8192;  // emission staging: 32 KB of LDS
 
 template <typename T, bool BACKWARD>
-__global__ __launch_bounds__(CTC_THREADS) void ctc_recursion_kernel(
+__device__ __forceinline__ void ctc_recursion_body(
+    float (&a)[2][CTC_MAX_S + 2], int (&ext)[CTC_MAX_S], float (&em)[CTC_CHUNK_FLOATS],
     const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
     const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ out /*alpha|beta*/,
     float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
-  __shared__ float a[2][CTC_MAX_S + 2];
-  __shared__ int ext[CTC_MAX_S];
-  __shared__ float em[CTC_CHUNK_FLOATS];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t Tb = min(in_len[b], Tmax);
   const int L = (int)min(tgt_len[b], Lmax);
@@ -232,6 +230,32 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_recursion_kernel(
     if (S > 1) ll = logaddexp(ll, last[S - 2]);
     nll[b] = -ll;
   }
+}
+
+template <typename T, bool BACKWARD>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_recursion_kernel(
+    const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
+    const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ out, float* __restrict__ nll,
+    int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+  __shared__ float a[2][CTC_MAX_S + 2];
+  __shared__ int ext[CTC_MAX_S];
+  __shared__ float em[CTC_CHUNK_FLOATS];
+  ctc_recursion_body<T, BACKWARD>(a, ext, em, x, lse, targets, in_len, tgt_len, out, nll, Tmax, V, Lmax, Smax, blank);
+}
+// alpha (blockIdx.y == 0) and beta (blockIdx.y == 1) in one launch: each recursion is a chain of Tmax dependent steps on
+// one block per utterance - run back to back they leave the chip idle twice as long
+template <typename T>
+__global__ __launch_bounds__(CTC_THREADS) void ctc_both_kernel(
+    const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
+    const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ alpha, float* __restrict__ beta,
+    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+  __shared__ float a[2][CTC_MAX_S + 2];
+  __shared__ int ext[CTC_MAX_S];
+  __shared__ float em[CTC_CHUNK_FLOATS];
+  if (blockIdx.y == 0)
+    ctc_recursion_body<T, false>(a, ext, em, x, lse, targets, in_len, tgt_len, alpha, nll, Tmax, V, Lmax, Smax, blank);
+  else
+    ctc_recursion_body<T, true>(a, ext, em, x, lse, targets, in_len, tgt_len, beta, nullptr, Tmax, V, Lmax, Smax, blank);
 }
 
 // loss_b = zero_infinity ? (isinf(nll) ? 0 : nll) : nll
@@ -336,15 +360,20 @@ extern "C" int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream s
 }
 
 extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
-                              const int64_t* tgt_len, float* alpha, float* nll, float* loss_rows, int64_t B, int64_t T_,
-                              int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream) {
+                              const int64_t* tgt_len, float* alpha, float* beta, float* nll, float* loss_rows, int64_t B,
+                              int64_t T_, int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream) {
   if (B == 0) return JS2T_OK;
   JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && nll && loss_rows, "ctc_alpha: null pointer");
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_alpha: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
   const int64_t Smax = 2 * Lmax + 1;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, false>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
-                                        (const T*)logits, lse, targets, in_len, tgt_len, alpha, nll, T_, V, Lmax, Smax, blank));
+  if (beta) {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_both_kernel<T>), dim3((unsigned)B, 2), dim3(CTC_THREADS), 0, s, (const T*)logits, lse,
+                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank));
+  } else {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, false>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
+                                          (const T*)logits, lse, targets, in_len, tgt_len, alpha, nll, T_, V, Lmax, Smax, blank));
+  }
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(ctc_loss_rows_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, nll, loss_rows, B, zero_infinity);
   JS2T_LAUNCH_CHECK();
@@ -354,17 +383,19 @@ extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, cons
 extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                             const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
                             float scale, void* dlogits, int64_t B, int64_t T_, int64_t V, int64_t Lmax, int64_t blank,
-                            int zero_infinity, js2t_stream stream) {
+                            int zero_infinity, int beta_ready, js2t_stream stream) {
   if (B == 0) return JS2T_OK;
   JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && beta && nll && dlogits, "ctc_bwd: null pointer");
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_bwd: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
   JS2T_CHECK(V * 4 <= 160 * 1024 - 1024, "ctc_bwd: vocabulary %lld too large for the LDS-staged gradient row", (long long)V);
   const int64_t Smax = 2 * Lmax + 1;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, true>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
-                                        (const T*)logits, lse, targets, in_len, tgt_len, beta, (float*)nullptr, T_, V, Lmax,
-                                        Smax, blank));
-  JS2T_LAUNCH_CHECK();
+  if (!beta_ready) {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, true>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
+                                          (const T*)logits, lse, targets, in_len, tgt_len, beta, (float*)nullptr, T_, V, Lmax,
+                                          Smax, blank));
+    JS2T_LAUNCH_CHECK();
+  }
   const size_t lds = (size_t)V * sizeof(float);
   if (dt == JS2T_F32) {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

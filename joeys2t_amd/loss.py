@@ -45,16 +45,18 @@ class _CtcFn(torch.autograd.Function):
         in_len = in_len.to(torch.int64).contiguous()
         tgt_len = tgt_len.to(torch.int64).contiguous()
         lse, _ = ops.row_lse(l3.view(B * T, V))
-        alpha, nll, loss_rows = ops.ctc_alpha(l3, lse, targets, in_len, tgt_len, blank, zero_infinity)
-        ctx.saved = (l3, lse, targets, in_len, tgt_len, alpha, nll)
+        # when a gradient will be asked for, the beta recursion runs beside alpha in the same launch
+        alpha, nll, loss_rows, beta = ops.ctc_alpha(l3, lse, targets, in_len, tgt_len, blank, zero_infinity,
+                                                    with_beta=logits.requires_grad)
+        ctx.saved = (l3, lse, targets, in_len, tgt_len, alpha, nll, beta)
         ctx.blank, ctx.zero_infinity = blank, zero_infinity
         return ops.sum_f32(loss_rows)
 
     @staticmethod
     def backward(ctx, g):
-        l3, lse, targets, in_len, tgt_len, alpha, nll = ctx.saved
+        l3, lse, targets, in_len, tgt_len, alpha, nll, beta = ctx.saved
         g = g.contiguous().float()
-        d = ops.ctc_bwd(l3, lse, targets, in_len, tgt_len, alpha, nll, g, 1.0, ctx.blank, ctx.zero_infinity)
+        d = ops.ctc_bwd(l3, lse, targets, in_len, tgt_len, alpha, nll, g, 1.0, ctx.blank, ctx.zero_infinity, beta=beta)
         return d, None, None, None, None, None
 
 

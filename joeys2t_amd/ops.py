@@ -438,29 +438,34 @@ def xent_bwd(logits2d, trg1d, lse, g_dev, scale: float, pad_idx: int, smoothing:
     return d
 
 
-def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity: bool):
+def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity: bool, with_beta: bool = False):
+    """Forward CTC recursion; with_beta=True also runs the (independent) backward recursion in the same launch and
+    returns it as the 4th value for ctc_bwd(beta=...)."""
     _dev(logits3d, lse, targets, in_len, tgt_len)
     B, T, V = logits3d.shape
     Lmax = targets.shape[1]
     dev = logits3d.device
     alpha = torch.empty((B, T, 2 * Lmax + 1), dtype=torch.float32, device=dev)
+    beta = torch.empty_like(alpha) if with_beta else None
     nll = torch.empty((B,), dtype=torch.float32, device=dev)
     loss_rows = torch.empty((B,), dtype=torch.float32, device=dev)
-    check(lib().js2t_ctc_alpha(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha),
+    check(lib().js2t_ctc_alpha(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha), _p(beta),
                                _p(nll), _p(loss_rows), C.c_int64(B), C.c_int64(T), C.c_int64(V), C.c_int64(Lmax),
                                C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_alpha")
-    return alpha, nll, loss_rows
+    return alpha, nll, loss_rows, beta
 
 
-def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: float, blank: int, zero_infinity: bool):
-    _dev(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev)
+def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: float, blank: int, zero_infinity: bool, beta=None):
+    _dev(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, beta)
     B, T, V = logits3d.shape
     Lmax = targets.shape[1]
-    beta = torch.empty_like(alpha)
+    ready = beta is not None
+    if beta is None:
+        beta = torch.empty_like(alpha)
     d = torch.empty_like(logits3d)
     check(lib().js2t_ctc_bwd(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha),
                              _p(beta), _p(nll), _p(g_dev), C.c_float(scale), _p(d), C.c_int64(B), C.c_int64(T), C.c_int64(V),
-                             C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_bwd")
+                             C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), int(ready), _stream()), "js2t_ctc_bwd")
     return d
 
 
