@@ -106,6 +106,9 @@ int js2t_gemm_grouped(const js2t_gemm_desc* d, int32_t count, const void* const*
 /* Test hook: when on, bf16 GEMMs use the register-staged kernel (the one implicit-conv operands always use)
  * instead of the LDS-DMA kernel, so both can be checked against each other. */
 void js2t_gemm_force_regstage(int on);
+/* Test hook: when on, every k-contiguous bf16 product with a bf16 result the 256x256 half-tile-ring kernel can run takes it
+ * (by default only products of >= 512 such tiles and K >= 1024 do). */
+void js2t_gemm_force_w256(int on);
 
 /* --------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels.

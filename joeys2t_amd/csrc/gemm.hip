@@ -18,6 +18,7 @@
 namespace {
 
 bool g_force_regstage = false;  // test hook: route non-conv bf16 GEMMs to the register-staged kernel
+bool g_force_w256 = false;      // test hook: take the 256x256 kernel for every product it can run, whatever the size
 
 // ------------------------------------------------------------------------------------------------
 // operand addressing shared by both kernels
@@ -807,14 +808,13 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 
 // BM = 128 (default) or 64: the 64-row tile doubles the number of blocks for outputs with few tiles (N = 512 layers,
 // decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
-template <int BM, bool TA, bool TB, bool SPLITK>
+template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
 __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tiles_m, int tiles_n, float* c_atomic, int split_k,
                                                int z) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
   constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
   constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
-  constexpr int NST = 2;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
@@ -846,9 +846,10 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
   typedef __attribute__((ext_vector_type(8))) short s16x8_ones_t;
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, s16x8_ones_t{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
 
-  // Two stages of 64 k.  A third stage with counted vmcnt + raw s_barrier (NST = 3, kept below) was measured on the
-  // 64-row tile: 72 KB of LDS leave two blocks per CU instead of three and the products got 25-60 % slower - what
-  // hides the DMA latency here is the third resident block, not a deeper ring.
+  // NST stages of 64 k.  Two by default: with the chip full (>= 2-3 blocks per CU) the other resident blocks hide the DMA
+  // latency, and a third stage on the 64-row tile (72 KB -> two blocks per CU instead of three) made those products 25-60 %
+  // slower.  Small grids (decoder-sized M: fewer blocks than CUs) have nothing else resident and LDS to spare: there
+  // NST = 4 keeps three stages in flight (counted vmcnt, raw s_barrier - __syncthreads() would drain the DMA queue).
   constexpr int PER = NPA + 4;  // DMA instructions per wave and stage
   int64_t oa[NPA], ob[4];
   auto issue_stage = [&](int s, int slot) {
@@ -858,12 +859,16 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
     dma_issue<4>(Bb, ob, smem + slot * STAGE + A_TILE, t);
   };
   issue_stage(0, 0);
-  if (NST == 3 && nk > 1) issue_stage(1, 1);
+#pragma unroll
+  for (int st = 1; st < NST - 1; ++st)
+    if (st < nk) issue_stage(st, st);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int k0 = (kt0 + kt) * F_BK;
     // stage kt has been issued; wait for it, patch a partial K tail, make it visible to all waves
-    if (NST == 3 && kt + 1 < nk) {
+    if (NST >= 4 && kt + 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    } else if (NST >= 3 && kt + 1 < nk) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -880,7 +885,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
       asm volatile("" ::: "memory");
     }
     // the slot requested now was consumed in iteration kt-1, which every wave has left (barrier above)
-    if (kt + NST - 1 < nk) issue_stage(kt + NST - 1, NST == 2 ? (cur ^ 1) : (cur == 0 ? 2 : cur - 1));
+    if (kt + NST - 1 < nk) issue_stage(kt + NST - 1, cur == 0 ? NST - 1 : cur - 1);
     const unsigned char* At = smem + cur * STAGE;
     const unsigned char* Bt = At + A_TILE;
 #pragma unroll
@@ -929,10 +934,10 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
   dma_tile_epilogue<BM, SPLITK, !TB>(d, acc, smem, z, co, m0, n0, c_atomic);
 }
 
-template <int BM, bool TA, bool TB, bool SPLITK>
+template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
                                                                int split_k) {
-  dma_gemm_block<BM, TA, TB, SPLITK>(d, tiles_m, tiles_n, c_atomic, split_k, blockIdx.y);
+  dma_gemm_block<BM, TA, TB, SPLITK, NST>(d, tiles_m, tiles_n, c_atomic, split_k, blockIdx.y);
 }
 
 // Grouped launch: blockIdx.y selects one of up to JS2T_GEMM_GROUP_MAX independent products of identical shape whose
@@ -955,12 +960,257 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_grouped_kernel(js2t_gemm
   dma_gemm_block<BM, TA, TB, SPLITK>(dd, tiles_m, tiles_n, (float*)dd.C, split_k, 0);
 }
 
-template <int BM, bool TA, bool TB, bool SPLITK>
-int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
-  constexpr int LDS = (BM == 128 || TA) ? 65536 : 2 * (BM * 128 + 16384);  // stages (the epilogue staging aliases them)
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+// ------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves, half-tile DMA ring: large k-contiguous products (A [M,K], B [N,K], bf16 C)
+// ------------------------------------------------------------------------------------------------
+// The 128x128 kernels above top out near 1000 TFLOP/s because every 2.1 MFLOP of a K step pull 32 KB from L2 into LDS
+// (about 16 TB/s aggregate at that rate).  A 256x256 tile halves the bytes per flop; with one 512-thread block per CU
+// nothing else is resident to hide latency, so the pipeline is explicit:
+//  * a K tile (64 k) arrives as four 16 KB half-tiles - A0 (rows 0-127), B0 (cols 0-127), B1, A1 - each its own DMA
+//    unit (2 global_load_lds per wave); two K tiles of slots (8 x 16 KB = 128 KB) form a ring, the half-tile of the NEXT
+//    K tile is requested in the phase that first uses its counterpart, i.e. four halves ahead;
+//  * a K tile is multiplied in four phases of 16 MFMAs per wave, one quadrant (A half x B half) each, ordered
+//    (A0,B0) (A0,B1) (A1,B1) (A1,B0) so that every phase needs at most one half-tile that the previous one did not;
+//    each phase waits with a COUNTED vmcnt for exactly that half-tile (later ones stay in flight) and crosses one raw
+//    s_barrier (a __syncthreads() fence would drain the DMA queue);
+//  * wave (wr, wc) owns rows {64wr..64wr+63} of both A halves and columns {32wc..32wc+31} of both B halves, with the
+//    B fragment rows permuted so that a lane ends up with 8 consecutive output columns -> 16-byte stores from registers.
+constexpr int W_HALF = 16384;
+constexpr int W_LDS = 8 * W_HALF;
+
+__device__ __forceinline__ bf16x8_t w256_frag(const unsigned char* img, int row, int kk, int lane) {
+  const int c = kk * 4 + (lane >> 4);
+  return *(const bf16x8_t*)(img + row * 128 + ((c ^ (row & 7)) << 4));
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_bf16_w256_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4;
+  const int wr = w >> 2, wc = w & 3;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * 256, n0 = (lid % tiles_n) * 256;
+  const int M = d.M, N = d.N, K = d.K;
+  const int nk = (K + 63) >> 6;
+  const int H = 4 * nk;  // half-tiles in the stream
+
+  // DMA sources: stream kind 0 = A0, 1 = B0, 2 = B1, 3 = A1; two 1 KB pieces per wave and half-tile
+  const uint16_t* src[4][2];
+  int kc;
+  {
+    const uint16_t* Ab = (const uint16_t*)d.A;
+    const uint16_t* Bb = (const uint16_t*)d.B;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = (w * 2 + q) * 64 + lane;
+      const int row = p >> 3, slot = p & 7, chunk = slot ^ (row & 7);
+      src[0][q] = Ab + (int64_t)min(m0 + row, M - 1) * d.lda + chunk * 8;
+      src[3][q] = Ab + (int64_t)min(m0 + 128 + row, M - 1) * d.lda + chunk * 8;
+      src[1][q] = Bb + (int64_t)min(n0 + row, N - 1) * d.ldb + chunk * 8;
+      src[2][q] = Bb + (int64_t)min(n0 + 128 + row, N - 1) * d.ldb + chunk * 8;
+    }
+    kc = (((lane & 7) ^ ((((w * 2) * 64 + lane) >> 3) & 7)) << 3);
+  }
+  auto issue_half = [&](int h) {  // h = global half-tile index
+    const int kt = h >> 2, kind = h & 3;
+    unsigned char* img = smem + ((kt & 1) * 4 + kind) * W_HALF;
+    const bool live = kt * 64 + kc < K;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint16_t* sp = kind == 0 ? src[0][q] : kind == 1 ? src[1][q] : kind == 2 ? src[2][q] : src[3][q];
+      const uint16_t* gsrc = live ? sp + kt * 64 : (const uint16_t*)&g_zero16;
+      __builtin_amdgcn_global_load_lds((g_cvoid*)gsrc, (l_void*)(img + (w * 2 + q) * 1024), 16, 0, 0);
+    }
+  };
+  // wait until at most `behind` younger half-tiles of this wave's own DMA are in flight
+  auto wait_halves = [&](int behind) {
+    if (behind >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (behind == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  f32x4_t acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int h = 0; h < 4; ++h) issue_half(h);  // K tile 0 (H >= 4 always)
+
+  const int arow = wr * 64 + (lane & 15);                                        // + 16 i
+  const int brow = wc * 32 + ((lane & 15) >> 2) * 8 + (lane & 3);                // + 4 j
+  bf16x8_t fA[4][2], fB0[2][2], fB1[2][2];
+  // one phase: wait for half-tile `need` (global index), barrier, request half-tile P + 4, read fragments, 16 MFMAs
+  auto phase_sync = [&](int P, int need) {
+    wait_halves(min(P + 3, H - 1) - need);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (P + 4 < H) issue_half(P + 4);
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* base = smem + (kt & 1) * 4 * W_HALF;
+    const unsigned char* iA0 = base, * iB0 = base + W_HALF, * iB1 = base + 2 * W_HALF, * iA1 = base + 3 * W_HALF;
+    const int P = 4 * kt;
+    // ---- phase 1: (A0, B0)
+    phase_sync(P, P + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fB0[j][kk] = w256_frag(iB0, brow + 4 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fA[i][kk] = w256_frag(iA0, arow + 16 * i, kk, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fB0[j][kk], fA[i][kk], acc[0][0][i][j], 0, 0, 0);
+    // ---- phase 2: (A0, B1)
+    phase_sync(P + 1, P + 2);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fB1[j][kk] = w256_frag(iB1, brow + 4 * j, kk, lane);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fB1[j][kk], fA[i][kk], acc[0][1][i][j], 0, 0, 0);
+    // ---- phase 3: (A1, B1)
+    phase_sync(P + 2, P + 3);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fA[i][kk] = w256_frag(iA1, arow + 16 * i, kk, lane);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fB1[j][kk], fA[i][kk], acc[1][1][i][j], 0, 0, 0);
+    // ---- phase 4: (A1, B0) - fragments already in registers
+    phase_sync(P + 3, P + 3);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fB0[j][kk], fA[i][kk], acc[1][0][i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue from registers: lane (g, r = lane & 15) holds 8 consecutive columns of row 16i + r of each quadrant
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+  const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
+  const bool has_drop = d.dropout_p > 0.f;
+  const uint32_t drop_key = has_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    const int n = n0 + hb * 128 + wc * 32 + g * 8;
+    if (n >= N) continue;  // N is a multiple of 8 (dispatcher): a column group is in or out as a whole
+    float bias_r[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bias_r[c] = d.bias ? d.bias[n + c] : 0.f;
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha) {
+      uint4 rg[4];
+      if (has_res || has_gate) {
+        const uint16_t* sp = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
+        const int64_t ld = has_res ? d.ldr : d.ldg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rg[i] = *(const uint4*)(sp + (int64_t)min(m0 + ha * 128 + wr * 64 + 16 * i + (lane & 15), M - 1) * ld);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ha * 128 + wr * 64 + 16 * i + (lane & 15);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[ha][hb][i][j][r] * alpha + bias_r[4 * j + r];
+        if (relu) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+        }
+        if (has_drop) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)m, (uint32_t)((n >> 2) + h2), d.dropout_p);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[4 * h2 + c] = ((keep >> c) & 1u) ? v[4 * h2 + c] * keep_scale : 0.f;
+          }
+        }
+        if (has_res) {
+          float rr[8];
+          unpack_bf16x8(rg[i], rr);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] += res_scale * rr[c];
+        }
+        if (has_gate) {
+          float rr[8];
+          unpack_bf16x8(rg[i], rr);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
+        }
+        if (m < M) {
+          uint4 pk;
+          pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+          pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+          pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+          *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
+        }
+      }
+    }
+  }
+}
+
+// products this kernel takes: k-contiguous bf16 operands, bf16 C, the epilogue terms of direct_tile_epilogue
+// ... and that are big enough for it to pay: one 512-thread block per CU has no second block to hide its prologue and
+// epilogue behind, and at fewer than two full rounds of 256x256 tiles the quantisation loss eats the gain (measured:
+// 8192^3 1069 vs 960 TFLOP/s for the 128x128 kernel, but FFN1 12000x2048x512 47 vs 39 us)
+inline bool w256_eligible(const js2t_gemm_desc& d) {
+  if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
+  if ((d.N & 7) || d.M < 256 || d.N < 256) return false;
+  if (!g_force_w256 && ((int64_t)cdiv(d.M, 256) * cdiv(d.N, 256) < 512 || d.K < 1024)) return false;
+  if (d.preact || d.beta != 0.f || !(d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) || (d.residual && d.gate)) return false;
+  if ((((uintptr_t)d.C) & 15) || (d.ldc & 7)) return false;
+  if (d.residual && ((d.ldr & 7) || (((uintptr_t)d.residual) & 15))) return false;
+  if (d.gate && ((d.ldg & 7) || (((uintptr_t)d.gate) & 15))) return false;
+  return true;
+}
+int launch_bf16_w256(const js2t_gemm_desc& d, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, TA, TB, SPLITK>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_w256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tm = cdiv(d.M, 256), tn = cdiv(d.N, 256);
+  hipLaunchKernelGGL(gemm_bf16_w256_kernel, dim3(tm * tn), dim3(512), W_LDS, s, d, tm, tn);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
+int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
+  constexpr int STAGE = ((BM == 128 || TA) ? 16384 : BM * 128) + 16384;
+  constexpr int LDS = NST * STAGE > BM * 128 * 4 ? NST * STAGE : BM * 128 * 4;  // stages (the epilogue staging aliases them)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<BM, TA, TB, SPLITK, NST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -969,8 +1219,8 @@ int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
     attr_set = true;
   }
   const int tm = cdiv(d.M, BM), tn = cdiv(d.N, F_BN);
-  hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, TA, TB, SPLITK>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS, s,
-                     d, tm, tn, (float*)d.C, d.split_k);
+  hipLaunchKernelGGL((gemm_bf16_dma_kernel<BM, TA, TB, SPLITK, NST>), dim3(tm * tn, d.batch, SPLITK ? d.split_k : 1), dim3(256), LDS,
+                     s, d, tm, tn, (float*)d.C, d.split_k);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -979,7 +1229,12 @@ int launch_bf16_dma(const js2t_gemm_desc& d, hipStream_t s) {
   if constexpr (!TA && !SPLITK) {
     // few 128x128 tiles (N = 512 layers, decoder-sized M): halve the row tile to put ~2x more blocks on the 256 CUs
     const int64_t tiles = (int64_t)cdiv(d.M, 128) * cdiv(d.N, F_BN) * d.batch;
-    if (tiles < 512 && d.M > 64) return launch_bf16_dma_bm<64, TA, TB, SPLITK>(d, s);
+    if (tiles < 512 && d.M > 64) {
+      // fewer 64-row tiles than CUs: one block per CU at most, so trade the idle LDS for a 4-deep DMA ring
+      if ((int64_t)cdiv(d.M, 64) * cdiv(d.N, F_BN) * d.batch <= 256 && d.K > 128)
+        return launch_bf16_dma_bm<64, TA, TB, SPLITK, 4>(d, s);
+      return launch_bf16_dma_bm<64, TA, TB, SPLITK>(d, s);
+    }
   }
   return launch_bf16_dma_bm<128, TA, TB, SPLITK>(d, s);
 }
@@ -1007,6 +1262,7 @@ int launch_bf16_impl(const js2t_gemm_desc& d, hipStream_t s) {
 }
 template <bool TA, bool TB>
 int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
+  if (!TA && !TB && !g_force_regstage && w256_eligible(d)) return launch_bf16_w256(d, s);
   if (!d.conv && !g_force_regstage)
     return d.split_k > 1 ? launch_bf16_dma<TA, TB, true>(d, s) : launch_bf16_dma<TA, TB, false>(d, s);
   return d.split_k > 1 ? launch_bf16_impl<TA, TB, true>(d, s) : launch_bf16_impl<TA, TB, false>(d, s);
@@ -1017,6 +1273,7 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 extern "C" void js2t_gemm_force_regstage(int on) { g_force_regstage = on != 0; }
+extern "C" void js2t_gemm_force_w256(int on) { g_force_w256 = on != 0; }
 
 template <bool SPLITK>
 static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {

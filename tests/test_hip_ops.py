@@ -512,3 +512,54 @@ def test_gemm_grouped_matches_single_products(device, split):
         ref = base_w[i] + dzs[i].float().cpu().t() @ xs[i].float().cpu()
         torch.testing.assert_close(Cs[i].cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
         torch.testing.assert_close(rs[i].cpu(), base_b[i] + dzs[i].float().cpu().sum(0), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 128, 72), (2592, 512, 2048), (333, 500, 1000), (65, 136, 136)])
+@pytest.mark.parametrize("tb", [0, 1])
+def test_gemm_bf16_small_grid_deep_ring(device, M, N, K, tb):
+    """Few 64-row tiles (<= one per CU): the 4-stage DMA ring variant, incl. K tails and ragged edges."""
+    A = rnd(M, K, seed=1).bfloat16()
+    B = (rnd(K, N, seed=2) if tb else rnd(N, K, seed=2)).bfloat16()
+    ref = A.float() @ (B.float() if tb else B.float().t())
+    C = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    bias = rnd(N, seed=3)
+    ops.gemm(A.to(device), B.to(device), C, M=M, N=N, K=K, lda=K, ldb=B.shape[1], ldc=N, trans_b=bool(tb), bias=bias.to(device))
+    torch.testing.assert_close(C.float().cpu(), (ref + bias).bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 256), (2300, 1032, 320), (2600, 1536, 264), (4096, 2048, 512)])
+def test_gemm_bf16_w256_tile(device, M, N, K):
+    """The 256x256 half-tile-ring kernel (large k-contiguous products) against fp32 math and, for the fused epilogue
+    (bias + ReLU + dropout, residual, gate), against the register-staged kernel - same dropout decisions by definition."""
+    from joeys2t_amd._lib import lib
+    A = rnd(M, K, seed=1).bfloat16().to(device)
+    B = rnd(N, K, seed=2).bfloat16().to(device)
+    ref = A.float().cpu() @ B.float().cpu().t()
+    C = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    lib().js2t_gemm_force_w256(1)
+    try:
+        _w256_checks(device, A, B, C, ref, M, N, K)
+    finally:
+        lib().js2t_gemm_force_w256(0)
+
+
+def _w256_checks(device, A, B, C, ref, M, N, K):
+    from joeys2t_amd._lib import lib
+    ops.gemm(A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    torch.testing.assert_close(C.float().cpu(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
+    bias = rnd(N, seed=3).to(device)
+    res = rnd(M, N, seed=4).bfloat16().to(device)
+    rng = ops.dropout_rng(device)
+    variants = [dict(bias=bias, act="relu", dropout_p=0.1, rng=rng, rng_stream=7), dict(bias=bias, dropout_p=0.2, rng=rng, rng_stream=9, residual=res, ldr=N, res_scale=0.7),
+                dict(gate=res, ldg=N, gate_scale=1.3, alpha=0.5)]
+    for kw in variants:
+        out1 = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+        out2 = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+        ops.gemm(A, B, out1, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+        lib().js2t_gemm_force_regstage(1)
+        try:
+            ops.gemm(A, B, out2, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+        finally:
+            lib().js2t_gemm_force_regstage(0)
+        assert torch.equal((out1 == 0), (out2 == 0)) or ((out1 == 0) != (out2 == 0)).float().mean() < 1e-4  # same masks
+        torch.testing.assert_close(out1.float(), out2.float(), rtol=2e-2, atol=2e-2)
