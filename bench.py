@@ -168,7 +168,39 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
         graph_holder["g"].replay()
         post_body(capturing=True)
 
-    return eager_step, graph_step, capture, step, frames * BATCH
+    return eager_step, graph_step, capture, step, frames * BATCH, (model, state)
+
+
+def encoder_forward(model, batch, reps=20):
+    """BASELINE.json's stated target is a fraction of the bf16 MFMA peak on the ENCODER FORWARD: time it alone (subsampler +
+    16 layers + final LayerNorm, train mode / dropout on, hipGraph replay) and price it with SURVEY 8(d)'s count:
+    7.06 MFLOP per token and layer x 16 layers x 12000 tokens = 1.355 TFLOP (+ 41 GFLOP of subsampler convolutions)."""
+    model.train()
+    kw = vars(batch)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                model(return_type="encode", **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            model(return_type="encode", **kw)
+        g.replay()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flops = 16 * 12000 * 7.06e6 * (BATCH / 32) + 41e9 * (BATCH / 32)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"ms": round(ms, 3), "flop": flops, "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "what": "subsampler + 16 encoder layers + final LN, forward only, bf16, dropout on"}
 
 
 def cpu_baseline(n_utts=8, threads=None):
@@ -293,7 +325,7 @@ def main():
         torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from joeys2t_amd import ops
-    eager_step, graph_step, capture, step, frames_per_step = build_step(device, world)
+    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world)
     use_graph = not args.no_graph
     one_step = eager_step
     if use_graph:
@@ -367,6 +399,9 @@ def main():
                     "avg_launch_us": round(secs / n * 1e6, 2), "event_pair_overhead_us": round(pair_overhead * 1e6, 2),
                     "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
                                              "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
+
+    if roofline is not None:
+        roofline["encoder_forward"] = encoder_forward(model, state["batch"])
 
     decode = None
     if rank == 0 and not args.no_decode:

@@ -67,3 +67,39 @@ def test_beam_step_kernel(device, beam, V, alpha):
     assert torch.equal(i.cpu(), ref_i)
     torch.testing.assert_close(s.cpu(), ref_s, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(logits, -1), rtol=1e-5, atol=1e-5)
+
+
+def test_wer_on_synthetic_set_equals_cpu_oracle(device):
+    """north_star: WER on a held-out synthetic set equal to the CPU reference.  Two synthetic batches the fixtures do not
+    contain are decoded (beam 3) by the HIP path and by the CPU oracle; hypotheses must be identical, hence the WER."""
+    from golden_cfg import SPECIALS, oracle_cfg
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.metrics import wer
+    from joeys2t_amd.prediction import predict
+    from joeys2t_amd.vocabulary import Vocabulary
+    from oracle import s2t_oracle as O
+    model, g = build("model_pre", device)
+    model.eval()
+    from conftest import golden_sd
+    sd = golden_sd(g)
+    cfg = oracle_cfg(FIXTURES["model_pre"]["cfg"])
+    vocab = Vocabulary.synthetic(20)
+    hyp_hip, hyp_cpu, refs = [], [], []
+    for seed in (501, 502):
+        gen = torch.Generator().manual_seed(seed)
+        B, T = 4, 41
+        lengths = torch.tensor([41, 33, 29, 37])
+        src = torch.randn(B, T, 8, generator=gen)
+        for b in range(B):
+            src[b, lengths[b]:] = 1.0
+        ref_ids = [torch.randint(4, 20, (int(n), ), generator=gen).tolist() for n in torch.randint(3, 7, (B, ), generator=gen)]
+        refs += [" ".join(vocab.array_to_sentence(r)) for r in ref_ids]
+        batch = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=None, trg_length=None, trg_prompt_mask=None,
+                      indices=torch.arange(B), device=device, pad_index=1, eos_index=3, is_train=False, task="S2T", n_gpu=1)
+        _, sents, _ = predict(model, [batch], beam_size=3, beam_alpha=1.0, n_best=1, max_output_length=10)
+        hyp_hip += [" ".join(s) for s in sents]
+        enc, mask, _ = O.encoder_forward(sd, cfg, src, lengths)
+        ids, _ = O.beam_search(sd, cfg, SPECIALS, enc, mask, beam_size=3, max_output_length=10, alpha=1.0, n_best=1)
+        hyp_cpu += [" ".join(vocab.array_to_sentence(row.tolist(), cut_at_eos=True)) for row in ids]
+    assert hyp_hip == hyp_cpu
+    assert wer(hyp_hip, refs) == wer(hyp_cpu, refs)
