@@ -326,6 +326,43 @@ def golden_train_steps(name="train_steps", n_updates=3, batch_multiplier=2):
     print(name, "losses", np.array(losses)[:, 0], "norms", norms, "lrs", lrs)
 
 
+def golden_conformer(name="conformer"):
+    """The reference's ConformerEncoder (encoders.py:376-445; not reachable from build_model, constructed directly): tiny
+    2-layer encoder, train-mode forward (BatchNorm batch statistics) with all parameter gradients of a random linear
+    functional of the output, the running statistics after that forward, and the eval-mode forward."""
+    from joeynmt.encoders import ConformerEncoder
+    torch.manual_seed(42)
+    out = {}
+    for ln in ("pre", "post"):
+        enc = ConformerEncoder(hidden_size=16, ff_size=32, num_layers=2, num_heads=2, dropout=0.0, emb_dropout=0.0, in_channels=8,
+                               conv_channels=24, conv_kernel_sizes=[5, 5], depthwise_conv_kernel_size=5, alpha=1.0, layer_norm=ln)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(123)
+            for n, p in enc.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        src, lengths, _, _ = synth_batch(3, 37, 8, 20, 3, 6, seed=11)
+        proj = torch.randn(16, generator=torch.Generator().manual_seed(5))
+        pre = f"{ln}."
+        out.update({f"{pre}sd0.{k}": v for k, v in np_sd(enc.state_dict()).items() if not k.endswith("pe.pe")})  # pe: analytic
+        out.update({f"{pre}src": src.numpy(), f"{pre}src_length": lengths.numpy(), f"{pre}proj": proj.numpy()})
+        enc.train()
+        y, _, mask = enc(src, lengths, None)
+        (y * proj).sum().backward()
+        out.update({f"{pre}out_train": y.detach().numpy(), f"{pre}mask": mask.numpy()})
+        for n, p in enc.named_parameters():
+            out[f"{pre}grad.{n}"] = p.grad.numpy().copy()
+        out.update({f"{pre}sd1.{k}": v for k, v in np_sd(enc.state_dict()).items() if "running" in k or "num_batches" in k})
+        enc.eval()
+        with torch.no_grad():
+            y2, _, _ = enc(src, lengths, None)
+        out[f"{pre}out_eval"] = y2.numpy()
+        print(name, ln, "train out", float(y.abs().mean()), "eval out", float(y2.abs().mean()))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -336,6 +373,7 @@ def main():
     golden_model("model_post", tiny_cfg("post", act="gelu"))
     golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1)
     golden_train_steps()
+    golden_conformer()
 
 
 if __name__ == "__main__":

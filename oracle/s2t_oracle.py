@@ -166,6 +166,72 @@ def encoder_forward(sd: SD, cfg: dict, src: Tensor, src_length: Tensor, prefix: 
     return x, mask, lengths
 
 
+# ------------------------------------------------------------------------------------------------ Conformer (a30)
+def conv_module(sd: SD, prefix: str, x: Tensor, train: bool, new_stats: Optional[dict] = None) -> Tensor:
+    """ConvolutionModule.forward, transformer_layers.py:458-475, on the tensor it is GIVEN: the layer hands it
+    x.transpose(0, 1) of a [B, T, C] tensor (:549-552), so "batch" = T and the depthwise convolution and the BatchNorm
+    length axis run over B.  This function takes the layer's [B, T, C] view and does that transposition itself.
+    BatchNorm1d: batch statistics (biased variance) in train mode, running statistics in eval mode; `new_stats` receives
+    the running statistics after the momentum-0.1 update (unbiased variance) when training."""
+    x = layer_norm(sd, prefix + ".layer_norm", x)
+    xt = x.transpose(0, 1).transpose(1, 2)  # [T, C, B]
+    xt = F.conv1d(xt, sd[prefix + ".pointwise_conv1.weight"], sd[prefix + ".pointwise_conv1.bias"])
+    xt = F.glu(xt, dim=1)
+    wd = sd[prefix + ".depthwise_conv.weight"]
+    xt = F.conv1d(xt, wd, sd[prefix + ".depthwise_conv.bias"], padding=(wd.size(-1) - 1) // 2, groups=wd.size(0))
+    rm, rv = sd[prefix + ".batch_norm.running_mean"], sd[prefix + ".batch_norm.running_var"]
+    if train:
+        mean = xt.mean(dim=(0, 2))
+        var = xt.var(dim=(0, 2), unbiased=False)
+        n = xt.size(0) * xt.size(2)
+        if new_stats is not None:
+            new_stats[prefix + ".batch_norm.running_mean"] = (0.9 * rm + 0.1 * mean).detach()
+            new_stats[prefix + ".batch_norm.running_var"] = (0.9 * rv + 0.1 * var * n / max(n - 1, 1)).detach()
+    else:
+        mean, var = rm, rv
+    xt = (xt - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5)
+    xt = xt * sd[prefix + ".batch_norm.weight"][None, :, None] + sd[prefix + ".batch_norm.bias"][None, :, None]
+    xt = F.hardswish(xt)  # named "swish" in the reference (:449)
+    xt = F.conv1d(xt, sd[prefix + ".pointwise_conv2.weight"], sd[prefix + ".pointwise_conv2.bias"])
+    return xt.transpose(1, 2).transpose(0, 1)
+
+
+def conformer_layer(sd: SD, prefix: str, x: Tensor, mask: Tensor, cfg: dict, train: bool, new_stats: Optional[dict] = None) -> Tensor:
+    """ConformerEncoderLayer.forward, transformer_layers.py:526-565 (dropout 0): half-step residuals on top of the
+    feed-forward modules' own residual, self-attention, the convolution module, final LayerNorm for post-LN."""
+    alpha, ln_pos = cfg["alpha"], cfg["layer_norm"]
+    residual = x
+    x = 0.5 * feed_forward(sd, prefix + ".initial_feed_forward", x, alpha, ln_pos, "relu") + residual
+    residual = x
+    if ln_pos == "pre":
+        x = layer_norm(sd, prefix + ".src_att_layer_norm", x)
+    x, _ = mha(sd, prefix + ".src_src_att", x, x, x, mask, cfg["num_heads"])
+    x = x + alpha * residual
+    if ln_pos == "post":
+        x = layer_norm(sd, prefix + ".src_att_layer_norm", x)
+    x = conv_module(sd, prefix + ".conv_module", x, train, new_stats) + alpha * x
+    residual = x
+    if ln_pos == "pre":
+        x = layer_norm(sd, prefix + ".final_layer_norm", x)
+    x = 0.5 * feed_forward(sd, prefix + ".final_feed_forward", x, alpha, ln_pos, "relu") + residual
+    if ln_pos == "post":
+        x = layer_norm(sd, prefix + ".final_layer_norm", x)
+    return x
+
+
+def conformer_encoder_forward(sd: SD, cfg: dict, src: Tensor, src_length: Tensor, train: bool = False, prefix: str = "encoder",
+                              new_stats: Optional[dict] = None):
+    """ConformerEncoder.forward, encoders.py:425-445: subsample -> mask -> pe -> Linear -> layers (no final LayerNorm)."""
+    e = cfg["encoder"]
+    x, lengths = conv_subsample(sd, prefix + ".subsampler", src, src_length, e["conv_kernel_sizes"])
+    mask = lengths_to_padding_mask(lengths).unsqueeze(1)
+    x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
+    x = linear(sd, prefix + ".linear", x)
+    for i in range(e["num_layers"]):
+        x = conformer_layer(sd, f"{prefix}.layers.{i}", x, mask, e, train, new_stats)
+    return x, mask, lengths
+
+
 def embed(sd: SD, cfg: dict, ids: Tensor) -> Tensor:
     """Embeddings.forward, embeddings.py:55-64"""
     w = sd["trg_embed.lut.weight"]

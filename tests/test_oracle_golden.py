@@ -142,3 +142,32 @@ def test_fbank_known_answer():
     for key in ("pcm_260-123440-0", "pcm_260-123440-6"):
         f = O.fbank(g[key].astype(np.float32) / 32768.0)
         assert f.shape[0] == int(g["tsv_n_frames"][names.index(key[4:])]) and np.isfinite(f).all()
+
+
+@pytest.mark.parametrize("ln", ["pre", "post"])
+def test_conformer_oracle_matches_reference(ln):
+    """a30: the reference's ConformerEncoder (quirks included: depthwise convolution and BatchNorm over the batch axis,
+    half-step residuals on top of the feed-forward modules' own) - train-mode output, every parameter gradient, the
+    BatchNorm running statistics after one forward, and the eval-mode output."""
+    g = load_golden("conformer")
+    pre = ln + "."
+    sd = {k[len(pre) + 4:]: torch.from_numpy(v).clone() for k, v in g.items() if k.startswith(pre + "sd0.")}
+    sd = {"encoder." + k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    cfg = {"encoder": {"num_layers": 2, "num_heads": 2, "alpha": 1.0, "layer_norm": ln, "conv_kernel_sizes": [5, 5]}}
+    src, lengths, proj = torch.from_numpy(g[pre + "src"]), torch.from_numpy(g[pre + "src_length"]), torch.from_numpy(g[pre + "proj"])
+    stats = {}
+    y, mask, _ = O.conformer_encoder_forward(sd, cfg, src, lengths, train=True, new_stats=stats)
+    np.testing.assert_allclose(y.detach().numpy(), g[pre + "out_train"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(mask.numpy(), g[pre + "mask"])
+    (y * proj).sum().backward()
+    for k, v in g.items():
+        if k.startswith(pre + "grad."):
+            got = sd["encoder." + k[len(pre) + 5:]].grad
+            np.testing.assert_allclose(got.numpy(), v, rtol=2e-4, atol=2e-4, err_msg=k)
+        if k.startswith(pre + "sd1.") and "running" in k:
+            np.testing.assert_allclose(stats["encoder." + k[len(pre) + 4:]].numpy(), v, rtol=1e-5, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        sd2 = {k: v.detach() for k, v in sd.items()}
+        sd2.update(stats)
+        y2, _, _ = O.conformer_encoder_forward(sd2, cfg, src, lengths, train=False)
+    np.testing.assert_allclose(y2.numpy(), g[pre + "out_eval"], rtol=1e-4, atol=1e-4)
