@@ -29,7 +29,7 @@ extern "C" {
 typedef void* js2t_stream; /* hipStream_t */
 
 enum { JS2T_F32 = 0, JS2T_BF16 = 1 };
-enum { JS2T_ACT_NONE = 0, JS2T_ACT_RELU = 1, JS2T_ACT_GELU = 2, JS2T_ACT_SWISH = 3, JS2T_ACT_TANH = 4 };
+enum { JS2T_ACT_NONE = 0, JS2T_ACT_RELU = 1, JS2T_ACT_GELU = 2, JS2T_ACT_SWISH = 3, JS2T_ACT_TANH = 4, JS2T_ACT_HARDSWISH = 5 };
 enum { JS2T_OK = 0, JS2T_ERR_INVALID = -1, JS2T_ERR_LAUNCH = -2, JS2T_ERR_UNSUPPORTED = -3 };
 
 /* Library identity / error channel. */
@@ -128,7 +128,8 @@ int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t 
 
 /* y[b,t,:] = dropout(x[b,t,:] + pe[t,:] (+ extra[b,t,:])) — PositionalEncoding.forward
  * (transformer_layers.py:204-213) + emb_dropout (encoders.py:273-276, decoders.py:599-602).
- * pe is f32[>=T, D]; extra (prompt-mask embedding) may be NULL. */
+ * pe is f32[>=T, D] or NULL (plain dropout: ConformerEncoder's emb_dropout after its input Linear, encoders.py:433-435);
+ * extra (prompt-mask embedding) may be NULL. */
 int js2t_add_pe_dropout(const void* x, const float* pe, const void* extra, void* y, int64_t B, int64_t T,
                         int64_t D, int dt, float p, const uint64_t* rng_state, uint32_t rng_stream,
                         js2t_stream stream);
@@ -246,6 +247,34 @@ int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* ta
                  const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
                  float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
                  int zero_infinity, int beta_ready, js2t_stream stream);
+
+/* --------------------------------------------------------------------------------------------------
+ * Conformer convolution module (reference transformer_layers.py:410-475, ConformerEncoderLayer :478-565).
+ * The reference hands the module x.transpose(0, 1) of a [B, T, C] tensor (:549-552): its depthwise Conv1d and the
+ * BatchNorm1d "length" axis therefore run over the BATCH index.  The kernels work on the [B, T, C] row-major activations
+ * directly: js2t_dwconv_outer convolves along the OUTER index of an [L, N, C] array.
+ * -------------------------------------------------------------------------------------------------- */
+/* y[l,n,c] = bias[c] + sum_k w[c,k] * x[l + k - (K-1)/2, n, c]  (zero outside [0, L)); w: f32[C,K] (nn.Conv1d weight
+ * [C,1,K], groups = C), bias: f32[C]; x, y: dt [L,N,C]. */
+int js2t_dwconv_outer_fwd(const void* x, const float* w, const float* bias, void* y, int64_t L, int64_t N, int64_t C, int K, int dt,
+                          js2t_stream stream);
+/* dx (may be NULL) = correlation of dy with the flipped taps; dw[c,k] += sum_{l,n} dy[l,n,c] x[l+k-pad,n,c] (f32 atomics onto
+ * the existing contents; NULL to skip).  The bias gradient is a column sum of dy (js2t_colsum). */
+int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int64_t L, int64_t N, int64_t C, int K,
+                          int dt, js2t_stream stream);
+/* nn.BatchNorm1d(C) over the rows of x[rows, C] followed by an activation (the module applies nn.Hardswish):
+ * train != 0: batch mean / biased variance -> mean[C], invstd[C] (saved for backward) and the running statistics are
+ * updated in place with `momentum` (unbiased variance), as torch does; train == 0: the running statistics are used.
+ * y = act((x - mean) * invstd * gamma + beta).  ws: f32[2*C] workspace. */
+int js2t_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* mean,
+                    float* invstd, void* y, float* ws, int64_t rows, int64_t C, float eps, float momentum, int train, int act, int dt,
+                    js2t_stream stream);
+/* Backward of the above given the saved mean / invstd: dz = dy * act'(z); train != 0: dx = gamma*invstd*(dz - mean_r(dz) -
+ * xhat*mean_r(dz*xhat)), else dx = gamma*invstd*dz; dgamma[c] += sum dz*xhat, dbeta[c] += sum dz (accumulated in place).
+ * ws: f32[2*C] workspace. */
+int js2t_bn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                    void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int64_t C, int train, int act, int dt,
+                    js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Audio front-end (raw waveform -> padded, normalised, augmented feature batch).

@@ -11,7 +11,7 @@ LIB_PATH = PKG_DIR / "libjoeys2t_hip.so"
 HEADER_PATH = PKG_DIR.parent / "include" / "joeys2t_hip.h"
 
 F32, BF16 = 0, 1
-ACT_CODES = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4}
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "hardswish": 5}
 
 
 class Js2tError(RuntimeError):

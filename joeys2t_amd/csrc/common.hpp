@@ -132,6 +132,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case JS2T_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     case JS2T_ACT_SWISH: return v / (1.f + __expf(-v));
     case JS2T_ACT_TANH: return tanhf(v);
+    case JS2T_ACT_HARDSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
     default: return v;
   }
 }
@@ -151,6 +152,7 @@ __device__ __forceinline__ float act_grad(float z, int act) {  // d act(z) / dz
       const float t = tanhf(z);
       return 1.f - t * t;
     }
+    case JS2T_ACT_HARDSWISH: return z < -3.f ? 0.f : (z > 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
     default: return 1.f;
   }
 }

@@ -1,0 +1,281 @@
+// Conformer convolution-module kernels (reference transformer_layers.py:410-475): depthwise convolution along the OUTER
+// index of an [L, N, C] array (the reference's module convolves over the batch index, see the header) and BatchNorm1d
+// over the rows of [rows, C] fused with the activation that follows it.  All HBM-bound element-wise / column-reduction
+// work: f32 arithmetic, bf16 or f32 storage, channel index fastest (coalesced).
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- depthwise conv
+constexpr int DW_MAXK = 63;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_outer_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ y, int64_t L,
+                                                               int64_t N, int64_t C, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * N * C) return;
+  const int64_t c = i % C, ln = i / C, n = ln % N, l = ln / N;
+  const int pad = (K - 1) / 2;
+  float acc = bias ? bias[c] : 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t ls = l + k - pad;
+    if (ls >= 0 && ls < L) acc += w[c * K + k] * io<T>::ld(x + (ls * N + n) * C + c);
+  }
+  io<T>::st(y + i, acc);
+}
+
+// dx[l,n,c] = sum_k w[c,k] * dy[l - k + pad, n, c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_outer_dx_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                                              int64_t L, int64_t N, int64_t C, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * N * C) return;
+  const int64_t c = i % C, ln = i / C, n = ln % N, l = ln / N;
+  const int pad = (K - 1) / 2;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int64_t ls = l - k + pad;
+    if (ls >= 0 && ls < L) acc += w[c * K + k] * io<T>::ld(dy + (ls * N + n) * C + c);
+  }
+  io<T>::st(dx + i, acc);
+}
+
+// dw[c,k] += sum_{l,n} dy[l,n,c] * x[l+k-pad,n,c]: block = 64 channels x 4 n-lanes over a slab of n; K accumulators per
+// thread, combined over the 4 lanes in LDS, one atomic per (c,k) and block
+constexpr int DW_SLAB = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_outer_dw_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw,
+                                                              int64_t L, int64_t N, int64_t C, int K) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  const int64_t n0 = (int64_t)blockIdx.y * DW_SLAB;
+  const int pad = (K - 1) / 2;
+  float acc[DW_MAXK];
+#pragma unroll
+  for (int k = 0; k < DW_MAXK; ++k) acc[k] = 0.f;
+  if (c < C) {
+    for (int64_t n = n0 + nl; n < min(n0 + DW_SLAB, N); n += 4)
+      for (int64_t l = 0; l < L; ++l) {
+        const float g = io<T>::ld(dy + (l * N + n) * C + c);
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k) {
+          if (k < K) {
+            const int64_t ls = l + k - pad;
+            if (ls >= 0 && ls < L) acc[k] += g * io<T>::ld(x + (ls * N + n) * C + c);
+          }
+        }
+      }
+  }
+  typedef __attribute__((address_space(1))) float gfloat;
+  for (int k = 0; k < K; ++k) {
+    float v = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < DW_MAXK; ++kk)
+      if (kk == k) v = acc[kk];
+    red[nl][cl] = v;
+    __syncthreads();
+    if (nl == 0 && c < C) {
+      const float tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+      __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)dw + c * K + k, tot);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- batch norm + activation
+// column reductions over a row slab: MODE 0: (sum x, -) ; 1: (sum (x-mean)^2, -) ; 2: (sum dz, sum dz*xhat) with
+// dz = dy * act'(z), z = xhat*gamma + beta.  Block = 64 columns x 4 row lanes; atomics onto out0 / out1 (pre-zeroed).
+constexpr int BN_SLAB = 64;
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* out0, float* out1, int64_t rows,
+                                                           int64_t C, int act) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_SLAB;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    const float mu = MODE >= 1 ? mean[c] : 0.f;
+    const float is = MODE == 2 ? invstd[c] : 0.f, ga = MODE == 2 ? gamma[c] : 0.f, be = MODE == 2 ? beta[c] : 0.f;
+    for (int64_t r = r0 + rl; r < min(r0 + BN_SLAB, rows); r += 4) {
+      const float v = io<T>::ld(x + r * C + c);
+      if (MODE == 0) {
+        a0 += v;
+      } else if (MODE == 1) {
+        a0 += (v - mu) * (v - mu);
+      } else {
+        const float xh = (v - mu) * is;
+        const float dz = io<T>::ld(dy + r * C + c) * (act == JS2T_ACT_NONE ? 1.f : act_grad(xh * ga + be, act));
+        a0 += dz;
+        a1 += dz * xh;
+      }
+    }
+  }
+  red[0][rl][cl] = a0;
+  red[1][rl][cl] = a1;
+  __syncthreads();
+  typedef __attribute__((address_space(1))) float gfloat;
+  if (rl == 0 && c < C) {
+    __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)out0 + c, (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]));
+    if (MODE == 2)
+      __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)out1 + c, (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]));
+  }
+}
+
+__global__ void bn_mean_kernel(const float* sum, float* mean, int64_t rows, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mean[c] = sum[c] / (float)rows;
+}
+// biased variance -> invstd; running statistics (momentum, unbiased variance) as torch.nn.BatchNorm1d
+__global__ void bn_finalize_kernel(const float* sqdev, const float* mean, float* invstd, float* running_mean, float* running_var,
+                                   int64_t rows, int64_t C, float eps, float momentum) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = sqdev[c] / (float)rows;
+  invstd[c] = rsqrtf(var + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (sqdev[c] / (float)max((int64_t)1, rows - 1));
+}
+__global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* mean, float* invstd, int64_t C,
+                                     float eps) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean[c] = running_mean[c];
+    invstd[c] = rsqrtf(running_var[c] + eps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y, int64_t n, int64_t C, int act) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = i % C;
+  const float z = (io<T>::ld(x + i) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+  io<T>::st(y + i, act == JS2T_ACT_NONE ? z : act_apply(z, act));
+}
+
+// dx = gamma*invstd*(dz - s0/R - xhat*s1/R)   (train)   |   gamma*invstd*dz   (eval)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ s0,
+                                                        const float* __restrict__ s1, T* __restrict__ dx, int64_t rows, int64_t C, int act,
+                                                        int train) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t c = i % C;
+  const float xh = (io<T>::ld(x + i) - mean[c]) * invstd[c];
+  const float dz = io<T>::ld(dy + i) * (act == JS2T_ACT_NONE ? 1.f : act_grad(xh * gamma[c] + beta[c], act));
+  const float inv_r = 1.f / (float)rows;
+  const float v = train ? dz - s0[c] * inv_r - xh * s1[c] * inv_r : dz;
+  io<T>::st(dx + i, gamma[c] * invstd[c] * v);
+}
+__global__ void bn_param_grad_kernel(const float* s0, const float* s1, float* dgamma, float* dbeta, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    if (dgamma) dgamma[c] += s1[c];
+    if (dbeta) dbeta[c] += s0[c];
+  }
+}
+
+#define DISPATCH_DT(dt, T, ...)                                   \
+  if ((dt) == JS2T_F32) { using T = float; __VA_ARGS__; }         \
+  else { using T = uint16_t; __VA_ARGS__; }
+
+}  // namespace
+
+extern "C" int js2t_dwconv_outer_fwd(const void* x, const float* w, const float* bias, void* y, int64_t L, int64_t N, int64_t C, int K,
+                                     int dt, js2t_stream stream) {
+  if (L * N * C == 0) return JS2T_OK;
+  JS2T_CHECK(x && w && y, "dwconv_outer_fwd: null pointer");
+  JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_fwd: kernel size must be odd and <= %d", DW_MAXK);
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_fwd_kernel<T>), dim3((unsigned)cdiv(L * N * C, 256)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)x, w, bias, (T*)y, L, N, C, K));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float* w, void* dx, float* dw, int64_t L, int64_t N, int64_t C,
+                                     int K, int dt, js2t_stream stream) {
+  if (L * N * C == 0) return JS2T_OK;
+  JS2T_CHECK(dy && w, "dwconv_outer_bwd: null pointer");
+  JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_bwd: kernel size must be odd and <= %d", DW_MAXK);
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dx_kernel<T>), dim3((unsigned)cdiv(L * N * C, 256)), dim3(256), 0, s,
+                                          (const T*)dy, w, (T*)dx, L, N, C, K));
+    JS2T_LAUNCH_CHECK();
+  }
+  if (dw) {
+    JS2T_CHECK(x, "dwconv_outer_bwd: x needed for the weight gradient");
+    JS2T_CHECK(cdiv(N, DW_SLAB) <= 65535, "dwconv_outer_bwd: too many rows");
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_kernel<T>), dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(N, DW_SLAB)), dim3(256),
+                                          0, s, (const T*)dy, (const T*)x, dw, L, N, C, K));
+    JS2T_LAUNCH_CHECK();
+  }
+  return JS2T_OK;
+}
+
+extern "C" int js2t_bn_act_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* mean,
+                               float* invstd, void* y, float* ws, int64_t rows, int64_t C, float eps, float momentum, int train, int act,
+                               int dt, js2t_stream stream) {
+  if (rows * C == 0) return JS2T_OK;
+  JS2T_CHECK(x && gamma && beta && mean && invstd && y, "bn_act_fwd: null pointer");
+  JS2T_CHECK(train || (running_mean && running_var), "bn_act_fwd: eval mode needs running statistics");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 cgrid((unsigned)cdiv(C, 256));
+  if (train) {
+    JS2T_CHECK(ws, "bn_act_fwd: workspace required in train mode");
+    JS2T_CHECK(cdiv(rows, BN_SLAB) <= 65535, "bn_act_fwd: too many rows");
+    const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, BN_SLAB));
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, s);
+    JS2T_CHECK(e == hipSuccess, "bn_act_fwd: memset failed: %s", hipGetErrorString(e));
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, nullptr,
+                                          nullptr, nullptr, nullptr, ws, nullptr, rows, C, act));
+    JS2T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_mean_kernel, cgrid, dim3(256), 0, s, ws, mean, rows, C);
+    JS2T_LAUNCH_CHECK();
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, mean, nullptr,
+                                          nullptr, nullptr, ws + C, nullptr, rows, C, act));
+    JS2T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, cgrid, dim3(256), 0, s, ws + C, mean, invstd, running_mean, running_var, rows, C, eps,
+                       momentum);
+    JS2T_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, cgrid, dim3(256), 0, s, running_mean, running_var, mean, invstd, C, eps);
+    JS2T_LAUNCH_CHECK();
+  }
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_act_apply_kernel<T>), dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, s, (const T*)x, mean,
+                                        invstd, gamma, beta, (T*)y, rows * C, C, act));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_bn_act_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                               void* dx, float* dgamma, float* dbeta, float* ws, int64_t rows, int64_t C, int train, int act, int dt,
+                               js2t_stream stream) {
+  if (rows * C == 0) return JS2T_OK;
+  JS2T_CHECK(dy && x && gamma && beta && mean && invstd && dx && ws, "bn_act_bwd: null pointer");
+  JS2T_CHECK(cdiv(rows, BN_SLAB) <= 65535, "bn_act_bwd: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, s);
+  JS2T_CHECK(e == hipSuccess, "bn_act_bwd: memset failed: %s", hipGetErrorString(e));
+  const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, BN_SLAB));
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, invstd, gamma,
+                                        beta, ws, ws + C, rows, C, act));
+  JS2T_LAUNCH_CHECK();
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_act_dx_kernel<T>), dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, s, (const T*)dy,
+                                        (const T*)x, mean, invstd, gamma, beta, ws, ws + C, (T*)dx, rows, C, act, train));
+  JS2T_LAUNCH_CHECK();
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, ws, ws + C, dgamma, dbeta, C);
+    JS2T_LAUNCH_CHECK();
+  }
+  return JS2T_OK;
+}

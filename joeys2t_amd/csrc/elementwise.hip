@@ -98,8 +98,10 @@ __global__ void add_pe_dropout_kernel(const T* __restrict__ x, const float* __re
     const int64_t row = i / D4, c4 = i - row * D4, t = row % T_;
     float v[4], e[4];
     vec4<T>::ld(x + row * D + 4 * c4, v);
-    const float4 pv = *(const float4*)(pe + t * D + 4 * c4);
-    v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+    if (pe) {  // pe == nullptr: plain dropout
+      const float4 pv = *(const float4*)(pe + t * D + 4 * c4);
+      v[0] += pv.x; v[1] += pv.y; v[2] += pv.z; v[3] += pv.w;
+    }
     if (extra) {
       vec4<T>::ld(extra + row * D + 4 * c4, e);
 #pragma unroll
@@ -340,7 +342,7 @@ extern "C" int js2t_add_pe_dropout(const void* x, const float* pe, const void* e
                                    int64_t D, int dt, float p, const uint64_t* rng_state, uint32_t rng_stream,
                                    js2t_stream stream) {
   if (B * T_ * D == 0) return JS2T_OK;
-  JS2T_CHECK(x && pe && y, "add_pe_dropout: null pointer");
+  JS2T_CHECK(x && y, "add_pe_dropout: null pointer");
   JS2T_CHECK(D % 4 == 0, "add_pe_dropout: D must be a multiple of 4 (got %lld)", (long long)D);
   JS2T_CHECK(p >= 0.f && p < 1.f && (p == 0.f || rng_state), "add_pe_dropout: bad dropout arguments");
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((add_pe_dropout_kernel<T>), dim3(ew_grid(B * T_ * D / 4)), dim3(EW_THREADS), 0,

@@ -473,6 +473,72 @@ class EmbedFn(torch.autograd.Function):
         return None, dt, None, None, None, None, None
 
 
+class AxpbyFn(torch.autograd.Function):
+    """a*x + b*y (the Conformer layer's half-step residuals, reference transformer_layers.py:535-537,553,560-561)."""
+
+    @staticmethod
+    def forward(ctx, x, a, y, b):
+        ctx.ab = (a, b)
+        return ops.axpby(x.contiguous(), a, y.contiguous(), b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        g = g.contiguous()
+        return (ops.axpby(g, a) if ctx.needs_input_grad[0] else None, None, ops.axpby(g, b) if ctx.needs_input_grad[2] else None, None)
+
+
+class ConvModuleFn(torch.autograd.Function):
+    """Conformer ConvolutionModule after its LayerNorm (reference transformer_layers.py:458-475) on [B, T, C] activations:
+    pointwise Linear C -> 2C, GLU, depthwise convolution and BatchNorm over the batch index (the reference convolves the
+    transposed tensor, see include/joeys2t_hip.h), Hardswish, pointwise Linear C -> C, dropout.  One autograd node;
+    parameter gradients come back through autograd (this module is off the LS100 hot path)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wd, bd, gamma, beta, running_mean, running_var, w2, b2, p, rng, training, compute_dtype):
+        B, T, Cc = x.shape
+        x2 = x.reshape(B * T, Cc)
+        if x2.dtype != compute_dtype:
+            x2 = ops.cast(x2, compute_dtype)
+        w1c = w1.reshape(w1.shape[0], Cc)
+        w2c = w2.reshape(w2.shape[0], -1)
+        w1c, w2c = (w1c, w2c) if compute_dtype == torch.float32 else (ops.cast(w1c, compute_dtype), ops.cast(w2c, compute_dtype))
+        h = linear_fwd(x2, w1c, b1)                                   # [B*T, 2C]
+        u = ops.glu_fwd(h)                                            # [B*T, C]
+        wd2 = wd.reshape(wd.shape[0], wd.shape[-1]).contiguous()
+        v = ops.dwconv_outer_fwd(u.view(B, T, -1), wd2, bd)           # conv along B
+        v2 = v.view(B * T, -1)
+        z, mean, invstd = ops.bn_act_fwd(v2, gamma, beta, running_mean, running_var, 1e-5, 0.1, training, "hardswish")
+        site = rng.next_site() if (training and p > 0) else 0
+        y = linear_fwd(z, w2c, b2, dropout_p=p if training else 0.0, rng=rng, site=site)
+        ctx.saved = (x2, w1c, h, u, wd2, v2, gamma, beta, mean, invstd, z, w2c)
+        ctx.cfg = (B, T, Cc, p if training else 0.0, rng, site, training, x.dtype)
+        return y.view(B, T, -1).to(x.dtype) if y.dtype != x.dtype else y.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1c, h, u, wd2, v2, gamma, beta, mean, invstd, z, w2c = ctx.saved
+        B, T, Cc, p, rng, site, training, in_dtype = ctx.cfg
+        dy2 = dy.reshape(B * T, -1)
+        if dy2.dtype != z.dtype:
+            dy2 = ops.cast(dy2.contiguous(), z.dtype)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if p > 0:
+            dy2 = ops.dropout_bwd(dy2, p, rng, site)
+        dz, dw2, db2 = linear_bwd(dy2, z, w2c)
+        dv, dgamma, dbeta = ops.bn_act_bwd(dz, v2, gamma, beta, mean, invstd, training, "hardswish")
+        du, dwd = ops.dwconv_outer_bwd(dv.view(B, T, -1), u.view(B, T, -1), wd2)
+        dbd = ops.colsum(dv)
+        dh = ops.glu_bwd(h, du.view(B * T, -1))
+        dx, dw1, db1 = linear_bwd(dh, x2, w1c)
+        dx = dx.view(B, T, Cc)
+        if dx.dtype != in_dtype:
+            dx = dx.to(in_dtype)
+        return (dx, dw1.view(dw1.shape[0], Cc, 1), db1, dwd.view(dwd.shape[0], 1, -1), dbd, dgamma, dbeta, None, None,
+                dw2.view(dw2.shape[0], -1, 1), db2, None, None, None, None)
+
+
 def conv_out_len(t_in: int, k: int, stride: int = 2) -> int:
     """Conv1d(k, stride=2, padding=k//2) output length (encoders.py:339-345)."""
     return (t_in + 2 * (k // 2) - (k - 1) - 1) // stride + 1

@@ -345,6 +345,62 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
     return dx, dgamma, dbeta
 
 
+# ----------------------------------------------------------------------------------------- Conformer convolution module
+def dwconv_outer_fwd(x3d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """Depthwise convolution along the OUTER index of x[L, N, C]; w f32[C, K] (js2t_dwconv_outer_fwd)."""
+    _dev(x3d, w, bias)
+    L, N, Cc = x3d.shape
+    x3d = x3d.contiguous()
+    y = torch.empty_like(x3d)
+    check(lib().js2t_dwconv_outer_fwd(_p(x3d), _p(w), _p(bias), _p(y), C.c_int64(L), C.c_int64(N), C.c_int64(Cc), int(w.shape[1]),
+                                      dt_code(x3d), _stream()), "js2t_dwconv_outer_fwd")
+    return y
+
+
+def dwconv_outer_bwd(dy3d, x3d, w, need_dx=True, dw_out: Optional[torch.Tensor] = None):
+    """-> (dx | None, dw f32[C, K]); dw_out: accumulate the weight gradient into this buffer instead."""
+    _dev(dy3d, x3d, w, dw_out)
+    L, N, Cc = x3d.shape
+    dy3d = dy3d.contiguous()
+    dx = torch.empty_like(x3d) if need_dx else None
+    dw = dw_out if dw_out is not None else torch.zeros((Cc, w.shape[1]), dtype=torch.float32, device=x3d.device)
+    check(lib().js2t_dwconv_outer_bwd(_p(dy3d), _p(x3d), _p(w), _p(dx), _p(dw), C.c_int64(L), C.c_int64(N), C.c_int64(Cc),
+                                      int(w.shape[1]), dt_code(x3d), _stream()), "js2t_dwconv_outer_bwd")
+    return dx, (None if dw_out is not None else dw)
+
+
+def bn_act_fwd(x2d, gamma, beta, running_mean, running_var, eps: float, momentum: float, train: bool, act: Optional[str]):
+    """BatchNorm over the rows of x[rows, C] + activation -> (y, mean, invstd); running statistics updated in place when training."""
+    _dev(x2d, gamma, beta, running_mean, running_var)
+    rows, Cc = x2d.shape
+    x2d = x2d.contiguous()
+    y = torch.empty_like(x2d)
+    mean = torch.empty((Cc,), dtype=torch.float32, device=x2d.device)
+    invstd = torch.empty_like(mean)
+    ws = torch.empty((2 * Cc,), dtype=torch.float32, device=x2d.device)
+    check(lib().js2t_bn_act_fwd(_p(x2d), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(y), _p(ws),
+                                C.c_int64(rows), C.c_int64(Cc), C.c_float(eps), C.c_float(momentum), int(train), ACT_CODES[act],
+                                dt_code(x2d), _stream()), "js2t_bn_act_fwd")
+    return y, mean, invstd
+
+
+def bn_act_bwd(dy2d, x2d, gamma, beta, mean, invstd, train: bool, act: Optional[str], grad_out=None):
+    """-> (dx, dgamma, dbeta); grad_out = (dgamma_buf, dbeta_buf) accumulates in place (returned grads are then None)."""
+    _dev(dy2d, x2d, gamma, beta, mean, invstd)
+    rows, Cc = x2d.shape
+    dy2d = dy2d.contiguous()
+    dx = torch.empty_like(x2d)
+    if grad_out is not None:
+        dg, db = grad_out
+    else:
+        dg = torch.zeros((Cc,), dtype=torch.float32, device=x2d.device)
+        db = torch.zeros_like(dg)
+    ws = torch.empty((2 * Cc,), dtype=torch.float32, device=x2d.device)
+    check(lib().js2t_bn_act_bwd(_p(dy2d), _p(x2d), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dx), _p(dg), _p(db), _p(ws),
+                                C.c_int64(rows), C.c_int64(Cc), int(train), ACT_CODES[act], dt_code(x2d), _stream()), "js2t_bn_act_bwd")
+    return (dx, None, None) if grad_out is not None else (dx, dg, db)
+
+
 # ----------------------------------------------------------------------------------------- softmax
 def softmax_fwd(S, mask, B, H, Tq, Tk, ld, p, rng: Optional[DropoutRng], site: int):
     _dev(S, mask)

@@ -219,3 +219,73 @@ class TransformerDecoderLayer(nn.Module):
                                              out_dropout=self.dropout.p, need_weights=return_attention)
         out = self.feed_forward(h2)
         return out, (att if return_attention else None)
+
+
+class ConvolutionModule(nn.Module):
+    """Conformer convolution block (reference :410-475): LayerNorm -> pointwise conv C->2C -> GLU -> depthwise conv ->
+    BatchNorm1d -> Hardswish -> pointwise conv -> dropout.  Parameter names / shapes as in the reference (Conv1d weights
+    [out, in, k]).  forward() takes the layer's [B, T, C] activations: the reference layer transposes dims 0 and 1 before
+    calling its module (:549-552), so the depthwise convolution and the BatchNorm length axis run over the BATCH index -
+    reproduced, not "fixed"."""
+
+    def __init__(self, hidden_size: int, channels: int, depthwise_kernel_size: int, dropout: float):
+        super().__init__()
+        assert (depthwise_kernel_size - 1) % 2 == 0, "kernel_size should be a odd number for 'SAME' padding"
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-6)
+        self.pointwise_conv1 = nn.Conv1d(hidden_size, 2 * channels, kernel_size=1, stride=1, padding=0)
+        self.glu = nn.GLU(dim=1)
+        self.depthwise_conv = nn.Conv1d(channels, channels, depthwise_kernel_size, stride=1,
+                                        padding=(depthwise_kernel_size - 1) // 2, groups=channels)
+        self.batch_norm = nn.BatchNorm1d(channels)
+        self.swish = nn.Hardswish()
+        self.pointwise_conv2 = nn.Conv1d(channels, hidden_size, kernel_size=1, stride=1, padding=0)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x: Tensor) -> Tensor:
+        rt = runtime_of(self)
+        x = rt.act_in(x)
+        x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None, None)
+        bn = self.batch_norm
+        p = self.dropout.p
+        rng = _rng(rt, x) if (self.training and p > 0) else None
+        if self.training:
+            bn.num_batches_tracked += 1
+        return Fn.ConvModuleFn.apply(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias, self.depthwise_conv.weight,
+                                     self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     self.pointwise_conv2.weight, self.pointwise_conv2.bias, p, rng, self.training, rt.compute_dtype)
+
+
+class ConformerEncoderLayer(nn.Module):
+    """Conformer block as the reference builds it (:478-565): half-step residuals around the two feed-forward modules
+    (which carry their own LayerNorm and residual), self-attention, the convolution module, final LayerNorm."""
+
+    def __init__(self, size: int = 512, ff_size: int = 2048, num_heads: int = 4, dropout: float = 0.1,
+                 depthwise_conv_kernel_size: int = 31, alpha: float = 1.0, layer_norm: str = "pre"):
+        super().__init__()
+        self.initial_feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha, layer_norm=layer_norm)
+        self.src_att_layer_norm = nn.LayerNorm(size, eps=1e-6)
+        self.src_att_dropout = nn.Dropout(dropout)
+        self.src_src_att = MultiHeadedAttention(num_heads, size, dropout=dropout)
+        self.conv_module = ConvolutionModule(hidden_size=size, channels=size, depthwise_kernel_size=depthwise_conv_kernel_size,
+                                             dropout=dropout)
+        self.final_feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha, layer_norm=layer_norm)
+        self.final_layer_norm = nn.LayerNorm(size, eps=1e-6)
+        self.alpha = alpha
+        self.size = size
+        self._layer_norm_position = layer_norm
+        assert self._layer_norm_position in {"pre", "post"}
+
+    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+        rt = runtime_of(self)
+        x = rt.act_in(x)
+        x = Fn.AxpbyFn.apply(self.initial_feed_forward(x), 0.5, x, 1.0)
+        x, _ = self.src_src_att.run_block(x, None, mask, ln=self.src_att_layer_norm, ln_mode=self._layer_norm_position,
+                                          alpha=self.alpha, out_dropout=self.src_att_dropout.p)
+        x = Fn.AxpbyFn.apply(self.conv_module(x), 1.0, x, self.alpha)
+        residual = x
+        if self._layer_norm_position == "pre":
+            x = Fn.LayerNormFn.apply(x, self.final_layer_norm.weight, self.final_layer_norm.bias, None, None)
+        x = Fn.AxpbyFn.apply(self.final_feed_forward(x), 0.5, residual, 1.0)
+        if self._layer_norm_position == "post":
+            x = Fn.LayerNormFn.apply(x, self.final_layer_norm.weight, self.final_layer_norm.bias, None, None)
+        return x
