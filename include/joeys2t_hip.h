@@ -248,6 +248,17 @@ int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* ta
                  float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
                  int zero_infinity, int beta_ready, js2t_stream stream);
 
+/* Single-query attention for KV-cached decoding (replaces the per-step full-prefix decoder pass of search.py:518-534 and
+ * the per-step re-projection of the encoder states, transformer_layers.py:75-107 under beam search):
+ * out[r, h*dh:(h+1)*dh] = softmax_j( (q[r,h]/sqrt(dh)) . K[row(r,j), j, h] ) V[row(r,j), j, h],  j < len.
+ * k / v: [*, Tmax, ldkv] (v may point into the same buffer as k).  idx_ld > 0: self-attention cache, row(r,j) =
+ * idx[r*idx_ld + j] (per-position ancestry table: beam re-ordering rewrites the table, never the cache);
+ * idx_ld == 0: cross-attention, row(r,j) = idx[r] (the hypothesis' utterance).  key_mask (optional) u8[*, Tmax] indexed
+ * like k: 0 = masked.  `scale` multiplies q before the product (pass 1/sqrt(dh)). */
+int js2t_attn_decode(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const int32_t* idx, int32_t idx_ld,
+                     int32_t Tmax, int32_t len, const uint8_t* key_mask, void* out, int64_t ldo, int32_t rows, int32_t H, int32_t dh,
+                     float scale, int dt, js2t_stream stream);
+
 /* --------------------------------------------------------------------------------------------------
  * Conformer convolution module (reference transformer_layers.py:410-475, ConformerEncoderLayer :478-565).
  * The reference hands the module x.transpose(0, 1) of a [B, T, C] tensor (:549-552): its depthwise Conv1d and the

@@ -16,6 +16,7 @@ from torch import Tensor
 
 from joeys2t_amd import ops
 from joeys2t_amd.helpers import tile
+from joeys2t_amd.incremental import IncrementalDecoder
 from joeys2t_amd.helpers_for_ddp import ddp_merge
 
 
@@ -62,8 +63,9 @@ def transformer_greedy(src_mask: Tensor, max_output_length: int, model, encoder_
     trg_mask = torch.ones((1, 1, 1), dtype=torch.bool, device=dev)
     finished = torch.zeros((B, 1), dtype=torch.bool, device=dev)
     zero_lp = torch.zeros((B, ), dtype=torch.float32, device=dev)
+    inc = IncrementalDecoder(model, encoder_output, src_mask, 1, max_output_length) if kwargs.get("incremental", True) else None
     for step in range(max_output_length):
-        logits = _decode_last(model, ys, encoder_output, src_mask, trg_mask)
+        logits = inc.step(ys[:, -1]) if inc is not None else _decode_last(model, ys, encoder_output, src_mask, trg_mask)
         forbid = _forbidden(model, False, generate_unk, step, min_output_length, V)
         # arg-max of the masked row == top-1 of a beam of one; scores are log-probs (the reference only normalises
         # when probabilities are requested, search.py:257-258, which does not change the arg-max)
@@ -94,8 +96,12 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
     V = model.decoder.output_size
     dev = encoder_output.device
 
-    encoder_output = tile(encoder_output.contiguous(), beam_size, dim=0)  # [B*k, S, d]
-    src_mask = tile(src_mask, beam_size, dim=0)
+    # KV-cached decoding (default): hypotheses index their utterance's encoder keys / values instead of carrying a tiled
+    # copy of the encoder states; incremental=False keeps the reference's full-prefix pass (used to cross-check)
+    inc = IncrementalDecoder(model, encoder_output, src_mask, beam_size, max_output_length) if kwargs.get("incremental", True) else None
+    if inc is None:
+        encoder_output = tile(encoder_output.contiguous(), beam_size, dim=0)  # [B*k, S, d]
+        src_mask = tile(src_mask, beam_size, dim=0)
     trg_mask = torch.ones((1, 1, 1), dtype=torch.bool, device=dev)
     batch_offset = torch.arange(B, dtype=torch.long)  # host: live example -> original position
     beam_offset = torch.arange(0, B * beam_size, step=beam_size, dtype=torch.long, device=dev)
@@ -108,7 +114,7 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
 
     for step in range(max_output_length):
         nb = alive_seq.size(0) // beam_size
-        logits = _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask)
+        logits = inc.step(alive_seq[:, -1]) if inc is not None else _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask)
         forbid = _forbidden(model, True, generate_unk, step, min_output_length, V)
         length_penalty = ((5.0 + (step + 1)) / 6.0)**alpha if alpha > 0 else 0.0
         topk_scores, topk_flat, _ = ops.beam_step(logits, topk_log_probs.reshape(-1), nb, beam_size, forbid, length_penalty)
@@ -155,8 +161,11 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             alive_seq = alive_seq.view(-1, beam_size, alive_seq.size(-1)).index_select(0, unfinished).view(-1, alive_seq.size(-1))
 
         select_indices = batch_index.view(-1)
-        encoder_output = encoder_output.index_select(0, select_indices)
-        src_mask = src_mask.index_select(0, select_indices)
+        if inc is not None:
+            inc.reorder(select_indices)
+        else:
+            encoder_output = encoder_output.index_select(0, select_indices)
+            src_mask = src_mask.index_select(0, select_indices)
 
     for b in range(B):
         for _ in range(n_best - len(results["predictions"][b])):

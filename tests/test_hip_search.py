@@ -103,3 +103,39 @@ def test_wer_on_synthetic_set_equals_cpu_oracle(device):
         hyp_cpu += [" ".join(vocab.array_to_sentence(row.tolist(), cut_at_eos=True)) for row in ids]
     assert hyp_hip == hyp_cpu
     assert wer(hyp_hip, refs) == wer(hyp_cpu, refs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_incremental_decoding_equals_full_prefix_pass(device, dtype):
+    """KV-cached decoding against the reference-style full-prefix decoder pass on a wider model (d = 256, head size 128,
+    ragged source lengths, beam 4): identical hypotheses in fp32; in bf16 the two orders of rounding may flip a near-tie,
+    so scores are compared instead."""
+    import copy
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.search import search
+    from joeys2t_amd.vocabulary import Vocabulary
+    cfg = copy.deepcopy(FIXTURES["model_pre"]["cfg"])
+    cfg["encoder"].update(hidden_size=256, ff_size=512, num_heads=2, conv_channels=64)
+    cfg["decoder"].update(hidden_size=256, ff_size=512, num_heads=2)
+    cfg["decoder"]["embeddings"]["embedding_dim"] = 256
+    torch.manual_seed(3)
+    model = build_model(cfg, None, Vocabulary.synthetic(50))
+    model.finalize(device, dtype).eval()
+    gen = torch.Generator().manual_seed(9)
+    B, T = 5, 64
+    lengths = torch.tensor([64, 51, 40, 64, 33])
+    src = torch.randn(B, T, 8, generator=gen)
+    for b in range(B):
+        src[b, lengths[b]:] = 1.0
+    batch = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=None, trg_length=None, trg_prompt_mask=None,
+                  indices=torch.arange(B), device=device, pad_index=1, eos_index=3, is_train=False, task="S2T", n_gpu=1)
+    for beam in (1, 4):
+        a_ids, a_sc, _ = search(model, batch, max_output_length=14, beam_size=beam, beam_alpha=1.0, n_best=1, return_prob="hyp")
+        b_ids, b_sc, _ = search(model, batch, max_output_length=14, beam_size=beam, beam_alpha=1.0, n_best=1, return_prob="hyp",
+                                incremental=False)
+        if dtype == torch.float32:
+            assert np.array_equal(a_ids, b_ids)
+            np.testing.assert_allclose(a_sc, b_sc, rtol=1e-4, atol=1e-4)
+        elif beam > 1:
+            np.testing.assert_allclose(a_sc, b_sc, rtol=5e-2, atol=5e-2)
