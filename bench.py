@@ -86,7 +86,7 @@ class GemmTimer:
         return agg
 
 
-def build_step(device, world, dtype=torch.bfloat16, seed=42):
+def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
     from joeys2t_amd.batch import Batch
     from joeys2t_amd.model import build_model
     from joeys2t_amd.tokenizers import SpeechProcessor
@@ -105,10 +105,21 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
                            specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
                            cmvn=dict(norm_means=True, norm_vars=True, before=True))
     rank = int(os.environ.get("RANK", 0))
-    wave = synth_waveforms(BATCH, SAMPLES, seed=1234 + rank).to(device)
     trg, trg_len = synth_targets(BATCH, VOCAB, seed=1234 + rank)
-    n_samples = [SAMPLES] * BATCH
-    frames = 1 + (SAMPLES - 400) // 160
+    if ragged:
+        # SURVEY 8(d)'s ragged variant: N_i ~ U{160000..272000} samples (10-17 s), pre-sorted by length (descending) so that
+        # batch.sort_by_src_length() is the identity and the replayed graph sees the same order every step
+        g = torch.Generator().manual_seed(4321 + rank)
+        n_samples = sorted(torch.randint(160000, 272001, (BATCH, ), generator=g).tolist(), reverse=True)
+        wave = synth_waveforms(BATCH, max(n_samples), seed=1234 + rank)
+        for i, n in enumerate(n_samples):
+            wave[i, n:] = 0.0
+        wave = wave.to(device)
+    else:
+        wave = synth_waveforms(BATCH, SAMPLES, seed=1234 + rank).to(device)
+        n_samples = [SAMPLES] * BATCH
+    frames_list = [1 + (n - 400) // 160 for n in n_samples]
+    frames = max(frames_list)
     step.optimizer.device_schedule = True
     # static per-step inputs: SpecAugment mask parameters are drawn on the host (np.random, reference order) and
     # copied into a fixed device buffer, so the same code runs eagerly or as a replayed hipGraph
@@ -117,7 +128,7 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
     state = {"batch": None}
 
     def pre_step():
-        masks_host.copy_(torch.from_numpy(proc.draw_masks([frames] * BATCH)))
+        masks_host.copy_(torch.from_numpy(proc.draw_masks(frames_list)))
         masks_dev.copy_(masks_host, non_blocking=True)
 
     def body():
@@ -168,7 +179,7 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42):
         graph_holder["g"].replay()
         post_body(capturing=True)
 
-    return eager_step, graph_step, capture, step, frames * BATCH, (model, state)
+    return eager_step, graph_step, capture, step, sum(frames_list), (model, state)
 
 
 def encoder_forward(model, batch, reps=20):
@@ -306,6 +317,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-5 decode RTF measurement")
+    ap.add_argument("--ragged", action="store_true", help="utterances of 10-17 s instead of 32 x 15 s (value counts un-padded frames)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -325,7 +337,7 @@ def main():
         torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from joeys2t_amd import ops
-    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world)
+    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world, ragged=args.ragged)
     use_graph = not args.no_graph
     one_step = eager_step
     if use_graph:
@@ -423,7 +435,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs/librispeech_100h.yaml ASR train step on synthetic 16 kHz waveforms",
-                       "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": 375,
+                       "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": ((int(state["batch"].src.shape[1]) - 1) // 2) // 2 + 1,
+                       "lengths": "ragged 10-17 s, un-padded frames counted" if args.ragged else "fixed 15 s",
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "loss": round(stats["loss"] / max(1, args.steps + 0), 4)},

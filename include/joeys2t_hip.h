@@ -254,10 +254,13 @@ int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* ta
  * k / v: [*, Tmax, ldkv] (v may point into the same buffer as k).  idx_ld > 0: self-attention cache, row(r,j) =
  * idx[r*idx_ld + j] (per-position ancestry table: beam re-ordering rewrites the table, never the cache);
  * idx_ld == 0: cross-attention, row(r,j) = idx[r] (the hypothesis' utterance).  key_mask (optional) u8[*, Tmax] indexed
- * like k: 0 = masked.  `scale` multiplies q before the product (pass 1/sqrt(dh)). */
+ * like k: 0 = masked.  `scale` multiplies q before the product (pass 1/sqrt(dh)).  len_dev (optional, device i32): the
+ * key count is read from device memory instead of `len`, so one captured hipGraph of a decoding step can be replayed
+ * for every position.  group > 1 (cross-attention only): hypotheses r, r+1, .. r+group-1 (r a multiple of group) share
+ * idx[r] - the beams of one utterance - and are served by one block, which reads the keys / values once for all of them. */
 int js2t_attn_decode(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const int32_t* idx, int32_t idx_ld,
-                     int32_t Tmax, int32_t len, const uint8_t* key_mask, void* out, int64_t ldo, int32_t rows, int32_t H, int32_t dh,
-                     float scale, int dt, js2t_stream stream);
+                     int32_t Tmax, int32_t len, const int32_t* len_dev, const uint8_t* key_mask, void* out, int64_t ldo, int32_t rows,
+                     int32_t H, int32_t dh, float scale, int32_t group, int dt, js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Conformer convolution module (reference transformer_layers.py:410-475, ConformerEncoderLayer :478-565).

@@ -525,15 +525,16 @@ def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: f
     return d
 
 
-def attn_decode(q2d, k_view, v_view, ldkv: int, idx, idx_ld: int, Tmax: int, length: int, key_mask, H: int, dh: int):
+def attn_decode(q2d, k_view, v_view, ldkv: int, idx, idx_ld: int, Tmax: int, length: int, key_mask, H: int, dh: int, len_dev=None,
+                group: int = 1):
     """Single-query attention over cached keys / values (js2t_attn_decode).  k_view / v_view: tensors whose data_ptr is the
     first key / value element (row 0, position 0, head 0); ldkv: elements between consecutive positions."""
-    _dev(q2d, k_view, v_view, idx, key_mask)
+    _dev(q2d, k_view, v_view, idx, key_mask, len_dev)
     rows = q2d.shape[0]
     out = torch.empty((rows, H * dh), dtype=q2d.dtype, device=q2d.device)
     check(lib().js2t_attn_decode(_p(q2d), C.c_int64(q2d.stride(0)), _p(k_view), _p(v_view), C.c_int64(ldkv), _p(idx), int(idx_ld), int(Tmax),
-                                 int(length), _p(key_mask), _p(out), C.c_int64(out.stride(0)), int(rows), int(H), int(dh),
-                                 C.c_float(1.0 / math.sqrt(dh)), dt_code(q2d), _stream()), "js2t_attn_decode")
+                                 int(length), _p(len_dev), _p(key_mask), _p(out), C.c_int64(out.stride(0)), int(rows), int(H), int(dh),
+                                 C.c_float(1.0 / math.sqrt(dh)), int(group), dt_code(q2d), _stream()), "js2t_attn_decode")
     return out
 
 
