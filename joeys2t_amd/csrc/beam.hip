@@ -88,6 +88,110 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(const float* __re
   }
 }
 
+
+// Beams of at most BS_LK hypotheses: ONE pass over the k*V scores.  Every thread keeps the BS_LK best candidates of its
+// strided share in registers (sorted insertion under the same total order); the k winners are then drawn by k block-wide
+// arg-max rounds over the heads of those lists - a thread can lose at most BS_LK >= k entries, so the result is exactly
+// the k best of all k*V.  Row log-sum-exps: one wave per row, single online pass, no block barrier.
+constexpr int BS_LK = 8;
+
+__global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float* __restrict__ logits, const float* __restrict__ beam_lp,
+                                                                   float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+                                                                   float* __restrict__ out_lse, int k, int V, ForbidList fb, float len_pen,
+                                                                   int use_pen) {
+  __shared__ float red[BS_THREADS / 64];
+  __shared__ int redi[BS_THREADS / 64];
+  __shared__ int redt[BS_THREADS / 64];
+  __shared__ float lse_s[BS_LK];
+  __shared__ float blp_s[BS_LK];
+  __shared__ int pick_t;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const float* lg = logits + (int64_t)b * k * V;
+  for (int r = w; r < k; r += BS_THREADS / 64) {
+    const float* row = lg + (int64_t)r * V;
+    float mx = -INFINITY, sm = 0.f;
+    for (int v = lane; v < V; v += 64) {
+      const float x = row[v];
+      if (x > mx) {
+        sm = sm * __expf(mx - x) + 1.f;
+        mx = x;
+      } else {
+        sm += __expf(x - mx);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sm, o, 64);
+      const float nm = fmaxf(mx, om);
+      sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+      mx = nm;
+    }
+    if (lane == 0) {
+      lse_s[r] = mx + __logf(sm);
+      out_lse[(int64_t)b * k + r] = lse_s[r];
+      blp_s[r] = beam_lp[(int64_t)b * k + r];
+    }
+  }
+  __syncthreads();
+  float ls[BS_LK];
+  int li[BS_LK];
+#pragma unroll
+  for (int i = 0; i < BS_LK; ++i) { ls[i] = -INFINITY; li[i] = 0x7fffffff; }
+  for (int r = 0; r < k; ++r) {
+    const float lse = lse_s[r], blp = blp_s[r];
+    const float* row = lg + (int64_t)r * V;
+    for (int v = t; v < V; v += BS_THREADS) {
+      float sc = row[v] - lse;
+      for (int f = 0; f < fb.n; ++f)
+        if (v == fb.ids[f]) sc = -INFINITY;
+      sc += blp;
+      if (use_pen) sc = sc / len_pen;  // true division, as curr_scores /= length_penalty (search.py:628)
+      const int c = r * V + v;
+      if (better(sc, c, ls[BS_LK - 1], li[BS_LK - 1])) {  // enters the list: bubble it up
+        ls[BS_LK - 1] = sc;
+        li[BS_LK - 1] = c;
+#pragma unroll
+        for (int i = BS_LK - 1; i > 0; --i) {
+          if (better(ls[i], li[i], ls[i - 1], li[i - 1])) {
+            const float ts = ls[i]; ls[i] = ls[i - 1]; ls[i - 1] = ts;
+            const int ti = li[i]; li[i] = li[i - 1]; li[i - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  // k rounds over the list heads
+  for (int rank = 0; rank < k; ++rank) {
+    float bs = ls[0];
+    int bi = li[0], bt = t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64);
+      const int oi = __shfl_xor(bi, o, 64), ot = __shfl_xor(bt, o, 64);
+      if (better(os, oi, bs, bi)) { bs = os; bi = oi; bt = ot; }
+    }
+    if (lane == 0) { red[w] = bs; redi[w] = bi; redt[w] = bt; }
+    __syncthreads();
+    if (t == 0) {
+      float fs = red[0];
+      int fi = redi[0], ft = redt[0];
+      for (int ww = 1; ww < BS_THREADS / 64; ++ww)
+        if (better(red[ww], redi[ww], fs, fi)) { fs = red[ww]; fi = redi[ww]; ft = redt[ww]; }
+      pick_t = ft;
+      out_scores[(int64_t)b * k + rank] = fs;
+      out_ids[(int64_t)b * k + rank] = fi == 0x7fffffff ? 0 : fi;
+    }
+    __syncthreads();
+    if (t == pick_t) {  // pop the winner's list
+#pragma unroll
+      for (int i = 0; i < BS_LK - 1; ++i) { ls[i] = ls[i + 1]; li[i] = li[i + 1]; }
+      ls[BS_LK - 1] = -INFINITY;
+      li[BS_LK - 1] = 0x7fffffff;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
@@ -103,8 +207,13 @@ extern "C" int js2t_beam_step(const float* logits, const float* beam_log_probs, 
   fb.n = n_forbid;
   for (int i = 0; i < BS_MAX_FORBID; ++i) fb.ids[i] = i < n_forbid ? forbid_ids[i] : -1;
   const int use_pen = length_penalty > 0.f ? 1 : 0;
-  hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
-                     out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen);
+  if (beam <= BS_LK) {
+    hipLaunchKernelGGL(beam_step_fast_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
+                       out_scores, out_ids, out_lse, beam, (int)V, fb, use_pen ? length_penalty : 1.f, use_pen);
+  } else {
+    hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
+                       out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen);
+  }
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
