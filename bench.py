@@ -304,8 +304,21 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     audio_s = BATCH * SAMPLES / 16000.0
+    # decoder FLOP of this decode with and without the key/value cache: per position and layer the projections
+    # cost 8 d^2 (self) + 4 d^2 (cross q, o) + 4 d ff (FFN); attention 4 d per key; without a cache every step redoes the
+    # whole prefix and re-projects the encoder states (4 d^2 per encoder position, hypothesis and layer)
+    e, dcfg = MUSTC_MODEL["encoder"], MUSTC_MODEL["decoder"]
+    d, ff, nl = dcfg["hidden_size"], dcfg["ff_size"], dcfg["num_layers"]
+    S = ((1 + (SAMPLES - 400) // 160 - 1) // 2) // 2 + 1
+    rows, steps = BATCH * beam, int(ids.shape[1])
+    per_pos = nl * (12 * d * d + 4 * d * ff)
+    cached = sum(rows * (per_pos + nl * 4 * d * (t + 1 + S) + 2 * d * VOCAB) for t in range(steps)) + BATCH * S * nl * 4 * d * d
+    uncached = sum(rows * ((t + 1) * per_pos + nl * (4 * d * (t + 1) * (t + 2) // 2 + 4 * d * S * (t + 1)) + nl * S * 4 * d * d + 2 * d * VOCAB)
+                   for t in range(steps))
     return {"rtf": round(dt / audio_s, 6), "wall_s": round(dt, 3), "audio_s": audio_s, "beam": beam, "alpha": alpha,
-            "steps": int(ids.shape[1]), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16"}
+            "steps": steps, "steps_per_s": round(steps / dt, 1), "decoder_tflop_kv_cached": round(cached / 1e12, 3),
+            "decoder_tflop_full_prefix": round(uncached / 1e12, 3), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16",
+            "decoding": "KV-cached, hipGraph-replayed step"}
 
 
 def main():
