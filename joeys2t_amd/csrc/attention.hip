@@ -264,22 +264,6 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO*O)
-__global__ void attn_delta_kernel(AttnArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Tq*H
-  if (row >= (int64_t)a.B * a.Tq * a.H) return;
-  const int64_t bt = row / a.H;
-  const int h = (int)(row - bt * a.H);
-  const int b = (int)(bt / a.Tq), q = (int)(bt - (int64_t)b * a.Tq);
-  const uint16_t* orow = a.o + bt * a.ldo + h * DH;
-  const uint16_t* grow = a.d_o + bt * a.lddo + h * DH;
-  float s = 0.f;
-  for (int c = lane; c < DH; c += 64) s += bf16_bits_to_f32(orow[c]) * bf16_bits_to_f32(grow[c]);
-  s = wave_sum(s);
-  if (lane == 0) a.delta[((int64_t)b * a.H + h) * a.Tq + q] = s;
-}
-
 // shared by both backward kernels: probability and dS for one (own row mt, tile rows) block
 // ------------------------------------------------------------------------------------------------ dQ
 // own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
@@ -329,7 +313,18 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
     own_frags(Gb, a.lddo, q0 + 16 * mt, a.Tq, lane, gf[mt]);
     const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
     lse2[mt] = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
-    dl2[mt] = a.delta[(int64_t)z * a.Tq + qc] * keep_p;
+    // delta = rowsum(dO * O) of the own rows: the dO fragments are in registers anyway, O's are fetched once; the four
+    // lanes of a row hold a quarter of the head columns each.  Written out for the dK/dV pass, which runs after this one.
+    bf16x8_t of[4];
+    own_frags(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0 + 16 * mt, a.Tq, lane, of);
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)gf[mt][ks][e] * (float)of[ks][e];
+    dsum = quad_sum(dsum);
+    if (g == 0 && q0 + 16 * mt + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + 16 * mt + m] = dsum;
+    dl2[mt] = dsum * keep_p;
   }
   f32x4_t dq[DQ_MT][8];
 #pragma unroll
@@ -663,11 +658,9 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
   }
   AttnArgs a = to_args(d);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv((int64_t)d->B * d->Tq * d->H, 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
-  JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
