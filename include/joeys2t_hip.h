@@ -126,6 +126,12 @@ int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_s
 /* dx[rows,2C] from dy[rows,C] and the saved x. */
 int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int dt, js2t_stream stream);
 
+/* Transposed bf16 shadows of the 2-D weights: for every group g (table[g] = {element offset, rows, cols, first 64x64 tile},
+ * int64 on the device) the [rows, cols] block at src + offset is written as [cols, rows] at dst + offset.  With W^T at
+ * hand the input gradient dX = dY W of every nn.Linear (autograd of transformer_layers.py:75-107,147-153) is a product of
+ * two k-contiguous operands, i.e. it takes the faster mainloop and the register-direct epilogue of js2t_gemm. */
+int js2t_transpose_groups(const void* src, void* dst, const int64_t* table, int32_t n_groups, int64_t total_tiles, js2t_stream stream);
+
 /* y[b,t,:] = dropout(x[b,t,:] + pe[t,:] (+ extra[b,t,:])) — PositionalEncoding.forward
  * (transformer_layers.py:204-213) + emb_dropout (encoders.py:273-276, decoders.py:599-602).
  * pe is f32[>=T, D] or NULL (plain dropout: ConformerEncoder's emb_dropout after its input Linear, encoders.py:433-435);

@@ -77,6 +77,8 @@ class FlatAdamW:
                                _C.c_float(grad_scale), int(zero_grad), ops._p(lr_dev), ops._p(step_dev), ops._stream()),
               "js2t_adamw")
         st.dirty = lp is None and st.dirty
+        if lp is not None and st.flat_lp_t is not None:
+            st.refresh_t()  # transposed shadows follow the updated weights (one kernel; part of the captured step)
 
     def state_dict(self) -> Dict:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}

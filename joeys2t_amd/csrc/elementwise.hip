@@ -292,6 +292,33 @@ __global__ void subsample_len_mask_kernel(const int64_t* __restrict__ lengths, i
   }
 }
 
+// Transposed bf16 shadows of 2-D parameter groups: table[g] = {element offset, rows, cols, first tile}; group g's
+// [rows, cols] block at src + offset is written as [cols, rows] at dst + offset.  One 64x64 tile per block through LDS
+// (coalesced reads along cols, coalesced writes along rows).
+__global__ __launch_bounds__(256) void transpose_groups_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                               const int64_t* __restrict__ table, int n_groups) {
+  __shared__ uint16_t tile[64][66];
+  const int64_t bid = blockIdx.x;
+  int lo = 0, hi = n_groups - 1;
+  while (lo < hi) {  // last group whose first tile <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 4 + 3] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t off = table[lo * 4], R = table[lo * 4 + 1], Cc = table[lo * 4 + 2], t0 = table[lo * 4 + 3];
+  const int64_t tiles_c = (Cc + 63) >> 6;
+  const int64_t tr = (bid - t0) / tiles_c, tc = (bid - t0) - tr * tiles_c;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int64_t rr = tr * 64 + r, cc = tc * 64 + tx;
+    if (rr < R && cc < Cc) tile[r][tx] = src[off + rr * Cc + cc];
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    const int64_t cc = tc * 64 + c, rr = tr * 64 + tx;
+    if (rr < R && cc < Cc) dst[off + cc * R + rr] = tile[tx][c];
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_DT(dt, T, ...)                                  \
@@ -448,6 +475,16 @@ extern "C" int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_
   for (int i = 0; i < n_layers; ++i) ks[i] = kernel_sizes[i];
   hipLaunchKernelGGL(subsample_len_mask_kernel, dim3(ew_grid(B * T_out)), dim3(EW_THREADS), 0, (hipStream_t)stream, lengths,
                      out_lengths, mask, B, T_out, ks[0], ks[1], ks[2], ks[3], n_layers);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_transpose_groups(const void* src, void* dst, const int64_t* table, int32_t n_groups, int64_t total_tiles,
+                                     js2t_stream stream) {
+  if (n_groups == 0 || total_tiles == 0) return JS2T_OK;
+  JS2T_CHECK(src && dst && table && n_groups > 0 && total_tiles > 0 && total_tiles < 0x7fffffff, "transpose_groups: bad arguments");
+  hipLaunchKernelGGL(transpose_groups_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src,
+                     (uint16_t*)dst, table, n_groups);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

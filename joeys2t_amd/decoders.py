@@ -46,7 +46,10 @@ class TransformerDecoder(Decoder):
         smap = {"w": [layer.weight]}
         if bias is not None:
             smap["b"] = [bias]
-        return Fn.LinearFn.apply(x, rt.weight([layer.weight]), layer.weight, bias, out_dtype, rt.sinks(smap), rt.grads_ready)
+        sk = rt.sinks(smap)
+        if sk is not None:
+            sk["_w_t"] = rt.weight_t([layer.weight])
+        return Fn.LinearFn.apply(x, rt.weight([layer.weight]), layer.weight, bias, out_dtype, sk, rt.grads_ready)
 
     def forward(self, trg_embed: Tensor, encoder_output: Tensor, encoder_hidden: Tensor, src_mask: Tensor,
                 unroll_steps: int, hidden: Tensor, trg_mask: Tensor, **kwargs):

@@ -47,7 +47,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
 
 
 def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None,
-               dw_out=None, db_out=None, queue=None):
+               dw_out=None, db_out=None, queue=None, w_t=None):
     """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32).
     dw_out / db_out: fp32 gradient buffers (views of the flat gradient store) to ACCUMULATE into; the corresponding
     return value is then None (nothing left for autograd to add)."""
@@ -58,8 +58,13 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
     if need_dx:
         # dx[M,K] = dz[M,N] . W[N,K]   (B(n'=k, red=n) lives at W[n*ldw + k] -> trans_b)
         dx = torch.empty((M, K), dtype=dx_dtype or x2d.dtype, device=x2d.device)
-        ops.gemm(dz2d, w, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w.stride(0), ldc=K, trans_b=True, gate=gate,
-                 ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+        if w_t is not None and w_t.dtype == dz2d.dtype:
+            # W^T [K, N] is at hand (ParamStore.view_t): both operands k-contiguous -> plain product, register-direct epilogue
+            ops.gemm(dz2d, w_t, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w_t.stride(0), ldc=K, gate=gate,
+                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+        else:
+            ops.gemm(dz2d, w, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w.stride(0), ldc=K, trans_b=True, gate=gate,
+                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
     # the bias gradient (column sums of dz) rides on the weight-gradient product when that runs on the bf16 LDS-DMA
     # kernel: its dz tiles are already in LDS, so no separate pass over dz is needed
     fuse_db = need_dw and need_db and _mfma_operand(dz2d) and _mfma_operand(x2d)
@@ -310,7 +315,7 @@ class ResidualBlockFn(torch.autograd.Function):
             relu = cfg.act == "relu"
             # dh = dz_o . W2, gated by the saved post-dropout activations for ReLU (sign carries both masks)
             dh, g["w2"], g["b2"] = linear_bwd(dz_o, c, wts["w2"], gate=c if relu else None,
-                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0, dw_out=sk("w2"), db_out=sk("b2"), queue=wq)
+                                              gate_scale=1.0 / (1.0 - p) if relu else 1.0, dw_out=sk("w2"), db_out=sk("b2"), queue=wq, w_t=wts.get("w2_t"))
             if relu or cfg.act is None:
                 dz1 = dh
                 if cfg.act is None and p > 0:
@@ -318,23 +323,23 @@ class ResidualBlockFn(torch.autograd.Function):
             else:
                 dz1 = ops.dropout_bwd(dh, p, rng, sites[0]) if p > 0 else dh
                 dz1 = ops.act_bwd(dz1, sv["pre"], cfg.act)
-            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"), queue=wq)
+            dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"), queue=wq, w_t=wts.get("w1_t"))
         elif cfg.kind == "self":
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq)
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
                      sites[0], ctx_out=c, mask=ctx.mask)
-            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"), queue=wq)
+            dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"), queue=wq, w_t=wts.get("w_in_t"))
         else:  # cross
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq)
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
             q, kv = sv["q"], sv["kv"]
             dq, dkv = torch.empty_like(q), torch.empty_like(kv)
             attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
                      ctx_out=c, mask=ctx.mask)
-            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"), queue=wq)
+            dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"), queue=wq, w_t=wts.get("w_q_t"))
             dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
-                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq)
+                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq, w_t=wts.get("w_kv_t"))
             dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
         if cfg.ln_mode == "pre":
             dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
@@ -431,7 +436,7 @@ class LinearFn(torch.autograd.Function):
         sink = ctx.sink or {}
         dx, dw, db = linear_bwd(dy2, x2, w, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[2],
                                 need_db=ctx.has_bias and ctx.needs_input_grad[3], dw_out=sink.get("w"), db_out=sink.get("b"),
-                                queue=sink.get("_wq"))
+                                queue=sink.get("_wq"), w_t=sink.get("_w_t"))
         if sink and ctx.notify is not None:
             ctx.notify(ctx.leaves)
         return (None if dx is None else dx.view(ctx.shape)), None, dw, db, None, None, None

@@ -193,6 +193,11 @@ def axpby(x, a: float, y=None, b: float = 0.0):
     return out
 
 
+def transpose_groups(src, dst, table, n_groups: int, total_tiles: int):
+    _dev(src, dst, table)
+    check(lib().js2t_transpose_groups(_p(src), _p(dst), _p(table), int(n_groups), C.c_int64(total_tiles), _stream()), "js2t_transpose_groups")
+
+
 def glu_fwd(x: torch.Tensor) -> torch.Tensor:
     _dev(x)
     rows, c2 = x.shape[0], x.shape[1]

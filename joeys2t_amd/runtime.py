@@ -59,6 +59,18 @@ class ParamStore:
         self.total = total
         self.offsets = offsets
         self.params: List[nn.Parameter] = [p for grp in groups for p in grp]
+        # 2-D weight groups ([k;v;q] as ONE [3d, d] matrix, every other matrix alone): their transposed bf16 shadows make the
+        # input gradient of every Linear a product of two k-contiguous operands (see refresh_t / view_t)
+        self._tgroups: List[Tuple[int, int, int, List[nn.Parameter]]] = []
+        self._tgroup_of: Dict[int, int] = {}
+        for grp in groups:
+            if all(p.dim() == 2 for p in grp) and len({p.shape[1] for p in grp}) == 1:
+                rows = sum(p.shape[0] for p in grp)
+                for p in grp:
+                    self._tgroup_of[id(p)] = len(self._tgroups)
+                self._tgroups.append((offsets[id(grp[0])], rows, grp[0].shape[1], list(grp)))
+        self.flat_lp_t: Optional[torch.Tensor] = None
+        self._ttable = None
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.flat_lp: Optional[torch.Tensor] = None
@@ -110,6 +122,45 @@ class ParamStore:
         if force or self.dirty:
             ops.cast(self.flat, torch.bfloat16, out=self.flat_lp)
             self.dirty = False
+            if self.flat_lp_t is not None:
+                self.refresh_t()
+
+    def refresh_t(self):
+        """(Re)build the transposed bf16 shadows of all 2-D weight groups from the bf16 shadow: one kernel over a table."""
+        if self.flat_lp is None:
+            self.refresh()
+        if self.flat_lp_t is None:
+            self.flat_lp_t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+            rows, t0 = [], 0
+            for off, R, Cc, _ in self._tgroups:
+                rows.append([off, R, Cc, t0])
+                t0 += ((R + 63) // 64) * ((Cc + 63) // 64)
+            self._ttable = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), t0)
+            self._cache_t: Dict[Tuple, torch.Tensor] = {}
+        table, n, tiles = self._ttable
+        ops.transpose_groups(self.flat_lp, self.flat_lp_t, table, n, tiles)
+
+    def view_t(self, params: Sequence[nn.Parameter]) -> Optional[torch.Tensor]:
+        """bf16 [cols, sum rows] view of the transposed shadow over adjacent parameters of one 2-D group (a strided view
+        when the parameters are only part of their group, e.g. the k|v rows of a [k;v;q] block), or None."""
+        gi = self._tgroup_of.get(id(params[0]))
+        if gi is None or any(self._tgroup_of.get(id(p)) != gi for p in params):
+            return None
+        if self.flat_lp_t is None:
+            self.refresh_t()
+        key = tuple(id(p) for p in params)
+        hit = self._cache_t.get(key)
+        if hit is not None:
+            return hit
+        off, R, Cc, members = self._tgroups[gi]
+        r0 = (self.offsets[id(params[0])] - off) // Cc
+        rows = sum(p.shape[0] for p in params)
+        for a, b in zip(params[:-1], params[1:]):
+            if self.offsets[id(b)] != self.offsets[id(a)] + a.numel():
+                return None
+        out = self.flat_lp_t[off:off + R * Cc].view(Cc, R)[:, r0:r0 + rows]
+        self._cache_t[key] = out
+        return out
 
     def mark_dirty(self):
         self.dirty = True
@@ -209,6 +260,13 @@ class Runtime:
         for p in params:
             ws.append(p.data if p.dtype == dt else ops.cast(p.data, dt))
         return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+
+    def weight_t(self, params: Sequence[nn.Parameter]) -> Optional[torch.Tensor]:
+        """Transposed compute-dtype weight [in, out] for the input-gradient product, when the store keeps one (bf16 compute,
+        gradients enabled); None otherwise (the caller then multiplies by the weight itself with trans_b)."""
+        if self.store is None or self.compute_dtype != torch.bfloat16 or not torch.is_grad_enabled():
+            return None
+        return self.store.view_t(params)
 
     def bias(self, params: Sequence[Optional[nn.Parameter]]) -> Optional[torch.Tensor]:
         if any(p is None for p in params):

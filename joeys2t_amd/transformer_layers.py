@@ -51,15 +51,18 @@ class MultiHeadedAttention(nn.Module):
 
     def _weights(self, rt, kind: str) -> dict:
         k, v, q, o = self.k_layer, self.v_layer, self.q_layer, self.output_layer
-        w = {"w_out": rt.weight([o.weight]), "b_out": rt.bias([o.bias])}
+        w = {"w_out": rt.weight([o.weight]), "b_out": rt.bias([o.bias]), "w_out_t": rt.weight_t([o.weight])}
         if kind == "self":
             w["w_in"] = rt.weight([k.weight, v.weight, q.weight])
             w["b_in"] = rt.bias([k.bias, v.bias, q.bias])
+            w["w_in_t"] = rt.weight_t([k.weight, v.weight, q.weight])
         else:
             w["w_kv"] = rt.weight([k.weight, v.weight])
             w["b_kv"] = rt.bias([k.bias, v.bias])
             w["w_q"] = rt.weight([q.weight])
             w["b_q"] = rt.bias([q.bias])
+            w["w_kv_t"] = rt.weight_t([k.weight, v.weight])
+            w["w_q_t"] = rt.weight_t([q.weight])
         return w
 
     def run_block(self, x: Tensor, memory: Optional[Tensor], mask: Optional[Tensor], *, ln: Optional[nn.LayerNorm],
@@ -134,6 +137,7 @@ class PositionwiseFeedForward(nn.Module):
                           training=self.training, attn_dropout=p, out_dropout=p)
         wts = {"w1": rt.weight([l1.weight]), "b1": rt.bias([l1.bias]), "w2": rt.weight([l2.weight]),
                "b2": rt.bias([l2.bias]), "ln_g": self.layer_norm.weight.data, "ln_b": self.layer_norm.bias.data,
+               "w1_t": rt.weight_t([l1.weight]), "w2_t": rt.weight_t([l2.weight]),
                "sink": rt.sinks({"w1": [l1.weight], "b1": [l1.bias], "w2": [l2.weight], "b2": [l2.bias],
                                  "ln_g": [self.layer_norm.weight], "ln_b": [self.layer_norm.bias]}),
                "notify": rt.grads_ready}

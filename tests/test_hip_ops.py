@@ -563,3 +563,32 @@ def _w256_checks(device, A, B, C, ref, M, N, K):
             lib().js2t_gemm_force_regstage(0)
         assert torch.equal((out1 == 0), (out2 == 0)) or ((out1 == 0) != (out2 == 0)).float().mean() < 1e-4  # same masks
         torch.testing.assert_close(out1.float(), out2.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_transposed_weight_shadow(device):
+    """ParamStore.view_t: the transposed bf16 shadow of fused / single 2-D weights follows the parameters (also after an update)."""
+    from joeys2t_amd.runtime import ParamStore
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.k, self.v, self.q = (torch.nn.Linear(24, 40) for _ in range(3))
+            self.o = torch.nn.Linear(40, 72)
+
+        def fuse_groups(self):
+            return [[self.k.weight, self.v.weight, self.q.weight]]
+
+    m = M()
+    st = ParamStore(m, device)
+    wt = st.view_t([m.k.weight, m.v.weight, m.q.weight])
+    ref = torch.cat([m.k.weight, m.v.weight, m.q.weight], 0).bfloat16()
+    assert wt.shape == (24, 120) and torch.equal(wt.cpu(), ref.cpu().t())
+    assert torch.equal(st.view_t([m.q.weight]).cpu(), m.q.weight.bfloat16().cpu().t())           # strided part of the group
+    assert torch.equal(st.view_t([m.k.weight, m.v.weight]).cpu(), ref[:80].cpu().t())
+    assert torch.equal(st.view_t([m.o.weight]).cpu(), m.o.weight.bfloat16().cpu().t())
+    assert st.view_t([m.o.bias]) is None
+    with torch.no_grad():
+        m.o.weight.mul_(2.0)
+    st.mark_dirty()
+    st.refresh()
+    assert torch.equal(st.view_t([m.o.weight]).cpu(), m.o.weight.bfloat16().cpu().t())
