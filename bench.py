@@ -142,11 +142,13 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
         state["batch"].src = feats
         # single GPU: the update is part of the captured step.  Multi-GPU: forward+backward only; the gradient
         # exchange (RCCL, bucketed) and the fused update follow the replay.
-        return step.micro_step(state["batch"], sort=False, update=(world == 1), overlap=False)
+        # multi-GPU: the deferred weight-gradient products stay OUT of the captured part (flush=False): they run after the
+        # replay, interleaved with the RCCL exchange of the gradient ranges they complete (TrainStep.exchange_and_flush)
+        return step.micro_step(state["batch"], sort=False, update=(world == 1), overlap=False, flush=(world == 1))
 
     def post_body(capturing=False):
         if world > 1:
-            step.reducer.reduce_all()
+            step.exchange_and_flush(state.get("plan"))
             step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
         if world > 1 or capturing:
             step.after_update()
@@ -171,6 +173,9 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
         pre_step()
         with torch.cuda.graph(g):
             body()
+        if world > 1:
+            # the products queued during capture reference the graph's static buffers: keep them as the per-step plan
+            state["plan"] = step.rt.wgrad_queue.take()
         post_body(capturing=True)
         graph_holder["g"] = g
 
@@ -377,7 +382,7 @@ def main():
     stats = step.read_stats()
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:  # N = 1 only: the eager passes would issue collectives on one rank alone
         timer = GemmTimer()
         # The eager pass is launch-bound on the host (~40 us of Python per kernel): an event pair around a launch
         # would also time the GPU waiting for the next packet.  A spin kernel in front of each step holds the GPU
@@ -429,14 +434,14 @@ def main():
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
 
     decode = None
-    if rank == 0 and not args.no_decode:
+    if rank == 0 and world == 1 and not args.no_decode:
         try:
             decode = decode_rtf(device)
         except Exception as exc:
             decode = {"error": repr(exc)}
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             try:
                 cpu = cpu_baseline()
             except Exception as exc:  # the baseline is a reported side figure; never lose the GPU line over it

@@ -88,7 +88,8 @@ class FlatGradReducer:
     exchange per optimizer step; the reference's DDP exchanges on every micro-batch (training.py:584-588 enters
     no_sync() after the forward, which does not disarm the reducer) — the summed gradient is identical."""
 
-    def __init__(self, store, n_buckets: int = 4, average: bool = True, comm_stream: Optional["torch.cuda.Stream"] = None):
+    def __init__(self, store, n_buckets: int = 4, average: bool = True, comm_stream: Optional["torch.cuda.Stream"] = None,
+                 ranges=None):
         self.store = store
         self.average = average
         self.world = dist.get_world_size() if use_ddp() else 1
@@ -104,6 +105,11 @@ class FlatGradReducer:
         if cuts[-1] != 0:
             cuts.append(0)
         self.ranges = [(cuts[i + 1], cuts[i]) for i in range(len(cuts) - 1)]  # (lo, hi), first = tail of flat
+        if ranges is not None:
+            # explicit buckets: the store's type ranges (prefix, then one per Linear shape) - see exchange_begin()
+            self.ranges = [(int(lo), int(hi)) for lo, hi in ranges]
+            assert self.ranges[0][0] == 0 and self.ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(self.ranges, self.ranges[1:]))
+        self.exchange_mode = False  # True between exchange_begin() and finish(): buckets go out by entries_done(), not by hooks
         self.bucket_of = {}
         self.need = [0] * len(self.ranges)
         for p in store.params:
@@ -136,7 +142,7 @@ class FlatGradReducer:
                 self._hook(p)
 
     def _hook(self, p):
-        if not self.armed:
+        if not self.armed or self.exchange_mode:
             return
         bi = self.bucket_of[id(p)]
         self.count[bi] += 1
@@ -160,6 +166,39 @@ class FlatGradReducer:
             w = dist.all_reduce(buf, op=op, async_op=True)
         self.works.append((w, buf, op))
 
+    # ---- exchange driven by the deferred weight-gradient products (runtime.WgradQueue) ------------------------------
+    def bucket_of_tensor(self, t) -> int:
+        off = (t.data_ptr() - self.store.flat_grad.data_ptr()) // 4
+        for bi, (lo, hi) in enumerate(self.ranges):
+            if lo <= off < hi:
+                return bi
+        raise ValueError("tensor is not a view of the flat gradient")
+
+    def exchange_begin(self, plan):
+        """Start the exchange of one optimizer step: `plan` = WgradQueue plan about to run.  Buckets no queued product writes
+        into (the non-Linear prefix: LayerNorm, convolution, embedding gradients, complete once backward is over) go out
+        at once; the others as soon as the last product writing into them has been launched (entries_done)."""
+        self.begin(armed=True)
+        if not self.armed:
+            return
+        self.exchange_mode = True
+        self.pending = [0] * len(self.ranges)
+        for _, items in plan:
+            for it in items:
+                self.pending[self.bucket_of_tensor(it[2])] += 1
+        for bi, n in enumerate(self.pending):
+            if n == 0:
+                self._launch(bi)
+
+    def entries_done(self, items):
+        if not self.armed:
+            return
+        for it in items:
+            bi = self.bucket_of_tensor(it[2])
+            self.pending[bi] -= 1
+            if self.pending[bi] == 0:
+                self._launch(bi)
+
     def reduce_all(self):
         """Exchange the whole flat gradient now (all buckets back to back on the side stream), e.g. after a
         hipGraph replay of forward+backward where no per-parameter hooks fire; blocks the compute stream until done."""
@@ -181,6 +220,7 @@ class FlatGradReducer:
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.armed = False
+        self.exchange_mode = False
 
 
 class DistributedSubsetSampler(Sampler):

@@ -48,14 +48,41 @@ class ParamStore:
             for q in grp:
                 seen.add(id(q))
             groups.append(grp)
+        # Type-major order for the nn.Linear parameters: after everything else (registration order), the weight groups of one
+        # shape from ALL layers are adjacent, followed by their bias groups.  The deferred weight-gradient products
+        # (WgradQueue) run type by type, so each such range of the flat gradient is complete - and can be handed to RCCL -
+        # while the next type's products still run.  `type_ranges` lists (lo, hi) of the prefix and of every type.
+        lin_key: Dict[int, Tuple] = {}
+        for m in module.modules():
+            if isinstance(m, nn.Linear):
+                wg = group_of.get(id(m.weight), [m.weight])
+                key = (sum(p.shape[0] for p in wg), wg[0].shape[1])
+                for p in wg:
+                    lin_key[id(p)] = key + (0, )
+                if m.bias is not None:
+                    for p in group_of.get(id(m.bias), [m.bias]):
+                        lin_key.setdefault(id(p), key + (1, ))
+        order = sorted(range(len(groups)), key=lambda i: ((1, ) + lin_key[id(groups[i][0])] if id(groups[i][0]) in lin_key else (0, )) + (i, ))
+        groups = [groups[i] for i in order]
         offsets: Dict[int, int] = {}
         total = 0
+        self.type_ranges: List[Tuple[int, int]] = []
+        cur_key, cur_lo = "prefix", 0
         for grp in groups:
+            k = lin_key.get(id(grp[0]))
+            k = "prefix" if k is None else k[:2]
+            if k != cur_key:
+                boundary = (total + _ALIGN - 1) // _ALIGN * _ALIGN
+                if boundary > cur_lo:
+                    self.type_ranges.append((cur_lo, boundary))
+                cur_key, cur_lo = k, boundary
             total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
             for p in grp:
                 offsets[id(p)] = total
                 total += p.numel()
         total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
+        if total > cur_lo:
+            self.type_ranges.append((cur_lo, total))
         self.total = total
         self.offsets = offsets
         self.params: List[nn.Parameter] = [p for grp in groups for p in grp]
@@ -214,19 +241,33 @@ class WgradQueue:
         if self.flush_every is not None and self.pending >= self.flush_every:
             self.flush()
 
-    def flush(self):
+    def flush(self, on_group_done=None):
+        """Run the queued products, one grouped launch per shape (largest first); `on_group_done(items)` is called after each
+        launch with its (dY, X, dW, db) entries (the gradient exchange of completed ranges starts from there)."""
+        self.run(self.take(), on_group_done)
+        cbs, self.after_flush = self.after_flush, []
+        for cb in cbs:
+            cb()
+
+    def take(self):
+        """The queued products as a plan [(key, items)], emptying the queue.  A plan built while a hipGraph was captured stays
+        valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches."""
+        plan = sorted(self.groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * len(kv[1]))
+        self.groups = {}
+        self.pending = 0
+        return plan
+
+    @staticmethod
+    def run(plan, on_group_done=None):
         from joeys2t_amd.functional import wgrad_split
-        for (N, K, M, lda, ldb, has_db), items in self.groups.items():
+        for (N, K, M, lda, ldb, has_db), items in plan:
             n = len(items)
             sk = wgrad_split(N, K, M, count=n)
             ops.gemm_grouped([it[0] for it in items], [it[1] for it in items], [it[2] for it in items], M=N, N=K, K=M, lda=lda,
                              ldb=ldb, ldc=K, split_k=sk, beta=0.0 if sk > 1 else 1.0,
                              a_rowsums=[it[3] for it in items] if has_db else None)
-        self.groups.clear()
-        self.pending = 0
-        cbs, self.after_flush = self.after_flush, []
-        for cb in cbs:
-            cb()
+            if on_group_done is not None:
+                on_group_done(items)
 
 
 class Runtime:
@@ -298,10 +339,10 @@ class Runtime:
             out["_wq"] = self.wgrad_queue
         return out
 
-    def flush_wgrads(self):
+    def flush_wgrads(self, on_group_done=None):
         """Run the deferred weight-gradient products (call after backward, before anything reads the gradients)."""
         if self.wgrad_queue is not None:
-            self.wgrad_queue.flush()
+            self.wgrad_queue.flush(on_group_done)
 
     def grads_ready(self, params):
         if self.on_grads_ready is not None:

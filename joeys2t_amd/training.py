@@ -47,33 +47,56 @@ class TrainStep:
         self.steps = 0
         self.micro = 0
         self.sync_every_backward = sync_every_backward
-        self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets) if use_ddp() else None
-        self.rt.on_grads_ready = self.reducer.params_ready if self.reducer is not None else None
-        # weight-gradient products are queued during backward and run grouped by layer type afterwards
+        # weight-gradient products are queued during backward and run grouped by layer type afterwards; under DDP the flat
+        # gradient is exchanged range by range (the store's type ranges) while those products run
         self.rt.wgrad_queue = WgradQueue() if defer_wgrads else None
+        self.reducer = None
+        if use_ddp():
+            self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None)
+        # bucket bookkeeping by per-parameter notifications only without the queue (with it: exchange_and_flush)
+        self.rt.on_grads_ready = self.reducer.params_ready if (self.reducer is not None and self.rt.wgrad_queue is None) else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
 
-    def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True):
+    def exchange_and_flush(self, plan=None):
+        """Deferred weight-gradient products + gradient exchange of one optimizer step, overlapped: each range of the flat
+        gradient goes to RCCL (side stream) as soon as the last product writing into it has been launched.  `plan`: a
+        WgradQueue plan kept from a hipGraph capture (replayed steps), default: whatever the queue holds now."""
+        q = self.rt.wgrad_queue
+        if plan is None:
+            plan = q.take() if q is not None else []
+        if self.reducer is None:
+            WgradQueue.run(plan)
+            return
+        self.reducer.exchange_begin(plan)
+        WgradQueue.run(plan, self.reducer.entries_done)
+        self.reducer.finish()
+
+    def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True, flush: bool = True):
         """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss.
         `sort=False` skips batch.sort_by_src_length() (a host sync) for callers that sorted already;
         `update=False` leaves the optimizer step to the caller (hipGraph capture of forward+backward only);
-        `overlap=False` disables the hook-driven bucket exchange (the caller runs reducer.reduce_all())."""
+        `overlap=False` disables the gradient exchange here (the caller runs exchange_and_flush() / reducer.reduce_all());
+        `flush=False` leaves the deferred weight-gradient products queued (the caller keeps them as a plan)."""
         model = self.model
         model.train()
         self.rt.rng.begin_step()
         if sort:
             batch.sort_by_src_length()
         last = (self.micro + 1) % self.batch_multiplier == 0
-        use_hooks = self.reducer is not None and overlap
+        exchange = self.reducer is not None and overlap and (last or self.sync_every_backward)
+        use_hooks = exchange and self.rt.wgrad_queue is None  # without the queue: bucket hooks fire during backward
         if use_hooks:
-            self.reducer.begin(armed=last or self.sync_every_backward)
+            self.reducer.begin(armed=True)
         total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
         norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
         norm.backward()
-        self.rt.flush_wgrads()
         if use_hooks:
             self.reducer.finish()
+        elif exchange:
+            self.exchange_and_flush()
+        elif flush:
+            self.rt.flush_wgrads()
         with torch.no_grad():
             s = self.stats
             s[0] += norm.detach()

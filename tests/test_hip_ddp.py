@@ -1,0 +1,69 @@
+"""GPU, two ranks on one card over gloo (RCCL needs one card per rank; the exchange logic is the same): the overlapped
+gradient exchange driven by the deferred weight-gradient products must leave, on every rank, the mean over ranks of the
+locally accumulated flat gradient - the reference's DistributedDataParallel average (helpers_for_ddp.py / training.py:508-515)."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from golden_cfg import FIXTURES
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)  # same model on both ranks
+    cfg = copy.deepcopy(FIXTURES["model_pre"]["cfg"])
+    model = build_model(cfg, None, Vocabulary.synthetic(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.finalize(dev, torch.bfloat16)
+    g = torch.Generator().manual_seed(100 + rank)  # different data per rank
+    B, T = 3, 37
+    src = torch.randn(B, T, 8, generator=g)
+    trg = torch.tensor([[2, 5, 6, 7, 3, 1], [2, 8, 9, 3, 1, 1], [2, 10, 11, 12, 13, 3]])
+    mk = lambda: Batch(src=src, src_length=torch.tensor([37, 30, 25]), src_prompt_mask=None, trg=trg, trg_length=torch.tensor([5, 4, 6]),
+                       trg_prompt_mask=None, indices=torch.arange(B), device=dev, pad_index=1, eos_index=3, is_train=True, task="S2T", n_gpu=1)
+    local = TrainStep(model, n_gpu=1)  # no process group yet: plain local gradients
+    assert local.reducer is None
+    local.micro_step(mk(), update=False)
+    g_local = local.store.flat_grad.clone()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ddp = TrainStep(model, n_gpu=1)  # re-attaches and zeroes the flat gradient; reducer over the store's type ranges
+        assert ddp.reducer is not None and len(ddp.reducer.ranges) == len(ddp.store.type_ranges) > 2
+        ddp.micro_step(mk(), update=False)
+        got = ddp.store.flat_grad.clone()
+        mean = g_local.clone()
+        dist.all_reduce(mean)
+        mean /= world
+        err = (got - mean).abs().max().item()
+        ref = mean.abs().max().item()
+        differs = (g_local - mean).abs().max().item()  # the ranks really had different gradients
+        ret[rank] = (err, ref, differs)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_averages_gradients(device):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        err, ref, differs = ret[r]
+        assert differs > 1e-3 * ref
+        assert err <= 2e-3 * ref, (err, ref)  # split-K atomics / bf16 products: not bit-reproducible run to run
