@@ -171,7 +171,8 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         pre_step()
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread may query its events while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
             body()
         if world > 1:
             # the products queued during capture reference the graph's static buffers: keep them as the per-step plan
