@@ -88,6 +88,45 @@ class FlatAdamW:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.param_groups = sd["param_groups"]
+        self.step_dev.fill_(self.t)
+        self.lr_dev.fill_(self.param_groups[0]["lr"])
+
+    # ---- torch.optim.AdamW layout, as the reference's checkpoints carry it (training.py:166-177,251-252) ----------
+    def torch_state_dict(self, params) -> Dict:
+        """`params`: the model's parameters in model.parameters() order (= the index space of torch's optimizer state)."""
+        st = self.store
+        state = {}
+        if self.t > 0:
+            for i, p in enumerate(params):
+                off, n = st.offsets[id(p)], p.numel()
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_state_dict(self, sd: Dict, params):
+        st = self.store
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, p in enumerate(params):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            off, n = st.offsets[id(p)], p.numel()
+            self.exp_avg[off:off + n].view(p.shape).copy_(s["exp_avg"])
+            self.exp_avg_sq[off:off + n].view(p.shape).copy_(s["exp_avg_sq"])
+            steps.add(int(float(s["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state with differing step counts {sorted(steps)} cannot be held by one fused AdamW")
+        self.t = steps.pop() if steps else 0
+        g, src = self.param_groups[0], sd["param_groups"][0]
+        g.update(lr=float(src["lr"]), betas=tuple(src["betas"]), eps=float(src["eps"]), weight_decay=float(src["weight_decay"]))
+        self.step_dev.fill_(self.t)
+        self.lr_dev.fill_(g["lr"])
 
 
 class WarmupInverseSquareRootScheduler:
@@ -117,5 +156,8 @@ class WarmupInverseSquareRootScheduler:
                 "decay_rate": self.decay_rate, "min_rate": self.min_rate}
 
     def load_state_dict(self, sd):
+        """The reference stores {"step", "rate"} only (BaseScheduler, builders.py:265-276); the shape parameters come from the
+        config in both implementations, extra keys of this class's own dumps are honoured when present."""
         self._step, self._rate = sd["step"], sd["rate"]
-        self.warmup, self.decay_rate, self.peak_rate, self.min_rate = sd["warmup"], sd["decay_rate"], sd["peak_rate"], sd["min_rate"]
+        self.warmup, self.peak_rate, self.min_rate = sd.get("warmup", self.warmup), sd.get("peak_rate", self.peak_rate), sd.get("min_rate", self.min_rate)
+        self.decay_rate = sd.get("decay_rate", self.peak_rate * (self.warmup**0.5))

@@ -76,3 +76,50 @@ def pad(x: Tensor, max_len: int, pad_index: int = 1, dim: int = 1) -> Tensor:
     shape[dim] = max_len - cur
     filler = torch.full(shape, pad_index, dtype=x.dtype, device=x.device)
     return torch.cat([x, filler], dim=dim if dim >= 0 else x.dim() + dim)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint I/O
+def load_checkpoint(path, map_location="cpu") -> dict:
+    """Read a JoeyNMT / JoeyS2T checkpoint (reference helpers.py:232-242): a dict with `model_state` (the state_dict this
+    package's Model loads as is - identical parameter names), `optimizer_state` (torch.optim.AdamW layout),
+    `scheduler_state`, `scaler_state`, `train_iter_state`, `stats_state`."""
+    from pathlib import Path
+    path = Path(path)
+    assert path.is_file(), f"Checkpoint {path} not found."
+    return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def init_layers(model: nn.Module, path, layer: str, map_location="cpu") -> None:
+    """Initialise the `encoder` / `decoder` sub-tree from a checkpoint (reference training.py:294-309)."""
+    ckpt = load_checkpoint(path, map_location)
+    model.load_state_dict({k: v for k, v in ckpt["model_state"].items() if k.startswith(layer)}, strict=False)
+
+
+def average_checkpoints(inputs: List[str]) -> dict:
+    """Average the `model_state` of several checkpoints (reference scripts/average_checkpoints.py:17-73): floating tensors
+    are averaged, integer ones floor-divided; everything else is taken from the first file; key lists must agree."""
+    import collections
+    params, keys, new_state = collections.OrderedDict(), None, None
+    for f in inputs:
+        state = load_checkpoint(f, "cpu")
+        if new_state is None:
+            new_state = state
+        ks = list(state["model_state"].keys())
+        if keys is None:
+            keys = ks
+        elif keys != ks:
+            raise KeyError(f"For checkpoint {f}, expected list of params: {keys}, but found: {ks}")
+        for k in keys:
+            p = state["model_state"][k]
+            p = p.float() if p.dtype == torch.float16 else p
+            if k not in params:
+                params[k] = p.clone()
+            else:
+                params[k] += p
+    for k, v in params.items():
+        if v.is_floating_point():
+            v.div_(len(inputs))
+        else:
+            v //= len(inputs)
+    new_state["model_state"] = params
+    return new_state

@@ -69,6 +69,14 @@ class Model(nn.Module):
             rt.store.refresh(force=True)
         return self
 
+    def load_state_dict(self, state_dict, strict: bool = True, **kwargs):
+        """As nn.Module.load_state_dict (parameters stay views of the flat store); the compute-dtype shadows are re-derived
+        before the next forward."""
+        out = super().load_state_dict(state_dict, strict=strict, **kwargs)
+        if self._rt_obj is not None and self._rt_obj.store is not None:
+            self._rt_obj.store.mark_dirty()
+        return out
+
     @property
     def runtime(self) -> Runtime:
         if self._rt_obj is None:

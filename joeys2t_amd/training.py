@@ -126,6 +126,31 @@ class TrainStep:
             self.optimizer.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
         self.steps += 1
 
+    # ---- checkpoints in the reference's layout (training.py:149-190,220-285) ---------------------------------------------
+    def state_for_checkpoint(self) -> Dict:
+        params = list(self.model.parameters())
+        return {"model_state": self.model.state_dict(), "optimizer_state": self.optimizer.torch_state_dict(params), "scaler_state": None,
+                "scheduler_state": None if self.scheduler is None else {"step": self.scheduler._step, "rate": self.scheduler._rate},
+                "train_iter_state": None, "stats_state": {"steps": self.steps}}
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_for_checkpoint(), str(path))
+
+    def init_from_checkpoint(self, path, reset_scheduler: bool = False, reset_optimizer: bool = False, map_location="cpu"):
+        """Model, optimizer moments / step count and schedule position from a JoeyS2T checkpoint - the reference's own files
+        load as they are (same parameter names and order)."""
+        from joeys2t_amd.helpers import load_checkpoint
+        ckpt = load_checkpoint(path, map_location)
+        self.model.load_state_dict(ckpt["model_state"])
+        if not reset_optimizer:
+            self.optimizer.load_torch_state_dict(ckpt["optimizer_state"], list(self.model.parameters()))
+        if not reset_scheduler and ckpt.get("scheduler_state") is not None and self.scheduler is not None:
+            self.scheduler.load_state_dict(ckpt["scheduler_state"])
+            self.optimizer.param_groups[0]["lr"] = ckpt["optimizer_state"]["param_groups"][0]["lr"] if not reset_optimizer else self.scheduler._rate
+        self.optimizer.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+        self.steps = int(ckpt.get("stats_state", {}).get("steps", ckpt.get("steps", 0)))
+        self.micro = 0
+
     def read_stats(self, reset: bool = True) -> Dict[str, float]:
         """One host sync (and, under DDP, one 6-element all-reduce) for everything the reference logs."""
         s = self.stats.clone()

@@ -10,6 +10,8 @@ import sys
 import types
 from pathlib import Path
 
+import copy
+
 import numpy as np
 import torch
 
@@ -320,6 +322,16 @@ def golden_train_steps(name="train_steps", n_updates=3, batch_multiplier=2):
             sched.step(steps)
             model.zero_grad(set_to_none=True)
             steps += 1
+            if steps == n_updates - 1:
+                # a checkpoint in the layout TrainManager._save_checkpoint writes (training.py:166-177), taken after the
+                # second update: resuming from it and running the third must land on sd1 (tests/test_hip_train_step.py)
+                state = {"model_state": {k: v.clone() for k, v in model.state_dict().items()},
+                         "optimizer_state": copy.deepcopy(opt.state_dict()), "scaler_state": None,
+                         "scheduler_state": dict(sched.state_dict()), "train_iter_state": None,
+                         "stats_state": {"steps": steps, "is_min_lr": False, "is_max_update": False, "total_tokens": 0,
+                                         "best_ckpt_iter": 0, "minimize_metric": True, "total_correct": 0}}
+                torch.save(state, OUT / "ref_checkpoint_after2.ckpt")
+    out["param_order"] = np.array([n for n, _ in model.named_parameters()])
     out.update({f"sd1.{k}": v for k, v in np_sd(model.state_dict()).items()})
     out.update(losses=np.array(losses), grad_norms=np.array(norms), lrs=np.array(lrs), lr_next=np.float64(opt.param_groups[0]["lr"]))
     np.savez_compressed(OUT / f"{name}.npz", **out)

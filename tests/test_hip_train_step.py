@@ -55,3 +55,48 @@ def test_three_updates_match_reference(device):
         worst = max(worst, err)
         assert err <= 3e-4, (n, err)
     print("worst parameter deviation after 3 updates:", worst)
+
+
+def test_resume_from_reference_checkpoint(device, tmp_path):
+    """A checkpoint written by the reference's code after its second update (model, torch AdamW state, scheduler, counters)
+    is loaded into the HIP train step; the third update then lands on the reference's parameters.  Saving and re-loading
+    through this package's own writer (same layout) gives the same state."""
+    from conftest import GOLDEN
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    g = load_golden("train_steps")
+
+    def fresh():
+        torch.manual_seed(1)
+        model = build_model(copy.deepcopy(tiny_cfg("pre")), None, Vocabulary.synthetic(20))
+        model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+        model.finalize(device, torch.float32)
+        return model, TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=1.0,
+                                learning_rate_warmup=2, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=2, n_gpu=1)
+
+    model, step = fresh()
+    step.init_from_checkpoint(GOLDEN / "ref_checkpoint_after2.ckpt")
+    assert step.steps == 2 and step.optimizer.t == 2
+    assert step.optimizer.param_groups[0]["lr"] == pytest.approx(float(g["lrs"][2]), rel=1e-12)
+    path = tmp_path / "resaved.ckpt"
+    step.save_checkpoint(path)
+    model2, step2 = fresh()
+    step2.init_from_checkpoint(path)
+    torch.testing.assert_close(step2.optimizer.exp_avg_sq, step.optimizer.exp_avg_sq)
+    for (n, a), (_, b) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(a, b), n
+    for st, mdl in ((step, model), (step2, model2)):
+        for i in (4, 5):
+            b = Batch(src=torch.from_numpy(g[f"mb{i}.src"]), src_length=torch.from_numpy(g[f"mb{i}.src_length"]), src_prompt_mask=None,
+                      trg=torch.from_numpy(g[f"mb{i}.trg"]), trg_length=torch.from_numpy(g[f"mb{i}.trg_length"]), trg_prompt_mask=None,
+                      indices=torch.arange(3), device=device, pad_index=1, eos_index=3, is_train=True, task="S2T", n_gpu=1)
+            loss = st.micro_step(b)
+            assert abs(loss.item() - g["losses"][i, 0]) <= 1e-4 * abs(g["losses"][i, 0])
+        assert float(st.optimizer.norm_clip[0]) == pytest.approx(float(g["grad_norms"][2]), rel=1e-4)
+        ref = golden_sd(g, "sd1.")
+        for n, p in mdl.named_parameters():
+            if "k_layer.bias" in n:
+                continue
+            assert (p.detach().cpu() - ref[n]).abs().max().item() <= 3e-4, n
