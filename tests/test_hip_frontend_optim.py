@@ -102,3 +102,33 @@ def test_flat_adamw_and_clip_match_torch(device):
             torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
     assert lrs == [ropt.param_groups[0]["lr"]] * 0 + lrs  # same schedule object semantics
     assert lrs[0] == 2e-3 * 1 / 4 and lrs[3] == 2e-3
+
+
+def test_wav_manifest_to_gpu_features(device, tmp_path):
+    """wav files listed in a JoeyS2T manifest -> SpeechFeatureLoader -> raw-sample batch -> GPU front-end
+    (fbank -> CMVN -> pad with 1.0) equals the CPU oracle per utterance."""
+    import wave
+
+    from joeys2t_amd.feature_store import SpeechFeatureLoader, save_tsv
+    from joeys2t_amd.helpers_for_audio import get_n_frames
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    from oracle import s2t_oracle as O
+    rs = np.random.RandomState(3)
+    (tmp_path / "wav").mkdir()
+    rows = []
+    for i, n in enumerate([24000, 16400, 31234]):
+        pcm = (rs.randn(n) * 2500).clip(-32768, 32767).astype("<i2")
+        with wave.open(str(tmp_path / "wav" / f"u{i}.wav"), "wb") as f:
+            f.setnchannels(1), f.setsampwidth(2), f.setframerate(16000)
+            f.writeframes(pcm.tobytes())
+        rows.append({"id": f"u{i}", "src": f"wav/u{i}.wav", "n_frames": get_n_frames(n, 16000), "trg": "x"})
+    save_tsv(rows, tmp_path / "dev.tsv")
+    loader = SpeechFeatureLoader(tmp_path / "dev.tsv", min_length=5)
+    wavs, n, sr = loader.waveform_batch(range(len(loader)))
+    proc = SpeechProcessor(num_freq=80, min_length=5, max_length=3000, cmvn=dict(norm_means=True, norm_vars=True, before=True))
+    feats, frames = proc.batch_from_waveforms(torch.from_numpy(wavs).to(device), n, is_train=False)
+    assert frames == [r["n_frames"] for r in rows]
+    for b in range(len(rows)):
+        ref = O.cmvn(O.fbank(wavs[b, :n[b]]))
+        np.testing.assert_allclose(feats[b, :frames[b]].cpu().numpy(), ref, rtol=2e-3, atol=2e-3)
+        assert torch.all(feats[b, frames[b]:] == 1.0)
