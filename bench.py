@@ -174,11 +174,14 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
         # thread_local: the RCCL watchdog thread may query its events while this thread captures
         with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
             body()
-        if world > 1:
-            # the products queued during capture reference the graph's static buffers: keep them as the per-step plan
-            state["plan"] = step.rt.wgrad_queue.take()
-        post_body(capturing=True)
         graph_holder["g"] = g
+        if world > 1:
+            # the products queued during capture reference the graph's static buffers: keep them as the per-step plan.
+            # Capturing executes nothing, so those buffers hold no gradients yet: run one real replayed step before the plan
+            # is ever used (exchange + update on never-written buffers would poison the weights)
+            state["plan"] = step.rt.wgrad_queue.take()
+            g.replay()
+        post_body(capturing=True)
 
     def graph_step():
         pre_step()

@@ -158,7 +158,7 @@ template <> struct ld8<float> {
   }
 };
 constexpr int LNV_MAXCH = 4;        // chunks of 8 columns per lane -> D <= 2048
-constexpr int LNV_ROWS = 32;        // rows per block in the backward kernel (shared by its 4..16 waves)
+constexpr int LNV_ROWS = 64;        // rows per block in the backward kernel (shared by its 4..16 waves)
 
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
     const int64_t row = r0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
-    float g[NCH][8], xh[NCH][8];
+    float g[NCH][8], xh[NCH][8], av[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
         float dyv[8], xv[8];
         ld8<T>::ld(dy + row * D + 8 * c, dyv);
         ld8<T>::ld(x + row * D + 8 * c, xv);
+        if (add) ld8<T>::ld(add + row * D + 8 * c, av[j]);  // requested with the other two rows: off the reduction's critical path
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           xh[j][i] = (xv[i] - mu) * rs;
@@ -262,10 +263,8 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = rs * (g[j][i] - s1 - xh[j][i] * s2);
         if (add) {
-          float av[8];
-          ld8<T>::ld(add + row * D + 8 * c, av);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] += add_scale * av[i];
+          for (int i = 0; i < 8; ++i) o[i] += add_scale * av[j][i];
         }
         ld8<T>::st(dx + row * D + 8 * c, o);
       }
