@@ -424,6 +424,14 @@ extern "C" int64_t js2t_colsum_partial_rows(int64_t rows) { return (rows + CS_RO
 extern "C" int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, int accumulate,
                            js2t_stream stream) {
   if (cols == 0) return JS2T_OK;
+  if (rows == 0) {  // empty sum: zero (or leave the accumulator untouched)
+    JS2T_CHECK(out, "colsum: bad arguments");
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * cols, (hipStream_t)stream);
+      JS2T_CHECK(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
+    }
+    return JS2T_OK;
+  }
   JS2T_CHECK(x && out && partial && rows > 0, "colsum: bad arguments");
   const int64_t nparts = js2t_colsum_partial_rows(rows);
   JS2T_CHECK(nparts <= 65535, "colsum: too many rows");
