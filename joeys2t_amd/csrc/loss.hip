@@ -15,6 +15,15 @@ __device__ __forceinline__ float logaddexp(float a, float b) {
   return m + log1pf(__expf(-fabsf(a - b)));
 }
 
+// the same with hardware exp / log (v_exp_f32, v_log_f32): log(1 + x) loses x below 6e-8, an absolute error far under the
+// 1e-4 relative budget of the accumulated log-likelihood; used where the function sits on a serial dependency chain
+__device__ __forceinline__ float logaddexp_fast(float a, float b) {
+  const float m = fmaxf(a, b);
+  const float d = -fabsf(a - b);  // nan when both are -inf
+  const float r = m + __logf(1.f + __expf(d));
+  return (m == -INFINITY) ? -INFINITY : r;
+}
+
 // ---------------------------------------------------------------- row statistics over V
 // lse[r] = log sum_v exp(x[r,v]); argmax[r] = first index of the row maximum (optional).
 template <typename T>
@@ -258,6 +267,121 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_both_kernel(
     ctc_recursion_body<T, true>(a, ext, em, x, lse, targets, in_len, tgt_len, beta, nullptr, Tmax, V, Lmax, Smax, blank);
 }
 
+// Short targets (2L+1 <= 192 states, i.e. every LS100 / MuST-C batch): the recursion of one utterance runs in ONE wave with
+// three states per lane in registers - neighbours come by lane shuffles - while the other three waves of the block gather
+// the emissions of the next chunk of time steps into LDS.  The chain of T dependent steps then costs a few hundred cycles
+// per step instead of an LDS round trip plus a block barrier.  blockIdx.y: 0 = alpha, 1 = beta.
+constexpr int CTCW_S = 192;
+constexpr int CTCW_CHUNK = 32;  // time steps staged per chunk: 2 x 32 x 192 floats = 48 KB of LDS
+
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_wave_kernel(const T* __restrict__ x, const float* __restrict__ lse,
+                                                       const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
+                                                       const int64_t* __restrict__ tgt_len, float* __restrict__ alpha,
+                                                       float* __restrict__ beta, float* __restrict__ nll, int64_t Tmax, int64_t V,
+                                                       int64_t Lmax, int64_t Smax, int64_t blank) {
+  __shared__ float em[2][CTCW_CHUNK * CTCW_S];
+  __shared__ int ext[CTCW_S + 2];
+  __shared__ float fin[CTCW_S];
+  const bool backward = blockIdx.y == 1;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t Tb = min(in_len[b], Tmax);
+  const int L = (int)min(tgt_len[b], Lmax);
+  const int S = 2 * L + 1;
+  float* ob = (backward ? beta : alpha) + (int64_t)b * Tmax * Smax;
+  for (int s2 = tid; s2 < CTCW_S + 2; s2 += 256) ext[s2] = (s2 < S) ? ((s2 & 1) ? (int)targets[b * Lmax + (s2 >> 1)] : (int)blank) : -1;
+  for (int64_t i = Tb * Smax + tid; i < Tmax * Smax; i += 256) ob[i] = -INFINITY;  // rows the gradient kernel never reads
+  __syncthreads();
+  if (Tb <= 0) {
+    if (!backward && tid == 0) nll[b] = INFINITY;
+    return;
+  }
+  auto stage = [&](int chunk, int t0, int nthreads) {  // emissions of steps chunk*CHUNK .. in recursion order
+    const int64_t c0 = (int64_t)chunk * CTCW_CHUNK;
+    const int nt = (int)min((int64_t)CTCW_CHUNK, Tb - c0);
+    float* dst = em[chunk & 1];
+    for (int i = t0; i < nt * S; i += nthreads) {
+      const int tt = i / S, s2 = i - tt * S;
+      const int64_t t = backward ? (Tb - 1 - (c0 + tt)) : (c0 + tt);
+      const int lab = ext[s2];
+      dst[tt * CTCW_S + s2] = (lab >= 0 && lab < V) ? io<T>::ld(x + ((int64_t)b * Tmax + t) * V + lab) - lse[(int64_t)b * Tmax + t] : -INFINITY;
+    }
+  };
+  const int nchunks = (int)((Tb + CTCW_CHUNK - 1) / CTCW_CHUNK);
+  stage(0, tid, 256);
+  __syncthreads();
+  // wave 0: the recursion; lane l owns states 3l, 3l+1, 3l+2
+  const int s0 = 3 * lane;
+  bool skip[3];  // may the state take the path that jumps over a blank?
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int s2 = s0 + j;
+    skip[j] = backward ? (s2 + 2 < S && ext[s2 + 2] != (int)blank && ext[s2 + 2] != ext[s2])
+                       : (s2 >= 2 && s2 < S && ext[s2] != (int)blank && ext[s2] != ext[s2 - 2]);
+  }
+  float a0 = -INFINITY, a1 = -INFINITY, a2 = -INFINITY;
+  for (int c = 0; c < nchunks; ++c) {
+    if (w != 0) {
+      if (c + 1 < nchunks) stage(c + 1, tid - 64, 192);
+    } else {
+      const int64_t c0 = (int64_t)c * CTCW_CHUNK;
+      const int nt = (int)min((int64_t)CTCW_CHUNK, Tb - c0);
+      const float* e = em[c & 1];
+      for (int tt = 0; tt < nt; ++tt) {
+        const int64_t step = c0 + tt;
+        const int64_t t = backward ? (Tb - 1 - step) : step;
+        const float e0 = s0 < S ? e[tt * CTCW_S + s0] : -INFINITY, e1 = s0 + 1 < S ? e[tt * CTCW_S + s0 + 1] : -INFINITY,
+                    e2 = s0 + 2 < S ? e[tt * CTCW_S + s0 + 2] : -INFINITY;
+        float n0, n1, n2;
+        if (step == 0) {
+          n0 = (backward ? (s0 >= S - 2 && s0 < S) : (s0 < 2)) ? e0 : -INFINITY;
+          n1 = (backward ? (s0 + 1 >= S - 2 && s0 + 1 < S) : (s0 + 1 < 2)) ? e1 : -INFINITY;
+          n2 = (backward ? (s0 + 2 >= S - 2 && s0 + 2 < S) : false) ? e2 : -INFINITY;
+        } else if (!backward) {
+          float p1 = __shfl_up(a1, 1, 64), p2 = __shfl_up(a2, 1, 64);  // states 3l-2, 3l-1
+          if (lane == 0) { p1 = -INFINITY; p2 = -INFINITY; }
+          float v0 = logaddexp_fast(a0, p2);
+          if (skip[0]) v0 = logaddexp_fast(v0, p1);
+          float v1 = logaddexp_fast(a1, a0);
+          if (skip[1]) v1 = logaddexp_fast(v1, p2);
+          float v2 = logaddexp_fast(a2, a1);
+          if (skip[2]) v2 = logaddexp_fast(v2, a0);
+          n0 = v0 + e0, n1 = v1 + e1, n2 = v2 + e2;
+        } else {
+          float q0 = __shfl_down(a0, 1, 64), q1 = __shfl_down(a1, 1, 64);  // states 3l+3, 3l+4
+          if (lane == 63) { q0 = -INFINITY; q1 = -INFINITY; }
+          float v2 = logaddexp_fast(a2, q0);
+          if (skip[2]) v2 = logaddexp_fast(v2, q1);
+          float v1 = logaddexp_fast(a1, a2);
+          if (skip[1]) v1 = logaddexp_fast(v1, q0);
+          float v0 = logaddexp_fast(a0, a1);
+          if (skip[0]) v0 = logaddexp_fast(v0, a2);
+          n0 = v0 + e0, n1 = v1 + e1, n2 = v2 + e2;
+        }
+        a0 = s0 < S ? n0 : -INFINITY, a1 = s0 + 1 < S ? n1 : -INFINITY, a2 = s0 + 2 < S ? n2 : -INFINITY;
+        float* orow = ob + t * Smax;
+        if (s0 < S) orow[s0] = a0;
+        if (s0 + 1 < S) orow[s0 + 1] = a1;
+        if (s0 + 2 < S) orow[s0 + 2] = a2;
+      }
+    }
+    __syncthreads();
+  }
+  if (!backward) {
+    if (w == 0) {
+      if (s0 < CTCW_S) fin[s0] = a0;
+      if (s0 + 1 < CTCW_S) fin[s0 + 1] = a1;
+      if (s0 + 2 < CTCW_S) fin[s0 + 2] = a2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float ll = fin[S - 1];
+      if (S > 1) ll = logaddexp_fast(ll, fin[S - 2]);
+      nll[b] = -ll;
+    }
+  }
+}
+
 // loss_b = zero_infinity ? (isinf(nll) ? 0 : nll) : nll
 __global__ void ctc_loss_rows_kernel(const float* __restrict__ nll, float* __restrict__ loss_rows, int64_t B, int zero_inf) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -367,7 +491,10 @@ extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, cons
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_alpha: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
   const int64_t Smax = 2 * Lmax + 1;
   hipStream_t s = (hipStream_t)stream;
-  if (beta) {
+  if (Smax <= CTCW_S) {  // short targets: register-resident recursion, alpha (and beta when asked for) in one launch
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_wave_kernel<T>), dim3((unsigned)B, beta ? 2 : 1), dim3(256), 0, s, (const T*)logits, lse,
+                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank));
+  } else if (beta) {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_both_kernel<T>), dim3((unsigned)B, 2), dim3(CTC_THREADS), 0, s, (const T*)logits, lse,
                                           targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank));
   } else {

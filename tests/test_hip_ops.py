@@ -352,10 +352,12 @@ def test_xent_ctc_golden(device):
     np.testing.assert_allclose(l2.grad.cpu().numpy(), g["xc_dctc_inf"], rtol=1e-4, atol=1e-5)
 
 
-def test_ctc_larger_random(device):
-    """CTC at a realistic size (T'=375, L<=80, V=500) incl. repeated labels, against F.ctc_loss on CPU."""
+@pytest.mark.parametrize("L", [80, 120])
+def test_ctc_larger_random(device, L):
+    """CTC at a realistic size (T'=375, V=500) incl. repeated labels, against F.ctc_loss on CPU: L <= 80 (2L+1 <= 192 states:
+    the register-resident wave recursion) and L <= 120 (the block recursion)."""
     g = torch.Generator().manual_seed(4)
-    B, T, V, L = 6, 375, 500, 80
+    B, T, V = 6, 375, 500
     logits = torch.randn(B, T, V, generator=g)
     tl = torch.randint(30, L + 1, (B, ), generator=g)
     trg = torch.full((B, L), 1, dtype=torch.long)
@@ -373,7 +375,8 @@ def test_ctc_larger_random(device):
     got = crit.ctc(ld, trg.to(device), in_len.to(device), tl.to(device))
     got.backward()
     assert abs(got.item() - ref.item()) <= 1e-4 * abs(ref.item())
-    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-3, atol=2e-5)
+    # gradients are differences of exponentials of sums over up to 375 steps: the long-target case accumulates more rounding
+    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-3 if L <= 80 else 3e-3, atol=2e-5 if L <= 80 else 3e-4)
 
 
 def test_log_softmax_and_lse(device):
