@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
 // ---------------------------------------------------------------- CMVN statistics (one block per utterance)
 // mean[u,c] = mean_t x ; istd[u,c] = 1/sqrt(max(sum x^2 / T - mean^2, 1e-10)) ; fill[u] = mean of the normalised
 // spectrogram (SpecAugment's mask value).  Accumulated in f64.
-constexpr int CM_GROUPS = 4;
+constexpr int CM_GROUPS = 12;  // frame groups per block: 12 x 80 bins = 960 threads share an utterance
 __global__ void cmvn_stats_kernel(const float* __restrict__ feat, const int64_t* __restrict__ frame_off, int F,
                                   float* __restrict__ mean, float* __restrict__ istd, float* __restrict__ fill, int norm_means,
                                   int norm_vars) {
