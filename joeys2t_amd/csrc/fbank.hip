@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
                                                     float preemph, float log_floor) {
   __shared__ float sre[FB_WAVES][FB_MAX_FFT];
   __shared__ float sim[FB_WAVES][FB_MAX_FFT];
+  __shared__ float stw_re[FB_MAX_FFT / 2], stw_im[FB_MAX_FFT / 2];  // twiddles: read every stage, fetched from HBM once per block
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < (n_fft >> 1); i += 256) {
+    stw_re[i] = tw_re[i];
+    stw_im[i] = tw_im[i];
+  }
   const int64_t total = frame_off[U];
   const int64_t f = (int64_t)blockIdx.x * FB_WAVES + w;
   const bool live = f < total;  // keep all waves in the barriers
@@ -87,14 +92,16 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
     for (int b = lane; b < (n_fft >> 1); b += 64) {
       const int k = b & (half - 1);
       const int i0 = ((b >> (sgs - 1)) << sgs) + k, i1 = i0 + half;
-      const float wr = tw_re[k * tw_step], wi = tw_im[k * tw_step];
+      const float wr = stw_re[k * tw_step], wi = stw_im[k * tw_step];
       const float xr = re[i1], xi = im[i1];
       const float tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
       const float ar = re[i0], ai = im[i0];
       re[i1] = ar - tr; im[i1] = ai - ti;
       re[i0] = ar + tr; im[i0] = ai + ti;
     }
-    __syncthreads();
+    // a frame belongs to one wave: its LDS accesses execute in issue order, so the stages only need the compiler (and the
+    // counter) kept honest - no block barrier between them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   // 4. power spectrum of bins 0 .. n_fft/2 - 1 (the Nyquist bin has zero mel weight)
   for (int k = lane; k < (n_fft >> 1); k += 64) {
