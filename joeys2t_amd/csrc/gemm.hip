@@ -410,7 +410,16 @@ __device__ __forceinline__ bf16x8_t frag_load2(const unsigned char* tile, int su
 
 // per-lane source element offsets of the NP DMA pieces this wave issues for one operand tile of ROWS rows
 // (kc image: ROWS x 64 k, NP = ROWS/32; tr image: 64 k x 128 rows, NP = 4)
-template <bool TR, int NP>
+// XOR key of a [row][64 k] image row.  Natural fragment rows (16 consecutive rows per read) are conflict-free with
+// row & 7; the column-permuted B fragments (rows 4j + (l&3) of four 16-row blocks, see dma_gemm_block) put blocks 0/3 and
+// 1/2 in one ds_read_b128 lane group, which row & 7 maps to the same 16-byte slots (2-way): their key takes bit 2 from
+// the block index instead.
+template <bool PERMB>
+__device__ __forceinline__ int kc_key(int row) {
+  return PERMB ? ((row & 3) | (((row >> 4) & 1) << 2)) : (row & 7);
+}
+
+template <bool TR, int NP, bool PERMB = false>
 __device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_max, int k0, int K, int t, int64_t (&off)[NP]) {
   const int w = t >> 6, lane = t & 63;
 #pragma unroll
@@ -418,7 +427,7 @@ __device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_ma
     const int p = (w * NP + q) * 64 + lane;  // 16-byte slot index inside the tile
     if (!TR) {
       const int row = p >> 3, slot = p & 7;
-      int chunk = slot ^ (row & 7);
+      int chunk = slot ^ kc_key<PERMB>(row);
       if (k0 + chunk * 8 >= K) chunk = 0;  // clamped; zero-filled afterwards
       off[q] = (int64_t)min(rowbase + row, rows_max - 1) * ld + k0 + chunk * 8;
     } else {
@@ -437,7 +446,7 @@ __device__ __forceinline__ void dma_issue(const uint16_t* base, const int64_t (&
     __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * NP + q) * 1024), 16, 0, 0);
 }
 // zero the LDS slots of a partial last K tile (k >= k_lim)
-template <bool TR, int NP>
+template <bool TR, int NP, bool PERMB = false>
 __device__ __forceinline__ void dma_zero_tail(unsigned char* tile, int k_lim, int t) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -445,7 +454,7 @@ __device__ __forceinline__ void dma_zero_tail(unsigned char* tile, int k_lim, in
     const int p = ((t >> 6) * NP + q) * 64 + (t & 63);  // the slots this wave's own DMA instructions filled
     if (!TR) {
       const int row = p >> 3, slot = p & 7;
-      if (((slot ^ (row & 7)) << 3) >= k_lim) *(uint4*)(tile + p * 16) = z;
+      if (((slot ^ kc_key<PERMB>(row)) << 3) >= k_lim) *(uint4*)(tile + p * 16) = z;
     } else {
       if ((p >> 4) >= k_lim) *(uint4*)(tile + p * 16) = z;
     }
@@ -854,7 +863,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
   int64_t oa[NPA], ob[4];
   auto issue_stage = [&](int s, int slot) {
     dma_offsets<TA, NPA>(lda, m0, M, (kt0 + s) * F_BK, K, t, oa);
-    dma_offsets<TB, 4>(ldb, n0, N, (kt0 + s) * F_BK, K, t, ob);
+    dma_offsets<TB, 4, !TB>(ldb, n0, N, (kt0 + s) * F_BK, K, t, ob);
     dma_issue<NPA>(Ab, oa, smem + slot * STAGE, t);
     dma_issue<4>(Bb, ob, smem + slot * STAGE + A_TILE, t);
   };
@@ -875,7 +884,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
     }
     if (k0 + F_BK > K) {
       dma_zero_tail<TA, NPA>(smem + cur * STAGE, K - k0, t);
-      dma_zero_tail<TB, 4>(smem + cur * STAGE + A_TILE, K - k0, t);
+      dma_zero_tail<TB, 4, !TB>(smem + cur * STAGE + A_TILE, K - k0, t);
     }
     if (NST == 2) {
       __syncthreads();
@@ -898,7 +907,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
           // CONSECUTIVE output columns 16g .. 16g+15 of its rows, i.e. 32-byte bf16 runs it can store straight
           // from registers (no LDS round trip, no barriers in the epilogue)
           const int row = wn * 64 + ((lane & 15) >> 2) * 16 + j * 4 + (lane & 3), c = kk * 4 + (lane >> 4);
-          fn[j] = *(const bf16x8_t*)(Bt + row * 128 + ((c ^ (row & 7)) << 4));
+          fn[j] = *(const bf16x8_t*)(Bt + row * 128 + ((c ^ kc_key<true>(row)) << 4));
         } else {
           // reduction-major B image: the same column ownership costs a 2-way bank conflict on the transposing reads
           // (the 8-byte offset inside a 32-byte group would be the same for all lanes) - measured slower, so these

@@ -10,6 +10,7 @@ from joeys2t_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+P_DROP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 
 
 def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
@@ -48,6 +49,6 @@ def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
         print(f"{name:24s} {nm} B={B} H={H} Tq={Tq} Tk={Tk} {us:8.1f} us {fl / us / 1e6:7.1f} TF", flush=True)
 
 
-bench("encoder self", 32, 4, 375, 375)
-bench("decoder self (causal)", 32, 4, 81, 81, causal=True)
-bench("decoder cross", 32, 4, 81, 375)
+bench("encoder self", 32, 4, 375, 375, p=P_DROP)
+bench("decoder self (causal)", 32, 4, 81, 81, p=P_DROP, causal=True)
+bench("decoder cross", 32, 4, 81, 375, p=P_DROP)

@@ -16,7 +16,7 @@ class ShapeTimer(bench.GemmTimer):
 
 def main():
     device = torch.device("cuda", 0)
-    eager_step, _, _, _, _ = bench.build_step(device, 1)
+    eager_step = bench.build_step(device, 1)[0]
     for _ in range(3):
         eager_step()
     timer = ShapeTimer()
