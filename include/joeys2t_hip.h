@@ -109,6 +109,10 @@ void js2t_gemm_force_regstage(int on);
 /* Test hook: when on, every k-contiguous bf16 product with a bf16 result the 256x256 half-tile-ring kernel can run takes it
  * (by default only products of >= 512 such tiles and K >= 1024 do). */
 void js2t_gemm_force_w256(int on);
+/* Kernel selection for the persistent 192x128 kernel (k-contiguous bf16 operands, bf16 result, N % 128 == 0,
+ * K % 64 == 0, K >= 192, bias / ReLU / dropout / residual-or-gate epilogue): 0 = never, 1 = every product that
+ * qualifies (test hook), -1 = products that qualify and have >= 200 tiles (default). */
+void js2t_gemm_p192_mode(int mode);
 
 /* --------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels.

@@ -1213,6 +1213,298 @@ int launch_bf16_w256(const js2t_gemm_desc& d, hipStream_t s) {
   return JS2T_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 192x128x64 tile, 4 waves of 96x64, persistent blocks with one DMA ring that runs across tiles
+// ------------------------------------------------------------------------------------------------
+// The 128x128 / 64x128 kernels above pull 32 / 24.6 KB from L2 into LDS per 2.1 / 1.05 MFLOP K step and sit at the
+// L2 -> LDS delivery rate (about 16-19 TB/s aggregate; MI355X_MICROARCH.md 'gather into LDS') long before the MFMA
+// pipe is busy.  This tile moves 40 KB per 3.1 MFLOP (0.55x the bytes per flop of the 64-row tile) and its 96x64 wave
+// tile needs 0.42 of the LDS read bandwidth at full MFMA rate.  One 256-thread block per CU has nothing else resident
+// to hide latency behind, so:
+//  * the grid is one block per CU; block b walks tiles b, b + G, ... (XCD-aware order) and treats all their K steps as
+//    ONE stream of 40 KB stages through a 3-slot ring: stages s+2 and s+3 are in flight while stage s is multiplied,
+//    also across a tile boundary, so a tile's epilogue overlaps the next tile's first loads;
+//  * one raw s_barrier per stage, in the MIDDLE of it: by then every wave holds the second k-half of stage s in
+//    registers, so slot s % 3 is free for stage s + 3, and a counted vmcnt has retired this wave's part of stage s + 1;
+//  * fragments are double-buffered by k-half: the reads of the next half are issued before the 24 MFMAs of the current
+//    one;
+//  * B fragment rows are permuted as in dma_gemm_block, so each lane owns 16 consecutive output columns and the tile is
+//    stored from registers (direct_tile_epilogue).
+constexpr int P_BM = 192, P_ATILE = P_BM * 128, P_STAGE = P_ATILE + 16384, P_NST = 3, P_LDS = P_NST * P_STAGE, P_PER = 10;
+#ifdef JS2T_P192_PROF
+__device__ unsigned long long g_p192_prof[8];
+#define P192_T(i)                                          \
+  do {                                                     \
+    const unsigned long long c_ = __builtin_readcyclecounter(); \
+    prof_[i] += c_ - last_;                                \
+    last_ = c_;                                            \
+  } while (0)
+#else
+#define P192_T(i)
+#endif
+
+typedef int frag_i4 __attribute__((ext_vector_type(4)));  // a bf16x8 fragment carried across loop iterations as 4 dwords
+__device__ __forceinline__ bf16x8_t as_bf16x8(const frag_i4& v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+// 16-byte granule index of B element block (tile column n, k-chunk c) inside a stage's B image.  Fragment j of a lane
+// (r = lane & 15) is column 8r + j, so that after eight MFMAs along N a lane holds 8 CONSECUTIVE output columns of each
+// of its rows and the 16 lanes of a row group store one contiguous 256-byte run.  The image keeps whole 128-byte
+// source lines inside a DMA piece (8 lines per instruction) and is conflict-free for the ds_read_b128 lane groups.
+__device__ __forceinline__ int p192_b_granule(int n, int c) {
+  const int r = n >> 3, j = n & 7;
+  return j * 128 + (r >> 3) * 64 + (r & 7) * 8 + (c ^ (r >> 1));
+}
+
+// epilogue of one wave's 48 x 128 sub-tile from registers: lane (g, r) holds, for row block i and register e, row
+// 16i + 4g + e, columns 8r .. 8r+7
+__device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane) {
+  const int g = lane >> 4, r = lane & 15;
+  const int M = d.M, n = n0 + 8 * r;
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+  const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
+  const bool has_drop = d.dropout_p > 0.f;
+  const uint32_t drop_key = has_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+  float bias_r[8];
+  if (d.bias && (((uintptr_t)d.bias) & 15) == 0) {
+    const float4 b0 = *(const float4*)(d.bias + n), b1 = *(const float4*)(d.bias + n + 4);
+    bias_r[0] = b0.x, bias_r[1] = b0.y, bias_r[2] = b0.z, bias_r[3] = b0.w;
+    bias_r[4] = b1.x, bias_r[5] = b1.y, bias_r[6] = b1.z, bias_r[7] = b1.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bias_r[c] = d.bias ? d.bias[n + c] : 0.f;
+  }
+  const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
+  const int64_t rld = has_res ? d.ldr : d.ldg;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int mrow = mw + 16 * i + 4 * g;
+    uint4 rg[4];
+    if (has_res || has_gate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rg[e] = *(const uint4*)(rsrc + (int64_t)min(mrow + e, M - 1) * rld);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = mrow + e;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = acc[i][j][e] * alpha + bias_r[j];
+      if (relu) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      if (has_drop) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)m, (uint32_t)((n >> 2) + h), d.dropout_p);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[4 * h + c] = ((keep >> c) & 1u) ? v[4 * h + c] * keep_scale : 0.f;
+        }
+      }
+      if (has_res) {
+        float rr[8];
+        unpack_bf16x8(rg[e], rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] += res_scale * rr[c];
+      }
+      if (has_gate) {
+        float rr[8];
+        unpack_bf16x8(rg[e], rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
+      }
+      if (m < M) {
+        uint4 pk;
+        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+        pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
+        pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+        *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (M0) stay on the scalar unit
+  const int M = d.M, N = d.N, nk = d.K >> 6;
+  const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+  const uint16_t* Ab = (const uint16_t*)d.A;
+  const uint16_t* Bb = (const uint16_t*)d.B;
+  const int64_t lda = d.lda, ldb = d.ldb;
+
+  // ---- issue side: runs up to three stages ahead of the multiply side, possibly already in the next tile
+  int iv = blockIdx.x, ik = 0, islot = 0;
+  const uint16_t* asrc[6];
+  const uint16_t* bsrc[4];
+  const int r8 = lane >> 3, s8 = lane & 7;
+  auto set_tile_src = [&](int v) {
+    const int lid = xcd_remap(v, ntiles);
+    const int m0 = (lid / tiles_n) * P_BM, n0 = (lid % tiles_n) * 128;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int row = (w * 6 + q) * 8 + r8;
+      asrc[q] = Ab + (int64_t)min(m0 + row, M - 1) * lda + ((s8 ^ kc_key<false>(row)) << 3);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // piece P = 4w + q of the B image: fragment index j = P >> 1, lanes r = 8 (P & 1) + r8
+      const int P = w * 4 + q, r = (P & 1) * 8 + r8;
+      bsrc[q] = Bb + (int64_t)min(n0 + 8 * r + (P >> 1), N - 1) * ldb + ((s8 ^ (r >> 1)) << 3);
+    }
+  };
+  // a stage is requested in ten 1 KB pieces per wave (six of A, four of B); the steady state spreads them between the
+  // MFMAs of two k-halves, because four waves issuing forty DMA instructions back to back keep the MFMA pipe idle for
+  // ~570 cycles (the texture-address path takes ~16 cycles per instruction).
+  // Past the block's last stage the requests go on (re-reading k = 0 of the last tile into a free slot): the loop and
+  // its vmcnt counts stay branch-free, at the price of three unused stages per block.
+  int p_k0 = 0;
+  unsigned char* p_st = smem;
+  auto issue_begin = [&]() {
+    p_k0 = iv < ntiles ? ik << 6 : 0;
+    p_st = smem + islot * P_STAGE;
+  };
+  auto issue_piece = [&](int q) {  // q is a compile-time constant at every call site
+    if (q < 6)
+      __builtin_amdgcn_global_load_lds((g_cvoid*)(asrc[q < 6 ? q : 0] + p_k0), (l_void*)(p_st + (w * 6 + q) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((g_cvoid*)(bsrc[q >= 6 ? q - 6 : 0] + p_k0), (l_void*)(p_st + P_ATILE + (w * 4 + q - 6) * 1024), 16, 0, 0);
+  };
+  auto issue_finish = [&]() {
+    if (iv < ntiles && ++ik == nk) {
+      ik = 0;
+      iv += G;
+      if (iv < ntiles) set_tile_src(iv);
+    }
+    islot = islot == P_NST - 1 ? 0 : islot + 1;
+  };
+  auto issue_next = [&]() {
+    issue_begin();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) issue_piece(q);
+    issue_finish();
+  };
+
+  // ---- multiply side: wave w owns rows 48w .. 48w+47 and all 128 columns of the tile
+  const int arow = w * 48 + (lane & 15);  // + 16 i
+  const int br = lane & 15;
+  // byte offsets of this lane's fragment pieces inside a stage, per k-half (the XOR keys do not depend on i / j)
+  const int aoff0 = arow * 128 + ((g ^ kc_key<false>(arow)) << 4), aoff1 = arow * 128 + (((4 + g) ^ kc_key<false>(arow)) << 4);
+  const int boff0 = P_ATILE + p192_b_granule(8 * br, g) * 16, boff1 = P_ATILE + p192_b_granule(8 * br, 4 + g) * 16;
+  auto read_half = [&](const unsigned char* st, int ao, int bo, frag_i4 (&fm)[3], frag_i4 (&fn)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fn[j] = *(const frag_i4*)(st + bo + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fm[i] = *(const frag_i4*)(st + ao + i * 2048);
+  };
+
+  set_tile_src(iv);
+  issue_next();
+  issue_next();
+  issue_begin();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue_piece(q);  // pieces 5..9 of stage 2 follow in the first k-half of stage 0
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 5) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  frag_i4 fm0[3], fn0[8], fm1[3], fn1[8];
+  f32x4_t acc[3][8];
+  read_half(smem, aoff0, boff0, fm0, fn0);
+  int cslot = 0;
+#ifdef JS2T_P192_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+  for (int v = blockIdx.x; v < ntiles; v += G) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nk; ++k) {  // this block's stages form one stream across its tiles
+      read_half(smem + cslot * P_STAGE, aoff1, boff1, fm1, fn1);
+      // first k-half; pieces 5..9 of the stage requested at the previous barrier ride between its MFMA groups
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int i = q >> 1, j = (q & 1) * 4 + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(fn0[j]), acc[i][j], 0, 0, 0);
+        }
+        if (q < 5) issue_piece(5 + q);
+      }
+      issue_finish();
+      const int nslot = cslot == P_NST - 1 ? 0 : cslot + 1;
+      P192_T(0);
+      // stage s + 1 must have landed: own part by the counted wait (stage s + 2 stays in flight), everybody's by the barrier
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");
+      P192_T(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P192_T(2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      P192_T(3);
+      issue_begin();  // stage s + 3 goes into the slot of stage s (every wave holds its second k-half in registers)
+      P192_T(4);
+      read_half(smem + nslot * P_STAGE, aoff0, boff0, fm0, fn0);  // after the last stage: an unused read of a stale slot
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int i = q >> 1, j = (q & 1) * 4 + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(fn1[j]), acc[i][j], 0, 0, 0);
+        }
+        if (q < 5) issue_piece(q);
+      }
+      cslot = nslot;
+      P192_T(5);
+    }
+    const int lid = xcd_remap(v, ntiles);
+    p192_store_tile(d, acc, (lid / tiles_n) * P_BM + w * 48, (lid % tiles_n) * 128, lane);
+    P192_T(6);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
+#ifdef JS2T_P192_PROF
+  if (blockIdx.x == 0 && t == 0)
+    for (int i = 0; i < 8; ++i) g_p192_prof[i] = prof_[i];
+#endif
+}
+
+// 0 = never, 1 = whenever the product qualifies, -1 = when it qualifies and fills the chip (default)
+int g_p192_mode = -1;
+inline bool p192_eligible(const js2t_gemm_desc& d) {
+  if (g_p192_mode == 0) return false;
+  if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
+  if ((d.N & 127) || (d.K & 63) || d.K < 192 || d.M < 1) return false;
+  if (d.preact || d.beta != 0.f || !(d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) || (d.residual && d.gate)) return false;
+  if ((((uintptr_t)d.C) & 15) || (d.ldc & 7)) return false;
+  if (d.residual && ((d.ldr & 7) || (((uintptr_t)d.residual) & 15))) return false;
+  if (d.gate && ((d.ldg & 7) || (((uintptr_t)d.gate) & 15))) return false;
+  if (g_p192_mode < 0 && (int64_t)cdiv(d.M, P_BM) * (d.N >> 7) < 200) return false;
+  return true;
+}
+int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    int dev = 0, cu = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cu <= 0) {
+      js2t_set_error("gemm p192 setup: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    n_cu = cu & ~7;  // a multiple of 8 keeps a block's tiles on one XCD's slice of the tile order
+    if (n_cu == 0) n_cu = cu;
+  }
+  const int tm = cdiv(d.M, P_BM), tn = d.N >> 7;
+  const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+  hipLaunchKernelGGL(gemm_bf16_p192_kernel, dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
 int launch_bf16_dma_bm(const js2t_gemm_desc& d, hipStream_t s) {
   constexpr int STAGE = ((BM == 128 || TA) ? 16384 : BM * 128) + 16384;
@@ -1272,6 +1564,7 @@ int launch_bf16_impl(const js2t_gemm_desc& d, hipStream_t s) {
 template <bool TA, bool TB>
 int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
   if (!TA && !TB && !g_force_regstage && w256_eligible(d)) return launch_bf16_w256(d, s);
+  if (!TA && !TB && !g_force_regstage && !g_force_w256 && p192_eligible(d)) return launch_bf16_p192(d, s);
   if (!d.conv && !g_force_regstage)
     return d.split_k > 1 ? launch_bf16_dma<TA, TB, true>(d, s) : launch_bf16_dma<TA, TB, false>(d, s);
   return d.split_k > 1 ? launch_bf16_impl<TA, TB, true>(d, s) : launch_bf16_impl<TA, TB, false>(d, s);
@@ -1283,6 +1576,12 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" void js2t_gemm_force_regstage(int on) { g_force_regstage = on != 0; }
 extern "C" void js2t_gemm_force_w256(int on) { g_force_w256 = on != 0; }
+#ifdef JS2T_P192_PROF
+extern "C" int js2t_debug_p192_prof(unsigned long long* out8) {
+  return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof), 64);
+}
+#endif
+extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
 
 template <bool SPLITK>
 static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
