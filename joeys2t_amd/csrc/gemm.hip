@@ -1257,22 +1257,30 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 
 // epilogue of one wave's 48 x 128 sub-tile from registers: lane (g, r) holds, for row block i and register e, row
 // 16i + 4g + e, columns 8r .. 8r+7
+// EPI < 0: every epilogue term is decided at run time; EPI >= 0: a bit mask of the terms that are present (alpha = 1),
+// so that the variants the train step uses carry no dead branches - with one wave per SIMD nothing overlaps the
+// epilogue, its instruction count is paid in full.
+constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16;
+template <int EPI>
 __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane) {
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 8 * r;
-  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
-  const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
-  const bool has_drop = d.dropout_p > 0.f;
+  const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
+  const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
+  const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
+  const bool has_res = EPI < 0 ? d.residual != nullptr : (EPI & PE_RES) != 0;
+  const bool has_gate = EPI < 0 ? d.gate != nullptr : (EPI & PE_GATE) != 0;
+  const bool has_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
   const uint32_t drop_key = has_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
   const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
   float bias_r[8];
-  if (d.bias && (((uintptr_t)d.bias) & 15) == 0) {
+  if (has_bias && (((uintptr_t)d.bias) & 15) == 0) {
     const float4 b0 = *(const float4*)(d.bias + n), b1 = *(const float4*)(d.bias + n + 4);
     bias_r[0] = b0.x, bias_r[1] = b0.y, bias_r[2] = b0.z, bias_r[3] = b0.w;
     bias_r[4] = b1.x, bias_r[5] = b1.y, bias_r[6] = b1.z, bias_r[7] = b1.w;
   } else {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) bias_r[c] = d.bias ? d.bias[n + c] : 0.f;
+    for (int c = 0; c < 8; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
   }
   const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
   const int64_t rld = has_res ? d.ldr : d.ldg;
@@ -1289,7 +1297,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
       const int m = mrow + e;
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = acc[i][j][e] * alpha + bias_r[j];
+      for (int j = 0; j < 8; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
       if (relu) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -1326,6 +1334,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   }
 }
 
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       P192_T(5);
     }
     const int lid = xcd_remap(v, ntiles);
-    p192_store_tile(d, acc, (lid / tiles_n) * P_BM + w * 48, (lid % tiles_n) * 128, lane);
+    p192_store_tile<EPI>(d, acc, (lid / tiles_n) * P_BM + w * 48, (lid % tiles_n) * 128, lane);
     P192_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
@@ -1484,10 +1493,11 @@ inline bool p192_eligible(const js2t_gemm_desc& d) {
   if (g_p192_mode < 0 && (int64_t)cdiv(d.M, P_BM) * (d.N >> 7) < 200) return false;
   return true;
 }
-int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
+template <int EPI>
+int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   static int n_cu = 0;
   if (n_cu == 0) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1500,9 +1510,25 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
   }
   const int tm = cdiv(d.M, P_BM), tn = d.N >> 7;
   const int grid = tm * tn < n_cu ? tm * tn : n_cu;
-  hipLaunchKernelGGL(gemm_bf16_p192_kernel, dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
+  hipLaunchKernelGGL(gemm_bf16_p192_kernel<EPI>, dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
+}
+int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
+  // the epilogue combinations of the Transformer train step get their own instantiation, anything else the generic one
+  if (d.alpha == 1.f && !d.alpha_dev) {
+    const int mask = (d.bias ? PE_BIAS : 0) | (d.act == JS2T_ACT_RELU ? PE_RELU : 0) | (d.dropout_p > 0.f ? PE_DROP : 0) |
+                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0);
+    switch (mask) {
+      case 0: return launch_bf16_p192_epi<0>(d, s);                                    // input gradients
+      case PE_BIAS: return launch_bf16_p192_epi<PE_BIAS>(d, s);                        // q/k/v projections
+      case PE_BIAS | PE_RELU | PE_DROP: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP>(d, s);  // FFN layer 1
+      case PE_BIAS | PE_DROP | PE_RES: return launch_bf16_p192_epi<PE_BIAS | PE_DROP | PE_RES>(d, s);    // FFN layer 2, attention output
+      case PE_GATE: return launch_bf16_p192_epi<PE_GATE>(d, s);                        // gradient through ReLU + dropout
+      default: break;
+    }
+  }
+  return launch_bf16_p192_epi<-1>(d, s);
 }
 
 template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
