@@ -1262,18 +1262,8 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 // epilogue, its instruction count is paid in full.
 constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16;
 template <int EPI>
-__device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane) {
-  const int g = lane >> 4, r = lane & 15;
-  const int M = d.M, n = n0 + 8 * r;
-  const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
+__device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, float (&bias_r)[8]) {
   const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
-  const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
-  const bool has_res = EPI < 0 ? d.residual != nullptr : (EPI & PE_RES) != 0;
-  const bool has_gate = EPI < 0 ? d.gate != nullptr : (EPI & PE_GATE) != 0;
-  const bool has_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
-  const uint32_t drop_key = has_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
-  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
-  float bias_r[8];
   if (has_bias && (((uintptr_t)d.bias) & 15) == 0) {
     const float4 b0 = *(const float4*)(d.bias + n), b1 = *(const float4*)(d.bias + n + 4);
     bias_r[0] = b0.x, bias_r[1] = b0.y, bias_r[2] = b0.z, bias_r[3] = b0.w;
@@ -1282,16 +1272,35 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
     for (int c = 0; c < 8; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
   }
+}
+// bias_r: the lane's 8 bias values, fetched when the tile started; drop_key: fetched when the kernel started (both
+// would otherwise expose a dependent global-load latency per tile)
+template <int EPI>
+__device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane,
+                                                const float (&bias_r)[8], uint32_t drop_key) {
+  const int g = lane >> 4, r = lane & 15;
+  const int M = d.M, n = n0 + 8 * r;
+  const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
+  const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
+  const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
+  const bool has_res = EPI < 0 ? d.residual != nullptr : (EPI & PE_RES) != 0;
+  const bool has_gate = EPI < 0 ? d.gate != nullptr : (EPI & PE_GATE) != 0;
+  const bool has_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
+  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+  const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
   const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
   const int64_t rld = has_res ? d.ldr : d.ldg;
+  // residual / gate rows: block i + 1 is requested before block i is used (twelve rows at once cost too many registers)
+  uint4 rg[3][4];
+  auto load_rg = [&](int i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rg[i][e] = *(const uint4*)(rsrc + (int64_t)min(mw + 16 * i + 4 * g + e, M - 1) * rld);
+  };
+  if (has_res || has_gate) load_rg(0);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int mrow = mw + 16 * i + 4 * g;
-    uint4 rg[4];
-    if (has_res || has_gate) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rg[e] = *(const uint4*)(rsrc + (int64_t)min(mrow + e, M - 1) * rld);
-    }
+    if ((has_res || has_gate) && i < 2) load_rg(i + 1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = mrow + e;
@@ -1302,23 +1311,24 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
       }
-      if (has_drop) {
+      if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, n/4 + h), taken straight from the hash halves
+        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t keep = dropout_keep4_key(drop_key, (uint32_t)m, (uint32_t)((n >> 2) + h), d.dropout_p);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[4 * h + c] = ((keep >> c) & 1u) ? v[4 * h + c] * keep_scale : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t h = hash32(rowkey + (uint32_t)q);
+          v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * keep_scale : 0.f;
+          v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * keep_scale : 0.f;
         }
       }
       if (has_res) {
         float rr[8];
-        unpack_bf16x8(rg[e], rr);
+        unpack_bf16x8(rg[i][e], rr);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] += res_scale * rr[c];
       }
       if (has_gate) {
         float rr[8];
-        unpack_bf16x8(rg[e], rr);
+        unpack_bf16x8(rg[i][e], rr);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
       }
@@ -1408,6 +1418,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #pragma unroll
     for (int i = 0; i < 3; ++i) fm[i] = *(const frag_i4*)(st + ao + i * 2048);
   };
+  // the same eleven reads in the order the next k-half consumes them, two per MFMA group q = 0..5 (one in the last):
+  // issued between the MFMAs of the current half instead of as a burst in front of them
+  auto read_part = [&](int q, const unsigned char* st, int ao, int bo, frag_i4 (&fm)[3], frag_i4 (&fn)[8]) {
+    auto rn = [&](int j) { fn[j] = *(const frag_i4*)(st + bo + j * 2048); };
+    auto rm = [&](int i) { fm[i] = *(const frag_i4*)(st + ao + i * 2048); };
+    if (q == 0) { rn(0); rn(1); }
+    if (q == 1) { rn(2); rn(3); }
+    if (q == 2) { rm(0); rn(4); }
+    if (q == 3) { rn(5); rn(6); }
+    if (q == 4) { rn(7); rm(1); }
+    if (q == 5) { rm(2); }
+  };
 
   set_tile_src(iv);
   issue_next();
@@ -1426,14 +1448,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #ifdef JS2T_P192_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
+  const bool any_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
+  const uint32_t drop_key = any_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+  bool stores_behind = false;
   for (int v = blockIdx.x; v < ntiles; v += G) {
+    const int lid = xcd_remap(v, ntiles);
+    const int tm0 = (lid / tiles_n) * P_BM, tn0 = (lid % tiles_n) * 128;
+    float bias_r[8];
+    p192_load_bias<EPI>(d, tn0 + 8 * (lane & 15), bias_r);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nk; ++k) {  // this block's stages form one stream across its tiles
-      read_half(smem + cslot * P_STAGE, aoff1, boff1, fm1, fn1);
-      // first k-half; pieces 5..9 of the stage requested at the previous barrier ride between its MFMA groups
+      // first k-half; pieces 5..9 of the stage requested at the previous barrier and the reads of the second half ride
+      // between its MFMA groups
+      const unsigned char* cst = smem + cslot * P_STAGE;
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
 #pragma unroll
@@ -1442,12 +1472,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(fn0[j]), acc[i][j], 0, 0, 0);
         }
         if (q < 5) issue_piece(5 + q);
+        read_part(q, cst, aoff1, boff1, fm1, fn1);
       }
       issue_finish();
       const int nslot = cslot == P_NST - 1 ? 0 : cslot + 1;
       P192_T(0);
-      // stage s + 1 must have landed: own part by the counted wait (stage s + 2 stays in flight), everybody's by the barrier
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");
+      // stage s + 1 must have landed: own part by the counted wait (stage s + 2 stays in flight), everybody's by the barrier.
+      // Right after a tile whose rows were all stored (12 stores per lane, none skipped) those stores sit between the
+      // two stages in the in-order count: letting them stay in flight too saves a write-acknowledge latency per tile.
+      // Any other tile keeps the smaller count, which only waits longer.
+      if (k == 0 && stores_behind) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 12) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");
+      }
       P192_T(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       P192_T(2);
@@ -1456,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       P192_T(3);
       issue_begin();  // stage s + 3 goes into the slot of stage s (every wave holds its second k-half in registers)
       P192_T(4);
-      read_half(smem + nslot * P_STAGE, aoff0, boff0, fm0, fn0);  // after the last stage: an unused read of a stale slot
+      const unsigned char* nst = smem + nslot * P_STAGE;  // after the last stage: unused reads of a stale slot
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
 #pragma unroll
@@ -1465,12 +1503,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(fn1[j]), acc[i][j], 0, 0, 0);
         }
         if (q < 5) issue_piece(q);
+        read_part(q, nst, aoff0, boff0, fm0, fn0);
       }
       cslot = nslot;
       P192_T(5);
     }
-    const int lid = xcd_remap(v, ntiles);
-    p192_store_tile<EPI>(d, acc, (lid / tiles_n) * P_BM + w * 48, (lid % tiles_n) * 128, lane);
+    p192_store_tile<EPI>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key);
+    stores_behind = tm0 + P_BM <= M;
     P192_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
