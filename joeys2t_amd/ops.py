@@ -80,6 +80,18 @@ def dropout_rng(device) -> DropoutRng:
 GEMM_TIMER = None  # bench.py installs an object with .wrap(key, flops, launch) to HIP-event-time every GEMM launch
 
 
+def _takes_p192(d) -> bool:
+    """Mirror of the library's default choice of the persistent 192x128 kernel (gemm.hip p192_eligible), used only to
+    label the launches bench.py times with the kernel rocprofv3 will show for them."""
+    if d.trans_a or d.trans_b or d.conv or d.split_k > 1 or d.batch != 1 or d.dtype_c != BF16:
+        return False
+    if (d.N & 127) or (d.K & 63) or d.K < 192 or d.preact or d.beta != 0.0 or d.act not in (0, 1) or (d.residual and d.gate):
+        return False
+    if ((d.C or 0) & 15) or (d.ldc & 7) or (d.residual and ((d.ldr & 7) or (d.residual & 15))) or (d.gate and ((d.ldg & 7) or (d.gate & 15))):
+        return False
+    return -(-d.M // 192) * (d.N >> 7) >= 200
+
+
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, batch=1, batch_inner=1,
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
@@ -134,7 +146,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     d.a_rowsum = None if a_rowsum is None else a_rowsum.data_ptr()
     if GEMM_TIMER is not None:
         if d.dtype_ab == BF16:
-            fam = "gemm_bf16_kernel" if d.conv else "gemm_bf16_dma_kernel"
+            fam = "gemm_bf16_kernel" if d.conv else ("gemm_bf16_p192_kernel" if _takes_p192(d) else "gemm_bf16_dma_kernel")
             key = f"{fam}<{int(d.trans_a)},{int(d.trans_b)},{int(d.split_k > 1)}>"
         else:
             key = "gemm_generic_kernel"
