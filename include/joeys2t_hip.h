@@ -196,6 +196,15 @@ int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
                        float* dbeta, float* partial, int accumulate, int64_t rows, int64_t D, int dt,
                        js2t_stream stream); /* accumulate != 0: dgamma/dbeta += (in-place gradient accumulation; the vectorised
                                               * kernel adds its block totals with f32 atomics, `partial` is unused) */
+/* Same, plus a second output dx_dropped (dt) = js2t_dropout_bwd(dx, drop_p, rng_stream): in a pre-LN layer stack
+ * (transformer_layers.py:226-262) the gradient leaving a block's LayerNorm is the gradient entering the previous block,
+ * whose backward starts with the dropout mask of its last projection - produced here while dx is still in registers.
+ * dx_dropped may be NULL (then identical to js2t_layernorm_bwd); needs D % 8 == 0, D <= 2048, 16-byte aligned rows. */
+int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean,
+                               const float* rstd, void* dx, const void* add, float add_scale, float* dgamma,
+                               float* dbeta, float* partial, int accumulate, int64_t rows, int64_t D, int dt,
+                               void* dx_dropped, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                               js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Masked softmax (+ dropout) over attention scores — transformer_layers.py:93-98.

@@ -860,10 +860,24 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
   // slower.  Small grids (decoder-sized M: fewer blocks than CUs) have nothing else resident and LDS to spare: there
   // NST = 4 keeps three stages in flight (counted vmcnt, raw s_barrier - __syncthreads() would drain the DMA queue).
   constexpr int PER = NPA + 4;  // DMA instructions per wave and stage
-  int64_t oa[NPA], ob[4];
+  // per-lane source offsets of a stage = offsets at k = 0 (computed once) + a wave-uniform step; only a partial last
+  // stage needs the clamped form (recomputing row * ld per stage cost 24 quarter-rate multiplies per K step on the
+  // reduction-major operands, where the clamp on k keeps the compiler from hoisting them)
+  int64_t oa0[NPA], ob0[4], oa[NPA], ob[4];
+  dma_offsets<TA, NPA>(lda, m0, M, 0, 0x7fffffff, t, oa0);
+  dma_offsets<TB, 4, !TB>(ldb, n0, N, 0, 0x7fffffff, t, ob0);
   auto issue_stage = [&](int s, int slot) {
-    dma_offsets<TA, NPA>(lda, m0, M, (kt0 + s) * F_BK, K, t, oa);
-    dma_offsets<TB, 4, !TB>(ldb, n0, N, (kt0 + s) * F_BK, K, t, ob);
+    const int k0 = (kt0 + s) * F_BK;
+    if (k0 + F_BK <= K) {
+      const int64_t sa = TA ? (int64_t)k0 * lda : (int64_t)k0, sb = TB ? (int64_t)k0 * ldb : (int64_t)k0;
+#pragma unroll
+      for (int q = 0; q < NPA; ++q) oa[q] = oa0[q] + sa;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ob[q] = ob0[q] + sb;
+    } else {
+      dma_offsets<TA, NPA>(lda, m0, M, k0, K, t, oa);
+      dma_offsets<TB, 4, !TB>(ldb, n0, N, k0, K, t, ob);
+    }
     dma_issue<NPA>(Ab, oa, smem + slot * STAGE, t);
     dma_issue<4>(Bb, ob, smem + slot * STAGE + A_TILE, t);
   };

@@ -214,8 +214,14 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
                                                                  const float* __restrict__ rstd, T* __restrict__ dx,
                                                                  const T* __restrict__ add, float add_scale,
                                                                  float* __restrict__ partial, float* dgamma_acc,
-                                                                 float* dbeta_acc, int64_t rows, int D) {
+                                                                 float* dbeta_acc, int64_t rows, int D, T* __restrict__ dxd,
+                                                                 float drop_p, const uint64_t* __restrict__ rng, uint32_t rng_stream) {
   extern __shared__ float red[];  // [waves][2][D]
+  // optional second output dxd = dropout_bwd(dx) for the mask of call site rng_stream: the block that produced this
+  // LayerNorm's input starts its backward with exactly that product (one read of dx and one launch less)
+  const uint32_t dkey = dxd ? dropout_key(rng, rng_stream) : 0u;
+  const uint32_t dthr = (uint32_t)(drop_p * 65536.0f);
+  const float dsc = 1.f / (1.f - drop_p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int nch = D >> 3;
   const int rpw = LNV_ROWS / nw;
@@ -267,6 +273,17 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
           for (int i = 0; i < 8; ++i) o[i] += add_scale * av[j][i];
         }
         ld8<T>::st(dx + row * D + 8 * c, o);
+        if (dxd) {  // the decisions of dropout_keep4_key(dkey, row, 2c) and (.., 2c + 1), straight from the hash halves
+          float od[8];
+          const uint32_t rowkey = hash32((uint32_t)row ^ dkey) + 4u * (uint32_t)c;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t h = hash32(rowkey + (uint32_t)q);
+            od[2 * q] = (h & 0xffffu) >= dthr ? o[2 * q] * dsc : 0.f;
+            od[2 * q + 1] = (h >> 16) >= dthr ? o[2 * q + 1] * dsc : 0.f;
+          }
+          ld8<T>::st(dxd + row * D + 8 * c, od);
+        }
       }
     }
   }
@@ -404,7 +421,8 @@ __global__ void attn_head_mean_kernel(const T* __restrict__ P, float* __restrict
 template <typename T, int NCH>
 static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                              const void* add, float add_scale, float* part, float* dga, float* dba, int64_t rows, int D,
-                             int64_t nblk, int nw, size_t lds, hipStream_t s) {
+                             int64_t nblk, int nw, size_t lds, hipStream_t s, void* dxd, float drop_p, const uint64_t* rng,
+                             uint32_t rng_stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_vec_kernel<T, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -415,7 +433,7 @@ static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, 
     attr_set = true;
   }
   hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T, NCH>), dim3((unsigned)nblk), dim3(64 * nw), lds, s, (const T*)dy, (const T*)x, gamma,
-                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D);
+                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D, (T*)dxd, drop_p, rng, rng_stream);
   return JS2T_OK;
 }
 
@@ -449,11 +467,22 @@ extern "C" int js2t_layernorm_fwd(const void* x, const float* gamma, const float
 extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, const void* add, float add_scale, float* dgamma, float* dbeta, float* partial,
                                   int accumulate, int64_t rows, int64_t D, int dt, js2t_stream stream) {
+  return js2t_layernorm_bwd_dropout(dy, x, gamma, mean, rstd, dx, add, add_scale, dgamma, dbeta, partial, accumulate, rows, D, dt,
+                                    nullptr, 0.f, nullptr, 0u, stream);
+}
+
+extern "C" int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                          void* dx, const void* add, float add_scale, float* dgamma, float* dbeta, float* partial,
+                                          int accumulate, int64_t rows, int64_t D, int dt, void* dx_dropped, float drop_p,
+                                          const uint64_t* rng_state, uint32_t rng_stream, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0, "layernorm_bwd: bad arguments");
+  JS2T_CHECK(!dx_dropped || (rng_state && drop_p > 0.f && drop_p < 1.f), "layernorm_bwd_dropout: dx_dropped needs rng_state and 0 < p < 1");
+  void* dxd = dx_dropped;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (D % 8 == 0) && D <= 64 * 8 * LNV_MAXCH &&
-                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)add) & 15) == 0;
+                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)add | (uintptr_t)dxd) & 15) == 0;
+  JS2T_CHECK(vec || !dxd, "layernorm_bwd_dropout: the fused dropout output needs the vectorised kernel (D % 8 == 0, D <= 2048, 16-byte aligned)");
   if (vec) {
     const bool want_p = dgamma && dbeta;
     const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
@@ -468,13 +497,13 @@ extern "C" int js2t_layernorm_bwd(const void* dy, const void* x, const float* ga
     float* dba = direct ? dbeta : (float*)nullptr;
     int rc;
     if (dt == JS2T_F32) {
-      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
-         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
-                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s);
+      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
+         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
+                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream);
     } else {
-      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
-         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s)
-                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s);
+      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
+         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
+                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream);
     }
     if (rc != JS2T_OK) return rc;
     JS2T_LAUNCH_CHECK();

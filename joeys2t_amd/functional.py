@@ -16,6 +16,8 @@ Reference semantics reproduced (file:line in the reference repo):
 import math
 from typing import List, Optional
 
+import os
+
 import torch
 
 from joeys2t_amd import ops
@@ -212,6 +214,23 @@ def _ln_fwd(x2d, gamma, beta):
     return ops.layernorm_fwd(x2d, gamma, beta, LN_EPS)
 
 
+# Hand-over of a fused product between two ResidualBlockFn nodes of a pre-LN stack.  Block i writes y = alpha x +
+# drop(core(LN(x))); block i+1 normalises y first, and its LayerNorm backward produces exactly the gradient block i's
+# backward then multiplies with its output-dropout mask.  Forward: block i leaves (p_out, site, rng) under y's address;
+# block i+1 picks it up.  Backward: block i+1 lets its LayerNorm backward emit the masked copy as well and leaves it under
+# the address of the gradient it returns; block i takes it only if the gradient it receives is that very tensor (no
+# fan-out accumulated in between) AND (p, site, rng) are its own - anything else falls back to js2t_dropout_bwd.
+# Entries hold their tensors, so an address cannot be re-used while it is a key; begin_step() clears both tables.
+_DROP_HINT = {}
+_DROP_READY = {}
+FUSE_LN_DROPOUT_BWD = os.environ.get("JS2T_LN_DROPOUT_HANDOVER", "1") != "0"  # tests flip this to compare with the separate kernel
+
+
+def reset_handover():
+    _DROP_HINT.clear()
+    _DROP_READY.clear()
+
+
 class ResidualBlockFn(torch.autograd.Function):
     """One residual block:  pre-LN:  y = drop(core(LN(x))) + alpha*x ;  post-LN: y = LN(drop(core(x)) + alpha*x).
 
@@ -236,6 +255,11 @@ class ResidualBlockFn(torch.autograd.Function):
         p_in, p_out = cfg.p_in, cfg.p_out
         sites = [rng.next_site() if rng is not None else 0 for _ in range(2)]
         saved = {}
+        hint = _DROP_HINT.pop(x.data_ptr(), None)
+        ctx.prev_drop = None
+        if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
+                ops.layernorm_bwd_supports_dropout(x2)):
+            ctx.prev_drop = hint[:3]  # (p, site, rng) of the block that produced x
         if cfg.ln_mode == "pre":
             n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
             saved.update(mean=mean, rstd=rstd)
@@ -281,6 +305,10 @@ class ResidualBlockFn(torch.autograd.Function):
         ctx.mem_shape = None if memory is None else tuple(memory.shape)
         ctx.nparams = len(params)
         y = y.view(B, T, d)
+        if p_out > 0 and rng is not None and cfg.ln_mode != "post" and FUSE_LN_DROPOUT_BWD and x.requires_grad:
+            if len(_DROP_HINT) > 64:  # forward passes without a training step around them: do not pile up activations
+                _DROP_HINT.clear()
+            _DROP_HINT[y.data_ptr()] = (p_out, sites[1], rng, y)
         if cfg.kind == "cross":
             if att_w is not None:
                 ctx.mark_non_differentiable(att_w)
@@ -309,7 +337,14 @@ class ResidualBlockFn(torch.autograd.Function):
             du = dy2
         else:
             du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"], grad_out=ln_sink)
-        dz_o = ops.dropout_bwd(du, p_out, rng, sites[1]) if p_out > 0 else du
+        dz_o = du
+        if p_out > 0:
+            ready = _DROP_READY.pop(dy2.data_ptr(), None)
+            if (ready is not None and cfg.ln_mode != "post" and ready[1] is not None and ready[1].data_ptr() == dy2.data_ptr() and
+                    ready[1].shape == dy2.shape and ready[2] == (p_out, sites[1]) and ready[3] is rng):
+                dz_o = ready[0]
+            else:
+                dz_o = ops.dropout_bwd(du, p_out, rng, sites[1])
         dmem = None
         if cfg.kind == "ffn":
             relu = cfg.act == "relu"
@@ -342,8 +377,14 @@ class ResidualBlockFn(torch.autograd.Function):
                                                      dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq, w_t=wts.get("w_kv_t"))
             dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
         if cfg.ln_mode == "pre":
-            dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
-                                                          add_scale=cfg.alpha, grad_out=ln_sink)
+            if ctx.prev_drop is not None:
+                pp, psite, prng = ctx.prev_drop
+                dx2, g["ln_g"], g["ln_b"], dxd = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du, add_scale=cfg.alpha,
+                                                                   grad_out=ln_sink, drop=(pp, prng, psite))
+                _DROP_READY[dx2.data_ptr()] = (dxd, dx2, (pp, psite), prng)
+            else:
+                dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
+                                                              add_scale=cfg.alpha, grad_out=ln_sink)
         elif cfg.alpha != 0.0:
             dx2 = ops.axpby(dn, 1.0, du, cfg.alpha)
         else:

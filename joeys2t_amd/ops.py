@@ -341,8 +341,9 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None):
-    """grad_out = (dgamma_buf, dbeta_buf): accumulate the parameter gradients into these buffers in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None, drop=None):
+    """grad_out = (dgamma_buf, dbeta_buf): accumulate the parameter gradients into these buffers in place.
+    drop = (p, rng, site): also return dropout_bwd(dx, p, rng, site) as a fourth value (js2t_layernorm_bwd_dropout)."""
     _dev(dy, x, gamma, mean, rstd, add)
     D = x.shape[-1]
     rows = x.numel() // D
@@ -356,10 +357,24 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
             dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
         nparts = (rows + 31) // 32  # >= one partial per row block of the vectorised backward kernel (64 rows)
         partial = torch.empty((2 * max(nparts, 1) * D,), dtype=torch.float32, device=x.device)
-    check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
-                                   _p(partial), int(grad_out is not None and need_param_grads),
-                                   C.c_int64(rows), C.c_int64(D), dt_code(x), _stream()), "js2t_layernorm_bwd")
-    return dx, dgamma, dbeta
+    if drop is None:
+        check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
+                                       _p(partial), int(grad_out is not None and need_param_grads),
+                                       C.c_int64(rows), C.c_int64(D), dt_code(x), _stream()), "js2t_layernorm_bwd")
+        return dx, dgamma, dbeta
+    p_drop, rng, site = drop
+    dxd = torch.empty_like(x)
+    check(lib().js2t_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma),
+                                           _p(dbeta), _p(partial), int(grad_out is not None and need_param_grads), C.c_int64(rows),
+                                           C.c_int64(D), dt_code(x), _p(dxd), C.c_float(p_drop), _p(rng.state), C.c_uint32(site & 0xFFFFFFFF),
+                                           _stream()), "js2t_layernorm_bwd_dropout")
+    return dx, dgamma, dbeta, dxd
+
+
+def layernorm_bwd_supports_dropout(x) -> bool:
+    """Shapes the fused second output of layernorm_bwd(drop=...) is available for (the vectorised kernel)."""
+    D = x.shape[-1]
+    return D % 8 == 0 and D <= 2048 and x.data_ptr() % 16 == 0 and x.is_contiguous()
 
 
 # ----------------------------------------------------------------------------------------- Conformer convolution module

@@ -17,6 +17,7 @@ from typing import Dict, Optional
 
 import torch
 
+from joeys2t_amd import functional
 from joeys2t_amd.batch import Batch
 from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
 from joeys2t_amd.helpers_for_ddp import FlatGradReducer, use_ddp
@@ -81,6 +82,7 @@ class TrainStep:
         model = self.model
         model.train()
         self.rt.rng.begin_step()
+        functional.reset_handover()
         if sort:
             batch.sort_by_src_length()
         last = (self.micro + 1) % self.batch_multiplier == 0

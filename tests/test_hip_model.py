@@ -122,6 +122,55 @@ def test_training_mode_dropout_runs_and_is_finite(device):
     assert abs(losses[0] - g["loss_total"]) < 0.5 * abs(g["loss_total"])
 
 
+def test_dropout_backward_rides_on_layernorm_backward(device):
+    """Pre-LN stack in training mode: the gradient leaving a block's LayerNorm backward is handed to the previous block
+    already multiplied with that block's output-dropout mask (js2t_layernorm_bwd_dropout).  Same loss, same gradients as
+    with the separate js2t_dropout_bwd launches, and the hand-over really happens for all but the first block of a stack."""
+    import copy
+
+    from joeys2t_amd import functional as Fn
+    from joeys2t_amd import ops
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    g = load_golden("model_pre")
+    cfg = copy.deepcopy(FIXTURES["model_pre"]["cfg"])
+    cfg["encoder"]["dropout"] = cfg["decoder"]["dropout"] = 0.1
+    cfg["decoder"]["embeddings"]["dropout"] = 0.1
+    model = build_model(cfg, None, Vocabulary.synthetic(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.load_state_dict(golden_sd(g))
+    model.finalize(device, torch.float32).train()
+    b = batch_kwargs(g, device)
+    calls = {"n": 0}
+    orig = ops.dropout_bwd
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    ops.dropout_bwd = counted
+    res = {}
+    try:
+        for fused in (False, True):
+            Fn.FUSE_LN_DROPOUT_BWD = fused
+            Fn.reset_handover()
+            calls["n"] = 0
+            model.zero_grad()
+            model.runtime.rng.begin_step()  # same call-site numbering, same offset: identical masks in both passes
+            total, *_ = model(return_type="loss", **vars(b))
+            total.backward()
+            res[fused] = (total.item(), {n: p.grad.clone() for n, p in model.named_parameters()}, calls["n"])
+    finally:
+        ops.dropout_bwd = orig
+        Fn.FUSE_LN_DROPOUT_BWD = True
+        Fn.reset_handover()
+    assert res[False][0] == res[True][0]
+    n_blocks = 2 * cfg["encoder"]["num_layers"] + 3 * cfg["decoder"]["num_layers"]
+    assert res[False][2] - res[True][2] == n_blocks - 2, (res[False][2], res[True][2], n_blocks)  # all but the first block of each stack
+    for n, gr in res[False][1].items():
+        torch.testing.assert_close(res[True][1][n], gr, rtol=1e-5, atol=1e-6, msg=n)
+
+
 @pytest.mark.parametrize("name", ["model_pre", "model_post"])
 def test_direct_gradient_accumulation_into_flat_store(device, name):
     """With param.grad attached to the flat store, kernels accumulate gradients in place (no autograd adds):

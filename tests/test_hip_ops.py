@@ -612,3 +612,21 @@ def test_transposed_weight_shadow(device):
     st.mark_dirty()
     st.refresh()
     assert torch.equal(st.view_t([m.o.weight]).cpu(), m.o.weight.bfloat16().cpu().t())
+
+
+def test_layernorm_bwd_fused_dropout_output(device):
+    """js2t_layernorm_bwd_dropout: the second output equals js2t_dropout_bwd of the first (same mask, same scaling)."""
+    rows, D = 777, 512
+    rng = ops.dropout_rng(device)
+    x = rnd(rows, D, seed=1).bfloat16().to(device)
+    dy = rnd(rows, D, seed=2).bfloat16().to(device)
+    add = rnd(rows, D, seed=3).bfloat16().to(device)
+    gamma = (1.0 + 0.1 * rnd(D, seed=4)).to(device)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma), 1e-6)
+    dx0, dg0, db0 = ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add, add_scale=0.5)
+    dx1, dg1, db1, dxd = ops.layernorm_bwd(dy, x, gamma, mean, rstd, add=add, add_scale=0.5, drop=(0.2, rng, 11))
+    assert torch.equal(dx0, dx1)
+    torch.testing.assert_close(dg0, dg1)
+    ref = ops.dropout_bwd(dx0, 0.2, rng, 11)
+    assert torch.equal((ref == 0), (dxd == 0))
+    torch.testing.assert_close(dxd.float(), ref.float(), rtol=1e-2, atol=1e-3)  # fused: scaled from f32, not from the bf16 dx
