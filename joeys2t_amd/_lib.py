@@ -3,6 +3,7 @@
 There is no fallback: if the shared library is missing or a call is rejected, we raise.
 """
 import ctypes as C
+import os
 import re
 from pathlib import Path
 
@@ -84,6 +85,8 @@ def lib():
         _lib.js2t_colsum_partial_rows.argtypes = [C.c_int64]
         _lib.js2t_sumsq_partials.restype = C.c_int64
         _lib.js2t_sumsq_partials.argtypes = [C.c_int64]
+        if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)
+            _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
     return _lib
 
 

@@ -90,6 +90,16 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// LDS-DMA request written as inline assembly.  With the builtin the compiler knows that LDS is being written behind its
+// back and puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 it cannot prove disjoint (the transposing read
+// is an intrinsic without usable alias information; plain loads are not affected) - which drains the prefetch that the
+// ring exists for.  The kernels order DMA and reads themselves (counted vmcnt + barrier), so the request is hidden:
+// compiler-generated vmcnt waits for its own loads can only become stricter by the extra in-order entries, never weaker.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "m0");
+}
+
 // ---------------------------------------------------------------- counter-based dropout RNG
 // Stateless: the keep decision of element (row, col) is a pure function of {seed, offset, call-site stream, row,
 // col}, so forward and backward kernels regenerate identical masks and nothing is stored.  One 32-bit integer hash

@@ -438,12 +438,17 @@ __device__ __forceinline__ void dma_offsets(int64_t ld, int rowbase, int rows_ma
     }
   }
 }
-template <int NP>
+// HIDDEN: issue through lds_dma16 (kernels whose fragments come from transposing reads, see there)
+template <int NP, bool HIDDEN = false>
 __device__ __forceinline__ void dma_issue(const uint16_t* base, const int64_t (&off)[NP], unsigned char* tile, int t) {
-  const int w = t >> 6;
+  const int w = HIDDEN ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6;
 #pragma unroll
-  for (int q = 0; q < NP; ++q)
-    __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * NP + q) * 1024), 16, 0, 0);
+  for (int q = 0; q < NP; ++q) {
+    if constexpr (HIDDEN)
+      lds_dma16(base + off[q], tile + (w * NP + q) * 1024);
+    else
+      __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off[q]), (l_void*)(tile + (w * NP + q) * 1024), 16, 0, 0);
+  }
 }
 // zero the LDS slots of a partial last K tile (k >= k_lim)
 template <bool TR, int NP, bool PERMB = false>
@@ -878,8 +883,8 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
       dma_offsets<TA, NPA>(lda, m0, M, k0, K, t, oa);
       dma_offsets<TB, 4, !TB>(ldb, n0, N, k0, K, t, ob);
     }
-    dma_issue<NPA>(Ab, oa, smem + slot * STAGE, t);
-    dma_issue<4>(Bb, ob, smem + slot * STAGE + A_TILE, t);
+    dma_issue<NPA, TA || TB>(Ab, oa, smem + slot * STAGE, t);
+    dma_issue<4, TA || TB>(Bb, ob, smem + slot * STAGE + A_TILE, t);
   };
   issue_stage(0, 0);
 #pragma unroll
@@ -1533,6 +1538,244 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same persistent 192x128 pipeline for reduction-major operands: grouped weight gradients
+// C_g[M,N] (f32) = alpha * A_g[K,M]^T B_g[K,N] + beta * C_g, optional row sums of A_g^T (bias gradients)
+// ------------------------------------------------------------------------------------------------
+// Stage = A^T image [64 k][192 m] split in a 128-wide part (256-byte rows, the XOR key of the two-stage kernel) and a
+// 64-wide part (128-byte rows, two k rows per 256-byte bank window, key from k bits 1 and 3), plus the B^T image
+// [64 k][128 n]; every fragment is two ds_read_b64_tr_b16 (4 k each).  Natural fragment columns: lane (g, r) ends
+// up with C[16i + 4g + e][16j + r] - 16 lanes store 64 contiguous bytes of f32; the epilogue is a read-modify-write of
+// single dwords, which only a K of thousands amortises (this form is used for K = tokens).  A partial last stage takes
+// its k >= K rows from a 16-byte zero constant.  Blocks walk the tiles of all group members in one XCD-aware order.
+constexpr int PT_A0 = 0, PT_A1 = 16384, PT_B = 24576;
+
+template <bool RS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_p192t_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n, int count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4, r = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = d.M, N = d.N, K = d.K, nk = (K + 63) >> 6;
+  const int per_member = tiles_m * tiles_n, ntiles = per_member * count, G = gridDim.x;
+  const int64_t lda = d.lda, ldb = d.ldb;
+  const uint16_t* zsrc = (const uint16_t*)&g_zero16;
+
+  // ---- issue side
+  int iv = blockIdx.x, ik = 0, islot = 0;
+  const uint16_t* src[10];   // 4 pieces of A0, 2 of A1, 4 of B: address of the lane's 16 bytes at k = 0
+  // k row (inside a stage) the lane's granule of piece q belongs to
+  auto krow = [&](int q) { return q < 4 ? (w * 4 + q) * 4 + (lane >> 4) : q < 6 ? (w * 2 + q - 4) * 8 + (lane >> 3) : (w * 4 + q - 6) * 4 + (lane >> 4); };
+  auto set_tile_src = [&](int v) {
+    const int lid = xcd_remap(v, ntiles);
+    const int mem = lid / per_member, rem = lid - mem * per_member;
+    const int m0 = (rem / tiles_n) * P_BM, n0 = (rem % tiles_n) * 128;
+    const uint16_t* Ab = (const uint16_t*)grp.A[mem];
+    const uint16_t* Bb = (const uint16_t*)grp.B[mem];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kr = krow(q);
+      int c = m0 + (((lane & 15) ^ (tr_g(kr) << 1)) << 3);
+      if (c >= M) c = m0;  // columns that are never stored
+      src[q] = Ab + (int64_t)kr * lda + c;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kr = krow(4 + q);
+      const int key2 = ((kr >> 1) & 1) | (((kr >> 3) & 1) << 1);
+      int c = m0 + 128 + (((lane & 7) ^ (key2 << 1)) << 3);
+      if (c >= M) c = m0;
+      src[4 + q] = Ab + (int64_t)kr * lda + c;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kr = krow(6 + q);
+      src[6 + q] = Bb + (int64_t)kr * ldb + n0 + (((lane & 15) ^ (tr_g(kr) << 1)) << 3);
+    }
+  };
+  int64_t p_ka = 0, p_kb = 0;
+  int p_klim = 64;  // valid k rows of the stage being requested
+  unsigned char* p_st = smem;
+  auto issue_begin = [&]() {
+    const int k0 = iv < ntiles ? ik << 6 : 0;
+    p_ka = (int64_t)k0 * lda;
+    p_kb = (int64_t)k0 * ldb;
+    p_klim = K - k0;
+    p_st = smem + islot * P_STAGE;
+  };
+  auto issue_piece = [&](int q) {  // q is a compile-time constant at every call site
+    const uint16_t* sp = src[q] + (q < 6 ? p_ka : p_kb);
+    if (p_klim < 64) {  // partial last stage (wave-uniform test): rows k >= K come from the zero constant
+      if (krow(q) >= p_klim) sp = zsrc;
+    }
+    unsigned char* dst = q < 4 ? p_st + PT_A0 + (w * 4 + q) * 1024
+                       : q < 6 ? p_st + PT_A1 + (w * 2 + q - 4) * 1024 : p_st + PT_B + (w * 4 + q - 6) * 1024;
+    lds_dma16(sp, dst);
+  };
+  auto issue_finish = [&]() {
+    if (iv < ntiles && ++ik == nk) {
+      ik = 0;
+      iv += G;
+      if (iv < ntiles) set_tile_src(iv);
+    }
+    islot = islot == P_NST - 1 ? 0 : islot + 1;
+  };
+  auto issue_next = [&]() {
+    issue_begin();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) issue_piece(q);
+    issue_finish();
+  };
+
+  // ---- multiply side: wave w owns the 16-row blocks w, w + 4 (128-wide part) and w + 8 (64-wide part) of the tile and
+  // all 128 columns, so that the image a fragment comes from is known at compile time.
+  // Per lane the XOR keys are constants: k = 32 kk + 8 g + q4 (+4 for the second read) has k & 3 = q4, (k >> 3) & 1 = g & 1,
+  // (k >> 1) & 1 = q4 >> 1.  offB / offA = byte offset inside a stage of the lane's first 8-byte piece at kk = 0; the
+  // other three pieces of a fragment pair are at immediate offsets (+4 k rows, +32 k rows).
+  const int q4 = r >> 2, p4 = r & 3;
+  const int key3 = q4 | ((g & 1) << 2), key2 = (q4 >> 1) | ((g & 1) << 1);
+  int offB[8], offA[3];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) offB[j] = PT_B + (8 * g + q4) * 256 + (((16 * j) * 2 + 8 * p4) ^ (key3 << 5));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA[i] = PT_A0 + (8 * g + q4) * 256 + (((16 * (w + 4 * i)) * 2 + 8 * p4) ^ (key3 << 5));
+  offA[2] = PT_A1 + (8 * g + q4) * 128 + (((16 * w) * 2 + 8 * p4) ^ (key2 << 5));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr_pair = [&](const unsigned char* p0, const unsigned char* p1) -> frag_i4 {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)p1);
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(frag_i4, v);
+  };
+  auto read_part = [&](int q, const unsigned char* st, int kk, frag_i4 (&fm)[3], frag_i4 (&fn)[8]) {
+    auto rn = [&](int j) { fn[j] = tr_pair(st + offB[j] + kk * 8192, st + offB[j] + kk * 8192 + 1024); };
+    auto rm = [&](int i) {
+      fm[i] = i < 2 ? tr_pair(st + offA[i] + kk * 8192, st + offA[i] + kk * 8192 + 1024)
+                    : tr_pair(st + offA[2] + kk * 4096, st + offA[2] + kk * 4096 + 512);
+    };
+    if (q == 0) { rn(0); rn(1); }
+    if (q == 1) { rn(2); rn(3); }
+    if (q == 2) { rm(0); rn(4); }
+    if (q == 3) { rn(5); rn(6); }
+    if (q == 4) { rn(7); rm(1); }
+    if (q == 5) { rm(2); }
+  };
+
+  set_tile_src(iv);
+  issue_next();
+  issue_next();
+  issue_begin();
+#pragma unroll
+  for (int q = 0; q < 5; ++q) issue_piece(q);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 5) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  frag_i4 fm0[3], fn0[8], fm1[3], fn1[8];
+  f32x4_t acc[3][8], racc[3];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) read_part(q, smem, 0, fm0, fn0);
+  const frag_i4 ones = {0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+  int cslot = 0;
+#ifdef JS2T_P192_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+  const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f), beta = d.beta;
+  for (int v = blockIdx.x; v < ntiles; v += G) {
+    const int lid = xcd_remap(v, ntiles);
+    const int mem = lid / per_member, rem = lid - mem * per_member;
+    const int tm0 = (rem / tiles_n) * P_BM, tn0 = (rem % tiles_n) * 128;
+    const bool do_rs = RS && tn0 == 0 && grp.rowsum[mem] != nullptr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      racc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int k = 0; k < nk; ++k) {
+      const unsigned char* cst = smem + cslot * P_STAGE;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int i = q >> 1, j = (q & 1) * 4 + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(fn0[j]), acc[i][j], 0, 0, 0);
+        }
+        if (q < 5) issue_piece(5 + q);
+        read_part(q, cst, 1, fm1, fn1);
+      }
+      if (RS && do_rs) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(ones), racc[i], 0, 0, 0);
+      }
+      issue_finish();
+      const int nslot = cslot == P_NST - 1 ? 0 : cslot + 1;
+      P192_T(0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");
+      P192_T(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P192_T(2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      P192_T(3);
+      issue_begin();
+      P192_T(4);
+      const unsigned char* nst = smem + nslot * P_STAGE;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int i = q >> 1, j = (q & 1) * 4 + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(fn1[j]), acc[i][j], 0, 0, 0);
+        }
+        if (q < 5) issue_piece(q);
+        read_part(q, nst, 0, fm0, fn0);
+      }
+      if (RS && do_rs) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(ones), racc[i], 0, 0, 0);
+      }
+      cslot = nslot;
+      P192_T(5);
+    }
+    // ---- epilogue: C[m][n] = alpha * acc + beta * C, one dword per lane and (i, e, j); rows beyond M are skipped
+    float* Cb = (float*)grp.C[mem];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = tm0 + 16 * (w + 4 * i) + 4 * g + e;
+        if (m < M) {
+          float* crow = Cb + (int64_t)m * d.ldc + tn0 + r;
+          float old[8];
+          if (beta != 0.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) old[j] = crow[16 * j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) crow[16 * j] = beta != 0.f ? acc[i][j][e] * alpha + beta * old[j] : acc[i][j][e] * alpha;
+        }
+      }
+    }
+    if (RS && do_rs && r == 0) {
+      typedef __attribute__((address_space(1))) float gfloat;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = tm0 + 16 * (w + 4 * i) + 4 * g + e;
+          if (m < M) __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)grp.rowsum[mem] + m, racc[i][e]);
+        }
+    }
+  }
+  P192_T(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef JS2T_P192_PROF
+  if (blockIdx.x == 0 && t == 0)
+    for (int i = 0; i < 8; ++i) g_p192_prof[i] = prof_[i];
+#endif
+}
+
 // 0 = never, 1 = whenever the product qualifies, -1 = when it qualifies and fills the chip (default)
 int g_p192_mode = -1;
 inline bool p192_eligible(const js2t_gemm_desc& d) {
@@ -1660,7 +1903,7 @@ extern "C" int js2t_debug_p192_prof(unsigned long long* out8) {
   return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof), 64);
 }
 #endif
-extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
+extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode); }
 
 template <bool SPLITK>
 static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
@@ -1678,6 +1921,38 @@ static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int 
   const int tm = cdiv(d.M, 128), tn = cdiv(d.N, F_BN);
   hipLaunchKernelGGL((gemm_bf16_dma_grouped_kernel<128, true, true, SPLITK>), dim3(tm * tn, count, SPLITK ? d.split_k : 1), dim3(256),
                      LDS, s, d, grp, tm, tn, d.split_k);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+// the persistent reduction-major kernel takes a grouped launch when it can fill the chip with 192x128 tiles
+static bool p192t_eligible(const js2t_gemm_desc& d, int count) {
+  if (g_p192_mode == 0 || g_p192_mode == 2 || d.split_k > 1 || d.dtype_c != JS2T_F32) return false;
+  if ((d.N & 127) || (d.M & 7) || d.K < 129 || (d.ldc & 0) != 0) return false;
+  // Measured in the train step (real activations) the fixed two-stage kernel wins on every weight-gradient group:
+  // 839 TFLOP/s over FFN1 / attention-output / key-value launches against 773 for this kernel on 16 x dW[1536,512]
+  // (exact fit: 512 tiles, no partial row tile) and 735 on dW[512,2048] + dW[1536,512]; synthetic normal operands
+  // favour it on the exact fit only (806 vs 698).  It stays selectable (mode 1) and tested, not the default.
+  if (g_p192_mode != 1) return false;
+  return true;
+}
+template <bool RS>
+static int launch_grouped_p192t(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192t_kernel<RS>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    int dev = 0, cu = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cu <= 0) {
+      js2t_set_error("gemm p192t setup: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    n_cu = (cu & ~7) ? (cu & ~7) : cu;
+  }
+  const int tm = cdiv(d.M, P_BM), tn = d.N >> 7;
+  const int total = tm * tn * count, grid = total < n_cu ? total : n_cu;
+  hipLaunchKernelGGL(gemm_bf16_p192t_kernel<RS>, dim3(grid), dim3(256), P_LDS, s, d, grp, tm, tn, count);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -1707,8 +1982,12 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
       grp.rowsum[i] = a_rowsum ? a_rowsum[j] : nullptr;
     }
     d.A = grp.A[0], d.B = grp.B[0], d.C = grp.C[0];
-    const int rc = d.split_k > 1 ? launch_grouped_tt<true>(d, grp, n, (hipStream_t)stream)
-                                 : launch_grouped_tt<false>(d, grp, n, (hipStream_t)stream);
+    int rc;
+    if (p192t_eligible(d, n)) {
+      rc = a_rowsum ? launch_grouped_p192t<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_p192t<false>(d, grp, n, (hipStream_t)stream);
+    } else {
+      rc = d.split_k > 1 ? launch_grouped_tt<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_tt<false>(d, grp, n, (hipStream_t)stream);
+    }
     if (rc != JS2T_OK) return rc;
   }
   return JS2T_OK;

@@ -517,6 +517,33 @@ def test_gemm_grouped_matches_single_products(device, split):
         torch.testing.assert_close(rs[i].cpu(), base_b[i] + dzs[i].float().cpu().sum(0), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("rows,cols,tokens,n,beta", [(200, 256, 777, 5, 1.0), (192, 128, 130, 1, 0.0), (2048, 512, 3000, 3, 1.0), (520, 384, 1000, 35, 1.0)])
+def test_gemm_grouped_persistent_reduction_major(device, rows, cols, tokens, n, beta):
+    """The persistent 192x128 kernel in its reduction-major form (grouped weight gradients): partial last K stage
+    (zero rows), partial last row tile, several tiles per block across group members, accumulate onto the gradient,
+    bias gradients by the ones-fragment; more members than one chunk holds."""
+    from joeys2t_amd._lib import lib
+    g = torch.Generator().manual_seed(7)
+    dzs = [torch.randn(tokens, rows, generator=g).bfloat16().to(device) for _ in range(n)]
+    xs = [torch.randn(tokens, cols, generator=g).bfloat16().to(device) for _ in range(n)]
+    base_w = [torch.randn(rows, cols, generator=g) for _ in range(n)]
+    base_b = [torch.randn(rows, generator=g) for _ in range(n)]
+    Cs = [b.clone().to(device) for b in base_w]
+    rs = [b.clone().to(device) for b in base_b]
+    lib().js2t_gemm_p192_mode(1)
+    try:
+        ops.gemm_grouped(dzs, xs, Cs, M=rows, N=cols, K=tokens, lda=rows, ldb=cols, ldc=cols, split_k=1, beta=beta, a_rowsums=rs)
+        C2 = [b.clone().to(device) for b in base_w]
+        ops.gemm_grouped(dzs, xs, C2, M=rows, N=cols, K=tokens, lda=rows, ldb=cols, ldc=cols, split_k=1, beta=beta)  # without row sums
+    finally:
+        lib().js2t_gemm_p192_mode(-1)
+    for i in sorted({0, n // 2, n - 1}):
+        ref = beta * base_w[i] + dzs[i].float().cpu().t() @ xs[i].float().cpu()
+        torch.testing.assert_close(Cs[i].cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
+        torch.testing.assert_close(C2[i].cpu(), ref, rtol=2e-3, atol=2e-3 * math.sqrt(tokens))
+        torch.testing.assert_close(rs[i].cpu(), base_b[i] + dzs[i].float().cpu().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(tokens) / 10)
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 128, 72), (2592, 512, 2048), (333, 500, 1000), (65, 136, 136)])
 @pytest.mark.parametrize("tb", [0, 1])
 def test_gemm_bf16_small_grid_deep_ring(device, M, N, K, tb):
