@@ -105,13 +105,19 @@ def _mfma_operand(t: torch.Tensor) -> bool:
     return t.dtype == torch.bfloat16 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0
 
 
+_WGRAD_BLOCKS = int(os.environ.get("JS2T_WGRAD_BLOCKS", "512"))
+
+
 def wgrad_split(rows: int, cols: int, red: int, count: int = 1) -> int:
     """Split-K factor for `count` weight-gradient GEMMs [rows, cols] = sum over `red` tokens launched together: one
     output has only rows*cols/128^2 tiles (16..64 for the 512/2048-wide layers) against 256 CUs, so the token
-    dimension is cut until about two blocks per CU exist."""
+    dimension is cut until up to two blocks per CU exist."""
     tiles = ((rows + 127) // 128) * ((cols + 127) // 128) * count
     nk = (red + 63) // 64
-    return max(1, min((512 + tiles - 1) // tiles, nk // 4 if nk >= 8 else 1, 32))
+    # at most two blocks per CU, rounded DOWN: a slice more costs another pass of f32 atomics over the whole output
+    # (6 x dW[2048,512] over 2592 tokens: 46.7 us unsplit, 76.2 us in two slices - tools/wgrad_small.py; whole train
+    # step, same box: 14.44 ms rounding up, 14.31 rounding down, 14.33-14.36 with 320-384 blocks as the target)
+    return max(1, min(_WGRAD_BLOCKS // tiles, nk // 4 if nk >= 8 else 1, 32))
 
 
 class AttnShape:
