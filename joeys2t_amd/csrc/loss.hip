@@ -59,6 +59,62 @@ __global__ __launch_bounds__(LB) void row_lse_kernel(const T* __restrict__ x, fl
   if (threadIdx.x == 0) lse[r] = bmx + __logf(s);
 }
 
+// bf16 rows of V % 8 == 0 (16-byte aligned): one 16-byte load per 8 logits, the row stays in registers between the
+// maximum and the sum pass (one read of the logits instead of two scalar ones)
+constexpr int RL_CH = 4;  // chunks of 8 per thread: V <= 8 * LB * RL_CH = 8192
+__global__ __launch_bounds__(LB) void row_lse_vec_kernel(const uint16_t* __restrict__ x, float* __restrict__ lse,
+                                                         int64_t* __restrict__ argmax, int64_t rows, int64_t V) {
+  __shared__ float red[LB / 64];
+  __shared__ int redi[LB / 64];
+  const int64_t r = blockIdx.x;
+  const uint4* xr = (const uint4*)(x + r * V);
+  const int nch = (int)(V >> 3);
+  float v[RL_CH][8];
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < RL_CH; ++j) {
+    const int c = threadIdx.x + LB * j;
+    if (c < nch) {
+      const uint4 q = xr[c];
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[j][2 * i] = __uint_as_float(w[i] << 16);
+        v[j][2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (v[j][i] > mx) { mx = v[j][i]; mi = 8 * c + i; }  // ascending index inside a thread: first maximum kept
+    }
+  }
+  const float bmx = block_max(mx, red);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < RL_CH; ++j) {
+    const int c = threadIdx.x + LB * j;
+    if (c < nch) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += __expf(v[j][i] - bmx);
+    }
+  }
+  s = block_sum(s, red);
+  if (argmax) {
+    int cand = (mx == bmx) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int best = redi[0];
+      for (int i = 1; i < LB / 64; ++i) best = min(best, redi[i]);
+      argmax[r] = best;
+    }
+  }
+  if (threadIdx.x == 0) lse[r] = bmx + __logf(s);
+}
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(LB) void log_softmax_kernel(const T* __restrict__ x, TO* __restrict__ y, int64_t rows, int64_t V) {
   __shared__ float red[LB / 64];
@@ -406,14 +462,32 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
   const float nl = nll[b];
   const int64_t Tb = min(in_len[b], Tmax);
   const bool dead = t >= Tb || (zero_inf && isinf(nl));
+  // 16-byte row accesses when the rows allow it (bf16, V % 8 == 0, aligned base)
+  const bool vec = sizeof(T) == 2 && (V & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0;
   if (dead) {
-    for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, 0.f);
+    if (vec) {
+      for (int c = threadIdx.x; c < (int)(V >> 3); c += LB) ((uint4*)dr)[c] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, 0.f);
+    }
     return;
   }
   const float gs = scale * (g_dev ? *g_dev : 1.f);
   const T* xr = x + bt * V;
   const float l = lse[bt];
-  for (int64_t v = threadIdx.x; v < V; v += LB) row[v] = __expf(io<T>::ld(xr + v) - l);
+  if (vec) {
+    for (int c = threadIdx.x; c < (int)(V >> 3); c += LB) {
+      const uint4 q = ((const uint4*)xr)[c];
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        row[8 * c + 2 * i] = __expf(__uint_as_float(w[i] << 16) - l);
+        row[8 * c + 2 * i + 1] = __expf(__uint_as_float(w[i] & 0xffff0000u) - l);
+      }
+    }
+  } else {
+    for (int64_t v = threadIdx.x; v < V; v += LB) row[v] = __expf(io<T>::ld(xr + v) - l);
+  }
   __syncthreads();
   const int L = (int)min(tgt_len[b], Lmax), S = 2 * L + 1;
   const float* ar = alpha + bt * Smax;
@@ -426,7 +500,18 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
     if (occ > -80.f) atomicAdd(&row[lab], -__expf(occ));
   }
   __syncthreads();
-  for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, gs * row[v]);
+  if (vec) {
+    for (int c = threadIdx.x; c < (int)(V >> 3); c += LB) {
+      uint4 q;
+      q.x = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 0]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 1]) << 16);
+      q.y = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 2]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 3]) << 16);
+      q.z = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 4]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 5]) << 16);
+      q.w = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 6]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 7]) << 16);
+      ((uint4*)dr)[c] = q;
+    }
+  } else {
+    for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, gs * row[v]);
+  }
 }
 
 }  // namespace
@@ -441,6 +526,11 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
 extern "C" int js2t_row_lse(const void* x, float* lse, int64_t* argmax, int64_t rows, int64_t V, int dt, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(x && lse && rows > 0 && V > 0, "row_lse: bad arguments");
+  if (dt == JS2T_BF16 && (V & 7) == 0 && V <= 8 * LB * RL_CH && (((uintptr_t)x) & 15) == 0) {
+    hipLaunchKernelGGL(row_lse_vec_kernel, dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream, (const uint16_t*)x, lse, argmax, rows, V);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((row_lse_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
                                         (const T*)x, lse, argmax, rows, V));
   JS2T_LAUNCH_CHECK();
