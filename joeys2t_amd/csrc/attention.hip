@@ -128,6 +128,14 @@ __device__ __forceinline__ uint32_t row_kbits(uint32_t bits, const uint8_t* mrow
   return bits;
 }
 
+#ifdef JS2T_ATTN_PROF  // s_memtime probes of one wave (tools/attn_fwd_prof.py); not part of the normal build
+__device__ unsigned long long g_attn_prof[8];
+#define ATT_T(i) do { const unsigned long long c_ = __builtin_readcyclecounter(); prof_[i] += c_ - last_; last_ = c_; } while (0)
+#define ATT_PIN(v) asm volatile("s_nop 0" ::"v"(v))
+#else
+#define ATT_T(i)
+#define ATT_PIN(v)
+#endif
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int FWD_MT = 1;  // own-query blocks of 16 per wave
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
@@ -165,13 +173,19 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
   img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
+#ifdef JS2T_ATTN_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_T(0);
     __syncthreads();
+    ATT_T(1);
     if (kt + 1 < nkt) {
       img_dma(Kb, a.ldk, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
       img_dma(Vb, a.ldv, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
+    ATT_T(2);
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
     const uint32_t kbits = tile_kbits(kmask, kt, g);
@@ -192,6 +206,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     // online softmax in base 2: mi = running max of s*scale*log2e, li = running sum of exp2(.. - mi); the dropped
     // probabilities go to the PV product unscaled, 1/(1-p) is applied with 1/li at the end
     const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
+    ATT_PIN(s[0][3][3]);
+    ATT_T(3);
     bf16x8_t pf[FWD_MT][2];
 #pragma unroll
     for (int mt = 0; mt < FWD_MT; ++mt) {
@@ -241,6 +257,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
       pf[mt][0] = pack8(s[mt][0], s[mt][1]);
       pf[mt][1] = pack8(s[mt][2], s[mt][3]);
     }
+    ATT_PIN(pf[0][1]);
+    ATT_T(4);
     // O^T += V^T P^T
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
@@ -251,7 +269,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
         for (int mt = 0; mt < FWD_MT; ++mt) o[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][ss], o[mt][ct], 0, 0, 0);
       }
     cur ^= 1;
+    ATT_PIN(o[0][7][3]);
+    ATT_T(5);
   }
+#ifdef JS2T_ATTN_PROF
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+    for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
+#endif
 #pragma unroll
   for (int mt = 0; mt < FWD_MT; ++mt) {
     const int qrow = q0 + 16 * mt + m;
@@ -624,6 +648,9 @@ AttnArgs to_args(const js2t_attn_desc* d) {
 
 }  // namespace
 
+#ifdef JS2T_ATTN_PROF
+extern "C" int js2t_debug_attn_prof(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 64); }
+#endif
 extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) {
   int rc = check_common(d);
   if (rc) return rc;
