@@ -45,6 +45,7 @@ class Model(nn.Module):
             assert isinstance(self.encoder, TransformerEncoder)
             assert isinstance(self.decoder, TransformerDecoder)
         self._rt_obj: Optional[Runtime] = None
+        self.overlap_ctc = False  # loss path: CTC branch on a second stream (TrainStep(overlap_ctc=True))
 
     # ------------------------------------------------------------------ HIP runtime binding
     def finalize(self, device, compute_dtype: torch.dtype = torch.float32, seed: int = 42) -> "Model":
@@ -116,13 +117,22 @@ class Model(nn.Module):
         if return_type.startswith("loss"):
             assert self.loss_function is not None
             assert "trg" in kwargs and "trg_mask" in kwargs
-            out, ctc_out, src_mask = self._encode_decode(**kwargs)
             lf = self.loss_function
+            ctc_loss = None
+            if (self.overlap_ctc and return_type == "loss" and lf.require_ctc_layer and kwargs["src"].is_cuda and
+                    getattr(self.decoder, "ctc_output_layer", None) is not None):
+                out, ctc_out, src_mask, ctc_loss = self._encode_decode_ctc_aside(lf, **kwargs)
+            else:
+                out, ctc_out, src_mask = self._encode_decode(**kwargs)
             xent_loss, n_correct = lf.xent(out, kwargs["trg"])
             ret = [None, None, None, None]
             if lf.require_ctc_layer and isinstance(ctc_out, Tensor):
-                in_len = src_mask.squeeze(1).sum(dim=1)  # subsampled mask (model.py:125; loss.py:159)
-                ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+                if ctc_loss is None:
+                    in_len = src_mask.squeeze(1).sum(dim=1)  # subsampled mask (model.py:125; loss.py:159)
+                    ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+                else:  # computed on the side stream: join before the two losses meet
+                    torch.cuda.current_stream().wait_stream(self.runtime.side_stream())
+                    ctc_loss.record_stream(torch.cuda.current_stream())
                 ret[0] = (1.0 - lf.ctc_weight) * xent_loss + lf.ctc_weight * ctc_loss
                 ret[1], ret[2] = xent_loss, ctc_loss
             else:
@@ -151,6 +161,26 @@ class Model(nn.Module):
                                                            src_mask=src_mask, trg_input=trg_input,
                                                            unroll_steps=trg_input.size(1), trg_mask=trg_mask, **kwargs)
         return decoder_output, ctc_output, src_mask
+
+    def _encode_decode_ctc_aside(self, lf, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
+                                 **kwargs):
+        """_encode_decode with the CTC branch (projection of the encoder states + CTC loss, model.py:121-126 of the
+        reference) on a second stream: it only needs the encoder output, its alpha/beta recursion keeps 32 of 256 CUs busy
+        for ~0.25 ms and the decoder's kernels (2592 target rows) leave most of the chip idle as well.  Autograd runs the
+        branch's backward on the same second stream.  Same kernels, same values."""
+        encoder_output, encoder_hidden, src_mask = self._encode(src=src, src_length=src_length, src_mask=src_mask, **kwargs)
+        cur, side = torch.cuda.current_stream(), self.runtime.side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ctc_out = self.decoder.project(self.decoder.ctc_output_layer, encoder_output, self.runtime.compute_dtype)
+            in_len = src_mask.squeeze(1).sum(dim=1)
+            ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+        for tns in (encoder_output, src_mask, kwargs["trg"], kwargs["trg_length"]):
+            tns.record_stream(side)
+        decoder_output, _, _, _, _ = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden, src_mask=src_mask,
+                                                  trg_input=trg_input, unroll_steps=trg_input.size(1), trg_mask=trg_mask,
+                                                  compute_ctc=False, **kwargs)
+        return decoder_output, ctc_out, src_mask, ctc_loss
 
     def _encode(self, src: Tensor, src_length: Tensor, src_mask: Tensor, **_kwargs):
         assert _kwargs.get("task", self.task) == self.task, (_kwargs.get("task"), self.task)

@@ -291,6 +291,12 @@ class Runtime:
         return self._rng
 
     # weights in compute dtype: fused view when the store has the params adjacent, else gathered by kernels
+    def side_stream(self) -> "torch.cuda.Stream":
+        """Second stream of this runtime's device for work that is independent of the main chain (Model.overlap_ctc)."""
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        return self._side_stream
+
     def weight(self, params: Sequence[nn.Parameter]) -> torch.Tensor:
         dt = self.compute_dtype
         if self.store is not None:

@@ -30,8 +30,9 @@ class TrainStep:
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
                  learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
                  batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False,
-                 defer_wgrads: bool = True):
+                 defer_wgrads: bool = True, overlap_ctc: bool = False):
         self.model = model
+        model.overlap_ctc = bool(overlap_ctc)
         self.rt = model.runtime
         self.store = self.rt.store
         self.normalization, self.batch_multiplier, self.n_gpu = normalization, batch_multiplier, n_gpu

@@ -14,7 +14,9 @@ from golden_cfg import tiny_cfg
 pytestmark = pytest.mark.gpu
 
 
-def test_three_updates_match_reference(device):
+@pytest.mark.parametrize("overlap_ctc", [False, True])
+def test_three_updates_match_reference(device, overlap_ctc):
+    """overlap_ctc: the CTC branch (projection, loss, their backward) on the runtime's second stream."""
     from joeys2t_amd.batch import Batch
     from joeys2t_amd.model import build_model
     from joeys2t_amd.training import TrainStep
@@ -25,7 +27,8 @@ def test_three_updates_match_reference(device):
     model.load_state_dict(golden_sd(g, "sd0."))
     model.finalize(device, torch.float32)
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=1.0,
-                     learning_rate_warmup=2, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=2, n_gpu=1)
+                     learning_rate_warmup=2, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=2, n_gpu=1,
+                     overlap_ctc=overlap_ctc)
     lrs, norms = [], []
     for i in range(6):
         b = Batch(src=torch.from_numpy(g[f"mb{i}.src"]), src_length=torch.from_numpy(g[f"mb{i}.src_length"]),
