@@ -100,7 +100,10 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
     model.finalize(device, dtype, seed=seed)
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
                      learning_rate_warmup=10000, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1,
-                     n_gpu=world, overlap_ctc=os.environ.get("JS2T_OVERLAP_CTC", "1") != "0")
+                     n_gpu=world,
+                     # second stream for the CTC branch: single-process runs only (two ranks time-slicing one card in
+                     # the gloo rehearsal turn its cross-stream waits into a 13x slowdown; not measurable over RCCL here)
+                     overlap_ctc=world == 1 and os.environ.get("JS2T_OVERLAP_CTC", "1") != "0")
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
                            specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
                            cmvn=dict(norm_means=True, norm_vars=True, before=True))
