@@ -173,6 +173,12 @@ int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_t cout, int
                           js2t_stream stream);
 int js2t_conv_weight_unpack_grad(const float* dwp_t, float* dw, int64_t cout, int64_t cin, int64_t k,
                                  int accumulate, js2t_stream stream); /* dwp_t is [K*Cin, Cout] (transposed wgrad) */
+/* col[(b*tout+t), kw*C+c] = x[b, t*stride-pad+kw, c], zero outside [0, tin): the strided convolution's A operand
+ * (nn.Conv1d(k, stride 2, padding k//2) of encoders.py:339-346 as a GEMM) written out once - forward and weight
+ * gradient then run on the LDS-DMA kernels, 2.4x faster than gathering the taps inside the GEMM.  16-byte pieces:
+ * C % 8 == 0 (bf16) / C % 4 == 0 (f32). */
+int js2t_im2col(const void* x, void* col, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
+                int64_t stride, int64_t pad, int dt, js2t_stream stream);
 /* dx[b,tau,c] = sum over taps of dcol[(b*tout+t), kw*C+c] with t*stride-pad+kw == tau (conv dgrad gather). */
 int js2t_col2im(const void* dcol, void* dx, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
                 int64_t stride, int64_t pad, int dt, js2t_stream stream);

@@ -274,6 +274,50 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, in
   }
 }
 
+// col[(b*tout + t), kw*C + c] = x[b, t*stride - pad + kw, c] (0 outside the utterance): the A operand of the strided
+// convolution as a plain row-major matrix, 16 bytes per thread (C % 8 == 0 for bf16, C % 4 == 0 for f32)
+template <typename T, int VEC>
+__global__ void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K,
+                              int64_t stride, int64_t pad) {
+  const int64_t cv = C / VEC, total = B * tout * K * cv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / (K * cv), rem = i - row * (K * cv), kw = rem / cv, c = (rem - kw * cv) * VEC;
+    const int64_t b = row / tout, t = row - b * tout, tau = t * stride - pad + kw;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (tau >= 0 && tau < tin) v = *(const uint4*)(x + (b * tin + tau) * C + c);
+    *(uint4*)(col + row * (K * C) + kw * C + c) = v;
+  }
+}
+
+// bf16, C % 8 == 0: one 16-byte piece of dx per thread, the (at most ceil(K / stride)) contributing taps summed in f32
+__global__ void col2im_vec_kernel(const uint16_t* __restrict__ dcol, uint16_t* __restrict__ dx, int64_t B, int64_t tin, int64_t tout,
+                                  int64_t C, int64_t K, int64_t stride, int64_t pad) {
+  const int64_t cv = C >> 3, total = B * tin * cv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / (tin * cv), rem = i - b * tin * cv, tau = rem / cv, c = (rem - tau * cv) << 3;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t kw = 0; kw < K; ++kw) {
+      const int64_t num = tau + pad - kw;
+      if (num < 0 || num % stride) continue;
+      const int64_t t = num / stride;
+      if (t >= tout) continue;
+      const uint4 q = *(const uint4*)(dcol + (b * tout + t) * (K * C) + kw * C + c);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[2 * j] += __uint_as_float(w[j] << 16);
+        s[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
+    }
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16_bits(s[0]) | ((uint32_t)f32_to_bf16_bits(s[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16_bits(s[2]) | ((uint32_t)f32_to_bf16_bits(s[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16_bits(s[4]) | ((uint32_t)f32_to_bf16_bits(s[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16_bits(s[6]) | ((uint32_t)f32_to_bf16_bits(s[7]) << 16);
+    *(uint4*)(dx + (b * tin + tau) * C + c) = o;
+  }
+}
+
 __global__ void subsample_len_mask_kernel(const int64_t* __restrict__ lengths, int64_t* __restrict__ out_lengths,
                                           uint8_t* __restrict__ mask, int64_t B, int64_t T_out, int k0, int k1, int k2, int k3,
                                           int n_layers) {
@@ -469,8 +513,32 @@ extern "C" int js2t_col2im(const void* dcol, void* dx, int64_t B, int64_t tin, i
                            int64_t stride, int64_t pad, int dt, js2t_stream stream) {
   if (B * tin * C == 0) return JS2T_OK;
   JS2T_CHECK(dcol && dx && stride > 0 && K > 0, "col2im: bad arguments");
+  if (dt == JS2T_BF16 && (C & 7) == 0 && ((((uintptr_t)dcol) | ((uintptr_t)dx)) & 15) == 0) {
+    hipLaunchKernelGGL(col2im_vec_kernel, dim3(ew_grid(B * tin * (C >> 3))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dcol, (uint16_t*)dx, B, tin, tout, C, K, stride, pad);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((col2im_kernel<T>), dim3(ew_grid(B * tin * C)), dim3(EW_THREADS), 0,
                                         (hipStream_t)stream, (const T*)dcol, (T*)dx, B, tin, tout, C, K, stride, pad));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_im2col(const void* x, void* col, int64_t B, int64_t tin, int64_t tout, int64_t C, int64_t K, int64_t stride,
+                           int64_t pad, int dt, js2t_stream stream) {
+  if (B * tout * C * K == 0) return JS2T_OK;
+  JS2T_CHECK(x && col && stride > 0 && K > 0 && tin > 0, "im2col: bad arguments");
+  JS2T_CHECK(dt == JS2T_F32 || dt == JS2T_BF16, "im2col: bad dtype");
+  const int vec = dt == JS2T_BF16 ? 8 : 4;
+  JS2T_CHECK(C % vec == 0 && ((((uintptr_t)x) | ((uintptr_t)col)) & 15) == 0, "im2col: channels must fill 16-byte pieces, buffers 16-byte aligned");
+  const int64_t work = B * tout * K * (C / vec);
+  if (dt == JS2T_BF16)
+    hipLaunchKernelGGL((im2col_kernel<uint16_t, 8>), dim3(ew_grid(work)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)col, B, tin, tout, C, K, stride, pad);
+  else
+    hipLaunchKernelGGL((im2col_kernel<float, 4>), dim3(ew_grid(work)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)col, B, tin, tout, C, K, stride, pad);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -308,6 +308,17 @@ def conv_weight_unpack_grad(dwp_t: torch.Tensor, cout: int, cin: int, k: int, ou
     return dw
 
 
+def im2col(x3d, K, stride, pad, tout):
+    """[B, T, C] -> [B*tout, K*C] (js2t_im2col): rows of the strided convolution's A operand."""
+    _dev(x3d)
+    B, tin, Cc = x3d.shape
+    x3d = x3d.contiguous()
+    col = torch.empty((B * tout, K * Cc), dtype=x3d.dtype, device=x3d.device)
+    check(lib().js2t_im2col(_p(x3d), _p(col), C.c_int64(B), C.c_int64(tin), C.c_int64(tout), C.c_int64(Cc), C.c_int64(K),
+                            C.c_int64(stride), C.c_int64(pad), dt_code(x3d), _stream()), "js2t_im2col")
+    return col
+
+
 def col2im(dcol, B, tin, tout, Cc, K, stride, pad):
     _dev(dcol)
     dx = torch.empty((B, tin, Cc), dtype=dcol.dtype, device=dcol.device)

@@ -657,3 +657,31 @@ def test_layernorm_bwd_fused_dropout_output(device):
     ref = ops.dropout_bwd(dx0, 0.2, rng, 11)
     assert torch.equal((ref == 0), (dxd == 0))
     torch.testing.assert_close(dxd.float(), ref.float(), rtol=1e-2, atol=1e-3)  # fused: scaled from f32, not from the bf16 dx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_im2col_matches_unfold(device, dtype):
+    """js2t_im2col: rows of the k=5, stride-2, pad-2 convolution's A operand ([b*tout+t, kw*C+c]), zeros outside."""
+    B, T, Cc, K, stride, pad = 3, 37, 16, 5, 2, 2
+    tout = (T + 2 * pad - K) // stride + 1
+    x = rnd(B, T, Cc, seed=5).to(dtype)
+    col = ops.im2col(x.to(device), K, stride, pad, tout).cpu()
+    xp = torch.nn.functional.pad(x.float(), (0, 0, pad, pad))  # [B, T+2p, C]
+    ref = torch.stack([xp[:, t * stride:t * stride + K, :].reshape(B, K * Cc) for t in range(tout)], dim=1).reshape(B * tout, K * Cc)
+    assert torch.equal(col.float(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_col2im_matches_scatter_add(device, dtype):
+    """js2t_col2im (scalar and 16-byte bf16 kernel): the adjoint of im2col."""
+    B, T, Cc, K, stride, pad = 3, 37, 16, 5, 2, 2
+    tout = (T + 2 * pad - K) // stride + 1
+    dcol = rnd(B * tout, K * Cc, seed=6).to(dtype)
+    dx = ops.col2im(dcol.to(device), B, T, tout, Cc, K, stride, pad).cpu().float()
+    ref = torch.zeros(B, T + 2 * pad, Cc)
+    d3 = dcol.float().view(B, tout, K, Cc)
+    for t in range(tout):
+        ref[:, t * stride:t * stride + K, :] += d3[:, t]
+    ref = ref[:, pad:pad + T]
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(dx, ref, **tol)
