@@ -351,6 +351,34 @@ __global__ __launch_bounds__(256) void transpose_groups_kernel(const uint16_t* _
   const int64_t off = table[lo * 4], R = table[lo * 4 + 1], Cc = table[lo * 4 + 2], t0 = table[lo * 4 + 3];
   const int64_t tiles_c = (Cc + 63) >> 6;
   const int64_t tr = (bid - t0) / tiles_c, tc = (bid - t0) - tr * tiles_c;
+  if (((R | Cc | off) & 7) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    // 16-byte accesses on both sides (all weight matrices of the models here): rows in as 8-element pieces, columns
+    // out as 8-element pieces gathered from the padded tile (33-dword row pitch: the 8 x 8 lanes of a wave hit 32
+    // different banks, the two halves of a dword are read by neighbouring lanes)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int o = threadIdx.x + 256 * k, r = o >> 3, c8 = (o & 7) << 3;
+      const int64_t rr = tr * 64 + r, cc = tc * 64 + c8;
+      if (rr < R && cc < Cc) {
+        const uint4 q = *(const uint4*)(src + off + rr * Cc + cc);
+        uint32_t* d = (uint32_t*)&tile[r][c8];
+        d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int o = threadIdx.x + 256 * k, c = o >> 3, r8 = (o & 7) << 3;
+      const int64_t cc = tc * 64 + c, rr = tr * 64 + r8;
+      if (rr < R && cc < Cc) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[r8 + 2 * j][c] | ((uint32_t)tile[r8 + 2 * j + 1][c] << 16);
+        *(uint4*)(dst + off + cc * R + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {
     const int64_t rr = tr * 64 + r, cc = tc * 64 + tx;
