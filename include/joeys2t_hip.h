@@ -197,7 +197,7 @@ int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_lengths, ui
 int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int64_t rows, int64_t D, float eps, int dt, js2t_stream stream);
 /* dx (dt) = LN'(dy) [+ add_scale * add]  (add: optional residual-branch gradient, same shape as dx);
- * dgamma/dbeta f32[D] (may both be NULL); partial = f32[2 * ceil(rows/32) * D] workspace. */
+ * dgamma/dbeta f32[D] (may both be NULL); partial = f32[2 * ceil(rows/16) * D] workspace. */
 int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                        const float* rstd, void* dx, const void* add, float add_scale, float* dgamma,
                        float* dbeta, float* partial, int accumulate, int64_t rows, int64_t D, int dt,

@@ -158,7 +158,8 @@ template <> struct ld8<float> {
   }
 };
 constexpr int LNV_MAXCH = 4;        // chunks of 8 columns per lane -> D <= 2048
-constexpr int LNV_ROWS = 64;        // rows per block in the backward kernel (shared by its 4..16 waves)
+constexpr int LNV_ROWS = 64;        // most rows per block in the backward kernel (shared by its 4..16 waves)
+constexpr int LNV_MIN_ROWS = 16;    // fewest (sizes the caller's partial-sum workspace: 2 * ceil(rows / 16) * D floats)
 
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
                                                                  const T* __restrict__ add, float add_scale,
                                                                  float* __restrict__ partial, float* dgamma_acc,
                                                                  float* dbeta_acc, int64_t rows, int D, T* __restrict__ dxd,
-                                                                 float drop_p, const uint64_t* __restrict__ rng, uint32_t rng_stream) {
+                                                                 float drop_p, const uint64_t* __restrict__ rng, uint32_t rng_stream,
+                                                                 int rows_per_block) {
   extern __shared__ float red[];  // [waves][2][D]
   // optional second output dxd = dropout_bwd(dx) for the mask of call site rng_stream: the block that produced this
   // LayerNorm's input starts its backward with exactly that product (one read of dx and one launch less)
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
   const float dsc = 1.f / (1.f - drop_p);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int nch = D >> 3;
-  const int rpw = LNV_ROWS / nw;
+  const int rpw = rows_per_block / nw;
   float gm[NCH][8], ag[NCH][8], ab[NCH][8];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
     for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; gm[j][i] = 0.f; }
     if (c < nch) ld8<float>::ld(gamma + 8 * c, gm[j]);
   }
-  const int64_t r0 = (int64_t)blockIdx.x * LNV_ROWS + w * rpw;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block + w * rpw;
   for (int rr = 0; rr < rpw; ++rr) {
     const int64_t row = r0 + rr;
     if (row >= rows) break;
@@ -422,7 +424,7 @@ template <typename T, int NCH>
 static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                              const void* add, float add_scale, float* part, float* dga, float* dba, int64_t rows, int D,
                              int64_t nblk, int nw, size_t lds, hipStream_t s, void* dxd, float drop_p, const uint64_t* rng,
-                             uint32_t rng_stream) {
+                             uint32_t rng_stream, int rows_per_block) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_vec_kernel<T, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -433,7 +435,7 @@ static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, 
     attr_set = true;
   }
   hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T, NCH>), dim3((unsigned)nblk), dim3(64 * nw), lds, s, (const T*)dy, (const T*)x, gamma,
-                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D, (T*)dxd, drop_p, rng, rng_stream);
+                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D, (T*)dxd, drop_p, rng, rng_stream, rows_per_block);
   return JS2T_OK;
 }
 
@@ -487,23 +489,30 @@ extern "C" int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const f
     const bool want_p = dgamma && dbeta;
     const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
     JS2T_CHECK(!want_p || direct || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
-    const int64_t nblk = (rows + LNV_ROWS - 1) / LNV_ROWS;
     // waves per block: as many as a 64 KB cross-wave reduction buffer allows (16 for D <= 512)
     int nw = 16;
     while (nw > 4 && (size_t)nw * 2 * D * sizeof(float) > 65536) nw >>= 1;
+    // rows per wave: one block per CU is resident (16 waves x 100 VGPRs), so the rows are cut to fill ONE round of the
+    // 256 CUs - 12000 rows: 3 per wave = 250 blocks (4 per wave left 68 CUs idle), 2592 rows: 1 per wave = 162 blocks
+    // (were 41)
+    int rpw = (int)((rows + 256 * (int64_t)nw - 1) / (256 * (int64_t)nw));
+    rpw = rpw < 1 ? 1 : (rpw > LNV_ROWS / nw ? LNV_ROWS / nw : rpw);
+    if (rpw * nw < LNV_MIN_ROWS) rpw = LNV_MIN_ROWS / nw;
+    const int rows_per_block = rpw * nw;
+    const int64_t nblk = (rows + rows_per_block - 1) / rows_per_block;
     const size_t lds = sizeof(float) * 2 * nw * D;
     float* part = (want_p && !direct) ? partial : (float*)nullptr;
     float* dga = direct ? dgamma : (float*)nullptr;
     float* dba = direct ? dbeta : (float*)nullptr;
     int rc;
     if (dt == JS2T_F32) {
-      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
-         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
-                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream);
+      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block)
+         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block)
+                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block);
     } else {
-      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
-         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream)
-                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream);
+      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block)
+         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block)
+                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block);
     }
     if (rc != JS2T_OK) return rc;
     JS2T_LAUNCH_CHECK();

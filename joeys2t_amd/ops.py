@@ -366,7 +366,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
         else:
             dgamma = torch.empty((D,), dtype=torch.float32, device=x.device)
             dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
-        nparts = (rows + 31) // 32  # >= one partial per row block of the vectorised backward kernel (64 rows)
+        nparts = (rows + 15) // 16  # >= one partial per row block of the vectorised backward kernel (16..64 rows)
         partial = torch.empty((2 * max(nparts, 1) * D,), dtype=torch.float32, device=x.device)
     if drop is None:
         check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
