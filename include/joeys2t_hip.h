@@ -109,8 +109,8 @@ void js2t_gemm_force_regstage(int on);
 /* Test hook: when on, every k-contiguous bf16 product with a bf16 result the 256x256 half-tile-ring kernel can run takes it
  * (by default only products of >= 512 such tiles and K >= 1024 do). */
 void js2t_gemm_force_w256(int on);
-/* Kernel selection for the persistent 192x128 kernel (k-contiguous bf16 operands, bf16 result, N % 128 == 0,
- * K % 64 == 0, K >= 192, bias / ReLU / dropout / residual-or-gate epilogue) and its reduction-major form inside
+/* Kernel selection for the persistent 192x128 kernel (k-contiguous bf16 operands, bf16 result, N % 8 == 0, N >= 128,
+ * K % 8 == 0, K >= 192, bias / ReLU / dropout / residual-or-gate epilogue) and its reduction-major form inside
  * js2t_gemm_grouped (f32 result, N % 128 == 0, M % 8 == 0, no split-K; only in mode 1): 0 = never, 1 = every product
  * that qualifies (test hook), -1 = k-contiguous products that qualify and have >= 200 tiles (default). */
 void js2t_gemm_p192_mode(int mode);

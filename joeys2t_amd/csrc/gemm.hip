@@ -1282,7 +1282,7 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16;
 template <int EPI>
 __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, float (&bias_r)[8]) {
-  const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
+  const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < d.N;  // n >= N: a column group of the N tail
   if (has_bias && (((uintptr_t)d.bias) & 15) == 0) {
     const float4 b0 = *(const float4*)(d.bias + n), b1 = *(const float4*)(d.bias + n + 4);
     bias_r[0] = b0.x, bias_r[1] = b0.y, bias_r[2] = b0.z, bias_r[3] = b0.w;
@@ -1299,6 +1299,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
                                                 const float (&bias_r)[8], uint32_t drop_key) {
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 8 * r;
+  if (n >= d.N) return;  // N is a multiple of 8: a lane's column group lies inside or outside as a whole
   const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
   const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
   const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (M0) stay on the scalar unit
-  const int M = d.M, N = d.N, nk = d.K >> 6;
+  const int M = d.M, N = d.N, K = d.K, nk = (K + 63) >> 6;
   const int ntiles = tiles_m * tiles_n, G = gridDim.x;
   const uint16_t* Ab = (const uint16_t*)d.A;
   const uint16_t* Bb = (const uint16_t*)d.B;
@@ -1398,17 +1399,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
   // ~570 cycles (the texture-address path takes ~16 cycles per instruction).
   // Past the block's last stage the requests go on (re-reading k = 0 of the last tile into a free slot): the loop and
   // its vmcnt counts stay branch-free, at the price of three unused stages per block.
-  int p_k0 = 0;
+  int p_k0 = 0, p_klim = 64;
   unsigned char* p_st = smem;
+  // k offset (inside a stage) of the lane's 8 elements: the same for every A piece, two values for the B pieces
+  const int kofs_a = (s8 ^ (r8 & 7)) << 3, kofs_b0 = (s8 ^ (r8 >> 1)) << 3, kofs_b1 = (s8 ^ ((8 + r8) >> 1)) << 3;
+  const uint16_t* zsrc = (const uint16_t*)&g_zero16;
   auto issue_begin = [&]() {
     p_k0 = iv < ntiles ? ik << 6 : 0;
+    p_klim = K - p_k0;  // < 64 only in the partial last stage of a tile (K % 64 != 0): those k come from a zero constant
     p_st = smem + islot * P_STAGE;
   };
   auto issue_piece = [&](int q) {  // q is a compile-time constant at every call site
-    if (q < 6)
-      __builtin_amdgcn_global_load_lds((g_cvoid*)(asrc[q < 6 ? q : 0] + p_k0), (l_void*)(p_st + (w * 6 + q) * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((g_cvoid*)(bsrc[q >= 6 ? q - 6 : 0] + p_k0), (l_void*)(p_st + P_ATILE + (w * 4 + q - 6) * 1024), 16, 0, 0);
+    if (q < 6) {
+      const uint16_t* sp = asrc[q < 6 ? q : 0] + p_k0;
+      if (p_klim < 64) {
+        if (kofs_a >= p_klim) sp = zsrc;
+      }
+      __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(p_st + (w * 6 + q) * 1024), 16, 0, 0);
+    } else {
+      const uint16_t* sp = bsrc[q >= 6 ? q - 6 : 0] + p_k0;
+      if (p_klim < 64) {
+        if ((((w * 4 + q - 6) & 1) ? kofs_b1 : kofs_b0) >= p_klim) sp = zsrc;
+      }
+      __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(p_st + P_ATILE + (w * 4 + q - 6) * 1024), 16, 0, 0);
+    }
   };
   auto issue_finish = [&]() {
     if (iv < ntiles && ++ik == nk) {
@@ -1781,7 +1795,7 @@ int g_p192_mode = -1;
 inline bool p192_eligible(const js2t_gemm_desc& d) {
   if (g_p192_mode == 0) return false;
   if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
-  if ((d.N & 127) || (d.K & 63) || d.K < 192 || d.M < 1) return false;
+  if ((d.N & 7) || d.N < 128 || (d.K & 7) || d.K < 192 || d.M < 1) return false;
   if (d.preact || d.beta != 0.f || !(d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) || (d.residual && d.gate)) return false;
   if ((((uintptr_t)d.C) & 15) || (d.ldc & 7)) return false;
   if (d.residual && ((d.ldr & 7) || (((uintptr_t)d.residual) & 15))) return false;
@@ -1804,7 +1818,7 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     n_cu = cu & ~7;  // a multiple of 8 keeps a block's tiles on one XCD's slice of the tile order
     if (n_cu == 0) n_cu = cu;
   }
-  const int tm = cdiv(d.M, P_BM), tn = d.N >> 7;
+  const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
   const int grid = tm * tn < n_cu ? tm * tn : n_cu;
   hipLaunchKernelGGL(gemm_bf16_p192_kernel<EPI>, dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
   JS2T_LAUNCH_CHECK();

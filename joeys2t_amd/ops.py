@@ -85,11 +85,13 @@ def _takes_p192(d) -> bool:
     label the launches bench.py times with the kernel rocprofv3 will show for them."""
     if d.trans_a or d.trans_b or d.conv or d.split_k > 1 or d.batch != 1 or d.dtype_c != BF16:
         return False
-    if (d.N & 127) or (d.K & 63) or d.K < 192 or d.preact or d.beta != 0.0 or d.act not in (0, 1) or (d.residual and d.gate):
+    if (d.N & 7) or d.N < 128 or (d.K & 7) or d.K < 192 or d.preact or d.beta != 0.0 or d.act not in (0, 1) or (d.residual and d.gate):
+        return False
+    if d.bias and (d.bias & 15):
         return False
     if ((d.C or 0) & 15) or (d.ldc & 7) or (d.residual and ((d.ldr & 7) or (d.residual & 15))) or (d.gate and ((d.ldg & 7) or (d.gate & 15))):
         return False
-    return -(-d.M // 192) * (d.N >> 7) >= 200
+    return -(-d.M // 192) * -(-d.N // 128) >= 200
 
 
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, batch=1, batch_inner=1,

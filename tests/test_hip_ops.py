@@ -595,11 +595,13 @@ def _w256_checks(device, A, B, C, ref, M, N, K):
         torch.testing.assert_close(out1.float(), out2.float(), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(192, 128, 192), (500, 256, 320), (12000, 512, 512), (7000, 1536, 256), (52000, 256, 192)])
+@pytest.mark.parametrize("M,N,K", [(192, 128, 192), (500, 256, 320), (12000, 512, 512), (7000, 1536, 256), (52000, 256, 192),
+                                   (500, 264, 200), (3000, 1000, 520), (2600, 136, 5000)])
 def test_gemm_bf16_p192_persistent_tile(device, M, N, K):
     """The persistent 192x128 kernel (one block per CU, one DMA ring across its tiles): fewer tiles than CUs, several
-    tiles per block (ring crossing tile boundaries), a ragged last row tile; plain result against fp32 math, fused
-    epilogues against the register-staged kernel (same dropout decisions by definition)."""
+    tiles per block (ring crossing tile boundaries), a ragged last row tile, partial last column tiles (N % 128 != 0) and
+    partial last K stages (K % 64 != 0: zero rows from a constant); plain result against fp32 math, fused epilogues
+    against the register-staged kernel (same dropout decisions by definition)."""
     from joeys2t_amd._lib import lib
     A = rnd(M, K, seed=1).bfloat16().to(device)
     B = rnd(N, K, seed=2).bfloat16().to(device)
