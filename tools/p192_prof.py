@@ -12,19 +12,26 @@ from joeys2t_amd import ops  # noqa: E402
 from joeys2t_amd._lib import lib  # noqa: E402
 
 M, N, K = (int(v) for v in sys.argv[1:4])
+mode = sys.argv[4] if len(sys.argv) > 4 else "plain"  # plain | gate | res
 dev = torch.device("cuda:0")
 lib().js2t_gemm_p192_mode(1)
 A = torch.randn(M, K, device=dev).bfloat16()
 B = torch.randn(N, K, device=dev).bfloat16()
 C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+kw = {}
+if mode == "gate":
+    kw = dict(gate=(torch.randn(M, N, device=dev) * (torch.rand(M, N, device=dev) > 0.5)).bfloat16(), ldg=N, gate_scale=1.1)
+elif mode == "res":
+    kw = dict(residual=torch.randn(M, N, device=dev).bfloat16(), ldr=N, res_scale=1.0, bias=torch.randn(N, device=dev),
+              dropout_p=0.1, rng=ops.dropout_rng(dev), rng_stream=3)
 for _ in range(3):
-    ops.gemm(A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N)
+    ops.gemm(A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 8)()
 fn = lib().js2t_debug_p192_prof
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(out) == 0
-tiles = -(-M // 192) * (N // 128)
+tiles = -(-M // 192) * -(-N // 128)
 per_block = -(-tiles // min(tiles, 256))
 steps = per_block * (K // 64)
 names = ["top: reads(F1)+MFMA(F0) issue", "vmcnt wait", "lgkmcnt wait", "barrier", "DMA issue", "reads(F0)+MFMA(F1) issue", "epilogue (per tile)"]
