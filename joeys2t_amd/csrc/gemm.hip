@@ -1251,6 +1251,13 @@ int launch_bf16_w256(const js2t_gemm_desc& d, hipStream_t s) {
 //    stored from registers (direct_tile_epilogue).
 constexpr int P_BM = 192, P_ATILE = P_BM * 128, P_STAGE = P_ATILE + 16384, P_NST = 3, P_LDS = P_NST * P_STAGE, P_PER = 10;
 #ifdef JS2T_P192_PROF
+__device__ unsigned long long g_p192_prof2[8];
+#define P192_E(i)                                                   \
+  do {                                                              \
+    const unsigned long long c_ = __builtin_readcyclecounter();     \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_p192_prof2[i] += c_ - e_last_; \
+    e_last_ = c_;                                                   \
+  } while (0)
 __device__ unsigned long long g_p192_prof[8];
 #define P192_T(i)                                          \
   do {                                                     \
@@ -1260,6 +1267,7 @@ __device__ unsigned long long g_p192_prof[8];
   } while (0)
 #else
 #define P192_T(i)
+#define P192_E(i)
 #endif
 
 typedef int frag_i4 __attribute__((ext_vector_type(4)));  // a bf16x8 fragment carried across loop iterations as 4 dwords
@@ -1316,11 +1324,19 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
     for (int e = 0; e < 4; ++e) rg[i][e] = *(const uint4*)(rsrc + (int64_t)min(mw + 16 * i + 4 * g + e, M - 1) * rld);
   };
+#ifdef JS2T_P192_PROF
+  unsigned long long e_last_ = __builtin_readcyclecounter();
+#endif
   if (has_res || has_gate) load_rg(0);
+  P192_E(0);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int mrow = mw + 16 * i + 4 * g;
     if ((has_res || has_gate) && i < 2) load_rg(i + 1);
+#ifdef JS2T_P192_PROF
+    if (has_res || has_gate) asm volatile("s_nop 0" ::"v"(rg[i][3].w));  // waits for block i's rows
+    P192_E(1 + 2 * i);
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = mrow + e;
@@ -1361,6 +1377,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
       }
     }
+    P192_E(2 + 2 * i);
   }
 }
 
@@ -1915,6 +1932,13 @@ extern "C" void js2t_gemm_force_w256(int on) { g_force_w256 = on != 0; }
 #ifdef JS2T_P192_PROF
 extern "C" int js2t_debug_p192_prof(unsigned long long* out8) {
   return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof), 64);
+}
+extern "C" int js2t_debug_p192_prof2(unsigned long long* out8, int reset) {
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p192_prof2), z, 64);
+  }
+  return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof2), 64);
 }
 #endif
 extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode); }

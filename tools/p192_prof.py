@@ -24,7 +24,12 @@ if mode == "gate":
 elif mode == "res":
     kw = dict(residual=torch.randn(M, N, device=dev).bfloat16(), ldr=N, res_scale=1.0, bias=torch.randn(N, device=dev),
               dropout_p=0.1, rng=ops.dropout_rng(dev), rng_stream=3)
-for _ in range(3):
+fn2 = lib().js2t_debug_p192_prof2
+fn2.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+for it in range(3):
+    if it == 2:
+        torch.cuda.synchronize()
+        fn2(None, 1)
     ops.gemm(A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 8)()
@@ -41,3 +46,9 @@ for i, n in enumerate(names):
     print(f"{n:34s} {out[i] / den:9.1f} cycles")
     tot += out[i]
 print(f"total per step {tot / steps:9.1f}   (MFMA-bound: 768)")
+out2 = (ctypes.c_ulonglong * 8)()
+assert fn2(out2, 0) == 0
+enames = ["issue rows of block 0", "wait block 0", "compute + store block 0", "wait block 1", "compute + store block 1", "wait block 2", "compute + store block 2"]
+print("epilogue of wave 0 (cycles per tile):")
+for i, n in enumerate(enames):
+    print(f"  {n:28s} {out2[i] / per_block:9.1f}")
