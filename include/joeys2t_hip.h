@@ -239,6 +239,12 @@ int js2t_attn_head_mean(const void* P, float* out, int64_t B, int64_t H, int64_t
  * F.log_softmax statistics of model.py:121,126 and search.py:562; argmax of model.py:139-143. */
 int js2t_row_lse(const void* x, float* lse, int64_t* argmax, int64_t rows, int64_t V, int dt, js2t_stream stream);
 
+/* CTC best-path decoding of the encoder-side output layer (`return_type="decode_ctc"` hands out ctc_out,
+ * model.py:162-166, but nothing in the reference consumes it): best[b,t] = argmax_v logits (js2t_row_lse's argmax);
+ * this call collapses repeats and drops blanks inside the first in_len[b] frames: out_ids i64[B,T] (pad-filled),
+ * out_len i64[B]. */
+int js2t_ctc_collapse(const int64_t* best, const int64_t* in_len, int64_t* out_ids, int64_t* out_len, int64_t B,
+                      int64_t T, int64_t blank, int64_t pad, js2t_stream stream);
 /* y = x - lse(x) row-wise — F.log_softmax(dim=-1) (model.py:121,126; search.py:258,562). */
 int js2t_log_softmax(const void* x, int dt, void* y, int y_dt, int64_t rows, int64_t V, js2t_stream stream);
 

@@ -514,6 +514,31 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------- CTC best path: collapse repeats, drop blanks
+// one wave per utterance: keep[t] = t < len and best[t] != blank and (t == 0 or best[t] != best[t-1]); kept labels are
+// compacted with a ballot prefix count, 64 frames per round
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int64_t* __restrict__ best, const int64_t* __restrict__ in_len,
+                                                         int64_t* __restrict__ out_ids, int64_t* __restrict__ out_len, int64_t T,
+                                                         int64_t blank, int64_t pad) {
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t len = min(in_len[b], T);
+  const int64_t* row = best + b * T;
+  int64_t* orow = out_ids + b * T;
+  int64_t n = 0;
+  for (int64_t t0 = 0; t0 < T; t0 += 64) {
+    const int64_t t = t0 + lane;
+    const int64_t cur = t < len ? row[t] : blank;
+    const int64_t prev = (t > 0 && t < len) ? row[t - 1] : -1;
+    const bool keep = t < len && cur != blank && cur != prev;
+    const unsigned long long m = __ballot(keep);
+    if (keep) orow[n + __popcll(m & ((1ull << lane) - 1ull))] = cur;
+    n += __popcll(m);
+  }
+  for (int64_t t = n + lane; t < T; t += 64) orow[t] = pad;
+  if (lane == 0) out_len[b] = n;
+}
+
 }  // namespace
 
 #define DISPATCH_DT(dt, T, ...)                                  \
@@ -533,6 +558,16 @@ extern "C" int js2t_row_lse(const void* x, float* lse, int64_t* argmax, int64_t 
   }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((row_lse_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
                                         (const T*)x, lse, argmax, rows, V));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_ctc_collapse(const int64_t* best, const int64_t* in_len, int64_t* out_ids, int64_t* out_len, int64_t B, int64_t T,
+                                 int64_t blank, int64_t pad, js2t_stream stream) {
+  if (B == 0) return JS2T_OK;
+  JS2T_CHECK(best && in_len && out_ids && out_len && B > 0 && T > 0, "ctc_collapse: bad arguments");
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, best, in_len, out_ids, out_len, T, blank,
+                     pad);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -498,6 +498,19 @@ def row_lse(x2d: torch.Tensor, want_argmax: bool = False):
     return lse, am
 
 
+def ctc_collapse(best: torch.Tensor, in_len: torch.Tensor, blank: int, pad: int):
+    """best i64[B,T] (frame-wise arg-max labels) -> (ids i64[B,T] pad-filled, lengths i64[B]): repeats merged, blanks dropped."""
+    _dev(best, in_len)
+    B, T = best.shape
+    best = best.contiguous()
+    in_len = in_len.to(torch.int64).contiguous()
+    out = torch.empty((B, T), dtype=torch.int64, device=best.device)
+    n = torch.empty((B,), dtype=torch.int64, device=best.device)
+    check(lib().js2t_ctc_collapse(_p(best), _p(in_len), _p(out), _p(n), C.c_int64(B), C.c_int64(T), C.c_int64(blank), C.c_int64(pad),
+                                  _stream()), "js2t_ctc_collapse")
+    return out, n
+
+
 def log_softmax(x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     _dev(x)
     x = x.contiguous()

@@ -202,3 +202,23 @@ def search(model, batch, max_output_length: int, beam_size: int, beam_alpha: flo
         return t.detach().cpu().numpy() if torch.is_tensor(t) else t
 
     return _np(out), _np(scores), _np(att)
+
+
+def ctc_greedy(model, batch):
+    """CTC best-path decoding of the encoder-side output layer (the reference's `decode_ctc` return type hands
+    out ctc_out, model.py:162-166, without a consumer): encode once, project with `decoder.ctc_output_layer`, take the
+    frame-wise arg-max inside each utterance's sub-sampled length (model.py:125), merge repeats, drop blanks
+    (blank = BOS, model.py:84).  Returns NumPy (ids i64[B, T'] pad-filled, lengths i64[B])."""
+    from joeys2t_amd import ops
+    layer = getattr(model.decoder, "ctc_output_layer", None)
+    if layer is None:
+        raise ValueError("ctc_greedy: the model has no CTC output layer (loss: crossentropy-ctc)")
+    with torch.no_grad():
+        encoder_output, _, src_mask, _ = model(return_type="encode", **vars(batch))
+        ctc_out = model.decoder.project(layer, encoder_output, model.runtime.compute_dtype)  # [B, T', V]
+        B, T, V = ctc_out.shape
+        _, best = ops.row_lse(ctc_out.reshape(B * T, V), want_argmax=True)
+        in_len = src_mask.squeeze(1).sum(dim=1)
+        ids, n = ops.ctc_collapse(best.view(B, T), in_len, model.bos_index, model.pad_index)
+    return ids.cpu().numpy(), n.cpu().numpy()
+

@@ -548,3 +548,24 @@ def make_batch(src: Tensor, src_length: Tensor, trg_full: Tensor, trg_length_ful
     trg = trg_full[:, 1:]
     return {"src": src, "src_length": src_length, "trg_input": trg_input, "trg": trg, "trg_length": trg_length_full - 1,
             "trg_mask": (trg != pad).unsqueeze(1)}
+
+
+def ctc_best_path(logits, in_len, blank, pad):
+    """CTC best-path decoding (the standard collapse rule of Graves et al. 2006, which `nn.CTCLoss` of
+    loss.py:132-168 is the training-side counterpart of): frame-wise arg-max (first maximum), merge repeats, drop blanks,
+    only inside the first in_len[b] frames.  logits [B, T, V] -> (ids [B, T] pad-filled, lengths [B])."""
+    logits = np.asarray(logits)
+    B, T, _ = logits.shape
+    ids = np.full((B, T), pad, dtype=np.int64)
+    lens = np.zeros((B,), dtype=np.int64)
+    for b in range(B):
+        prev, n = -1, 0
+        for t in range(min(int(in_len[b]), T)):
+            cur = int(np.argmax(logits[b, t]))
+            if cur != blank and cur != prev:
+                ids[b, n] = cur
+                n += 1
+            prev = cur
+        lens[b] = n
+    return ids, lens
+

@@ -139,3 +139,43 @@ def test_incremental_decoding_equals_full_prefix_pass(device, dtype):
             np.testing.assert_allclose(a_sc, b_sc, rtol=1e-4, atol=1e-4)
         elif beam > 1:
             np.testing.assert_allclose(a_sc, b_sc, rtol=5e-2, atol=5e-2)
+
+
+def test_ctc_collapse_kernel_matches_oracle(device):
+    """js2t_ctc_collapse against the oracle's best-path rule on random label paths: repeats, blanks, ragged lengths, an
+    empty utterance, more than 64 frames (several ballot rounds)."""
+    from joeys2t_amd import ops
+    from oracle import s2t_oracle as O
+    rs = np.random.RandomState(0)
+    B, T, V, blank, pad = 7, 150, 6, 2, 1
+    best = rs.randint(0, V, size=(B, T))
+    best[1, 10:40] = blank
+    best[2, :] = 4
+    lens = np.array([150, 97, 150, 0, 64, 65, 1])
+    logits = np.full((B, T, V), -5.0, dtype=np.float32)
+    np.put_along_axis(logits, best[..., None], 3.0, axis=2)
+    ref_ids, ref_len = O.ctc_best_path(logits, lens, blank, pad)
+    ids, n = ops.ctc_collapse(torch.from_numpy(best).to(device), torch.from_numpy(lens).to(device), blank, pad)
+    assert np.array_equal(n.cpu().numpy(), ref_len)
+    assert np.array_equal(ids.cpu().numpy(), ref_ids)
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_ctc_greedy_matches_oracle(device, name):
+    """search.ctc_greedy: encoder + CTC output layer + best path on the HIP path == the oracle's encoder and
+    projection followed by the oracle's collapse rule (label ids bit-exact)."""
+    from golden_cfg import oracle_cfg
+    from joeys2t_amd.search import ctc_greedy
+    from oracle import s2t_oracle as O
+    model, g = build(name, device)
+    model.eval()
+    b = batch_kwargs(g, device)
+    ids, n = ctc_greedy(model, b)
+    sd = {k: v for k, v in model.state_dict().items()}
+    sd = {k: v.detach().cpu().float() for k, v in sd.items()}
+    with torch.no_grad():
+        x, mask, lengths = O.encoder_forward(sd, oracle_cfg(FIXTURES[name]["cfg"]), torch.from_numpy(g["src"]), torch.from_numpy(g["src_length"]))
+        logits = x @ sd["decoder.ctc_output_layer.weight"].t()
+    ref_ids, ref_len = O.ctc_best_path(logits.numpy(), mask.squeeze(1).sum(1).numpy(), model.bos_index, model.pad_index)
+    assert np.array_equal(n, ref_len)
+    assert np.array_equal(ids, ref_ids)

@@ -171,3 +171,17 @@ def test_conformer_oracle_matches_reference(ln):
         sd2.update(stats)
         y2, _, _ = O.conformer_encoder_forward(sd2, cfg, src, lengths, train=False)
     np.testing.assert_allclose(y2.numpy(), g[pre + "out_eval"], rtol=1e-4, atol=1e-4)
+
+
+def test_ctc_best_path_known_answer():
+    """The collapse rule of CTC best-path decoding on the textbook example: a a - a b b - -> a a b; frames
+    beyond the input length are ignored, an all-blank utterance decodes to nothing."""
+    from oracle import s2t_oracle as O
+    blank, pad, V = 2, 1, 6
+    paths = np.array([[4, 4, 2, 4, 5, 5, 2], [2, 2, 2, 2, 2, 2, 2], [3, 3, 3, 4, 4, 2, 5]])
+    logits = np.full((3, 7, V), -1.0, dtype=np.float32)
+    np.put_along_axis(logits, paths[..., None], 1.0, axis=2)
+    ids, lens = O.ctc_best_path(logits, np.array([7, 7, 4]), blank, pad)
+    assert lens.tolist() == [3, 0, 2]
+    assert ids[0, :3].tolist() == [4, 4, 5] and ids[2, :2].tolist() == [3, 4]
+    assert (ids[0, 3:] == pad).all() and (ids[1] == pad).all() and (ids[2, 2:] == pad).all()
