@@ -86,7 +86,7 @@ class GemmTimer:
         return agg
 
 
-def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
+def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_inputs=False):
     from joeys2t_amd.batch import Batch
     from joeys2t_amd.model import build_model
     from joeys2t_amd.tokenizers import SpeechProcessor
@@ -130,9 +130,15 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False):
     masks_dev = torch.zeros((BATCH, 8), dtype=torch.int32, device=device)
     state = {"batch": None}
 
+    # --host-inputs: the waveforms arrive from (pinned) host memory every step, as a DataLoader would hand them over; the
+    # copy is enqueued on the step's stream in front of it (PCIe-inclusive rate, reported in DESIGN.md, never `value`)
+    wave_host = wave.cpu().pin_memory() if host_inputs else None
+
     def pre_step():
         masks_host.copy_(torch.from_numpy(proc.draw_masks(frames_list)))
         masks_dev.copy_(masks_host, non_blocking=True)
+        if wave_host is not None:
+            wave.copy_(wave_host, non_blocking=True)
 
     def body():
         feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype, masks_dev=masks_dev)
@@ -343,6 +349,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-5 decode RTF measurement")
     ap.add_argument("--ragged", action="store_true", help="utterances of 10-17 s instead of 32 x 15 s (value counts un-padded frames)")
+    ap.add_argument("--host-inputs", action="store_true", help="copy the waveforms from pinned host memory every step (PCIe-inclusive rate; not the headline value)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -362,7 +369,7 @@ def main():
         torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from joeys2t_amd import ops
-    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world, ragged=args.ragged)
+    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world, ragged=args.ragged, host_inputs=args.host_inputs)
     use_graph = not args.no_graph
     one_step = eager_step
     if use_graph:
