@@ -6,7 +6,7 @@ while the statistics, normalisation, masking and batch padding run on the GPU fo
 (js2t_cmvn_stats + js2t_feature_finalize)."""
 import ctypes as C
 import math
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

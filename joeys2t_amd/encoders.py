@@ -5,7 +5,6 @@ Layout note: the reference transposes to [B,C,T] for nn.Conv1d and back (:363,:3
 [B,T,C] end to end and each Conv1d(k, stride 2)+GLU is an implicit-im2col GEMM (functional.Conv1dGluFn)."""
 from typing import List, Tuple
 
-import torch
 from torch import Tensor, nn
 
 from joeys2t_amd import functional as Fn

@@ -9,7 +9,7 @@ produced all of its gradients, overlapping the exchange with the rest of backwar
 One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" serves the CPU tests."""
 import math
 import os
-from typing import List, Optional, Union
+from typing import Optional, Union
 
 import torch
 import torch.distributed as dist

@@ -2,7 +2,6 @@
 normal/zeros per group ("embed" in name -> embed initializer, "bias" -> bias initializer, >1-D -> main), DeepNet
 alpha/beta when initializer == xavier_normal (:63-76,:138-152,:193-203), zeroed padding row (:213-215).
 torch.nn.init is used as the RNG / filler; this is one-off setup, not part of the hot path."""
-import math
 from typing import Dict
 
 import torch

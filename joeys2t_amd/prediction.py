@@ -4,7 +4,6 @@
 from typing import Iterable, List, Optional, Tuple
 
 import numpy as np
-import torch
 
 from joeys2t_amd.batch import Batch
 from joeys2t_amd.helpers import expand_reverse_index

@@ -10,7 +10,7 @@ MI355X-first design notes
       - q/k/v (and k/v) projection weights are adjacent, so a fused [3d,d] weight is a *view*.
   * With 288 GB of HBM per GPU there is no reason to shard or recompute any of this.
 """
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn

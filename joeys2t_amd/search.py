@@ -10,7 +10,6 @@ that finished / n-best handling is identical.  Unsupported reference options (fo
 penalty, n-gram blocking: all off in the S2T configs, config.py:422,445) raise."""
 from typing import List, Optional, Tuple
 
-import numpy as np
 import torch
 from torch import Tensor
 
