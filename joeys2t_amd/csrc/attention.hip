@@ -81,13 +81,32 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
                      (short)f32_to_bf16_bits(b[2]), (short)f32_to_bf16_bits(b[3])};
   return __builtin_bit_cast(bf16x8_t, v);
 }
-__device__ __forceinline__ float quad_max(float v) {  // over the 4 lanes that share (lane & 15)
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions over the 4 lanes that share (lane & 15), i.e. over the wave's four 16-lane rows.  gfx950's row swaps do the
+// exchange in the VALU: v_permlane16_swap(a, b) trades the odd rows of a for the even rows of b, v_permlane32_swap the upper
+// half of a for the lower half of b - applied to two copies of v, the pair holds {own, partner} in every lane.
+// (__shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): two LDS round trips per reduction that also drain the
+// fragment reads in flight.)
+__device__ __forceinline__ void row_partners16(float v, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void row_partners32(float v, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float quad_max(float v) {
+  float a, b;
+  row_partners16(v, a, b);
+  v = fmaxf(a, b);
+  row_partners32(v, a, b);
+  return fmaxf(a, b);
 }
 __device__ __forceinline__ float quad_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  float a, b;
+  row_partners16(v, a, b);
+  v = a + b;
+  row_partners32(v, a, b);
+  return a + b;
 }
 __device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) {
   uint2 pk;
