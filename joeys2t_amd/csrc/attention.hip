@@ -160,6 +160,9 @@ constexpr int FWD_MT = 1;  // own-query blocks of 16 per wave
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+#ifdef JS2T_ATTN_PROF
+  const unsigned long long t_start_ = __builtin_readcyclecounter();
+#endif
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
   const int q0 = blockIdx.x * (64 * FWD_MT) + w * (16 * FWD_MT);
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
-  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = t_start_;
+  ATT_T(6);  // prologue: own query fragments, key mask, first K / V request
 #endif
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,10 +295,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     ATT_PIN(o[0][7][3]);
     ATT_T(5);
   }
-#ifdef JS2T_ATTN_PROF
-  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
-    for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
-#endif
+
 #pragma unroll
   for (int mt = 0; mt < FWD_MT; ++mt) {
     const int qrow = q0 + 16 * mt + m;
@@ -305,6 +306,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     for (int ct = 0; ct < 8; ++ct) store4(orow + 16 * ct + 4 * g, o[mt][ct], inv);
     if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi[mt] * 0.6931471805599453f + __logf(li[mt]);  // natural-log units
   }
+#ifdef JS2T_ATTN_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATT_T(7);  // epilogue: output rows + log-sum-exp, stores acknowledged
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+    for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
+#endif
 }
 
 // shared by both backward kernels: probability and dS for one (own row mt, tile rows) block

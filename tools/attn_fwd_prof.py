@@ -28,3 +28,5 @@ names = ["vmcnt wait (prefetch landed?)", "barrier", "request next K/V", "K read
 for i, n in enumerate(names):
     print(f"{n:32s} {out[i] / tiles:9.1f} cycles / tile")
 print(f"per tile {sum(out[:6]) / tiles:9.1f}   (MFMA-bound: 512)")
+print(f"prologue (query fragments, key mask, first request) {out[6]:9d} cycles, epilogue (stores) {out[7]:9d} cycles, "
+      f"{tiles} tiles {sum(out[:6]):9d} cycles")
