@@ -164,8 +164,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   const unsigned long long t_start_ = __builtin_readcyclecounter();
 #endif
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * (64 * FWD_MT) + w * (16 * FWD_MT);
+  // 1-D grid, XCD-aware: the query tiles of one (batch, head) pair are neighbours in the logical order, so they run on
+  // one XCD and its L2 serves their common K / V (round-robin placement had every XCD fetch every head's K / V: six times
+  // the fabric traffic, which is what bound these kernels)
+  const int ntile = (a.Tq + 64 * FWD_MT - 1) / (64 * FWD_MT);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
+  const int q0 = (lid - z * ntile) * (64 * FWD_MT) + w * (16 * FWD_MT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
 #ifdef JS2T_ATTN_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ATT_T(7);  // epilogue: output rows + log-sum-exp, stores acknowledged
-  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+  if (blockIdx.x == 0 && t == 0)
     for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
 #endif
 }
@@ -347,8 +352,10 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int q0 = blockIdx.x * (64 * DQ_MT) + w * (16 * DQ_MT);
+  const int ntile = (a.Tq + 64 * DQ_MT - 1) / (64 * DQ_MT);  // XCD-aware 1-D grid, see flash_fwd_kernel
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
+  const int q0 = (lid - z * ntile) * (64 * DQ_MT) + w * (16 * DQ_MT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
@@ -504,8 +511,10 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
   __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
-  const int z = blockIdx.y, b = z / a.H, h = z - b * a.H;
-  const int k0 = blockIdx.x * (64 * DKV_NT) + w * (16 * DKV_NT);
+  const int ntile = (a.Tk + 64 * DKV_NT - 1) / (64 * DKV_NT);  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
+  const int k0 = (lid - z * ntile) * (64 * DKV_NT) + w * (16 * DKV_NT);
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
@@ -688,7 +697,7 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 64 * FWD_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 64 * FWD_MT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -711,9 +720,9 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
   }
   AttnArgs a = to_args(d);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT), d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

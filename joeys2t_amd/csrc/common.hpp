@@ -100,6 +100,14 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "m0");
 }
 
+// bijective XCD-aware remap of a linear block id (blocks b and b+8 share an XCD): every XCD gets a contiguous range of
+// the logical ids, so work items that read the same operand panel (neighbouring GEMM tiles, the query tiles of one
+// attention head) hit in one L2 instead of pulling the panel through the fabric once per XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ---------------------------------------------------------------- counter-based dropout RNG
 // Stateless: the keep decision of element (row, col) is a pure function of {seed, offset, call-site stream, row,
 // col}, so forward and backward kernels regenerate identical masks and nothing is stored.  One 32-bit integer hash

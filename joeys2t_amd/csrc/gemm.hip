@@ -108,11 +108,6 @@ __device__ __forceinline__ void batch_offsets(const js2t_gemm_desc& d, int z, in
   co = (int64_t)zo * d.c_stride_o + (int64_t)zi * d.c_stride_i;
 }
 
-// bijective XCD-aware remap of a linear block id (blocks b and b+8 share an XCD)
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // ------------------------------------------------------------------------------------------------
 // generic kernel: 64x64x16 tile, f32 MFMA 16x16x4, element-wise bounds-checked staging
