@@ -819,13 +819,12 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 // decoder-sized M) at the price of re-reading the B panel twice as often; transposed A images are 128 rows only.
 template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
 __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tiles_m, int tiles_n, float* c_atomic, int split_k,
-                                               int z) {
+                                               int z, int lid, int slice) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(BM == 128 || (BM == 64 && !TA), "64-row tiles need a k-contiguous A operand");
   constexpr int A_TILE = TA ? 16384 : BM * 128, TILE = 16384, STAGE = A_TILE + TILE;
   constexpr int NPA = TA ? 4 : BM / 32, MI = BM / 32;  // DMA pieces per wave for A; 16-row MFMA blocks per wave
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * F_BN;
   int64_t ao, bo, co;
   batch_offsets(d, z, ao, bo, co);
@@ -842,7 +841,7 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
 
   const int nk_all = (K + F_BK - 1) / F_BK;
   const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
-  const int kt0 = SPLITK ? blockIdx.z * per : 0;
+  const int kt0 = SPLITK ? slice * per : 0;
   const int nk = min(per, nk_all - kt0);
   if (SPLITK && nk <= 0) return;
 
@@ -960,11 +959,15 @@ __device__ __forceinline__ void dma_gemm_block(const js2t_gemm_desc& d, int tile
 template <int BM, bool TA, bool TB, bool SPLITK, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n, float* c_atomic,
                                                                int split_k) {
-  dma_gemm_block<BM, TA, TB, SPLITK, NST>(d, tiles_m, tiles_n, c_atomic, split_k, blockIdx.y);
+  dma_gemm_block<BM, TA, TB, SPLITK, NST>(d, tiles_m, tiles_n, c_atomic, split_k, blockIdx.y, xcd_remap(blockIdx.x, tiles_m * tiles_n),
+                                          blockIdx.z);
 }
 
-// Grouped launch: blockIdx.y selects one of up to JS2T_GEMM_GROUP_MAX independent products of identical shape whose
-// operands live at unrelated addresses (the deferred weight gradients of one layer type: see js2t_gemm_grouped).
+// Grouped launch: up to JS2T_GEMM_GROUP_MAX independent products of identical shape whose operands live at unrelated
+// addresses (the deferred weight gradients of one layer type: see js2t_gemm_grouped).  1-D grid over (member, K slice,
+// tile), XCD-aware as a whole: an XCD gets whole members (16 members: two each), so each member's dY and X stream
+// through ONE L2 - with the tiles of every member spread over all eight XCDs (one remap per member) each XCD read
+// every member's X: 2.4 GB instead of 1 GB per launch of the FFN weight gradients, at fabric speed.
 struct GemmGroup {
   const void* A[JS2T_GEMM_GROUP_MAX];
   const void* B[JS2T_GEMM_GROUP_MAX];
@@ -974,13 +977,16 @@ struct GemmGroup {
 template <int BM, bool TA, bool TB, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_grouped_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n,
                                                                        int split_k) {
-  const int g = blockIdx.y;
+  const int tiles = tiles_m * tiles_n, nsplit = SPLITK ? split_k : 1;
+  const int lid_all = xcd_remap(blockIdx.x, gridDim.x);
+  const int vm = lid_all / tiles, tile = lid_all - vm * tiles;  // vm = member * nsplit + slice
+  const int g = vm / nsplit, slice = vm - g * nsplit;
   js2t_gemm_desc dd = d;
   dd.A = grp.A[g];
   dd.B = grp.B[g];
   dd.C = grp.C[g];
   dd.a_rowsum = grp.rowsum[g];
-  dma_gemm_block<BM, TA, TB, SPLITK>(dd, tiles_m, tiles_n, (float*)dd.C, split_k, 0);
+  dma_gemm_block<BM, TA, TB, SPLITK>(dd, tiles_m, tiles_n, (float*)dd.C, split_k, 0, tile, slice);
 }
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -1952,7 +1958,7 @@ static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int 
     attr_set = true;
   }
   const int tm = cdiv(d.M, 128), tn = cdiv(d.N, F_BN);
-  hipLaunchKernelGGL((gemm_bf16_dma_grouped_kernel<128, true, true, SPLITK>), dim3(tm * tn, count, SPLITK ? d.split_k : 1), dim3(256),
+  hipLaunchKernelGGL((gemm_bf16_dma_grouped_kernel<128, true, true, SPLITK>), dim3(tm * tn * count * (SPLITK ? d.split_k : 1)), dim3(256),
                      LDS, s, d, grp, tm, tn, d.split_k);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
