@@ -69,7 +69,7 @@ class TransformerDecoder(Decoder):
                            return_attention=(return_attention and i == last_layer))
         if self.layer_norm is not None:
             sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
-            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"]),
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")),
                                      rt.grads_ready)
         # decoding only scores the newest position (search.py:534 `logits[:, -1]`): project just that row
         out = self.project(self.output_layer, x[:, -1:].contiguous() if kwargs.get("last_only", False) else x, torch.float32)

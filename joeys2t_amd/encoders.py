@@ -108,7 +108,7 @@ class TransformerEncoder(Encoder):
         if self.layer_norm is not None:
             rt = runtime_of(self)
             sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
-            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"]),
+            x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")),
                                      rt.grads_ready)
         if kwargs.get("repad", False) and "src_max_len" in kwargs and self.subsample:
             x, mask = self._repad(x, mask, kwargs["src_max_len"])

@@ -333,6 +333,7 @@ class ResidualBlockFn(torch.autograd.Function):
         g = {}
         sink = wts.get("sink") or {}
         ln_sink = (sink["ln_g"], sink["ln_b"]) if "ln_g" in sink else None
+        ln_copies = sink.get("_copies") if ln_sink is not None else None
 
         wq = sink.get("_wq")
 
@@ -342,7 +343,8 @@ class ResidualBlockFn(torch.autograd.Function):
         if cfg.ln_mode != "post":
             du = dy2
         else:
-            du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"], grad_out=ln_sink)
+            du, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dy2, sv["u"], wts["ln_g"], sv["mean"], sv["rstd"], grad_out=ln_sink,
+                                                         copies=ln_copies)
         dz_o = du
         if p_out > 0:
             ready = _DROP_READY.pop(dy2.data_ptr(), None)
@@ -386,11 +388,11 @@ class ResidualBlockFn(torch.autograd.Function):
             if ctx.prev_drop is not None:
                 pp, psite, prng = ctx.prev_drop
                 dx2, g["ln_g"], g["ln_b"], dxd = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du, add_scale=cfg.alpha,
-                                                                   grad_out=ln_sink, drop=(pp, prng, psite))
+                                                                   grad_out=ln_sink, drop=(pp, prng, psite), copies=ln_copies)
                 _DROP_READY[dx2.data_ptr()] = (dxd, dx2, (pp, psite), prng)
             else:
                 dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
-                                                              add_scale=cfg.alpha, grad_out=ln_sink)
+                                                              add_scale=cfg.alpha, grad_out=ln_sink, copies=ln_copies)
         elif cfg.alpha != 0.0:
             dx2 = ops.axpby(dn, 1.0, du, cfg.alpha)
         else:
@@ -450,7 +452,9 @@ class LayerNormFn(torch.autograd.Function):
         dy2 = dy.reshape(x2.shape)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, grad_out=ctx.sink)
+        sink = ctx.sink  # (dgamma view, dbeta view[, ops.GradCopies])
+        dx, dg, db = ops.layernorm_bwd(dy2, x2, gamma, mean, rstd, grad_out=None if sink is None else sink[:2],
+                                       copies=sink[2] if sink is not None and len(sink) > 2 else None)
         if ctx.sink is not None:
             if ctx.notify is not None:
                 ctx.notify(ctx.leaves)

@@ -354,9 +354,48 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None, drop=None):
+class GradCopies:
+    """Workspace for parameter-gradient sums that many blocks would otherwise add onto the same few addresses (LayerNorm
+    gamma / beta): `copies` partial copies per destination, folded into the real gradients once per step (js2t_fold_copies).
+    Destinations are registered on first use (before any hipGraph capture: warm-up steps); capacity is fixed."""
+    COPIES, MAX_D, MAX_SLOTS = 8, 1024, 256
+
+    def __init__(self, device):
+        self.stride = 2 * self.MAX_D  # floats per copy: [gamma | beta]
+        self.ws = torch.zeros(self.MAX_SLOTS * self.COPIES * self.stride, dtype=torch.float32, device=device)
+        self.slots = {}   # (dgamma ptr, dbeta ptr) -> slot
+        self.rows = []    # table rows
+        self.table = None
+
+    def lookup(self, dg: torch.Tensor, db: torch.Tensor):
+        """-> (ws view for gamma, ws view for beta) of the slot registered for these gradient views, or None."""
+        D = dg.numel()
+        if D > self.MAX_D or db.numel() != D or dg.dtype != torch.float32:
+            return None
+        key = (dg.data_ptr(), db.data_ptr())
+        slot = self.slots.get(key)
+        if slot is None:
+            if len(self.slots) >= self.MAX_SLOTS or torch.cuda.is_current_stream_capturing():
+                return None
+            slot = len(self.slots)
+            self.slots[key] = slot
+            base = slot * self.COPIES * self.stride
+            self.rows += [[base, dg.data_ptr(), D], [base + self.MAX_D, db.data_ptr(), D]]
+            self.table = torch.tensor(self.rows, dtype=torch.int64, device=self.ws.device)
+        base = slot * self.COPIES * self.stride
+        return self.ws[base:base + D], self.ws[base + self.MAX_D:base + self.MAX_D + D]
+
+    def fold(self):
+        if self.table is not None:
+            check(lib().js2t_fold_copies(_p(self.ws), _p(self.table), C.c_int32(self.table.shape[0]), C.c_int32(self.COPIES),
+                                         C.c_int64(self.stride), _stream()), "js2t_fold_copies")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None, drop=None,
+                  copies: Optional[GradCopies] = None):
     """grad_out = (dgamma_buf, dbeta_buf): accumulate the parameter gradients into these buffers in place.
-    drop = (p, rng, site): also return dropout_bwd(dx, p, rng, site) as a fourth value (js2t_layernorm_bwd_dropout)."""
+    drop = (p, rng, site): also return dropout_bwd(dx, p, rng, site) as a fourth value (js2t_layernorm_bwd_dropout).
+    copies: with grad_out, accumulate into that workspace's copies of (dgamma_buf, dbeta_buf) instead (folded by its owner)."""
     _dev(dy, x, gamma, mean, rstd, add)
     D = x.shape[-1]
     rows = x.numel() // D
@@ -370,17 +409,25 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
             dbeta = torch.empty((D,), dtype=torch.float32, device=x.device)
         nparts = (rows + 15) // 16  # >= one partial per row block of the vectorised backward kernel (16..64 rows)
         partial = torch.empty((2 * max(nparts, 1) * D,), dtype=torch.float32, device=x.device)
+    acc_g, acc_b, stride = dgamma, dbeta, 0
+    if grad_out is not None and need_param_grads and copies is not None:
+        views = copies.lookup(dgamma, dbeta)
+        ws = copies
+        copies = 1
+        if views is not None:
+            acc_g, acc_b = views
+            copies, stride = ws.COPIES, ws.stride
+    else:
+        copies = 1
+    p_drop, rng, site = drop if drop is not None else (0.0, None, 0)
+    dxd = torch.empty_like(x) if drop is not None else None
+    check(lib().js2t_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(acc_g),
+                                           _p(acc_b), _p(partial), int(grad_out is not None and need_param_grads), C.c_int64(rows),
+                                           C.c_int64(D), dt_code(x), _p(dxd), C.c_float(p_drop), None if rng is None else _p(rng.state),
+                                           C.c_uint32(site & 0xFFFFFFFF), C.c_int32(copies), C.c_int64(stride), _stream()),
+          "js2t_layernorm_bwd_dropout")
     if drop is None:
-        check(lib().js2t_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma), _p(dbeta),
-                                       _p(partial), int(grad_out is not None and need_param_grads),
-                                       C.c_int64(rows), C.c_int64(D), dt_code(x), _stream()), "js2t_layernorm_bwd")
         return dx, dgamma, dbeta
-    p_drop, rng, site = drop
-    dxd = torch.empty_like(x)
-    check(lib().js2t_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(dgamma),
-                                           _p(dbeta), _p(partial), int(grad_out is not None and need_param_grads), C.c_int64(rows),
-                                           C.c_int64(D), dt_code(x), _p(dxd), C.c_float(p_drop), _p(rng.state), C.c_uint32(site & 0xFFFFFFFF),
-                                           _stream()), "js2t_layernorm_bwd_dropout")
     return dx, dgamma, dbeta, dxd
 
 

@@ -281,6 +281,7 @@ class Runtime:
         self.direct_grads = True  # kernels accumulate parameter gradients straight into the flat gradient buffer
         self.on_grads_ready = None  # callable(list of params): DDP bucket bookkeeping for directly written gradients
         self.wgrad_queue: Optional[WgradQueue] = None  # set (TrainStep) to defer + group the weight-gradient products
+        self.grad_copies = None  # ops.GradCopies (TrainStep): LayerNorm parameter gradients accumulate into folded copies
 
     @property
     def rng(self) -> ops.DropoutRng:
@@ -343,6 +344,8 @@ class Runtime:
             out[name] = v
         if self.wgrad_queue is not None:
             out["_wq"] = self.wgrad_queue
+        if self.grad_copies is not None:
+            out["_copies"] = self.grad_copies
         return out
 
     def flush_wgrads(self, on_group_done=None):

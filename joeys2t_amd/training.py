@@ -17,7 +17,7 @@ from typing import Dict, Optional
 
 import torch
 
-from joeys2t_amd import functional
+from joeys2t_amd import functional, ops
 from joeys2t_amd.batch import Batch
 from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
 from joeys2t_amd.helpers_for_ddp import FlatGradReducer, use_ddp
@@ -52,6 +52,9 @@ class TrainStep:
         # weight-gradient products are queued during backward and run grouped by layer type afterwards; under DDP the flat
         # gradient is exchanged range by range (the store's type ranges) while those products run
         self.rt.wgrad_queue = WgradQueue() if defer_wgrads else None
+        # LayerNorm gamma / beta gradients go through per-XCD copies that are folded right after backward (ops.GradCopies);
+        # only with the deferred products: the hook-driven exchange (no queue) may send a bucket while backward still runs
+        self.rt.grad_copies = ops.GradCopies(self.store.device) if defer_wgrads else None
         self.reducer = None
         if use_ddp():
             self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None)
@@ -94,6 +97,8 @@ class TrainStep:
         total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
         norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
         norm.backward()
+        if self.rt.grad_copies is not None:
+            self.rt.grad_copies.fold()
         if use_hooks:
             self.reducer.finish()
         elif exchange:

@@ -687,3 +687,29 @@ def test_col2im_matches_scatter_add(device, dtype):
     ref = ref[:, pad:pad + T]
     tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(dx, ref, **tol)
+
+
+def test_layernorm_bwd_gradient_copies_fold(device):
+    """Parameter gradients of the LayerNorm backward accumulated into per-block copies (ops.GradCopies) and folded once:
+    same sums as the direct atomics, workspace back to zero, two LayerNorms sharing one workspace."""
+    rows, D = 3000, 512
+    ws = ops.GradCopies(device)
+    outs = []
+    for seed in (1, 2):
+        x = rnd(rows, D, seed=seed).bfloat16().to(device)
+        dy = rnd(rows, D, seed=seed + 10).bfloat16().to(device)
+        gamma = (1.0 + 0.1 * rnd(D, seed=seed + 20)).to(device)
+        _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros_like(gamma), 1e-6)
+        base_g, base_b = rnd(D, seed=seed + 30).to(device), rnd(D, seed=seed + 40).to(device)
+        g0, b0 = base_g.clone(), base_b.clone()
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, grad_out=(g0, b0))
+        g1, b1 = base_g.clone(), base_b.clone()
+        for _ in range(2):  # two micro-batches accumulate in the copies before the fold
+            ops.layernorm_bwd(dy, x, gamma, mean, rstd, grad_out=(g1, b1), copies=ws)
+        outs.append((g0, b0, g1, b1, base_g, base_b))
+    assert all(torch.equal(o[2], o[4]) for o in outs)  # nothing reaches the gradients before the fold
+    ws.fold()
+    for g0, b0, g1, b1, base_g, base_b in outs:
+        torch.testing.assert_close(g1 - base_g, 2 * (g0 - base_g), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(b1 - base_b, 2 * (b0 - base_b), rtol=1e-4, atol=1e-3)
+    assert float(ws.ws.abs().max()) == 0.0
