@@ -7,7 +7,12 @@ One step = one pass of the whole hot path over one batch that is already residen
 (configs/librispeech_100h.yaml shapes, bf16 compute, dropout 0.1, batch_multiplier 1 so that every step carries
 its optimizer update).  Metric: input fbank frames per second over all GPUs (47,936 frames per GPU per step).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set: how the driver starts it) the process is one of
+the ranks; started plainly, `bench.py --gpus N` spawns its own N ranks (torch.distributed.run as a child process, before
+this process has touched a GPU - the reference starts its ranks itself too, joeynmt/__main__.py:72-79) and exits with the
+child's code.  Rank 0 prints the JSON line either way.
 
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel = bf16 MFMA GEMM, HIP-event timed on its
 launch stream) and `cpu_baseline` (the CPU oracle restatement on a bounded sample) objects.
@@ -86,7 +91,11 @@ class GemmTimer:
         return agg
 
 
-def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_inputs=False):
+def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_inputs=False, ddp=None):
+    """`ddp`: run the data-parallel form of the step (graph-replayed forward + backward, graph-replayed weight-gradient
+    groups interleaved with the RCCL exchange of the ranges they complete, graph-replayed update).  Default: world > 1;
+    JS2T_BENCH_FORCE_DDP=1 takes that path on a single rank (a one-rank RCCL communicator) to rehearse it on a 1-GPU box."""
+    ddp = (world > 1) if ddp is None else ddp
     from joeys2t_amd.batch import Batch
     from joeys2t_amd.model import build_model
     from joeys2t_amd.tokenizers import SpeechProcessor
@@ -101,9 +110,9 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
                      learning_rate_warmup=10000, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1,
                      n_gpu=world,
-                     # second stream for the CTC branch: single-process runs only (two ranks time-slicing one card in
-                     # the gloo rehearsal turn its cross-stream waits into a 13x slowdown; not measurable over RCCL here)
-                     overlap_ctc=world == 1 and os.environ.get("JS2T_OVERLAP_CTC", "1") != "0")
+                     # second stream for the CTC branch - except in the gloo rehearsal, where several ranks time-slice ONE card
+                     # and its cross-stream waits turn into a 13x slowdown (an artefact of that set-up, not of RCCL)
+                     overlap_ctc=(world == 1 or torch.distributed.get_backend() == "nccl") and os.environ.get("JS2T_OVERLAP_CTC", "1") != "0")
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
                            specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
                            cmvn=dict(norm_means=True, norm_vars=True, before=True))
@@ -149,28 +158,26 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
             b.sort_by_src_length()  # batch.sort_by_src_length() of training.py:555 (all lengths equal here)
             state["batch"] = b
         state["batch"].src = feats
-        # single GPU: the update is part of the captured step.  Multi-GPU: forward+backward only; the gradient
-        # exchange (RCCL, bucketed) and the fused update follow the replay.
-        # multi-GPU: the deferred weight-gradient products stay OUT of the captured part (flush=False): they run after the
-        # replay, interleaved with the RCCL exchange of the gradient ranges they complete (TrainStep.exchange_and_flush)
-        return step.micro_step(state["batch"], sort=False, update=(world == 1), overlap=False, flush=(world == 1))
-
-    def post_body(capturing=False):
-        if world > 1:
-            step.exchange_and_flush(state.get("plan"))
-            step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
-        if world > 1 or capturing:
-            step.after_update()
+        # single GPU: the whole step incl. the update is ONE captured graph.  Data parallel: the same kernels in the same
+        # order, cut where the RCCL calls go: forward + backward (the deferred weight-gradient products stay queued:
+        # flush=False), then one piece per weight-gradient group, then the update (see capture()).
+        return step.micro_step(state["batch"], sort=False, update=not ddp, overlap=False, flush=not ddp)
 
     def eager_step():
         pre_step()
         out = body()
-        post_body()
+        if ddp:
+            step.exchange_and_flush()
+            step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+            step.after_update()
         return out
 
-    graph_holder = {}
+    graphs = {}
+    # thread_local: the RCCL watchdog thread may query its events while this thread captures
+    mode = "thread_local" if ddp else "global"
 
     def capture():
+        from joeys2t_amd.runtime import WgradQueue
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -180,22 +187,40 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         pre_step()
-        # thread_local: the RCCL watchdog thread may query its events while this thread captures
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+        with torch.cuda.graph(g, capture_error_mode=mode):
             body()
-        graph_holder["g"] = g
-        if world > 1:
-            # the products queued during capture reference the graph's static buffers: keep them as the per-step plan.
-            # Capturing executes nothing, so those buffers hold no gradients yet: run one real replayed step before the plan
-            # is ever used (exchange + update on never-written buffers would poison the weights)
-            state["plan"] = step.rt.wgrad_queue.take()
-            g.replay()
-        post_body(capturing=True)
+        graphs["step"] = g
+        if ddp:
+            # the products queued during capture reference the graph's static buffers: they are the per-step plan.  Each
+            # group (one grouped launch per Linear shape = one range of the flat gradient) becomes a graph of its own, so
+            # that the range's all-reduce can be handed to RCCL between two replays; the update is the last piece.
+            plan = step.rt.wgrad_queue.take()
+            state["plan"], graphs["wgrad"] = plan, []
+            for entry in plan:
+                gw = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
+                    WgradQueue.run([entry])
+                graphs["wgrad"].append(gw)
+            gu = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
+                step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+            graphs["update"] = gu
+        # capturing executes nothing (and the graph's buffers hold no gradients yet): one real replayed step, which also puts
+        # the host-side update counter / learning-rate schedule in line with the device's
+        graph_step()
 
     def graph_step():
         pre_step()
-        graph_holder["g"].replay()
-        post_body(capturing=True)
+        graphs["step"].replay()
+        if ddp:
+            plan, red = state["plan"], step.reducer
+            red.exchange_begin(plan)
+            for (_, items), gw in zip(plan, graphs["wgrad"]):
+                gw.replay()
+                red.entries_done(items)
+            red.finish()
+            graphs["update"].replay()
+        step.after_update()
 
     return eager_step, graph_step, capture, step, sum(frames_list), (model, state)
 
@@ -352,24 +377,33 @@ def main():
     ap.add_argument("--host-inputs", action="store_true", help="copy the waveforms from pinned host memory every step (PCIe-inclusive rate; not the headline value)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     # JS2T_BENCH_BACKEND=gloo + several ranks on one card rehearses the N > 1 code path on a single-GPU box
     # (gradient exchange through gloo instead of RCCL); never set by the driver
     backend = os.environ.get("JS2T_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, backend))  # this process never touches a GPU
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; measuring {world} ranks", file=sys.stderr)
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_ddp = world == 1 and os.environ.get("JS2T_BENCH_FORCE_DDP", "0") == "1"
+    if force_ddp:
+        os.environ["JS2T_DDP_SINGLE"] = "1"  # the one-rank communicator really issues its all-reduces
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world, **kw)
+    n_ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     from joeys2t_amd import ops
-    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(device, world, ragged=args.ragged, host_inputs=args.host_inputs)
+    eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(
+        device, world, ragged=args.ragged, host_inputs=args.host_inputs, ddp=(world > 1 or force_ddp))
     use_graph = not args.no_graph
     one_step = eager_step
     if use_graph:
@@ -384,6 +418,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
+    step.read_stats(reset=True)  # statistics of the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -465,20 +500,42 @@ def main():
         value = world * frames_per_step * args.steps / elapsed
         out = {
             "metric": "audio frames/sec (train step, 80-mel, 15 s utt, bs32 per GPU)", "value": round(value, 1),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "frames/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs/librispeech_100h.yaml ASR train step on synthetic 16 kHz waveforms",
                        "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": ((int(state["batch"].src.shape[1]) - 1) // 2) // 2 + 1,
                        "lengths": "ragged 10-17 s, un-padded frames counted" if args.ragged else "fixed 15 s",
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay" if use_graph else "eager",
-                       "loss": round(stats["loss"] / max(1, args.steps + 0), 4)},
+                       "launch": ("hipGraph replay" if world == 1 and not force_ddp else
+                                  "hipGraph replay in pieces (fwd+bwd | weight-gradient groups | update) around the RCCL calls") if use_graph else "eager",
+                       "backend": backend if n_ranks_seen > 1 or force_ddp else None,
+                       "loss": round(stats["loss"] / max(1, args.steps), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def self_launch(n, backend):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a child torch.distributed.run and hand its exit
+    code back.  Nothing in this process has initialised the GPU (device_count() does not), and nothing is exec'ed."""
+    import socket
+    import subprocess
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs, this node shows {torch.cuda.device_count()} "
+              "(JS2T_BENCH_BACKEND=gloo rehearses the path with several ranks on one card)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 if __name__ == "__main__":

@@ -350,9 +350,11 @@ int js2t_fbank(const float* wave, const int64_t* sample_off, const int64_t* fram
 
 /* Utterance-level CMVN statistics — CMVN.__call__ (data_augmentation.py:96-109): mean[u,c], istd[u,c] =
  * 1/sqrt(max(E[x^2] - mean^2, 1e-10)) and fill[u] = mean of the normalised spectrogram, which is the value
- * SpecAugment writes into its masks (data_augmentation.py:45-46).  f32[U,F], f32[U,F], f32[U]. */
+ * SpecAugment writes into its masks (data_augmentation.py:45-46).  f32[U,F], f32[U,F], f32[U].
+ * max_frames > 0: only the first max_frames frames of an utterance count - SpeechProcessor.__call__ truncates an
+ * over-long evaluation utterance BEFORE CMVN (tokenizers.py:474-487). */
 int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd,
-                    float* fill, int32_t norm_means, int32_t norm_vars, js2t_stream stream);
+                    float* fill, int32_t norm_means, int32_t norm_vars, int64_t max_frames, js2t_stream stream);
 
 /* out[u,t,c] = masked((feat - mean) * istd) for t < T_u, pad_value beyond — CMVN apply + SpecAugment masks
  * (data_augmentation.py:54-68; mask parameters drawn on the host to keep np.random parity) + pad_features

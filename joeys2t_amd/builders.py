@@ -34,6 +34,33 @@ from typing import Dict, Optional  # noqa: E402
 import torch  # noqa: E402
 
 
+def trainable_ranges(store):
+    """Contiguous [lo, hi) element ranges of the flat store that hold trainable parameters (alignment padding between
+    two trainable parameters included; every boundary a multiple of 4 elements, as js2t_adamw's float4 passes need).
+    A frozen parameter (requires_grad False; reference helpers.py:258-261 `freeze_params`) is left out entirely."""
+    spans = sorted((store.offsets[id(p)], store.offsets[id(p)] + p.numel(), bool(p.requires_grad)) for p in store.params)
+    if all(t for _, _, t in spans):
+        return [(0, store.total)]
+    ranges = []
+    for i, (lo, hi, train) in enumerate(spans):
+        if not train:
+            continue
+        nxt = spans[i + 1][0] if i + 1 < len(spans) else store.total
+        hi = nxt if (i + 1 == len(spans) or spans[i + 1][2]) else (hi + 3) // 4 * 4  # padding rides with its predecessor
+        if lo % 4 or hi % 4 or hi > nxt:
+            raise ValueError("frozen and trainable parameters share a 16-byte granule of the flat store")
+        if ranges and ranges[-1][1] == lo:
+            ranges[-1] = (ranges[-1][0], hi)
+        else:
+            ranges.append((lo, hi))
+    return ranges
+
+
+def _off(t, lo: int):
+    """device pointer of element `lo` of a flat buffer (None stays a null pointer)"""
+    return None if t is None else _C.c_void_p(t.data_ptr() + lo * t.element_size())
+
+
 class FlatAdamW:
     """AdamW over a runtime.ParamStore: one fused kernel (js2t_adamw) updates the fp32 master, both moments, the
     bf16 shadow and clears the gradient buffer.  Numerically the torch.optim.AdamW update the reference builds at
@@ -54,6 +81,8 @@ class FlatAdamW:
         self.lr_dev = torch.full((1, ), float(lr), dtype=torch.float32, device=store.device)
         self.step_dev = torch.zeros((1, ), dtype=torch.int64, device=store.device)
         self.device_schedule = False
+        self.update_ranges = trainable_ranges(store)
+
 
     def clip_and_step(self, max_norm: Optional[float], grad_scale: float = 1.0, zero_grad: bool = True):
         """clip_grad_norm_(max_norm) (builders.py:68-71) folded into the update: the coefficient stays on the device."""
@@ -71,11 +100,14 @@ class FlatAdamW:
         if self.device_schedule:  # graph-replayable form: count and learning rate live on the device
             self.step_dev.add_(1)
             lr_dev, step_dev = self.lr_dev, self.step_dev
-        check(lib().js2t_adamw(ops._p(st.flat), ops._p(st.flat_grad), ops._p(self.exp_avg), ops._p(self.exp_avg_sq), ops._p(lp),
-                               _C.c_int64(st.total), _C.c_float(g["lr"]), _C.c_float(g["betas"][0]), _C.c_float(g["betas"][1]),
-                               _C.c_float(g["eps"]), _C.c_float(g["weight_decay"]), _C.c_int64(self.t), ops._p(coef),
-                               _C.c_float(grad_scale), int(zero_grad), ops._p(lr_dev), ops._p(step_dev), ops._stream()),
-              "js2t_adamw")
+        # torch.optim.AdamW skips parameters without a gradient: frozen sub-networks (`freeze: True`) get no weight decay
+        # and no moment update - one launch per contiguous trainable range (the whole store when nothing is frozen)
+        for lo, hi in self.update_ranges:
+            check(lib().js2t_adamw(_off(st.flat, lo), _off(st.flat_grad, lo), _off(self.exp_avg, lo), _off(self.exp_avg_sq, lo),
+                                   _off(lp, lo), _C.c_int64(hi - lo), _C.c_float(g["lr"]), _C.c_float(g["betas"][0]),
+                                   _C.c_float(g["betas"][1]), _C.c_float(g["eps"]), _C.c_float(g["weight_decay"]), _C.c_int64(self.t),
+                                   ops._p(coef), _C.c_float(grad_scale), int(zero_grad), ops._p(lr_dev), ops._p(step_dev),
+                                   ops._stream()), "js2t_adamw")
         st.dirty = lp is None and st.dirty
         if lp is not None and st.flat_lp_t is not None:
             st.refresh_t()  # transposed shadows follow the updated weights (one kernel; part of the captured step)

@@ -1,4 +1,4 @@
-// Fused ("flash") multi-head attention for bf16, head size 128 — forward, dK/dV and dQ kernels.
+// Fused ("flash") multi-head attention for bf16, head sizes 128 and 64 — forward, dK/dV and dQ kernels.
 //
 // Replaces the materialised chain of MultiHeadedAttention.forward (transformer_layers.py:86-105):
 //   scores = (q/sqrt(dh)) k^T ; masked_fill(~mask, -inf) ; softmax ; dropout ; @ v
@@ -14,14 +14,24 @@
 // tile rows — the probability registers are then directly the B operand of the next product, with the k index
 // permuted as {sub-tile 2s rows 4g..4g+3, sub-tile 2s+1 rows 4g..4g+3}; the transposed LDS reads use the same order.
 //
+// Head size 64 (mustc_st.yaml: 8 heads of 64) uses the SAME 16 KiB image and the same access patterns: a tile is then 128
+// rows of the swept sequence, rows 0-63 in chunk columns 0-7 and rows 64-127 in chunk columns 8-15 of the [64][128]
+// image (the k-steps over the head columns halve, the tile rows double: 32 MFMAs per wave and tile either way).
+//
 // Dropout uses the same counter hash and (row, col4) indexing as softmax_fwd_kernel, so fused and unfused paths
 // draw identical masks (tests compare them).  A row whose keys are all masked yields NaN like the reference.
 #include "common.hpp"
 
 namespace {
 
-constexpr int DH = 128;
-constexpr int IMG_BYTES = 64 * DH * 2;  // 16 KiB
+constexpr int IMG_BYTES = 64 * 128 * 2;  // 16 KiB
+// geometry of one head size: KT tile rows (of the swept sequence) per image, NTT 16-row blocks, NKS 32-wide k-steps over
+// the head columns, NCT 16-column blocks of the head, NSS 32-row k-steps over the tile rows, CPR 16-byte chunks per row
+template <int DH> struct Geo {
+  static_assert(DH == 128 || DH == 64, "head size");
+  static constexpr int KT = 8192 / DH, NTT = KT / 16, NKS = DH / 32, NCT = DH / 16, NSS = KT / 32, CPR = DH / 8;
+  static constexpr uint32_t FULL = NTT == 8 ? 0xffffffffu : 0xffffu;
+};
 typedef __attribute__((address_space(1))) const void g_cvoid;
 typedef __attribute__((address_space(3))) void l_void;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
@@ -41,7 +51,8 @@ struct AttnArgs {
   uint32_t stream;
 };
 
-// HBM -> LDS image of 64 rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave
+// HBM -> LDS image of KT rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave
+template <int DH>
 __device__ __forceinline__ void img_dma(const uint16_t* base, int64_t ld, int row0, int rows_max, unsigned char* img, int t) {
   const int w = t >> 6, lane = t & 63;
 #pragma unroll
@@ -49,31 +60,35 @@ __device__ __forceinline__ void img_dma(const uint16_t* base, int64_t ld, int ro
     const int p = (w * 4 + q) * 64 + lane;
     const int row = p >> 4, slot = p & 15;
     const int chunk = slot ^ ((row & 7) << 1);
-    const uint16_t* src = base + (int64_t)min(row0 + row, rows_max - 1) * ld + chunk * 8;
+    const int trow = DH == 128 ? row : row + 64 * (chunk >> 3), col = DH == 128 ? chunk * 8 : (chunk & 7) * 8;
+    const uint16_t* src = base + (int64_t)min(row0 + trow, rows_max - 1) * ld + col;
     __builtin_amdgcn_global_load_lds((g_cvoid*)src, (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
   }
 }
-// row fragment: 8 consecutive head columns (32*ks + 8*(lane>>4) ..) of image row rb + (lane&15)
-__device__ __forceinline__ bf16x8_t img_row(const unsigned char* img, int rb, int ks, int lane) {
-  const int row = rb + (lane & 15), chunk = 4 * ks + (lane >> 4);
+// row fragment: 8 consecutive head columns (32*ks + 8*(lane>>4) ..) of tile row 16*tt + (lane&15)
+template <int DH>
+__device__ __forceinline__ bf16x8_t img_row(const unsigned char* img, int tt, int ks, int lane) {
+  const int row = ((16 * tt) & 63) + (lane & 15), chunk = (tt >> 2) * Geo<DH>::CPR + 4 * ks + (lane >> 4);
   return *(const bf16x8_t*)(img + row * 256 + ((chunk ^ ((row & 7) << 1)) << 4));
 }
 // transposed fragment for k-step s and head-column tile ct: element j<4 = row 32s+4g+j, j>=4 = row 32s+16+4g+(j-4),
 // column 16*ct + (lane&15)
+template <int DH>
 __device__ __forceinline__ bf16x8_t img_tr(const unsigned char* img, int s, int ct, int lane) {
   const int gl = lane & 15, qq = gl >> 2, p = gl & 3, g = lane >> 4;
-  const int r1 = 32 * s + 4 * g + qq, r2 = r1 + 16;
-  const int cc = 2 * ct + (p >> 1), off = 8 * (p & 1);
+  const int r1 = ((32 * s) & 63) + 4 * g + qq, r2 = r1 + 16;
+  const int cc = (s >> 1) * Geo<DH>::CPR + 2 * ct + (p >> 1), off = 8 * (p & 1);
   const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r1 * 256 + ((cc ^ ((r1 & 7) << 1)) << 4) + off));
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + r2 * 256 + ((cc ^ ((r2 & 7) << 1)) << 4) + off));
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
 // own-row fragments straight from HBM: rows rb + (lane&15) (clamped), columns 32*ks + 8*(lane>>4) ..
-__device__ __forceinline__ void own_frags(const uint16_t* base, int64_t ld, int rb, int rows_max, int lane, bf16x8_t (&f)[4]) {
+template <int NKS>
+__device__ __forceinline__ void own_frags(const uint16_t* base, int64_t ld, int rb, int rows_max, int lane, bf16x8_t (&f)[NKS]) {
   const int row = min(rb + (lane & 15), rows_max - 1);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8_t*)(base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
+  for (int ks = 0; ks < NKS; ++ks) f[ks] = *(const bf16x8_t*)(base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
   const s16x8_t v = {(short)f32_to_bf16_bits(a[0]), (short)f32_to_bf16_bits(a[1]), (short)f32_to_bf16_bits(a[2]),
@@ -116,7 +131,7 @@ __device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) 
 }
 
 // Key validity for key-padding masks (mask_sq == 0) is staged ONCE per block in LDS as bytes; per tile a lane then
-// needs 4 ds_read_b32 instead of 16-32 dependent global byte loads in the inner loop.
+// needs NTT ds_read_b32 instead of 16-32 dependent global byte loads in the inner loop.
 constexpr int KMASK_MAX = 8192;
 __device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, int b, int nkeys_padded, int t) {
   for (int k = t; k < nkeys_padded; k += 256) {
@@ -125,23 +140,25 @@ __device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, i
     kmask[k] = on ? 1 : 0;
   }
 }
-// 16 validity bits of this lane's keys in tile kt: bit (4*tt + r) <-> key 64kt + 16tt + 4g + r
+// validity bits of this lane's keys in tile kt: bit (4*tt + r) <-> key KT*kt + 16tt + 4g + r
+template <int DH>
 __device__ __forceinline__ uint32_t tile_kbits(const uint8_t* kmask, int kt, int g) {
   uint32_t bits = 0;
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const uint32_t w4 = *(const uint32_t*)(kmask + 64 * kt + 16 * tt + 4 * g);  // 4 bytes, each 0/1
+  for (int tt = 0; tt < Geo<DH>::NTT; ++tt) {
+    const uint32_t w4 = *(const uint32_t*)(kmask + Geo<DH>::KT * kt + 16 * tt + 4 * g);  // 4 bytes, each 0/1
     bits |= ((w4 & 1u) | ((w4 >> 7) & 2u) | ((w4 >> 14) & 4u) | ((w4 >> 21) & 8u)) << (4 * tt);
   }
   return bits;
 }
 // per-query full mask (mask_sq != 0): AND the row's bytes into the key bits
+template <int DH>
 __device__ __forceinline__ uint32_t row_kbits(uint32_t bits, const uint8_t* mrow, int kt, int g, int Tk) {
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt)
+  for (int tt = 0; tt < Geo<DH>::NTT; ++tt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int key = 64 * kt + 16 * tt + 4 * g + r;
+      const int key = Geo<DH>::KT * kt + 16 * tt + 4 * g + r;
       if (key < Tk && !mrow[key]) bits &= ~(1u << (4 * tt + r));
     }
   return bits;
@@ -156,8 +173,11 @@ __device__ unsigned long long g_attn_prof[8];
 #define ATT_PIN(v)
 #endif
 // ------------------------------------------------------------------------------------------------ forward
-constexpr int FWD_MT = 1;  // own-query blocks of 16 per wave
+// a wave owns 16 queries; a block 64
+template <int DH>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
+  using G = Geo<DH>;
+  constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
 #ifdef JS2T_ATTN_PROF
@@ -167,38 +187,30 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   // 1-D grid, XCD-aware: the query tiles of one (batch, head) pair are neighbours in the logical order, so they run on
   // one XCD and its L2 serves their common K / V (round-robin placement had every XCD fetch every head's K / V: six times
   // the fabric traffic, which is what bound these kernels)
-  const int ntile = (a.Tq + 64 * FWD_MT - 1) / (64 * FWD_MT);
+  const int ntile = (a.Tq + 63) / 64;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
-  const int q0 = (lid - z * ntile) * (64 * FWD_MT) + w * (16 * FWD_MT);
+  const int q0 = (lid - z * ntile) * 64 + w * 16;
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  bf16x8_t qf[FWD_MT][4];
+  bf16x8_t qf[NKS];
+  own_frags<NKS>(Qb, a.ldq, q0, a.Tq, lane, qf);
+  f32x4_t o[NCT];
+  float mi = -INFINITY, li = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < FWD_MT; ++mt) own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
-  f32x4_t o[FWD_MT][8];
-  float mi[FWD_MT], li[FWD_MT];
-#pragma unroll
-  for (int mt = 0; mt < FWD_MT; ++mt) {
-    mi[mt] = -INFINITY;
-    li[mt] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) o[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const bool drop = a.p > 0.f;
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float drop_sc = drop ? 1.f / (1.f - a.p) : 1.f;
   const float scale2 = a.scale * 1.4426950408889634f;
-  const int nkt = (a.Tk + 63) / 64;
+  const int nkt = (a.Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  uint32_t rowkey[FWD_MT];
-#pragma unroll
-  for (int mt = 0; mt < FWD_MT; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, nkt * 64, t);
-  img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
-  img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  stage_kmask(kmask, a, b, nkt * KT, t);
+  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
+  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = t_start_;
@@ -210,106 +222,97 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     __syncthreads();
     ATT_T(1);
     if (kt + 1 < nkt) {
-      img_dma(Kb, a.ldk, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma(Vb, a.ldv, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
     ATT_T(2);
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
-    const uint32_t kbits = tile_kbits(kmask, kt, g);
-    // S^T = K Q^T : s[mt][tt][r] = score(query q0+16mt+m, key 64kt + 16tt + 4g + r)
-    f32x4_t s[FWD_MT][4];
+    const uint32_t kbits = tile_kbits<DH>(kmask, kt, g);
+    // S^T = K Q^T : s[tt][r] = score(query q0+m, key KT*kt + 16tt + 4g + r)
+    f32x4_t s[NTT];
 #pragma unroll
-    for (int mt = 0; mt < FWD_MT; ++mt)
+    for (int tt = 0; tt < NTT; ++tt) s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) s[mt][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = img_row(Ki, 16 * tt, ks, lane);
-#pragma unroll
-        for (int mt = 0; mt < FWD_MT; ++mt) s[mt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], s[mt][tt], 0, 0, 0);
-      }
+      for (int ks = 0; ks < NKS; ++ks)
+        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Ki, tt, ks, lane), qf[ks], s[tt], 0, 0, 0);
     // online softmax in base 2: mi = running max of s*scale*log2e, li = running sum of exp2(.. - mi); the dropped
     // probabilities go to the PV product unscaled, 1/(1-p) is applied with 1/li at the end
-    const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
-    ATT_PIN(s[0][3][3]);
+    const bool tile_clear = !full_mask && __all(kbits == G::FULL) != 0;  // wave-uniform: every key of the tile is live
+    ATT_PIN(s[NTT - 1][3]);
     ATT_T(3);
-    bf16x8_t pf[FWD_MT][2];
-#pragma unroll
-    for (int mt = 0; mt < FWD_MT; ++mt) {
+    bf16x8_t pf[NSS];
+    {
       uint32_t bits = kbits;
       if (!tile_clear) {
-        const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
-        if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+        const int qc = min(q0 + m, a.Tq - 1);
+        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[mt][tt][r] = ((bits >> (4 * tt + r)) & 1u) ? s[mt][tt][r] : -INFINITY;
+          for (int r = 0; r < 4; ++r) s[tt][r] = ((bits >> (4 * tt + r)) & 1u) ? s[tt][r] : -INFINITY;
       }
       float mx = -INFINITY;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[mt][tt][r]);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tt][r]);
       mx = quad_max(mx) * scale2;  // scale > 0: the max commutes with it
-      const float mnew = fmaxf(mi[mt], mx);
+      const float mnew = fmaxf(mi, mx);
       const float msafe = mnew == -INFINITY ? 0.f : mnew;
-      const float corr = __builtin_amdgcn_exp2f(mi[mt] - msafe);  // exp2(-inf) = 0 on the first live tile
+      const float corr = __builtin_amdgcn_exp2f(mi - msafe);  // exp2(-inf) = 0 on the first live tile
       float rs = 0.f;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < NTT; ++tt) {
         uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
         if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
-          const uint32_t c4 = (uint32_t)(16 * kt + 4 * tt + g);
-          h0 = hash32(rowkey[mt] + 2u * c4), h1 = hash32(rowkey[mt] + 2u * c4 + 1u);
+          const uint32_t c4 = (uint32_t)((KT / 4) * kt + 4 * tt + g);
+          h0 = hash32(rowkey + 2u * c4), h1 = hash32(rowkey + 2u * c4 + 1u);
         }
         const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(s[mt][tt][r], scale2, -msafe));
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -msafe));
           rs += pv;
-          s[mt][tt][r] = hv[r] >= thr ? pv : 0.f;
+          s[tt][r] = hv[r] >= thr ? pv : 0.f;
         }
       }
       rs = quad_sum(rs);
-      li[mt] = li[mt] * corr + rs;
-      mi[mt] = mnew;
+      li = li * corr + rs;
+      mi = mnew;
       if (!__all(corr == 1.f)) {  // the running maximum moved for some row of this wave: rescale the accumulators
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[mt][ct][r] *= corr;
+          for (int r = 0; r < 4; ++r) o[ct][r] *= corr;
       }
-      pf[mt][0] = pack8(s[mt][0], s[mt][1]);
-      pf[mt][1] = pack8(s[mt][2], s[mt][3]);
+#pragma unroll
+      for (int ss = 0; ss < NSS; ++ss) pf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
     }
-    ATT_PIN(pf[0][1]);
+    ATT_PIN(pf[NSS - 1]);
     ATT_T(4);
     // O^T += V^T P^T
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8_t vf = img_tr(Vi, ss, ct, lane);
-#pragma unroll
-        for (int mt = 0; mt < FWD_MT; ++mt) o[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][ss], o[mt][ct], 0, 0, 0);
-      }
+      for (int ss = 0; ss < NSS; ++ss)
+        o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Vi, ss, ct, lane), pf[ss], o[ct], 0, 0, 0);
     cur ^= 1;
-    ATT_PIN(o[0][7][3]);
+    ATT_PIN(o[NCT - 1][3]);
     ATT_T(5);
   }
 
+  {
+    const int qrow = q0 + m;
+    if (qrow < a.Tq) {
+      const float inv = li > 0.f ? drop_sc / li : NAN;  // all keys masked -> NaN, as softmax over -inf
+      uint16_t* orow = a.out + ((int64_t)b * a.Tq + qrow) * a.ldo + h * DH;
 #pragma unroll
-  for (int mt = 0; mt < FWD_MT; ++mt) {
-    const int qrow = q0 + 16 * mt + m;
-    if (qrow >= a.Tq) continue;
-    const float inv = li[mt] > 0.f ? drop_sc / li[mt] : NAN;  // all keys masked -> NaN, as softmax over -inf
-    uint16_t* orow = a.out + ((int64_t)b * a.Tq + qrow) * a.ldo + h * DH;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) store4(orow + 16 * ct + 4 * g, o[mt][ct], inv);
-    if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi[mt] * 0.6931471805599453f + __logf(li[mt]);  // natural-log units
+      for (int ct = 0; ct < NCT; ++ct) store4(orow + 16 * ct + 4 * g, o[ct], inv);
+      if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi * 0.6931471805599453f + __logf(li);  // natural-log units
+    }
   }
 #ifdef JS2T_ATTN_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,17 +322,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
 #endif
 }
 
-// shared by both backward kernels: probability and dS for one (own row mt, tile rows) block
 // ------------------------------------------------------------------------------------------------ dQ
 // own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
-// 1 wave per SIMD: the 128 persistent accumulator/operand registers + tile temporaries need the wide register budget
 // dS' of one (own query block, key tile): pv * ((keep ? dp : 0) - delta*(1-p)); the common factor scale/(1-p) is applied to
 // dQ once at the end.  lse2 = lse*log2e, scale2 = scale*log2e.  MASKED = some key of the tile is padded / masked out.
-template <bool MASKED>
-__device__ __forceinline__ void dq_elements(f32x4_t (&s)[4], const f32x4_t (&dp)[4], float scale2, float lse2, float dl2, uint32_t bits,
-                                            uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop) {
+template <bool MASKED, int NTT>
+__device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float dl2,
+                                            uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop) {
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
+  for (int tt = 0; tt < NTT; ++tt) {
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
     if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
       const uint32_t c4 = c4base + 4u * tt;
@@ -346,118 +347,111 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[4], const f32x4_t (&dp)
   }
 }
 
-// DQ_MT own-query blocks of 16 per wave (see DKV_NT: two need 346 registers, one wave per SIMD)
-constexpr int DQ_MT = 1;
+// one own-query block of 16 per wave (two need ~350 registers: one wave per SIMD, slower)
+template <int DH>
 __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
+  using G = Geo<DH>;
+  constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
-  const int ntile = (a.Tq + 64 * DQ_MT - 1) / (64 * DQ_MT);  // XCD-aware 1-D grid, see flash_fwd_kernel
+  const int ntile = (a.Tq + 63) / 64;  // XCD-aware 1-D grid, see flash_fwd_kernel
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
-  const int q0 = (lid - z * ntile) * (64 * DQ_MT) + w * (16 * DQ_MT);
+  const int q0 = (lid - z * ntile) * 64 + w * 16;
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
   const bool drop = a.p > 0.f;
   const float keep_p = 1.f - a.p;
-  bf16x8_t qf[DQ_MT][4], gf[DQ_MT][4];
-  float lse2[DQ_MT], dl2[DQ_MT];
-#pragma unroll
-  for (int mt = 0; mt < DQ_MT; ++mt) {
-    own_frags(Qb, a.ldq, q0 + 16 * mt, a.Tq, lane, qf[mt]);
-    own_frags(Gb, a.lddo, q0 + 16 * mt, a.Tq, lane, gf[mt]);
-    const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
-    lse2[mt] = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
+  bf16x8_t qf[NKS], gf[NKS];
+  float lse2, dl2;
+  {
+    own_frags<NKS>(Qb, a.ldq, q0, a.Tq, lane, qf);
+    own_frags<NKS>(Gb, a.lddo, q0, a.Tq, lane, gf);
+    const int qc = min(q0 + m, a.Tq - 1);
+    lse2 = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
     // delta = rowsum(dO * O) of the own rows: the dO fragments are in registers anyway, O's are fetched once; the four
     // lanes of a row hold a quarter of the head columns each.  Written out for the dK/dV pass, which runs after this one.
-    bf16x8_t of[4];
-    own_frags(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0 + 16 * mt, a.Tq, lane, of);
+    bf16x8_t of[NKS];
+    own_frags<NKS>(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0, a.Tq, lane, of);
     float dsum = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += (float)gf[mt][ks][e] * (float)of[ks][e];
+      for (int e = 0; e < 8; ++e) dsum += (float)gf[ks][e] * (float)of[ks][e];
     dsum = quad_sum(dsum);
-    if (g == 0 && q0 + 16 * mt + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + 16 * mt + m] = dsum;
-    dl2[mt] = dsum * keep_p;
+    if (g == 0 && q0 + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
+    dl2 = dsum * keep_p;
   }
-  f32x4_t dq[DQ_MT][8];
+  f32x4_t dq[NCT];
 #pragma unroll
-  for (int mt = 0; mt < DQ_MT; ++mt)
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) dq[mt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < NCT; ++ct) dq[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float scale2 = a.scale * 1.4426950408889634f;
-  const int nkt = (a.Tk + 63) / 64;
+  const int nkt = (a.Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  uint32_t rowkey[DQ_MT];
-#pragma unroll
-  for (int mt = 0; mt < DQ_MT; ++mt) rowkey[mt] = hash32((uint32_t)(z * a.Tq + min(q0 + 16 * mt + m, a.Tq - 1)) ^ dkey);
+  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, nkt * 64, t);
-  img_dma(Kb, a.ldk, 0, a.Tk, smem, t);
-  img_dma(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  stage_kmask(kmask, a, b, nkt * KT, t);
+  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
+  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) {
-      img_dma(Kb, a.ldk, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma(Vb, a.ldv, (kt + 1) * 64, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
-    const uint32_t kbits = tile_kbits(kmask, kt, g);
-    const bool tile_clear = !full_mask && __all(kbits == 0xffffu) != 0;  // wave-uniform: every key of the tile is live
-    bf16x8_t dsf[DQ_MT][2];
+    const uint32_t kbits = tile_kbits<DH>(kmask, kt, g);
+    const bool tile_clear = !full_mask && __all(kbits == G::FULL) != 0;  // wave-uniform: every key of the tile is live
+    bf16x8_t dsf[NSS];
+    {
+      f32x4_t s[NTT], dp[NTT];
 #pragma unroll
-    for (int mt = 0; mt < DQ_MT; ++mt) {
-      f32x4_t s[4], dp[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < NTT; ++tt) {
         s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         dp[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Ki, 16 * tt, ks, lane), qf[mt][ks], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Vi, 16 * tt, ks, lane), gf[mt][ks], dp[tt], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) {
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Ki, tt, ks, lane), qf[ks], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Vi, tt, ks, lane), gf[ks], dp[tt], 0, 0, 0);
         }
-      const uint32_t c4base = (uint32_t)(16 * kt + g);
+      const uint32_t c4base = (uint32_t)((KT / 4) * kt + g);
       if (tile_clear) {
-        dq_elements<false>(s, dp, scale2, lse2[mt], dl2[mt], 0xffffu, rowkey[mt], c4base, thr, drop);
+        dq_elements<false, NTT>(s, dp, scale2, lse2, dl2, G::FULL, rowkey, c4base, thr, drop);
       } else {
-        const int qc = min(q0 + 16 * mt + m, a.Tq - 1);
+        const int qc = min(q0 + m, a.Tq - 1);
         uint32_t bits = kbits;
-        if (full_mask) bits = row_kbits(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
-        dq_elements<true>(s, dp, scale2, lse2[mt], dl2[mt], bits, rowkey[mt], c4base, thr, drop);
+        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+        dq_elements<true, NTT>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop);
       }
-      dsf[mt][0] = pack8(s[0], s[1]);
-      dsf[mt][1] = pack8(s[2], s[3]);
+#pragma unroll
+      for (int ss = 0; ss < NSS; ++ss) dsf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
     }
     // dQ^T += K^T dS^T
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8_t kt_f = img_tr(Ki, ss, ct, lane);
-#pragma unroll
-        for (int mt = 0; mt < DQ_MT; ++mt) dq[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[mt][ss], dq[mt][ct], 0, 0, 0);
-      }
+      for (int ss = 0; ss < NSS; ++ss)
+        dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Ki, ss, ct, lane), dsf[ss], dq[ct], 0, 0, 0);
     cur ^= 1;
   }
   const float dq_sc = a.scale * (drop ? 1.f / keep_p : 1.f);
+  {
+    const int qrow = q0 + m;
+    if (qrow < a.Tq) {
+      uint16_t* drow = a.dq + ((int64_t)b * a.Tq + qrow) * a.lddq + h * DH;
 #pragma unroll
-  for (int mt = 0; mt < DQ_MT; ++mt) {
-    const int qrow = q0 + 16 * mt + m;
-    if (qrow >= a.Tq) continue;
-    uint16_t* drow = a.dq + ((int64_t)b * a.Tq + qrow) * a.lddq + h * DH;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) store4(drow + 16 * ct + 4 * g, dq[mt][ct], dq_sc);
+      for (int ct = 0; ct < NCT; ++ct) store4(drow + 16 * ct + 4 * g, dq[ct], dq_sc);
+    }
   }
 }
 
@@ -469,12 +463,12 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
 //   ds' = pv * ((keep ? dp : 0) - delta*(1-p))      (dK gets scale/(1-p) once, at the end)
 // Dropout: the decision of (query row, key) is the half (key & 1) of hash32(rowhash + (key >> 1)) - the same value for
 // the two neighbouring lanes of a key pair, so each lane hashes two of the four rows and swaps with its neighbour (DPP).
-template <bool KEYCHECK, bool FULLMASK>
-__device__ __forceinline__ void dkv_elements(f32x4_t (&s)[4], f32x4_t (&dp)[4], const float* lse2, const float* dl2, const uint32_t* rkp,
-                                             float scale2, bool key_ok, int key, uint32_t thr, bool drop, int g, int par,
-                                             const uint8_t* mcol, int64_t msq, int qbase, int Tq) {
+template <bool KEYCHECK, bool FULLMASK, int NTT>
+__device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NTT], const float* lse2, const float* dl2,
+                                             const uint32_t* rkp, float scale2, bool key_ok, int key, uint32_t thr, bool drop, int g,
+                                             int par, const uint8_t* mcol, int64_t msq, int qbase, int Tq) {
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
+  for (int tt = 0; tt < NTT; ++tt) {
     const f32x4_t l4 = *(const f32x4_t*)(lse2 + 16 * tt + 4 * g);
     const f32x4_t d4 = *(const f32x4_t*)(dl2 + 16 * tt + 4 * g);
     uint32_t h[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -502,79 +496,70 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[4], f32x4_t (&dp)[4], 
   }
 }
 
-// DKV_NT own-key blocks of 16 per wave: with two (32 keys per wave) the dK / dV accumulators, the own K / V fragments and the
+// one own-key block of 16 per wave: with two (32 keys per wave) the dK / dV accumulators, the own K / V fragments and the
 // S / dP tiles need > 400 registers - one wave per SIMD, nothing to overlap the MFMA, exp / dropout VALU work and LDS
 // latency with.  One block per wave fits 256 registers, i.e. two waves per SIMD.
-constexpr int DKV_NT = 1;
+template <int DH>
 __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
+  using G = Geo<DH>;
+  constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;  // KT = queries per swept tile here
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
-  __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][64];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][KT], dl_s[2][KT];
+  __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][KT];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
-  const int ntile = (a.Tk + 64 * DKV_NT - 1) / (64 * DKV_NT);  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
+  const int ntile = (a.Tk + 63) / 64;  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
-  const int k0 = (lid - z * ntile) * (64 * DKV_NT) + w * (16 * DKV_NT);
+  const int k0 = (lid - z * ntile) * 64 + w * 16;
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  bf16x8_t kf[DKV_NT][4], vf[DKV_NT][4];
+  bf16x8_t kf[NKS], vf[NKS];
+  own_frags<NKS>(Kb, a.ldk, k0, a.Tk, lane, kf);
+  own_frags<NKS>(Vb, a.ldv, k0, a.Tk, lane, vf);
+  f32x4_t dk[NCT], dv[NCT];
 #pragma unroll
-  for (int nt = 0; nt < DKV_NT; ++nt) {
-    own_frags(Kb, a.ldk, k0 + 16 * nt, a.Tk, lane, kf[nt]);
-    own_frags(Vb, a.ldv, k0 + 16 * nt, a.Tk, lane, vf[nt]);
+  for (int ct = 0; ct < NCT; ++ct) {
+    dk[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    dv[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  f32x4_t dk[DKV_NT][8], dv[DKV_NT][8];
-#pragma unroll
-  for (int nt = 0; nt < DKV_NT; ++nt)
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      dk[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dv[nt][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
   const bool drop = a.p > 0.f;
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float keep_p = 1.f - a.p;  // delta is pre-multiplied by it so that dS carries a common 1/(1-p)
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   const float scale2 = a.scale * 1.4426950408889634f;
   const bool full_mask = a.mask && a.msq != 0;
-  bool key_valid[DKV_NT];  // key-padding masks depend on the own key only: resolved once, outside the query sweep
-#pragma unroll
-  for (int nt = 0; nt < DKV_NT; ++nt) {
-    const int key = k0 + 16 * nt + m;
-    key_valid[nt] = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
-  }
-  bool kv_all = true;
-#pragma unroll
-  for (int nt = 0; nt < DKV_NT; ++nt) kv_all = kv_all && key_valid[nt];
-  const bool all_keys = __all(kv_all) != 0;  // wave-uniform: no per-element key test needed
-  const int nqt = (a.Tq + 63) / 64;
-  img_dma(Qb, a.ldq, 0, a.Tq, smem, t);
-  img_dma(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
-  // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in wave 0's registers: fetching
+  const int key = k0 + m;
+  // key-padding masks depend on the own key only: resolved once, outside the query sweep
+  const bool key_valid = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
+  const bool all_keys = __all(key_valid) != 0;  // wave-uniform: no per-element key test needed
+  const int nqt = (a.Tq + KT - 1) / KT;
+  img_dma<DH>(Qb, a.ldq, 0, a.Tq, smem, t);
+  img_dma<DH>(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
+  // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in registers: fetching
   // them at the top of the iteration they are used in put a global-load round trip in front of every tile
   float lse_r = 0.f, dl_r = 0.f;
-  if (t < 64) {
+  if (t < KT) {
     const int qc = min(t, a.Tq - 1);
     lse_r = a.lse[(int64_t)z * a.Tq + qc];
     dl_r = a.delta[(int64_t)z * a.Tq + qc];
   }
   int cur = 0;
   for (int qt = 0; qt < nqt; ++qt) {
-    if (t < 64) {
-      const bool live = qt * 64 + t < a.Tq;
+    if (t < KT) {
+      const bool live = qt * KT + t < a.Tq;
       lse_s[cur][t] = live ? lse_r * 1.4426950408889634f : INFINITY;  // rows past Tq: exp2(-inf) = 0
       dl_s[cur][t] = dl_r * keep_p;
-      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * 64 + t, a.Tq - 1)) ^ dkey);
+      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, a.Tq - 1)) ^ dkey);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) {
-      img_dma(Qb, a.ldq, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma(Gb, a.lddo, (qt + 1) * 64, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
-      if (t < 64) {
-        const int qc = min((qt + 1) * 64 + t, a.Tq - 1);
+      img_dma<DH>(Qb, a.ldq, (qt + 1) * KT, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Gb, a.lddo, (qt + 1) * KT, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      if (t < KT) {
+        const int qc = min((qt + 1) * KT + t, a.Tq - 1);
         lse_r = a.lse[(int64_t)z * a.Tq + qc];
         dl_r = a.delta[(int64_t)z * a.Tq + qc];
       }
@@ -582,10 +567,10 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Gi = Qi + IMG_BYTES;
     // S = Q K^T and dP = dO V^T with D rows = tile queries, D cols = own keys:
-    // s[nt][tt][r] <-> (query 64qt + 16tt + 4g + r, key k0 + 16nt + m)
-    bf16x8_t pf[DKV_NT][2], dsf[DKV_NT][2];
+    // s[tt][r] <-> (query KT*qt + 16tt + 4g + r, key k0 + m)
+    bf16x8_t pf[NSS], dsf[NSS];
 #pragma unroll
-    for (int nt = 0; nt < DKV_NT; ++nt) {  // one own-key block at a time (register budget)
+    for (int hf = 0; hf < NTT / 4; ++hf) {  // 64 queries at a time (register budget: S and dP of 128 queries spill)
       f32x4_t s[4], dp[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -595,52 +580,44 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Qi, 16 * tt, ks, lane), kf[nt][ks], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row(Gi, 16 * tt, ks, lane), vf[nt][ks], dp[tt], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) {
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Qi, 4 * hf + tt, ks, lane), kf[ks], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Gi, 4 * hf + tt, ks, lane), vf[ks], dp[tt], 0, 0, 0);
         }
-      const int key = k0 + 16 * nt + m;
       const uint8_t* mcol = full_mask ? a.mask + (int64_t)b * a.msb + min(key, a.Tk - 1) : nullptr;
+      const float* lp = lse_s[cur] + 64 * hf;
+      const float* dlp = dl_s[cur] + 64 * hf;
+      const uint32_t* rp = rk_s[cur] + 64 * hf;
+      const int qbase = qt * KT + 64 * hf;
       if (full_mask)
-        dkv_elements<true, true>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, key_valid[nt], key, thr, drop, g, m & 1, mcol, a.msq,
-                                 qt * 64, a.Tq);
+        dkv_elements<true, true, 4>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, mcol, a.msq, qbase, a.Tq);
       else if (!all_keys)
-        dkv_elements<true, false>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, key_valid[nt], key, thr, drop, g, m & 1, nullptr, 0,
-                                  qt * 64, a.Tq);
+        dkv_elements<true, false, 4>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq);
       else
-        dkv_elements<false, false>(s, dp, lse_s[cur], dl_s[cur], rk_s[cur], scale2, true, key, thr, drop, g, m & 1, nullptr, 0,
-                                   qt * 64, a.Tq);
-      pf[nt][0] = pack8(s[0], s[1]);
-      pf[nt][1] = pack8(s[2], s[3]);
-      dsf[nt][0] = pack8(dp[0], dp[1]);
-      dsf[nt][1] = pack8(dp[2], dp[3]);
+        dkv_elements<false, false, 4>(s, dp, lp, dlp, rp, scale2, true, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq);
+      pf[2 * hf] = pack8(s[0], s[1]);
+      pf[2 * hf + 1] = pack8(s[2], s[3]);
+      dsf[2 * hf] = pack8(dp[0], dp[1]);
+      dsf[2 * hf + 1] = pack8(dp[2], dp[3]);
     }
     // dV^T += dO^T Pd ; dK^T += Q^T dS   (contraction over the tile's queries)
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8_t gt = img_tr(Gi, ss, ct, lane);
-        const bf16x8_t qt_f = img_tr(Qi, ss, ct, lane);
-#pragma unroll
-        for (int nt = 0; nt < DKV_NT; ++nt) {
-          dv[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt, pf[nt][ss], dv[nt][ct], 0, 0, 0);
-          dk[nt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[nt][ss], dk[nt][ct], 0, 0, 0);
-        }
+      for (int ss = 0; ss < NSS; ++ss) {
+        dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Gi, ss, ct, lane), pf[ss], dv[ct], 0, 0, 0);
+        dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Qi, ss, ct, lane), dsf[ss], dk[ct], 0, 0, 0);
       }
     cur ^= 1;
   }
   const float dv_sc = drop ? 1.f / keep_p : 1.f, dk_sc = a.scale * dv_sc;
-#pragma unroll
-  for (int nt = 0; nt < DKV_NT; ++nt) {
-    const int key = k0 + 16 * nt + m;
-    if (key >= a.Tk) continue;
+  if (key < a.Tk) {
     uint16_t* krow = a.dk + ((int64_t)b * a.Tk + key) * a.lddk + h * DH;
     uint16_t* vrow = a.dv + ((int64_t)b * a.Tk + key) * a.lddv + h * DH;
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-      store4(krow + 16 * ct + 4 * g, dk[nt][ct], dk_sc);
-      store4(vrow + 16 * ct + 4 * g, dv[nt][ct], dv_sc);
+    for (int ct = 0; ct < NCT; ++ct) {
+      store4(krow + 16 * ct + 4 * g, dk[ct], dk_sc);
+      store4(vrow + 16 * ct + 4 * g, dv[ct], dv_sc);
     }
   }
 }
@@ -657,9 +634,10 @@ int set_lds(K kernel, int bytes) {
 
 int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK(d != nullptr, "flash_attn: null descriptor");
-  JS2T_CHECK(d->head_dim == DH, "flash_attn: head size %d not supported (128 only; use the unfused path)", d->head_dim);
+  JS2T_CHECK(d->head_dim == 128 || d->head_dim == 64, "flash_attn: head size %d not supported (128 or 64; use the unfused path)",
+             d->head_dim);
   JS2T_CHECK(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "flash_attn: bad sizes");
-  JS2T_CHECK(d->Tk <= KMASK_MAX - 64, "flash_attn: at most %d keys", KMASK_MAX - 64);
+  JS2T_CHECK(d->Tk <= KMASK_MAX - 128, "flash_attn: at most %d keys", KMASK_MAX - 128);
   JS2T_CHECK((int64_t)d->B * d->H <= 65535, "flash_attn: B*H too large");
   JS2T_CHECK(d->q && d->k && d->v && d->lse, "flash_attn: null pointer");
   JS2T_CHECK((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "flash_attn: leading dims must be multiples of 8");
@@ -681,6 +659,38 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   return a;
 }
 
+template <int DH>
+int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    const int rc = set_lds(flash_fwd_kernel<DH>, 4 * IMG_BYTES);
+    if (rc) return rc;
+    once = true;
+  }
+  AttnArgs a = to_args(d);
+  hipLaunchKernelGGL(flash_fwd_kernel<DH>, dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+template <int DH>
+int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    int rc = set_lds(flash_dq_kernel<DH>, 4 * IMG_BYTES);
+    if (rc) return rc;
+    rc = set_lds(flash_dkv_kernel<DH>, 4 * IMG_BYTES);
+    if (rc) return rc;
+    once = true;
+  }
+  AttnArgs a = to_args(d);
+  hipLaunchKernelGGL(flash_dq_kernel<DH>, dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(flash_dkv_kernel<DH>, dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 }  // namespace
 
 #ifdef JS2T_ATTN_PROF
@@ -690,39 +700,17 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
   int rc = check_common(d);
   if (rc) return rc;
   JS2T_CHECK(d->o && (d->ldo % 4) == 0 && ((((uintptr_t)d->o)) & 7) == 0, "flash_attn_fwd: bad output");
-  static bool once = false;
-  if (!once) {
-    rc = set_lds(flash_fwd_kernel, 4 * IMG_BYTES);
-    if (rc) return rc;
-    once = true;
-  }
-  AttnArgs a = to_args(d);
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3(cdiv(d->Tq, 64 * FWD_MT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, (hipStream_t)stream, a);
-  JS2T_LAUNCH_CHECK();
-  return JS2T_OK;
+  return d->head_dim == 128 ? launch_fwd<128>(d, (hipStream_t)stream) : launch_fwd<64>(d, (hipStream_t)stream);
 }
 
 extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) {
   int rc = check_common(d);
   if (rc) return rc;
   JS2T_CHECK(d->o && d->d_o && d->dq && d->dk && d->dv && d->delta, "flash_attn_bwd: null pointer");
-  JS2T_CHECK((d->ld_do % 8) == 0 && (d->ld_dq % 4) == 0 && (d->ld_dk % 4) == 0 && (d->ld_dv % 4) == 0 && (d->ldo % 1) == 0,
+  JS2T_CHECK((d->ld_do % 8) == 0 && (d->ld_dq % 4) == 0 && (d->ld_dk % 4) == 0 && (d->ld_dv % 4) == 0 && (d->ldo % 8) == 0,
              "flash_attn_bwd: bad leading dims");
-  JS2T_CHECK((((uintptr_t)d->d_o) & 15) == 0 && ((((uintptr_t)d->dq) | ((uintptr_t)d->dk) | ((uintptr_t)d->dv)) & 7) == 0,
+  JS2T_CHECK(((((uintptr_t)d->d_o) | ((uintptr_t)d->o)) & 15) == 0 &&
+                 ((((uintptr_t)d->dq) | ((uintptr_t)d->dk) | ((uintptr_t)d->dv)) & 7) == 0,
              "flash_attn_bwd: misaligned gradient buffers");
-  static bool once = false;
-  if (!once) {
-    rc = set_lds(flash_dq_kernel, 4 * IMG_BYTES);
-    if (rc) return rc;
-    rc = set_lds(flash_dkv_kernel, 4 * IMG_BYTES);
-    if (rc) return rc;
-    once = true;
-  }
-  AttnArgs a = to_args(d);
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(flash_dq_kernel, dim3(cdiv(d->Tq, 64 * DQ_MT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
-  JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dkv_kernel, dim3(cdiv(d->Tk, 64 * DKV_NT) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
-  JS2T_LAUNCH_CHECK();
-  return JS2T_OK;
+  return d->head_dim == 128 ? launch_bwd<128>(d, (hipStream_t)stream) : launch_bwd<64>(d, (hipStream_t)stream);
 }

@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
 constexpr int CM_GROUPS = 12;  // frame groups per block: 12 x 80 bins = 960 threads share an utterance
 __global__ void cmvn_stats_kernel(const float* __restrict__ feat, const int64_t* __restrict__ frame_off, int F,
                                   float* __restrict__ mean, float* __restrict__ istd, float* __restrict__ fill, int norm_means,
-                                  int norm_vars) {
+                                  int norm_vars, int64_t max_frames) {
   extern __shared__ double sh[];  // [2][CM_GROUPS][F] + [F]
   const int u = blockIdx.x;
-  const int64_t t0 = frame_off[u], T = frame_off[u + 1] - t0;
+  // an over-long evaluation utterance is cut to max_length BEFORE CMVN (tokenizers.py:474-487): statistics over the kept frames
+  const int64_t t0 = frame_off[u], T = max_frames > 0 ? min(frame_off[u + 1] - t0, max_frames) : frame_off[u + 1] - t0;
   const int c = threadIdx.x % F, gi = threadIdx.x / F;
   double s = 0.0, q = 0.0;
   if (gi < CM_GROUPS) {
@@ -218,7 +219,7 @@ extern "C" int js2t_fbank(const float* wave, const int64_t* sample_off, const in
 }
 
 extern "C" int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd,
-                               float* fill, int32_t norm_means, int32_t norm_vars, js2t_stream stream) {
+                               float* fill, int32_t norm_means, int32_t norm_vars, int64_t max_frames, js2t_stream stream) {
   if (U == 0) return JS2T_OK;
   JS2T_CHECK(feat && frame_off && mean && istd && fill, "cmvn_stats: null pointer");
   JS2T_CHECK(F > 0 && F <= 256, "cmvn_stats: 1..256 feature bins supported");
@@ -226,7 +227,7 @@ extern "C" int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int3
   JS2T_CHECK(threads <= 1024, "cmvn_stats: too many feature bins");
   const size_t lds = sizeof(double) * (2 * CM_GROUPS * F + F);
   hipLaunchKernelGGL(cmvn_stats_kernel, dim3(U), dim3(threads), lds, (hipStream_t)stream, feat, frame_off, F, mean, istd, fill,
-                     norm_means, norm_vars);
+                     norm_means, norm_vars, max_frames);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

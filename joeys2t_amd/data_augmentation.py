@@ -68,7 +68,7 @@ def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Seque
     """feat f32 [sum T, F] (ragged, frame_off int64[U+1]) -> padded batch [U, Tmax, F] on the device:
     CMVN (before) -> SpecAugment -> pad with 1.0, i.e. SpeechProcessor.__call__ (tokenizers.py:480-492) followed by
     pad_features (helpers_for_audio.py:130-170), in two launches.  `max_length` truncates (evaluation-time rule,
-    tokenizers.py:474-478)."""
+    tokenizers.py:474-478) BEFORE the CMVN statistics are taken, as the reference does."""
     ops._dev(feat, frame_off)
     U, F = len(frames), feat.shape[1]
     dev = feat.device
@@ -82,7 +82,8 @@ def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Seque
         istd = torch.empty((U, F), dtype=torch.float32, device=dev)
         fill = torch.empty((U, ), dtype=torch.float32, device=dev)
         check(lib().js2t_cmvn_stats(_p(feat), _p(frame_off), C.c_int32(U), C.c_int32(F), _p(mean), _p(istd), _p(fill),
-                                    C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)), _stream()),
+                                    C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)),
+                                    C.c_int64(int(max_length) if max_length else 0), _stream()),
               "js2t_cmvn_stats")
     if specaugment is not None:
         if masks_dev is not None:  # caller-managed static int32[U,8] buffer (hipGraph replay): already drawn

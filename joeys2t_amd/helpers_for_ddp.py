@@ -130,7 +130,9 @@ class FlatGradReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in store.params if p.requires_grad]
 
     def begin(self, armed: bool = True):
-        self.armed = armed and self.world > 1
+        # a one-rank communicator exchanges nothing - unless JS2T_DDP_SINGLE=1 asks for the calls anyway (rehearsal of the
+        # RCCL path, its side stream and its event ordering on a 1-GPU box: bench.py JS2T_BENCH_FORCE_DDP)
+        self.armed = armed and (self.world > 1 or (use_ddp() and os.environ.get("JS2T_DDP_SINGLE", "0") == "1"))
         self.count = [0] * len(self.ranges)
         self.launched = [False] * len(self.ranges)
         self.works = []

@@ -675,8 +675,8 @@ def _mask_strides(mask, B, Tq, Tk):
 
 
 def flash_supported(q_t, k_t, v_t, dh: int) -> bool:
-    """Fused attention kernel constraints: bf16, head size 128, 16-byte aligned rows."""
-    ok = q_t.dtype == torch.bfloat16 and dh == 128 and k_t.shape[0] >= 1
+    """Fused attention kernel constraints: bf16, head size 128 or 64, 16-byte aligned rows."""
+    ok = q_t.dtype == torch.bfloat16 and dh in (128, 64) and k_t.shape[0] >= 1
     for t in (q_t, k_t, v_t):
         ok = ok and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
     return ok

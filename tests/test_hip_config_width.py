@@ -1,0 +1,341 @@
+"""GPU: parity at the layer WIDTHS of the BASELINE configs (depth reduced so that the CPU oracle finishes in seconds).
+
+  * mustc_st.yaml (:97-131): d 512, 8 heads of 64, DeepNet alpha of the 12+6 stack, ctc 0.1 - fp32 at 1e-4 against the
+    oracle incl. every parameter gradient; bf16 through the fused head-size-64 attention kernels.
+  * librispeech_100h.yaml: bf16 (the only mode bench.py runs) gradients of the composed backward - TrainStep with the
+    deferred grouped weight gradients, the LayerNorm hand-over, gradient copies and the CTC side stream - against the
+    fp32 oracle's autograd (reference training.py:558-588).
+  * librispeech_960h.yaml (:39,85): V = 10000 through xent / ctc / row_lse / beam_step(k = 20), batch_multiplier 8
+    through TrainStep against torch.optim.AdamW on the oracle's gradients.
+"""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_cfg import SPECIALS
+
+pytestmark = pytest.mark.gpu
+
+
+def width_cfg(heads, enc_layers, dec_layers, initializer="xavier_uniform"):
+    return {
+        "initializer": initializer, "bias_initializer": "zeros", "embed_initializer": "xavier_uniform",
+        "tied_embeddings": False, "tied_softmax": False,
+        "encoder": {"type": "transformer", "num_layers": enc_layers, "num_heads": heads, "embeddings": {"embedding_dim": 80},
+                    "hidden_size": 512, "ff_size": 2048, "dropout": 0.0, "freeze": False, "subsample": True,
+                    "conv_kernel_sizes": [5, 5], "conv_channels": 512, "in_channels": 80, "layer_norm": "pre",
+                    "activation": "relu"},
+        "decoder": {"type": "transformer", "num_layers": dec_layers, "num_heads": heads,
+                    "embeddings": {"embedding_dim": 512, "scale": True, "dropout": 0.0}, "hidden_size": 512, "ff_size": 2048,
+                    "dropout": 0.0, "freeze": False, "layer_norm": "pre", "activation": "relu"},
+    }
+
+
+def synth_batch(V, lengths, tl, seed):
+    g = torch.Generator().manual_seed(seed)
+    lengths, tl = torch.tensor(lengths), torch.tensor(tl)
+    B, T = len(lengths), int(lengths.max())
+    src = torch.randn(B, T, 80, generator=g)
+    for b in range(B):
+        src[b, lengths[b]:] = 1.0
+    L = int(tl.max()) + 2
+    trg = torch.full((B, L), 1, dtype=torch.long)
+    for b in range(B):
+        trg[b, 0] = 2
+        trg[b, 1:1 + tl[b]] = torch.randint(4, V, (int(tl[b]), ), generator=g)
+        trg[b, 1 + tl[b]] = 3
+    return src, lengths, trg, tl + 2
+
+
+def set_alpha(model, a_enc, a_dec):
+    """what initialization.py does for `xavier_normal`, with the alpha of the FULL-depth stack"""
+    for side, a in (("encoder", a_enc), ("decoder", a_dec)):
+        for layer in getattr(model, side).layers:
+            layer.alpha = a
+            layer.feed_forward.alpha = a
+
+
+def make_model(cfg, V, sd, device, dtype, ctc_w, alpha=None, train=False):
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    model = build_model(copy.deepcopy(cfg), None, Vocabulary.synthetic(V))
+    if sd is not None:
+        model.load_state_dict(sd)
+    if alpha is not None:
+        set_alpha(model, *alpha)
+    model.loss_function = ("crossentropy-ctc", 0.1, ctc_w)
+    if device is not None:
+        model.finalize(device, dtype)
+        model.train(train)
+    return model
+
+
+def hip_batch(src, lengths, trg, tlen, device):
+    from joeys2t_amd.batch import Batch
+    return Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=trg, trg_length=tlen, trg_prompt_mask=None,
+                 indices=torch.arange(src.shape[0]), device=device, pad_index=1, eos_index=3, is_train=True, task="S2T", n_gpu=1)
+
+
+def oracle_loss_and_grads(sd, ocfg, names, src, lengths, trg, tlen, ctc_w, scale=1.0):
+    from oracle import s2t_oracle as O
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    ob = O.make_batch(src, lengths, trg, tlen, 1, 3)
+    total, xent, ctc, ncor, _, _ = O.model_loss(sdg, ocfg, ob, SPECIALS, 0.1, ctc_w)
+    (total * scale).backward()
+    return (total.item(), xent.item(), ctc.item(), int(ncor)), {k: sdg[k].grad for k in names}
+
+
+def grad_report(model, ref):
+    """per-tensor (relative L2 error, cosine) of model gradients against the oracle's"""
+    rep = {}
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().flatten().double(), ref[n].flatten().double()
+        rn = r.norm().item()
+        rep[n] = ((g - r).norm().item() / max(rn, 1e-30), F.cosine_similarity(g, r, dim=0).item(), rn)
+    return rep
+
+
+MUSTC_ALPHA = (0.81 * (12**4 * 6)**(1 / 16), (3 * 6)**(1 / 4))  # initialization.py: DeepNet alpha of the 12 + 6 stack
+
+
+@pytest.fixture(scope="module")
+def mustc_case():
+    cfg = width_cfg(8, 2, 1, "xavier_normal")
+    V = 5000
+    torch.manual_seed(11)
+    base = make_model(cfg, V, None, None, None, 0.1)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    names = {n for n, _ in base.named_parameters()}
+    batch = synth_batch(V, [1498, 1203, 899], [60, 41, 72], seed=7)
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"], ocfg["decoder"]["alpha"] = MUSTC_ALPHA
+    ref = oracle_loss_and_grads(sd, ocfg, names, *batch, 0.1)
+    # the same restatement in double precision: the yardstick for what fp32 arithmetic can deliver at this size
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = oracle_loss_and_grads(sd64, ocfg, names, batch[0].double(), *batch[1:], 0.1)
+    return cfg, V, sd, batch, ref, ref64
+
+
+def test_mustc_width_fp32_loss_and_gradients_match_oracle(device, mustc_case):
+    """Losses within 1e-4 of the fp32 oracle.  Gradients: at T' = 375 the CTC posteriors (differences of exponentials of
+    sums over 375 frames) are conditioned at a few 1e-4 in fp32 - the fp32 CPU oracle itself misses its own double-precision
+    run by up to 5e-4 of a tensor's largest entry on the encoder side (tools/width_parity.py prints the table).  So every
+    gradient is compared with the fp64 oracle, and the HIP path may be off by 1e-4 or by 2.5 x what the fp32 oracle is off
+    by, whichever is larger."""
+    cfg, V, sd, batch, (rloss, rgrads), (rloss64, rgrads64) = mustc_case
+    model = make_model(cfg, V, sd, device, torch.float32, 0.1, alpha=MUSTC_ALPHA)
+    total, xent, ctc, ncor = model(return_type="loss", **vars(hip_batch(*batch, device)))
+    total.backward()
+    got = (total.item(), xent.item(), ctc.item())
+    for a, b, c in zip(got, rloss[:3], rloss64[:3]):
+        assert abs(a - b) <= 1e-4 * abs(b) and abs(a - c) <= 1e-4 * abs(c), (got, rloss, rloss64)
+    assert int(ncor) == rloss[3]
+    worst = worst32 = 0.0
+    for n, p in model.named_parameters():
+        ref = rgrads64[n]
+        scale = ref.abs().max().item()
+        if scale < 1e-9:
+            continue  # key-projection biases: the true gradient is exactly zero (softmax is shift-invariant)
+        err = (p.grad.cpu().double() - ref).abs().max().item() / scale
+        err32 = (rgrads[n].double() - ref).abs().max().item() / scale
+        worst, worst32 = max(worst, err), max(worst32, err32)
+        assert err <= max(1e-4, 2.5 * err32), (n, err, err32, scale)
+    print(f"mustc width fp32 vs fp64 oracle: worst relative gradient error HIP {worst:.2e}, fp32 CPU oracle {worst32:.2e}")
+    assert worst <= 1.5e-3
+
+
+def check_bf16_grads(rep, gmax_norm, rel_l2=2e-2, cos_min=0.999):
+    bad = []
+    for n, (rl2, cos, rn) in rep.items():
+        if rn < 1e-3 * gmax_norm:
+            continue  # e.g. key-projection biases: the true gradient is zero, only rounding noise is left
+        if rl2 > rel_l2 or cos < cos_min:
+            bad.append((n, round(rl2, 4), round(cos, 5)))
+    return bad
+
+
+def test_mustc_width_bf16_uses_fused_attention_dh64(device, mustc_case):
+    """bf16 compute on MuST-C shapes takes the fused kernels (head size 64) - no [B,H,T,T] scores in HBM - and its loss /
+    gradients stay within bf16 tolerance of the fp32 oracle: per-tensor relative L2 <= 2e-2, cosine >= 0.999."""
+    from joeys2t_amd import ops
+    cfg, V, sd, batch, (rloss, rgrads), _ = mustc_case
+    model = make_model(cfg, V, sd, device, torch.bfloat16, 0.1, alpha=MUSTC_ALPHA)
+    calls = {"fwd": 0, "bwd": 0}
+    of, ob = ops.flash_attn_fwd, ops.flash_attn_bwd
+
+    def cf(*a, **k):
+        calls["fwd"] += 1
+        assert a[10] == 64  # dh
+        return of(*a, **k)
+
+    def cb(*a, **k):
+        calls["bwd"] += 1
+        return ob(*a, **k)
+
+    ops.flash_attn_fwd, ops.flash_attn_bwd = cf, cb
+    try:
+        total, xent, ctc, ncor = model(return_type="loss", **vars(hip_batch(*batch, device)))
+        total.backward()
+    finally:
+        ops.flash_attn_fwd, ops.flash_attn_bwd = of, ob
+    n_attn = cfg["encoder"]["num_layers"] + 2 * cfg["decoder"]["num_layers"]
+    assert calls == {"fwd": n_attn, "bwd": n_attn}, calls
+    assert abs(total.item() - rloss[0]) <= 1e-2 * abs(rloss[0]), (total.item(), rloss[0])
+    rep = grad_report(model, rgrads)
+    gmax = max(v[2] for v in rep.values())
+    print("mustc width bf16: worst rel L2", max(v[0] for v in rep.values() if v[2] >= 1e-3 * gmax), "worst cos",
+          min(v[1] for v in rep.values() if v[2] >= 1e-3 * gmax))
+    assert not check_bf16_grads(rep, gmax), check_bf16_grads(rep, gmax)
+
+
+@pytest.mark.parametrize("overlap_ctc", [True, False])
+def test_ls100_width_bf16_gradients_through_trainstep(device, overlap_ctc):
+    """LS100 width (d 512, 4 heads of 128, ff 2048, V 5000, T 1498 -> T' 375), 2 + 1 layers, B = 3: the bf16 backward as
+    bench.py runs it (TrainStep: deferred grouped weight gradients, LayerNorm -> dropout hand-over, gradient copies, CTC
+    branch on the side stream) against the fp32 oracle's autograd, normalised like training.py:565-570."""
+    from joeys2t_amd.training import TrainStep
+    cfg, V = width_cfg(4, 2, 1), 5000
+    torch.manual_seed(3)
+    base = make_model(cfg, V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    names = {n for n, _ in base.named_parameters()}
+    batch = synth_batch(V, [1498, 1200, 901], [60, 45, 70], seed=5)
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"] = ocfg["decoder"]["alpha"] = 1.0
+    rloss, rgrads = oracle_loss_and_grads(sd, ocfg, names, *batch, 0.3, scale=1.0 / 3)
+    model = make_model(cfg, V, sd, device, torch.bfloat16, 0.3, train=True)
+    step = TrainStep(model, learning_rate=2e-3, adam_betas=(0.9, 0.98), clip_grad_norm=10.0, normalization="batch",
+                     batch_multiplier=1, n_gpu=1, overlap_ctc=overlap_ctc)
+    loss = step.micro_step(hip_batch(*batch, device), update=False)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - rloss[0] / 3) <= 1e-2 * abs(rloss[0] / 3), (loss.item(), rloss[0] / 3)
+    rep = grad_report(model, rgrads)
+    gmax = max(v[2] for v in rep.values())
+    print("ls100 width bf16: worst rel L2", max(v[0] for v in rep.values() if v[2] >= 1e-3 * gmax), "worst cos",
+          min(v[1] for v in rep.values() if v[2] >= 1e-3 * gmax))
+    assert not check_bf16_grads(rep, gmax), check_bf16_grads(rep, gmax)
+    # the global norm clip_grad_norm_ would see
+    ref_norm = math.sqrt(sum(float(g.double().pow(2).sum()) for g in rgrads.values()))
+    got_norm = float(step.store.flat_grad.double().norm())
+    assert abs(got_norm - ref_norm) <= 1e-2 * ref_norm, (got_norm, ref_norm)
+
+
+# ------------------------------------------------------------------------------------------------ LS960: V = 10000
+def test_ls960_vocab_xent_ctc_lse(device):
+    from joeys2t_amd import ops
+    from joeys2t_amd.loss import XentCTCLoss, XentLoss
+    from oracle import s2t_oracle as O
+    V = 10000
+    g = torch.Generator().manual_seed(960)
+    N, L = 6, 40
+    logits = torch.randn(N, L, V, generator=g) * 2
+    trg = torch.randint(4, V, (N, L), generator=g)
+    trg[:, -3:] = 1
+    lr = logits.clone().requires_grad_(True)
+    ref = O.xent_loss(torch.log_softmax(lr, -1), trg, 1, 0.1)
+    ref.backward()
+    ld = logits.to(device).requires_grad_(True)
+    loss, ncor = XentLoss(pad_index=1, smoothing=0.1).xent(ld, trg.to(device))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-4, atol=1e-6)
+    tm = trg != 1
+    assert int(ncor.item()) == int((logits.argmax(-1)[tm] == trg[tm]).sum())
+    # CTC at T' = 375, V = 10000 (240 MB of logits at B = 16; B = 4 here)
+    B, T = 4, 375
+    cl = torch.randn(B, T, V, generator=g)
+    tl = torch.tensor([60, 33, 75, 48])
+    ct = torch.full((B, 76), 1, dtype=torch.long)
+    for b in range(B):
+        ct[b, :tl[b] - 1] = torch.randint(4, V, (int(tl[b]) - 1, ), generator=g)
+        ct[b, tl[b] - 1] = 3
+    in_len = torch.tensor([375, 300, 351, 210])
+    cr = cl.clone().requires_grad_(True)
+    rc = F.ctc_loss(torch.log_softmax(cr, -1).transpose(0, 1), ct, in_len, tl, blank=2, reduction="sum", zero_infinity=True)
+    rc.backward()
+    cd = cl.to(device).requires_grad_(True)
+    gc = XentCTCLoss(pad_index=1, bos_index=2).ctc(cd, ct.to(device), in_len.to(device), tl.to(device))
+    gc.backward()
+    assert abs(gc.item() - rc.item()) <= 1e-4 * abs(rc.item())
+    torch.testing.assert_close(cd.grad.cpu(), cr.grad, rtol=1e-3, atol=2e-5)
+    x = cl[0, :100] * 3
+    lse, am = ops.row_lse(x.to(device).contiguous(), want_argmax=True)
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(x, -1), rtol=1e-5, atol=1e-5)
+    assert torch.equal(am.cpu(), x.argmax(-1))
+    torch.testing.assert_close(ops.log_softmax(x.to(device)).cpu(), torch.log_softmax(x, -1), rtol=1e-5, atol=1e-5)
+
+
+def test_ls960_beam_step_k20_v10000(device):
+    """librispeech_960h.yaml:58-59: beam 20, alpha 1.0, V 10000 - the fused log-softmax + forbid + length penalty + top-k
+    step against the reference's chain (search.py:562-646) in torch on the CPU: indices bit-exact."""
+    from joeys2t_amd import ops
+    beam, V, nb = 20, 10000, 4
+    g = torch.Generator().manual_seed(20)
+    logits = torch.randn(nb * beam, V, generator=g) * 3
+    blp = torch.randn(nb, beam, generator=g)
+    blp[0, 1:] = float("-inf")  # first step: only hypothesis 0 is live (search.py:477-479)
+    forbid = [1, 2]
+    lp = torch.log_softmax(logits, -1)
+    lp[:, forbid] = float("-inf")
+    lp = lp + blp.view(-1, 1)
+    pen = ((5.0 + 7) / 6.0)**1.0
+    ref_s, ref_i = (lp / pen).reshape(nb, beam * V).topk(beam, dim=-1)
+    s, i, lse = ops.beam_step(logits.to(device), blp.view(-1).to(device), nb, beam, forbid, pen)
+    assert torch.equal(i.cpu(), ref_i)
+    torch.testing.assert_close(s.cpu(), ref_s, rtol=1e-5, atol=1e-5)
+
+
+def test_ls960_batch_multiplier_8_update_matches_torch(device):
+    """librispeech_960h.yaml:85 `batch_multiplier: 8` (V = 10000): eight micro-batches accumulate into the flat gradient,
+    then ONE clip(10) + AdamW update.  Reference: the oracle's autograd on each micro-batch normalised by nseqs * 8
+    (batch.py:135-175), torch's clip_grad_norm_ and torch.optim.AdamW (builders.py:68-71,112-114)."""
+    from joeys2t_amd.training import TrainStep
+    cfg, V = width_cfg(4, 1, 1), 10000
+    torch.manual_seed(960)
+    base = make_model(cfg, V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    names = [n for n, _ in base.named_parameters()]
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"] = ocfg["decoder"]["alpha"] = 1.0
+    mbs = [synth_batch(V, [300 + 13 * i, 260 - 7 * i], [20 + i, 12 + 2 * i], seed=100 + i) for i in range(8)]
+    acc = {n: torch.zeros_like(sd[n]) for n in names}
+    ref_losses = []
+    for mb in mbs:
+        rl, rg = oracle_loss_and_grads(sd, ocfg, set(names), *mb, 0.3, scale=1.0 / (2 * 8))
+        ref_losses.append(rl[0] / 16)
+        for n in names:
+            acc[n] += rg[n]
+    params = [torch.nn.Parameter(sd[n].clone()) for n in names]
+    for p, n in zip(params, names):
+        p.grad = acc[n].clone()
+    ref_norm = float(torch.nn.utils.clip_grad_norm_(params, 10.0))
+    ropt = torch.optim.AdamW(params, lr=2e-3, betas=(0.9, 0.98), weight_decay=0.0)
+    ropt.step()
+    model = make_model(cfg, V, sd, device, torch.float32, 0.3, train=True)
+    step = TrainStep(model, learning_rate=2e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
+                     learning_rate_warmup=10000, normalization="batch", batch_multiplier=8, n_gpu=1)
+    for i, mb in enumerate(mbs):
+        loss = step.micro_step(hip_batch(*mb, device))
+        assert abs(loss.item() - ref_losses[i]) <= 1e-4 * abs(ref_losses[i]), (i, loss.item(), ref_losses[i])
+        assert step.steps == (1 if i == 7 else 0)
+    assert abs(float(step.optimizer.norm_clip[0]) - ref_norm) <= 1e-4 * ref_norm
+    assert torch.all(step.store.flat_grad == 0)
+    # first moment = (1 - beta1) * clipped gradient: linear in the gradient, compared per tensor
+    st = step.store
+    worst = 0.0
+    for p, n, q in zip(model.parameters(), names, params):
+        off = st.offsets[id(p)]
+        m_hip = step.optimizer.exp_avg[off:off + p.numel()].view(p.shape).cpu()
+        m_ref = ropt.state[q]["exp_avg"]
+        scale = m_ref.abs().max().item() + 1e-9
+        err = (m_hip - m_ref).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 1e-4 * scale + 1e-9, (n, err, scale)
+        # Adam's first step is lr * g / (|g| + eps): elements whose gradient is not rounding noise land on torch's values
+        big = acc[n].abs() > 1e-5 * acc[n].abs().max()
+        assert (p.detach().cpu() - q.detach())[big].abs().max().item() <= 2e-5, n
+    print("ls960 bm8: worst relative first-moment error", worst)

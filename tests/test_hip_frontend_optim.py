@@ -63,10 +63,13 @@ def test_cmvn_specaugment_pad(device, out_dtype):
     assert lens == rl and tuple(out.shape) == padded.shape
     tol = dict(rtol=1e-5, atol=2e-5) if out_dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(out.float().cpu().numpy(), padded, **tol)
-    # no augmentation, truncation to max_length (evaluation rule)
+    # no augmentation, truncation to max_length (evaluation rule): the reference cuts item[:max_length] FIRST and runs
+    # CMVN on what is left (tokenizers.py:474-487), so the statistics cover the kept frames only
     out2, lens2 = finalize_features(flat, foff, frames, cmvn=CMVN(), specaugment=None, out_dtype=torch.float32, max_length=40)
     assert lens2 == [40, 20, 40] and out2.shape[1] == 40
-    np.testing.assert_allclose(out2[0].cpu().numpy(), O.cmvn(feats[0].copy())[:40], rtol=1e-5, atol=2e-5)
+    for u in (0, 2):
+        np.testing.assert_allclose(out2[u].cpu().numpy(), O.cmvn(feats[u][:40].copy()), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(out2[1, :20].cpu().numpy(), O.cmvn(feats[1].copy()), rtol=1e-5, atol=2e-5)
     assert torch.all(out2[1, 20:] == 1.0)
 
 
@@ -102,6 +105,42 @@ def test_flat_adamw_and_clip_match_torch(device):
             torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
     assert lrs == [ropt.param_groups[0]["lr"]] * 0 + lrs  # same schedule object semantics
     assert lrs[0] == 2e-3 * 1 / 4 and lrs[3] == 2e-3
+
+
+def test_flat_adamw_leaves_frozen_parameters_alone(device):
+    """`freeze: True` sub-networks (requires_grad False; reference helpers.py freeze_params) are not in torch's optimizer
+    at all: no weight decay, no moment update.  The flat update must skip their ranges of the store."""
+    from joeys2t_amd.builders import FlatAdamW, trainable_ranges
+    from joeys2t_amd.runtime import ParamStore
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(36, 52), torch.nn.Linear(52, 12), torch.nn.Linear(12, 8))
+    ref = torch.nn.Sequential(torch.nn.Linear(36, 52), torch.nn.Linear(52, 12), torch.nn.Linear(12, 8))
+    ref.load_state_dict(net.state_dict())
+    for m in (net, ref):
+        for p in m[1].parameters():
+            p.requires_grad = False
+    store = ParamStore(net, device)
+    store.attach_grads()
+    ranges = trainable_ranges(store)
+    assert len(ranges) >= 2 and all(lo % 4 == 0 and hi % 4 == 0 for lo, hi in ranges)
+    opt = FlatAdamW(store, lr=1e-2, betas=(0.9, 0.98), weight_decay=0.1)
+    ropt = torch.optim.AdamW([p for p in ref.parameters() if p.requires_grad], lr=1e-2, betas=(0.9, 0.98), weight_decay=0.1)
+    frozen_before = [p.detach().clone() for p in net[1].parameters()]
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        for p, q in zip(net.parameters(), ref.parameters()):
+            if q.requires_grad:
+                gr = torch.randn(q.shape, generator=g)
+                p.grad.copy_(gr)
+                q.grad = gr.clone()
+        ropt.step()
+        opt.clip_and_step(None)
+    for p, b in zip(net[1].parameters(), frozen_before):
+        assert torch.equal(p.detach(), b)  # bit-identical: neither decayed nor updated
+    for p, q in zip(net.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=1e-5, atol=1e-6)
+    lo = store.offsets[id(net[1].weight)]
+    assert torch.all(opt.exp_avg[lo:lo + net[1].weight.numel()] == 0)
 
 
 def test_wav_manifest_to_gpu_features(device, tmp_path):

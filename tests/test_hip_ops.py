@@ -413,11 +413,12 @@ def _attn_ref(q, k, v, mask, H):
     return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Tq, d)
 
 
+@pytest.mark.parametrize("dh", [128, 64])
 @pytest.mark.parametrize("B,H,Tq,Tk,mask_kind", [(2, 2, 75, 75, "pad"), (1, 4, 200, 333, "pad"), (2, 1, 40, 40, "full"),
-                                                 (1, 2, 130, 64, None)])
-def test_flash_attention_matches_reference(device, B, H, Tq, Tk, mask_kind):
-    """Fused bf16 attention (fwd + bwd) against fp32 math on the bf16-rounded inputs."""
-    dh = 128
+                                                 (1, 2, 130, 64, None), (1, 3, 129, 257, "full"), (2, 2, 64, 128, "pad")])
+def test_flash_attention_matches_reference(device, B, H, Tq, Tk, mask_kind, dh):
+    """Fused bf16 attention (fwd + bwd) against fp32 math on the bf16-rounded inputs, head sizes 128 (LS100: 4 heads) and
+    64 (mustc_st.yaml:109-110,130-131: 8 heads)."""
     d = H * dh
     q = rnd(B, Tq, d, seed=1).bfloat16()
     kv = rnd(B, Tk, 2 * d, seed=2).bfloat16()
@@ -450,9 +451,10 @@ def test_flash_attention_matches_reference(device, B, H, Tq, Tk, mask_kind):
     bf16_close(dkv.view(B, Tk, 2 * d)[..., d:], vr.grad, 3e-2)
 
 
-def test_flash_attention_dropout_matches_unfused(device):
+@pytest.mark.parametrize("dh", [128, 64])
+def test_flash_attention_dropout_matches_unfused(device, dh):
     """Same RNG state and call site: the fused kernels must draw exactly the masks of the unfused softmax path."""
-    B, H, Tq, Tk, dh, p = 2, 2, 96, 150, 128, 0.2
+    B, H, Tq, Tk, p = 2, 2, 96, 150, 0.2
     d = H * dh
     rng = ops.DropoutRng(device, seed=11)
     qkv = rnd(B * Tq, 3 * d, seed=1).bfloat16().to(device)
