@@ -393,6 +393,26 @@ int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_
                    float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
                    int32_t n_forbid, float length_penalty, js2t_stream stream);
 
+/* The same step over rows that already ARE log-probabilities (no normalisation; out_lse := 0): the decoding options
+ * of search.py:564-618 edit the log-softmax output before the beam scores are added - n-gram blocking, repetition
+ * penalty, forced prompt tokens - so on that path log_softmax (js2t_log_softmax), the edits below and this selection
+ * are separate launches. */
+int js2t_beam_step_logp(const float* log_probs, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
+                        float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
+                        int32_t n_forbid, float length_penalty, js2t_stream stream);
+
+/* penalize_repetition (search.py:972-1001): for every id in tokens[row, 0..L) (int64[rows, L]; hypothesis prefix or
+ * source tokens) log_probs[row, id] := x * penalty if x < 0 else x / penalty, x = the value BEFORE this call (gather,
+ * scale, scatter: an id that occurs several times is penalised once).  In place on f32[rows, V].
+ * The reference's `exclude_tokens` restore is a no-op there (scores_before aliases scores, :986,996-999): none here. */
+int js2t_rep_penalty(float* log_probs, const int64_t* tokens, int64_t rows, int64_t V, int64_t L, float penalty,
+                     js2t_stream stream);
+
+/* log_probs[rows[i], cols[i]] := value for i < n (device index arrays): the -inf of block_repeat_ngrams
+ * (search.py:966-969) and of the forbidden ids (:590-601), the 0 of a forced prompt token (:614-618). */
+int js2t_logp_set(float* log_probs, const int64_t* rows, const int64_t* cols, int64_t n, int64_t V, float value,
+                  js2t_stream stream);
+
 /* --------------------------------------------------------------------------------------------------
  * Fused multi-head attention (bf16, head size 128): softmax(mask(q k^T * scale)) [dropout] v without
  * materialising the [B,H,Tq,Tk] scores — MultiHeadedAttention.forward, transformer_layers.py:86-105, and its

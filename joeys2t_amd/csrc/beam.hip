@@ -20,7 +20,7 @@ __device__ __forceinline__ bool better(float s, int i, float bs, int bi) { retur
 __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(const float* __restrict__ logits, const float* __restrict__ beam_lp,
                                                               float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
                                                               float* __restrict__ out_lse, int k, int64_t V, ForbidList fb,
-                                                              float len_pen, int use_pen) {
+                                                              float len_pen, int use_pen, int normalized) {
   __shared__ float red[BS_THREADS / 64];
   __shared__ int redi[BS_THREADS / 64];
   __shared__ float lse_s[BS_MAX_BEAM];
@@ -28,8 +28,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_kernel(const float* __re
   __shared__ int pick_i;
   const int b = blockIdx.x, t = threadIdx.x;
   const float* lg = logits + (int64_t)b * k * V;
-  // 1. row log-sum-exp for the k hypotheses of this element
-  for (int r = 0; r < k; ++r) {
+  // 1. row log-sum-exp for the k hypotheses of this element (input already log-probabilities: nothing to take off)
+  if (normalized && t < k) {
+    lse_s[t] = 0.f;
+    out_lse[(int64_t)b * k + t] = 0.f;
+  }
+  for (int r = 0; r < (normalized ? 0 : k); ++r) {
     const float* row = lg + (int64_t)r * V;
     float mx = -INFINITY;
     for (int64_t v = t; v < V; v += BS_THREADS) mx = fmaxf(mx, row[v]);
@@ -98,7 +102,7 @@ constexpr int BS_LK = 8;
 __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float* __restrict__ logits, const float* __restrict__ beam_lp,
                                                                    float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
                                                                    float* __restrict__ out_lse, int k, int V, ForbidList fb, float len_pen,
-                                                                   int use_pen) {
+                                                                   int use_pen, int normalized) {
   __shared__ float red[BS_THREADS / 64];
   __shared__ int redi[BS_THREADS / 64];
   __shared__ int redt[BS_THREADS / 64];
@@ -107,7 +111,12 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float*
   __shared__ int pick_t;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float* lg = logits + (int64_t)b * k * V;
-  for (int r = w; r < k; r += BS_THREADS / 64) {
+  if (normalized && t < k) {
+    lse_s[t] = 0.f;
+    out_lse[(int64_t)b * k + t] = 0.f;
+    blp_s[t] = beam_lp[(int64_t)b * k + t];
+  }
+  for (int r = w; r < (normalized ? 0 : k); r += BS_THREADS / 64) {
     const float* row = lg + (int64_t)r * V;
     float mx = -INFINITY, sm = 0.f;
     for (int v = lane; v < V; v += 64) {
@@ -192,11 +201,77 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float*
   }
 }
 
+// Repetition penalty (search.py:972-1001, after Huggingface's RepetitionPenaltyLogitsProcessor): for every token id in
+// tokens[row, :] the row's log-probability x becomes x * penalty if x < 0 else x / penalty.  gather -> scale -> scatter like
+// the reference: every occurrence reads the ORIGINAL value (staged in LDS before anything is written), so a token that
+// occurs several times is penalised once.  One block per row.
+__global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ logp, const int64_t* __restrict__ tokens, int L, int64_t V,
+                                                         float penalty) {
+  extern __shared__ float orig[];
+  float* row = logp + (int64_t)blockIdx.x * V;
+  const int64_t* tk = tokens + (int64_t)blockIdx.x * L;
+  for (int i = threadIdx.x; i < L; i += 256) orig[i] = row[tk[i]];
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const float x = orig[i];
+    row[tk[i]] = x < 0.f ? x * penalty : x / penalty;
+  }
+}
+
+// logp[rows[i], cols[i]] = value: banned n-grams (search.py:966-969), forbidden ids ahead of a forced token (:590-601) and
+// the forced tokens of a decoder prompt themselves (:614-618)
+__global__ void logp_set_kernel(float* __restrict__ logp, const int64_t* __restrict__ rows, const int64_t* __restrict__ cols, int64_t n,
+                                int64_t V, float value) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) logp[rows[i] * V + cols[i]] = value;
+}
+
+int beam_step_launch(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids, float* out_lse,
+                     int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids, int32_t n_forbid, float length_penalty,
+                     int normalized, js2t_stream stream);
+
 }  // namespace
+
+extern "C" int js2t_rep_penalty(float* log_probs, const int64_t* tokens, int64_t rows, int64_t V, int64_t L, float penalty,
+                                js2t_stream stream) {
+  if (rows == 0 || L == 0) return JS2T_OK;
+  JS2T_CHECK(log_probs && tokens && V > 0, "rep_penalty: null pointer");
+  JS2T_CHECK(L <= 8192, "rep_penalty: at most 8192 tokens per row");
+  JS2T_CHECK(penalty > 0.f, "rep_penalty: penalty must be positive");
+  hipLaunchKernelGGL(rep_penalty_kernel, dim3((unsigned)rows), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, log_probs,
+                     tokens, (int)L, V, penalty);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_logp_set(float* log_probs, const int64_t* rows, const int64_t* cols, int64_t n, int64_t V, float value,
+                             js2t_stream stream) {
+  if (n == 0) return JS2T_OK;
+  JS2T_CHECK(log_probs && rows && cols && V > 0, "logp_set: null pointer");
+  hipLaunchKernelGGL(logp_set_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_probs, rows, cols, n, V,
+                     value);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
 
 extern "C" int js2t_beam_step(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
                               float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
                               int32_t n_forbid, float length_penalty, js2t_stream stream) {
+  return beam_step_launch(logits, beam_log_probs, out_scores, out_ids, out_lse, n_batch, beam, V, forbid_ids, n_forbid, length_penalty, 0,
+                          stream);
+}
+
+extern "C" int js2t_beam_step_logp(const float* log_probs, const float* beam_log_probs, float* out_scores, int64_t* out_ids,
+                                   float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
+                                   int32_t n_forbid, float length_penalty, js2t_stream stream) {
+  return beam_step_launch(log_probs, beam_log_probs, out_scores, out_ids, out_lse, n_batch, beam, V, forbid_ids, n_forbid, length_penalty,
+                          1, stream);
+}
+
+namespace {
+int beam_step_launch(const float* logits, const float* beam_log_probs, float* out_scores, int64_t* out_ids, float* out_lse,
+                     int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids, int32_t n_forbid, float length_penalty,
+                     int normalized, js2t_stream stream) {
   if (n_batch == 0) return JS2T_OK;
   JS2T_CHECK(logits && beam_log_probs && out_scores && out_ids && out_lse, "beam_step: null pointer");
   JS2T_CHECK(beam >= 1 && beam <= BS_MAX_BEAM, "beam_step: beam size 1..%d", BS_MAX_BEAM);
@@ -209,11 +284,12 @@ extern "C" int js2t_beam_step(const float* logits, const float* beam_log_probs, 
   const int use_pen = length_penalty > 0.f ? 1 : 0;
   if (beam <= BS_LK) {
     hipLaunchKernelGGL(beam_step_fast_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
-                       out_scores, out_ids, out_lse, beam, (int)V, fb, use_pen ? length_penalty : 1.f, use_pen);
+                       out_scores, out_ids, out_lse, beam, (int)V, fb, use_pen ? length_penalty : 1.f, use_pen, normalized);
   } else {
     hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
-                       out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen);
+                       out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen, normalized);
   }
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
+}  // namespace

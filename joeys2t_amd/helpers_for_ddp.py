@@ -263,7 +263,9 @@ class DistributedSubsetSampler(Sampler):
         return iter(per_replica)
 
     def __len__(self) -> int:
-        return self.num_samples // self.num_replicas
+        # the reference defines no __len__ of its own: torch's DistributedSampler.__len__ returns self.num_samples, which the
+        # class overrides with the TOTAL number of (kept) indices, not the per-rank share (helpers_for_ddp.py:293-296)
+        return self.num_samples
 
     def _subsample(self):
         orig_len, subset_len = len(self.data_source), getattr(self.data_source, "random_subset", -1)

@@ -644,9 +644,40 @@ def attn_decode(q2d, k_view, v_view, ldkv: int, idx, idx_ld: int, Tmax: int, len
 
 
 # ----------------------------------------------------------------------------------------- beam search
-def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int, beam: int, forbid_ids, length_penalty: float):
+def rep_penalty(log_probs: torch.Tensor, tokens: torch.Tensor, penalty: float):
+    """penalize_repetition (search.py:972-1001) in place on f32 [rows, V]; tokens int64 [rows, L] with ids in [0, V)."""
+    _dev(log_probs, tokens)
+    if log_probs.dtype != torch.float32 or not log_probs.is_contiguous() or tokens.dtype != torch.int64:
+        raise Js2tError("rep_penalty: log_probs must be contiguous float32, tokens int64")
+    tokens = tokens.contiguous()
+    rows, V = log_probs.shape
+    if tokens.shape[0] != rows:
+        raise Js2tError(f"rep_penalty: {tokens.shape[0]} token rows for {rows} score rows")
+    check(lib().js2t_rep_penalty(_p(log_probs), _p(tokens), C.c_int64(rows), C.c_int64(V), C.c_int64(tokens.shape[1]),
+                                 C.c_float(penalty), _stream()), "js2t_rep_penalty")
+    return log_probs
+
+
+def logp_set(log_probs: torch.Tensor, rows, cols, value: float):
+    """log_probs[rows[i], cols[i]] = value (host index lists or device int64 tensors), in place."""
+    _dev(log_probs)
+    if log_probs.dtype != torch.float32 or not log_probs.is_contiguous():
+        raise Js2tError("logp_set: log_probs must be contiguous float32")
+    dev = log_probs.device
+    rows = torch.as_tensor(rows, dtype=torch.int64).to(dev).contiguous()
+    cols = torch.as_tensor(cols, dtype=torch.int64).to(dev).contiguous()
+    if rows.numel() != cols.numel():
+        raise Js2tError("logp_set: rows and cols differ in length")
+    check(lib().js2t_logp_set(_p(log_probs), _p(rows), _p(cols), C.c_int64(rows.numel()), C.c_int64(log_probs.shape[1]),
+                              C.c_float(value), _stream()), "js2t_logp_set")
+    return log_probs
+
+
+def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int, beam: int, forbid_ids, length_penalty: float,
+              normalized: bool = False):
     """Fused log-softmax + masks + beam score + length penalty + top-k (js2t_beam_step).  Returns
-    (scores [n_batch, beam], flat ids [n_batch, beam] int64, row lse [n_batch*beam])."""
+    (scores [n_batch, beam], flat ids [n_batch, beam] int64, row lse [n_batch*beam]).
+    normalized=True: the rows already are (edited) log-probabilities (js2t_beam_step_logp)."""
     _dev(logits2d, beam_log_probs)
     if logits2d.dtype != torch.float32 or not logits2d.is_contiguous():
         raise Js2tError("beam_step: logits must be contiguous float32")
@@ -657,8 +688,9 @@ def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int
     lse = torch.empty((n_batch * beam, ), dtype=torch.float32, device=dev)
     fb = (C.c_int32 * max(1, len(forbid_ids)))(*forbid_ids)
     blp = beam_log_probs.contiguous().float()
-    check(lib().js2t_beam_step(_p(logits2d), _p(blp), _p(scores), _p(ids), _p(lse), C.c_int64(n_batch), C.c_int32(beam),
-                               C.c_int64(V), fb, C.c_int32(len(forbid_ids)), C.c_float(length_penalty), _stream()),
+    fn = lib().js2t_beam_step_logp if normalized else lib().js2t_beam_step
+    check(fn(_p(logits2d), _p(blp), _p(scores), _p(ids), _p(lse), C.c_int64(n_batch), C.c_int32(beam),
+             C.c_int64(V), fb, C.c_int32(len(forbid_ids)), C.c_float(length_penalty), _stream()),
           "js2t_beam_step")
     return scores, ids, lse
 

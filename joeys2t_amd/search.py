@@ -6,24 +6,83 @@
 
 Per step the scoring chain (log-softmax, forbidden-token masks, beam score add, length penalty, top-k over beam*V) is
 ONE kernel (js2t_beam_step); the hypothesis bookkeeping (:671-755) is integer logic kept in the reference's order so
-that finished / n-best handling is identical.  Unsupported reference options (forced decoding prompts, repetition
-penalty, n-gram blocking: all off in the S2T configs, config.py:422,445) raise."""
+that finished / n-best handling is identical.
+
+The decoding options of the reference (all off in the S2T configs, config.py:422,445) edit the log-softmax output
+between those stages, so with any of them on the step runs as js2t_log_softmax -> edits -> js2t_beam_step_logp:
+  * `no_repeat_ngram_size`: banned continuations are found on the host exactly like block_repeat_ngrams (:915-969;
+    the reference walks Python lists too) and written as -inf by js2t_logp_set;
+  * `repetition_penalty` (+ `encoder_input` source tokens): js2t_rep_penalty (:972-1001);
+  * `decoder_prompt` / `trg_prompt_mask` (forced decoding, :489-499,603-618,648-655): the forced token's log-prob is set
+    to 0 AFTER the forbidden ids were masked; the prompt mask is embedded and added to the decoder input (model.py:271-282),
+    which needs the full-prefix decoder pass (no KV cache on this path);
+  * `return_attention` (greedy only, :318-325): cross-attention weights of the last layer, full-prefix pass."""
 from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor
 
 from joeys2t_amd import ops
-from joeys2t_amd.helpers import tile
+from joeys2t_amd.helpers import adjust_mask_size, tile
 from joeys2t_amd.incremental import IncrementalDecoder
 from joeys2t_amd.helpers_for_ddp import ddp_merge
 
 
-def _check_unsupported(kwargs):
-    if kwargs.get("repetition_penalty", -1) > 1.0 or kwargs.get("no_repeat_ngram_size", -1) > 0:
-        raise NotImplementedError("repetition_penalty / no_repeat_ngram_size are not on the HIP decoding path")
-    if kwargs.get("decoder_prompt") is not None or kwargs.get("trg_prompt_mask") is not None:
-        raise NotImplementedError("forced (prompt) decoding is not on the HIP decoding path")
+class _Options:
+    """Generation options of search.py:195-207,389-397 that are not part of the fused step."""
+
+    def __init__(self, kwargs, greedy: bool):
+        self.repetition_penalty = float(kwargs.get("repetition_penalty", -1))
+        self.ngram = int(kwargs.get("no_repeat_ngram_size", -1))
+        self.encoder_input = kwargs.get("encoder_input", None)
+        self.decoder_prompt = kwargs.get("decoder_prompt", None)
+        self.trg_prompt_mask = kwargs.get("trg_prompt_mask", None)
+        self.return_attention = bool(kwargs.get("return_attention", False)) and greedy
+        # greedy blocks for n > 1 (:248), beam search for n > 0 (:565); the penalty needs > 1.0 in both (:259,:576)
+        self.block = self.ngram > (1 if greedy else 0)
+        self.penalize = self.repetition_penalty > 1.0
+        self.prompted = self.decoder_prompt is not None or self.trg_prompt_mask is not None
+        self.edits = self.block or self.penalize or self.prompted
+        self.full_prefix = self.prompted or self.return_attention
+
+
+def banned_ngram_tokens(trg_tokens: List[List[int]], n: int, step: int, src_tokens: Optional[List[List[int]]],
+                        exclude: List[int]):
+    """block_repeat_ngrams (search.py:915-969), the search for banned continuations: -> (rows, tokens) to set to -inf."""
+    rows, toks = [], []
+    check_end_pos, offset = step + 2 - n, n - 1
+    for h, seq in enumerate(trg_tokens):
+        banned = set()
+        if len(seq) > n:
+            # (n-1)-token suffix; for n == 1 the reference's seq[-0:] is the WHOLE sequence, which never equals an empty
+            # slice: nothing is banned - kept as is
+            ngram = seq[-offset:]
+            for i in range(1, check_end_pos):  # position 0 is BOS
+                if ngram == seq[i:i + offset]:
+                    banned.add(seq[i + offset])
+            if src_tokens is not None:
+                src = src_tokens[h]
+                for i in range(len(src) + 1 - n):
+                    if ngram == src[i:i + offset]:
+                        banned.add(src[i + offset])
+        for t in sorted(banned - set(exclude)):
+            rows.append(h)
+            toks.append(t)
+    return rows, toks
+
+
+def _edit_log_probs(model, opt: _Options, log_probs: Tensor, seqs: Tensor, step: int, encoder_input: Optional[Tensor]) -> Tensor:
+    """n-gram blocking, then the repetition penalty on the hypothesis tokens, then on the source tokens (:564-588)."""
+    if opt.block:
+        src = None if encoder_input is None else encoder_input.cpu().tolist()
+        rows, toks = banned_ngram_tokens(seqs.cpu().tolist(), opt.ngram, step, src, model.specials + model.lang_tags)
+        if rows:
+            ops.logp_set(log_probs, rows, toks, float("-inf"))
+    if opt.penalize:
+        ops.rep_penalty(log_probs, seqs, opt.repetition_penalty)
+        if encoder_input is not None:
+            ops.rep_penalty(log_probs, encoder_input, opt.repetition_penalty)
+    return log_probs
 
 
 def _forbidden(model, include_pad: bool, generate_unk: bool, step: int, min_output_length: int, vocab: int) -> List[int]:
@@ -37,56 +96,100 @@ def _forbidden(model, include_pad: bool, generate_unk: bool, step: int, min_outp
     return sorted({int(i) for i in ids if i is not None and i < vocab})
 
 
-def _decode_last(model, ys: Tensor, encoder_output: Tensor, src_mask: Tensor, trg_mask: Tensor) -> Tensor:
+def _decode_last(model, ys: Tensor, encoder_output: Tensor, src_mask: Tensor, trg_mask: Tensor,
+                 trg_prompt_mask: Optional[Tensor] = None, return_attention: bool = False):
     """Logits of the newest position for every hypothesis: the decoder runs over the whole prefix (as the reference
-    does, search.py:518-534) but projects only the last row onto the vocabulary."""
+    does, search.py:518-534) but projects only the last row onto the vocabulary.  With return_attention also the last
+    layer's cross-attention weights of that position [B, src_len]."""
     with torch.no_grad():
-        logits, _, _, _ = model(return_type="decode", trg_input=ys, encoder_output=encoder_output, encoder_hidden=None,
-                                src_mask=src_mask, unroll_steps=None, decoder_hidden=None, trg_mask=trg_mask, last_only=True)
+        logits, _, att, _ = model(return_type="decode", trg_input=ys, encoder_output=encoder_output, encoder_hidden=None,
+                                  src_mask=src_mask, unroll_steps=None, decoder_hidden=None, trg_mask=trg_mask, last_only=True,
+                                  return_attention=return_attention,
+                                  trg_prompt_mask=adjust_mask_size(trg_prompt_mask, ys.size(0), ys.size(1)))
+    if return_attention:
+        return logits[:, -1].contiguous(), att[:, -1, :].float()
     return logits[:, -1].contiguous()
 
 
 def transformer_greedy(src_mask: Tensor, max_output_length: int, model, encoder_output: Tensor, encoder_hidden: Tensor,
-                       **kwargs) -> Tuple[Tensor, Optional[Tensor], None]:
-    _check_unsupported(kwargs)
+                       **kwargs) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    opt = _Options(kwargs, greedy=True)
     generate_unk = kwargs.get("generate_unk", True)
     return_prob = kwargs.get("return_prob", "none") == "hyp"
     min_output_length = kwargs.get("min_output_length", 1)
-    if kwargs.get("return_attention", False):
-        raise NotImplementedError("attention scores are not exported by the HIP greedy search")
-    B = src_mask.size(0)
+    B, _, src_len = src_mask.size()
     dev = encoder_output.device
     V = model.decoder.output_size
+    pad = model.pad_index
     ys = torch.full((B, 1), model.bos_index, dtype=torch.long, device=dev)
     yv = torch.zeros((B, 1), dtype=torch.float32, device=dev) if return_prob else None
+    yt = torch.zeros((B, 1, src_len), dtype=torch.float32, device=dev) if opt.return_attention else None
     trg_mask = torch.ones((1, 1, 1), dtype=torch.bool, device=dev)
     finished = torch.zeros((B, 1), dtype=torch.bool, device=dev)
     zero_lp = torch.zeros((B, ), dtype=torch.float32, device=dev)
-    inc = IncrementalDecoder(model, encoder_output, src_mask, 1, max_output_length) if kwargs.get("incremental", True) else None
+    enc_in = None if opt.encoder_input is None else opt.encoder_input.to(dev).long()
+    prompt = None if opt.decoder_prompt is None else opt.decoder_prompt.to(dev).long()
+    pmask = None if opt.trg_prompt_mask is None else opt.trg_prompt_mask.to(dev).long()
+    pmask_host = None if pmask is None else pmask.bool().cpu()
+    # the reference normalises only when something downstream reads probabilities (:204-207)
+    compute_softmax = return_prob or opt.repetition_penalty > 0 or opt.ngram > 0 or enc_in is not None
+    inc = None
+    if kwargs.get("incremental", True) and not opt.full_prefix:
+        inc = IncrementalDecoder(model, encoder_output, src_mask, 1, max_output_length)
     for step in range(max_output_length):
-        logits = inc.step(ys[:, -1]) if inc is not None else _decode_last(model, ys, encoder_output, src_mask, trg_mask)
-        forbid = _forbidden(model, False, generate_unk, step, min_output_length, V)
-        # arg-max of the masked row == top-1 of a beam of one; scores are log-probs (the reference only normalises
-        # when probabilities are requested, search.py:257-258, which does not change the arg-max)
-        scores, ids, _ = ops.beam_step(logits, zero_lp, B, 1, forbid, 0.0)
+        has_col = prompt is not None and prompt.size(1) > step + 1
+        forced_word = prompt[:, step + 1:step + 2] if has_col else None
+        has_mask = pmask is not None and pmask.size(1) > step + 1
+        forced_mask = pmask[:, step + 1:step + 2].bool() if has_mask else None
+        all_forced = has_mask and bool(pmask_host[:, step + 1].all())
+        att = None
+        if not all_forced:
+            if inc is not None:
+                logits = inc.step(ys[:, -1])
+            elif opt.return_attention:
+                logits, att = _decode_last(model, ys, encoder_output, src_mask, trg_mask, pmask, True)
+            else:
+                logits = _decode_last(model, ys, encoder_output, src_mask, trg_mask, pmask)
+            forbid = _forbidden(model, False, generate_unk, step, min_output_length, V)
+            if opt.edits and compute_softmax:
+                log_probs = _edit_log_probs(model, opt, ops.log_softmax(logits), ys, step, enc_in)
+                scores, ids, _ = ops.beam_step(log_probs, zero_lp, B, 1, forbid, 0.0, normalized=True)
+            else:
+                # arg-max of the masked row == top-1 of a beam of one; scores are log-probs (without compute_softmax the
+                # reference takes the arg-max of the raw logits, :257-258 - the same token, and no score is returned)
+                scores, ids, _ = ops.beam_step(logits, zero_lp, B, 1, forbid, 0.0)
+            if forced_mask is not None:
+                fw = forced_word if forced_word is not None else torch.full_like(ids, pad)
+                ids = torch.where(forced_mask, fw, ids)
+                scores = torch.where(forced_mask, torch.zeros_like(scores), scores)
+                if att is not None:
+                    att = torch.where(forced_mask.expand(-1, src_len), torch.zeros_like(att), att)
+        else:
+            ids = forced_word if forced_word is not None else torch.full((B, 1), pad, dtype=torch.long, device=dev)
+            scores = torch.zeros((B, 1), dtype=torch.float32, device=dev)
+            att = torch.zeros((B, src_len), dtype=torch.float32, device=dev) if opt.return_attention else None
         ys = torch.cat([ys, ids], dim=1)
         if return_prob:
             yv = torch.cat([yv, scores], dim=1)
+        if opt.return_attention:
+            yt = torch.cat([yt, att.unsqueeze(1)], dim=1)
         finished |= ids.eq(model.eos_index)
         if bool(finished.all()):
             break
     ys = ddp_merge(ys, model.pad_index)
     yv = ddp_merge(yv, 0.0) if return_prob else None
+    yt = ddp_merge(yt, 0.0) if opt.return_attention else None
     output = ys[:, 1:].detach().cpu().long()
     scores = yv[:, 1:].detach().cpu().float() if return_prob else None
-    return output, scores, None
+    attention = yt[:, 1:, :].detach().cpu().float() if opt.return_attention else None
+    return output, scores, attention
 
 
 def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: Tensor, src_mask: Tensor,
                 max_output_length: int, alpha: float, n_best: int = 1, **kwargs) -> Tuple[Tensor, Optional[Tensor], None]:
     assert beam_size > 0, "Beam size must be >0."
     assert n_best <= beam_size, f"Can only return {beam_size} best hypotheses."
-    _check_unsupported(kwargs)
+    opt = _Options(kwargs, greedy=False)
     bos, eos, pad, unk = model.bos_index, model.eos_index, model.pad_index, model.unk_index
     generate_unk = kwargs.get("generate_unk", True)
     return_prob = kwargs.get("return_prob", "none") == "hyp"
@@ -97,10 +200,18 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
 
     # KV-cached decoding (default): hypotheses index their utterance's encoder keys / values instead of carrying a tiled
     # copy of the encoder states; incremental=False keeps the reference's full-prefix pass (used to cross-check)
-    inc = IncrementalDecoder(model, encoder_output, src_mask, beam_size, max_output_length) if kwargs.get("incremental", True) else None
+    inc = None
+    if kwargs.get("incremental", True) and not opt.full_prefix:
+        inc = IncrementalDecoder(model, encoder_output, src_mask, beam_size, max_output_length)
     if inc is None:
         encoder_output = tile(encoder_output.contiguous(), beam_size, dim=0)  # [B*k, S, d]
         src_mask = tile(src_mask, beam_size, dim=0)
+    # per-hypothesis copies of the option tensors, filtered with the live examples below (:441-458,764-781)
+    enc_in = None if opt.encoder_input is None else tile(opt.encoder_input.to(dev).long().contiguous(), beam_size, dim=0).view(B * beam_size, -1)
+    prompt = None if opt.decoder_prompt is None else tile(opt.decoder_prompt.to(dev).long().contiguous(), beam_size, dim=0).view(B * beam_size, -1)
+    pmask = None if opt.trg_prompt_mask is None else tile(opt.trg_prompt_mask.to(dev).long().contiguous(), beam_size, dim=0).view(B * beam_size, -1)
+    if pmask is not None:
+        assert prompt is not None and prompt.size(1) == pmask.size(1)
     trg_mask = torch.ones((1, 1, 1), dtype=torch.bool, device=dev)
     batch_offset = torch.arange(B, dtype=torch.long)  # host: live example -> original position
     beam_offset = torch.arange(0, B * beam_size, step=beam_size, dtype=torch.long, device=dev)
@@ -113,13 +224,41 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
 
     for step in range(max_output_length):
         nb = alive_seq.size(0) // beam_size
-        logits = inc.step(alive_seq[:, -1]) if inc is not None else _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask)
+        rows = nb * beam_size
         forbid = _forbidden(model, True, generate_unk, step, min_output_length, V)
         length_penalty = ((5.0 + (step + 1)) / 6.0)**alpha if alpha > 0 else 0.0
-        topk_scores, topk_flat, _ = ops.beam_step(logits, topk_log_probs.reshape(-1), nb, beam_size, forbid, length_penalty)
+        forced_rows = None
+        if not opt.edits:
+            logits = inc.step(alive_seq[:, -1]) if inc is not None else _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask)
+            topk_scores, topk_flat, _ = ops.beam_step(logits, topk_log_probs.reshape(-1), nb, beam_size, forbid, length_penalty)
+        else:
+            # forced tokens of this step (:489-499): hypotheses whose prompt mask is set at position step + 1
+            has_mask = pmask is not None and pmask.size(1) > step + 1
+            padding_mask = pmask[:, step + 1].bool() if has_mask else torch.zeros((rows, ), dtype=torch.bool, device=dev)
+            forced_tok = prompt[:, step + 1] if (prompt is not None and prompt.size(1) > step + 1) else torch.full((rows, ), pad, dtype=torch.long, device=dev)
+            pm_host = padding_mask.cpu()
+            if not bool(pm_host.all()):
+                if inc is not None:
+                    logits = inc.step(alive_seq[:, -1])
+                else:
+                    logits = _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask, pmask)
+                log_probs = _edit_log_probs(model, opt, ops.log_softmax(logits), alive_seq, step, enc_in)
+                if forbid:  # masked BEFORE the forced overwrite: a forced SEP / tag must survive (:590-618)
+                    ops.logp_set(log_probs, [r for r in range(rows) for _ in forbid], forbid * rows, float("-inf"))
+            else:
+                log_probs = torch.full((rows, V), float("-inf"), dtype=torch.float32, device=dev)  # dummy (:607-611)
+            if bool(pm_host.any()):
+                forced_rows = pm_host.nonzero(as_tuple=False).view(-1).to(dev)
+                ops.logp_set(log_probs, forced_rows, forced_tok.index_select(0, forced_rows), 0.0)
+            topk_scores, topk_flat, _ = ops.beam_step(log_probs, topk_log_probs.reshape(-1), nb, beam_size, [], length_penalty,
+                                                      normalized=True)
         topk_log_probs = topk_scores * length_penalty if alpha > 0 else topk_scores.clone()
         topk_beam_index = topk_flat.div(V, rounding_mode="floor")
         topk_ids = topk_flat.fmod(V)
+        if forced_rows is not None:
+            # forced decoding overwrites the picks themselves as well (:648-655): flat position r of [nb, k] <- hypothesis r
+            topk_ids = topk_ids.view(-1).index_put((forced_rows, ), forced_tok.index_select(0, forced_rows)).view(-1, beam_size)
+            topk_scores = topk_scores.view(-1).index_put((forced_rows, ), torch.zeros_like(forced_rows, dtype=topk_scores.dtype)).view(-1, beam_size)
         batch_index = topk_beam_index + beam_offset[:nb].unsqueeze(1)
         select_indices = batch_index.view(-1)
         alive_seq = torch.cat([alive_seq.index_select(0, select_indices), topk_ids.view(-1, 1)], -1)
@@ -158,6 +297,12 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             topk_log_probs = topk_log_probs.index_select(0, unfinished)
             batch_offset = batch_offset.index_select(0, unfinished_h)
             alive_seq = alive_seq.view(-1, beam_size, alive_seq.size(-1)).index_select(0, unfinished).view(-1, alive_seq.size(-1))
+            if enc_in is not None:
+                enc_in = enc_in.view(-1, beam_size, enc_in.size(1)).index_select(0, unfinished).view(-1, enc_in.size(1))
+            if prompt is not None:
+                prompt = prompt.view(-1, beam_size, prompt.size(1)).index_select(0, unfinished).view(-1, prompt.size(1))
+            if pmask is not None:
+                pmask = pmask.view(-1, beam_size, pmask.size(1)).index_select(0, unfinished).view(-1, pmask.size(1))
 
         select_indices = batch_index.view(-1)
         if inc is not None:

@@ -375,17 +375,213 @@ def golden_conformer(name="conformer"):
     np.savez_compressed(OUT / f"{name}.npz", **out)
 
 
+def golden_search_options(name="search_options"):
+    """The decoding options the reference's own unit tests pin (test/unit/test_search.py:101-500): forced-decoding prompts,
+    repetition penalty (target and source side), n-gram blocking, generate_unk, attention export - on the decoder-only
+    model those tests build (TestSearchTransformer._build after set_seed(42); vocabulary of 8 with <sep> = 4 and two
+    language tags).  Stored per case: the arguments, the outputs of the reference's greedy / beam_search (full precision)
+    and the constants the reference test hard-codes (transcribed as data, `exp_*`); the generator asserts that the two agree
+    the way the reference test does (ids exact, scores / attention 1e-4)."""
+    from types import SimpleNamespace
+
+    from joeynmt.decoders import TransformerDecoder
+    from joeynmt.embeddings import Embeddings
+    from joeynmt.helpers import set_seed
+    from joeynmt.model import Model
+    from joeynmt.search import beam_search, greedy
+    from joeynmt.vocabulary import Vocabulary
+    special = SimpleNamespace(unk_token="<unk>", pad_token="<pad>", bos_token="<s>", eos_token="</s>", sep_token="<sep>", unk_id=0,
+                              pad_id=1, bos_id=2, eos_id=3, sep_id=4, lang_tags=["<de>", "<en>"])
+    vocab = Vocabulary(tokens=["word"], cfg=special)
+    assert len(vocab) == 8
+    autocast = {"device_type": "cpu", "enabled": False}
+
+    def build(batch_size):
+        set_seed(42)
+        emb = Embeddings(embedding_dim=12, vocab_size=8, padding_idx=1)
+        dec = TransformerDecoder(num_layers=3, num_heads=4, hidden_size=12, ff_size=24, dropout=0.0, emb_dropout=0.0, vocab_size=8,
+                                 layer_norm="pre")
+        enc_out = torch.rand(size=(batch_size, 4, 12))
+        for p in dec.parameters():
+            torch.nn.init.trunc_normal_(p, mean=0.0, std=1.0, a=-2.0, b=2.0)
+        src_mask = torch.ones(size=(batch_size, 1, 4)) == 1
+        model = Model(encoder=None, decoder=dec, src_embed=emb, trg_embed=emb, src_vocab=vocab, trg_vocab=vocab)
+        model.eval()
+        return src_mask, model, enc_out
+
+    out = {"vocab_size": np.int64(8), "specials": np.array(model_specials := [0, 1, 2, 3, 4]), "lang_tags": np.array([5, 6])}
+    T = torch.tensor
+
+    def t2n(x):
+        return None if x is None else (x.numpy() if torch.is_tensor(x) else np.asarray(x))
+
+    def record(case, res, exp):
+        names = ("ids", "scores", "att")
+        for nm, r in zip(names, res):
+            if r is not None:
+                out[f"{case}.{nm}"] = t2n(r)
+        for nm, e in exp.items():
+            out[f"{case}.exp_{nm}"] = t2n(e)
+            got = torch.as_tensor(out[f"{case}.{nm}"])
+            if nm == "ids":
+                assert torch.equal(got.long(), e.long()), (case, got, e)
+            else:
+                torch.testing.assert_close(got.float(), e.float(), rtol=1e-4, atol=1e-4)
+
+    for bs in (2, 3):
+        src_mask, model, enc_out = build(bs)
+        assert model.specials == model_specials and model.lang_tags == [5, 6] and model.sep_index == 4
+        out.update({f"bs{bs}.sd.{k}": v for k, v in np_sd(model.state_dict()).items() if not k.endswith("pe.pe") and not k.startswith("src_embed")})
+        out[f"bs{bs}.encoder_output"] = enc_out.numpy()
+    exp_ids = T([[0, 0, 0], [0, 0, 7]])
+    exp_scores = T([[-0.5425, -0.4908, -0.5439], [-0.8726, -0.9898, -0.9668]])
+    src_mask, model, enc_out = build(2)
+    common = dict(src_mask=src_mask, model=model, encoder_output=enc_out, encoder_hidden=None, autocast=autocast)
+    with torch.no_grad():
+        record("greedy", greedy(max_output_length=3, return_prob="hyp", **common), dict(ids=exp_ids, scores=exp_scores))
+        prompt, pmask = T([[2, 7, 7, 4], [0, 7, 4, 1]]), T([[1, 1, 1, 1], [1, 1, 1, 0]])
+        out["prompt"], out["prompt_mask"] = prompt.numpy(), pmask.numpy()
+        record("greedy_prompt", greedy(max_output_length=7, return_prob="hyp", return_attention=True, decoder_prompt=prompt,
+                                       trg_prompt_mask=pmask, **common),
+               dict(ids=T([[7, 7, 4, 0, 0, 0, 0], [7, 4, 0, 0, 0, 0, 0]]),
+                    scores=T([[0.0000, 0.0000, 0.0000, -0.4631, -0.3289, -0.3042, -0.3404],
+                              [0.0000, 0.0000, -0.7532, -0.6751, -0.5730, -0.4957, -0.5718]]),
+                    att=T([[[0.0000, 0.0000, 0.0000, 0.0000], [0.0000, 0.0000, 0.0000, 0.0000], [0.0000, 0.0000, 0.0000, 0.0000],
+                            [0.3926, 0.2844, 0.3191, 0.0039], [0.4019, 0.2798, 0.3156, 0.0027], [0.4072, 0.2809, 0.3093, 0.0026],
+                            [0.4004, 0.2799, 0.3169, 0.0027]],
+                           [[0.0000, 0.0000, 0.0000, 0.0000], [0.0000, 0.0000, 0.0000, 0.0000], [0.3194, 0.0042, 0.4271, 0.2492],
+                            [0.3523, 0.0036, 0.3957, 0.2484], [0.3335, 0.0034, 0.4143, 0.2488], [0.3135, 0.0031, 0.4346, 0.2488],
+                            [0.3322, 0.0034, 0.4158, 0.2486]]])))
+        record("beam1", beam_search(beam_size=1, max_output_length=3, alpha=0.0, n_best=1, return_prob="hyp", **common),
+               dict(ids=exp_ids, scores=T([[-1.5772], [-2.8292]])))
+        record("beam7", beam_search(beam_size=7, max_output_length=3, alpha=1.0, n_best=5, return_prob="hyp", **common),
+               dict(ids=T([[0, 0, 0], [0, 0, 7], [0, 7, 0], [7, 0, 0], [7, 0, 7], [0, 0, 7], [7, 0, 0], [0, 0, 0], [0, 7, 0], [7, 0, 7]]),
+                    scores=T([[-1.1829], [-1.6948], [-1.7128], [-2.0805], [-2.9899], [-2.1219], [-2.1881], [-2.1931], [-2.3707],
+                              [-2.4195]])))
+        record("beam7_prompt", beam_search(beam_size=7, max_output_length=10, alpha=1.0, n_best=5, return_prob="hyp",
+                                           decoder_prompt=prompt, trg_prompt_mask=pmask, **common),
+               dict(ids=T([[7, 7, 4, 0, 0, 0, 0, 0, 0, 0], [7, 7, 4, 0, 0, 0, 0, 0, 7, 0], [7, 7, 4, 0, 0, 0, 0, 0, 0, 7],
+                           [7, 7, 4, 0, 0, 0, 0, 0, 0, 0], [7, 7, 4, 0, 0, 0, 0, 7, 0, 0], [7, 4, 0, 0, 0, 0, 0, 0, 0, 0],
+                           [7, 4, 0, 0, 0, 0, 0, 0, 0, 7], [7, 4, 0, 0, 0, 0, 0, 0, 7, 7], [7, 4, 0, 0, 0, 0, 0, 0, 7, 0],
+                           [7, 4, 0, 0, 0, 0, 0, 7, 7, 0]]),
+                    scores=T([[-1.2273], [-1.3972], [-1.3999], [-1.4480], [-1.6088], [-2.2729], [-2.2850], [-2.3435], [-2.4353],
+                              [-2.4680]])))
+        src_tokens_b = T([[5, 5, 4], [5, 6, 6]]).long()
+        out["beam7_penalty.src_tokens"] = src_tokens_b.numpy()
+        record("beam7_penalty", beam_search(beam_size=7, max_output_length=3, alpha=1.0, n_best=5, return_prob="hyp",
+                                            encoder_input=src_tokens_b, repetition_penalty=1.5, **common),
+               dict(ids=T([[0, 0, 0], [0, 7, 0], [0, 0, 7], [7, 0, 0], [7, 0, 7], [7, 0, 0], [0, 0, 7], [7, 0, 7], [0, 7, 0], [0, 0, 0]]),
+                    scores=T([[-1.5709], [-1.8617], [-1.8788], [-2.2284], [-3.5925], [-2.4791], [-2.4931], [-2.8261], [-2.8357],
+                              [-2.9624]])))
+        record("greedy_ngram", greedy(max_output_length=7, return_prob="hyp", encoder_input=None, no_repeat_ngram_size=3, **common),
+               dict(ids=T([[0, 0, 0, 0, 0, 0, 0], [0, 0, 7, 0, 1, 0, 0]]),
+                    scores=T([[-0.5425, -0.4908, -0.5439, -0.7328, -0.6922, -0.6422, -0.6464],
+                              [-0.8726, -0.9898, -0.9668, -1.3988, -0.6783, -1.0269, -0.6804]])))
+        record("beam3_ngram", beam_search(beam_size=3, max_output_length=7, alpha=1.0, n_best=3, return_prob="hyp", encoder_input=None,
+                                          no_repeat_ngram_size=3, **common),
+               dict(ids=T([[0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 7], [0, 0, 0, 0, 0, 7, 7], [7, 0, 0, 0, 0, 0, 7],
+                           [0, 0, 0, 7, 3, 1, 1], [7, 0, 0, 0, 0, 0, 0]]),
+                    scores=T([[-2.1454], [-2.4287], [-2.4680], [-3.2931], [-3.3489], [-3.4080]])))
+        # batch of 3 (a different random decoder: the encoder-output draw precedes the parameter draw)
+        src_mask, model, enc_out = build(3)
+        common = dict(src_mask=src_mask, model=model, encoder_output=enc_out, encoder_hidden=None, autocast=autocast)
+        record("greedy_nounk", greedy(max_output_length=3, generate_unk=False, **common), dict(ids=T([[1, 1, 1], [1, 1, 1], [1, 1, 1]])))
+        record("greedy_nounk_penalty", greedy(max_output_length=3, generate_unk=False, encoder_input=None, repetition_penalty=1.5, **common),
+               dict(ids=T([[1, 1, 1], [1, 1, 1], [1, 1, 3]])))
+        src_tokens = T([[4, 3, 1, 1], [5, 4, 3, 1], [5, 5, 6, 3]]).long()
+        out["greedy_src_penalty.src_tokens"] = src_tokens.numpy()
+        common["src_mask"] = (src_tokens != 1).unsqueeze(1)
+        record("greedy_src_penalty", greedy(max_output_length=3, generate_unk=False, encoder_input=src_tokens, repetition_penalty=1.5,
+                                            return_attention=True, **common),
+               dict(ids=T([[1, 7, 3], [1, 7, 1], [1, 1, 1]]),
+                    att=T([[[0.5292, 0.4708, 0.0000, 0.0000], [0.5269, 0.4731, 0.0000, 0.0000], [0.5264, 0.4736, 0.0000, 0.0000]],
+                           [[0.3075, 0.6322, 0.0602, 0.0000], [0.2890, 0.6350, 0.0760, 0.0000], [0.3343, 0.6314, 0.0343, 0.0000]],
+                           [[0.2648, 0.1326, 0.5174, 0.0852], [0.2642, 0.1167, 0.5365, 0.0825], [0.2646, 0.1125, 0.5421, 0.0809]]])))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(name, sorted(k for k in out if k.endswith(".ids")))
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import_reference()
+    from joeynmt.helpers_for_ddp import DistributedSubsetSampler, ddp_merge, ddp_reduce
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # ddp_setup hard-codes nccl (helpers_for_ddp.py:17-38)
+    res = {}
+    # ddp_merge: ragged 2-D ids and 3-D attention-like tensors, pad_index -1 / 1 / 0.0
+    g = torch.Generator().manual_seed(100 + rank)
+    a2 = torch.randint(4, 20, (2 + rank, 5 - 2 * rank), generator=g)
+    a3 = torch.rand((3 - rank, 2 + rank, 4), generator=g)
+    res["merge2_in"], res["merge3_in"] = a2.numpy(), a3.numpy()
+    res["merge2"] = ddp_merge(a2, -1).numpy()
+    res["merge2_pad1"] = ddp_merge(a2, 1).numpy()
+    res["merge3"] = ddp_merge(a3, 0.0).numpy()
+    # ddp_reduce: 0-d tensor, 1-d tensor, python int
+    res["reduce0"] = ddp_reduce(torch.tensor(1.5 + rank)).numpy()
+    res["reduce1"] = ddp_reduce(torch.tensor([1.0 + rank, 2.0, -3.0 * rank])).numpy()
+    res["reduce_int"] = ddp_reduce(7 + rank, torch.device("cpu"), torch.long).numpy()
+
+    class DS:
+        def __init__(self, n):
+            self.indices = list(range(n))
+            self.random_subset = -1
+
+        def __len__(self):
+            return len(self.indices)
+
+        def reset_indices(self):
+            self.indices = list(range(len(self.indices)))
+
+    for n in (11, 16):
+        ds = DS(n)
+        sampler = DistributedSubsetSampler(ds, shuffle=True, drop_last=True, generator=torch.Generator().manual_seed(42))
+        res[f"sampler{n}_epoch0"] = np.array(list(iter(sampler)))
+        res[f"sampler{n}_epoch1"] = np.array(list(iter(sampler)))
+        res[f"sampler{n}_len"] = np.int64(len(sampler))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def golden_ddp(name="ddp", world=2):
+    """The reference's ddp_merge / ddp_reduce / DistributedSubsetSampler (helpers_for_ddp.py:58-174,244-342) run under a
+    2-rank gloo group on the CPU: per-rank inputs and outputs."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    out = {"world": np.int64(world)}
+    for r in range(world):
+        out.update({f"rank{r}.{k}": v for k, v in got[r].items()})
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items() if k.startswith("rank0.")})
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
     torch.set_num_threads(4)
-    golden_units()
-    golden_audio()
-    golden_model("model_pre", tiny_cfg("pre"))
-    golden_model("model_post", tiny_cfg("post", act="gelu"))
-    golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1)
-    golden_train_steps()
-    golden_conformer()
+    jobs = {
+        "units": golden_units, "audio": golden_audio,
+        "model_pre": lambda: golden_model("model_pre", tiny_cfg("pre")),
+        "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
+        "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
+        "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp,
+    }
+    for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
+        jobs[name]()
 
 
 if __name__ == "__main__":

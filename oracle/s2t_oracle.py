@@ -240,11 +240,15 @@ def embed(sd: SD, cfg: dict, ids: Tensor) -> Tensor:
 
 
 def decoder_forward(sd: SD, cfg: dict, trg_input: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor,
-                    return_attention: bool = False, prefix: str = "decoder"):
-    """TransformerDecoder.forward, decoders.py:567-625 (eval mode) -> (logits, hidden, att, ctc_logits|None)."""
+                    return_attention: bool = False, prefix: str = "decoder", trg_prompt_mask: Optional[Tensor] = None):
+    """TransformerDecoder.forward, decoders.py:567-625 (eval mode) -> (logits, hidden, att, ctc_logits|None).
+    trg_prompt_mask (0/1 ids [B, L]): embedded with the target table and added after the positional encoding
+    (model.py:271-282, decoders.py:600-602)."""
     dcfg = cfg["decoder"]
     x = embed(sd, cfg, trg_input)
     x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
+    if trg_prompt_mask is not None:
+        x = x + embed(sd, cfg, trg_prompt_mask)
     tmask = trg_mask & subsequent_mask(trg_input.size(1))
     att = None
     n = dcfg["num_layers"]
@@ -314,42 +318,124 @@ def _forbid(log_probs: Tensor, ids: List[Optional[int]]):
             log_probs[:, i] = float("-inf")
 
 
+def adjust_mask_size(mask: Optional[Tensor], batch_size: int, hyp_len: int) -> Optional[Tensor]:
+    """helpers.py:307-326"""
+    if mask is None:
+        return None
+    if mask.size(1) < hyp_len:
+        out = mask.new_zeros((batch_size, hyp_len))
+        out[:, :mask.size(1)] = mask
+        return out
+    return mask[:, :hyp_len]
+
+
+def block_repeat_ngrams(tokens: Tensor, scores: Tensor, n: int, step: int, src_tokens: Optional[Tensor] = None,
+                        exclude_tokens: Optional[List[int]] = None) -> Tensor:
+    """search.py:915-969: ban every token that would complete an n-gram already present in the hypothesis (or the source)."""
+    trg = tokens.tolist()
+    src = None if src_tokens is None else src_tokens.tolist()
+    check_end_pos, offset = step + 2 - n, n - 1
+    for h in range(tokens.size(0)):
+        banned = set()
+        if len(trg[h]) > n:
+            ngram = trg[h][-offset:]
+            for i in range(1, check_end_pos):
+                if ngram == trg[h][i:i + offset]:
+                    banned.add(trg[h][i + offset])
+            if src is not None:
+                for i in range(len(src[h]) + 1 - n):
+                    if ngram == src[h][i:i + offset]:
+                        banned.add(src[h][i + offset])
+        banned -= set(exclude_tokens or [])
+        scores[h, list(banned)] = float("-inf")
+    return scores
+
+
+def penalize_repetition(tokens: Tensor, scores: Tensor, penalty: float) -> Tensor:
+    """search.py:972-1001: gather, x*penalty if x<0 else x/penalty, scatter.  The reference's `exclude_tokens` restore copies
+    from an alias of `scores` itself (:986), i.e. restores nothing - so there is no such parameter here."""
+    score = torch.gather(scores, 1, tokens)
+    score = torch.where(score < 0, score * penalty, score / penalty)
+    scores.scatter_(1, tokens, score)
+    return scores
+
+
 def greedy(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor, max_output_length: int,
-           min_output_length: int = 1, generate_unk: bool = True, return_prob: bool = False):
-    """transformer_greedy, search.py:162-342 (no prompts / penalties) -> (ids [B,L], scores|None)"""
-    B = src_mask.size(0)
+           min_output_length: int = 1, generate_unk: bool = True, return_prob: bool = False, repetition_penalty: float = -1,
+           no_repeat_ngram_size: int = -1, encoder_input: Optional[Tensor] = None, decoder_prompt: Optional[Tensor] = None,
+           trg_prompt_mask: Optional[Tensor] = None, return_attention: bool = False):
+    """transformer_greedy, search.py:162-342 -> (ids [B,L], scores|None) or, with return_attention, (ids, scores, att).
+    specials may carry "sep", "lang_tags" (list) and "all" (model.specials)."""
+    B, _, src_len = src_mask.size()
+    tags = list(specials.get("lang_tags", []))
+    excl = list(specials.get("all", [])) + tags
     ys = torch.full((B, 1), specials["bos"], dtype=torch.long)
     yv = torch.zeros((B, 1)) if return_prob else None
+    yt = torch.zeros((B, 1, src_len)) if return_attention else None
     trg_mask = torch.ones(1, 1, 1, dtype=torch.bool)
     finished = torch.zeros(B, 1, dtype=torch.uint8)
+    compute_softmax = return_prob or repetition_penalty > 0 or no_repeat_ngram_size > 0 or encoder_input is not None
     for step in range(max_output_length):
-        logits, _, _, _ = decoder_forward(sd, cfg, ys, enc, src_mask, trg_mask)
-        lp = logits[:, -1]
+        forced_word = decoder_prompt[:, step + 1].unsqueeze(1) if decoder_prompt is not None and decoder_prompt.size(1) > step + 1 \
+            else torch.full((B, 1), specials["pad"], dtype=torch.long)
+        forced_mask = trg_prompt_mask[:, step + 1].unsqueeze(1).bool() if trg_prompt_mask is not None and trg_prompt_mask.size(1) > step + 1 \
+            else torch.zeros((B, 1), dtype=torch.bool)
+        if torch.any(~forced_mask).item():
+            logits, _, att, _ = decoder_forward(sd, cfg, ys, enc, src_mask, trg_mask, return_attention=return_attention,
+                                                trg_prompt_mask=adjust_mask_size(trg_prompt_mask, B, ys.size(1)))
+            lp = logits[:, -1]
+            if compute_softmax:
+                lp = F.log_softmax(lp, dim=-1)
+                if no_repeat_ngram_size > 1:
+                    lp = block_repeat_ngrams(ys, lp, no_repeat_ngram_size, step, encoder_input, excl)
+                if repetition_penalty > 1.0:
+                    lp = penalize_repetition(ys, lp, repetition_penalty)
+                    if encoder_input is not None:
+                        lp = penalize_repetition(encoder_input, lp, repetition_penalty)
+            _forbid(lp, [specials["bos"], specials.get("sep")] + tags)
+            if not generate_unk:
+                lp[:, specials["unk"]] = float("-inf")
+            if step < min_output_length:
+                lp[:, specials["eos"]] = float("-inf")
+            prob, nxt = torch.max(lp, dim=1)
+            nxt = torch.where(forced_mask, forced_word, nxt.unsqueeze(-1))
+            prob = torch.where(forced_mask, torch.zeros(B, 1), prob.unsqueeze(-1))
+            if return_attention:
+                att = torch.where(forced_mask.expand(-1, src_len).unsqueeze(1), torch.zeros(B, 1, src_len), att[:, -1, :].unsqueeze(1))
+        else:
+            nxt, prob = forced_word, torch.zeros(B, 1)
+            att = torch.zeros(B, 1, src_len) if return_attention else None
+        ys = torch.cat([ys, nxt], dim=1)
         if return_prob:
-            lp = F.log_softmax(lp, dim=-1)
-        _forbid(lp, [specials["bos"], specials.get("sep")])
-        if not generate_unk:
-            lp[:, specials["unk"]] = float("-inf")
-        if step < min_output_length:
-            lp[:, specials["eos"]] = float("-inf")
-        prob, nxt = torch.max(lp, dim=1)
-        ys = torch.cat([ys, nxt.unsqueeze(-1)], dim=1)
-        if return_prob:
-            yv = torch.cat([yv, prob.unsqueeze(-1)], dim=1)
-        finished += nxt.unsqueeze(-1).eq(specials["eos"]).to(torch.uint8)
+            yv = torch.cat([yv, prob], dim=1)
+        if return_attention:
+            yt = torch.cat([yt, att], dim=1)
+        finished += nxt.eq(specials["eos"]).to(torch.uint8)
         if (finished >= 1).sum() == B:
             break
+    if return_attention:
+        return ys[:, 1:], (yv[:, 1:] if return_prob else None), yt[:, 1:]
     return ys[:, 1:], (yv[:, 1:] if return_prob else None)
 
 
 def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor, beam_size: int, max_output_length: int,
-                alpha: float, n_best: int = 1, min_output_length: int = 1, generate_unk: bool = True):
-    """beam_search, search.py:345-825 (Transformer branch, no prompts / penalties) -> (ids [B*n_best,L], scores [B*n_best,1])"""
+                alpha: float, n_best: int = 1, min_output_length: int = 1, generate_unk: bool = True,
+                repetition_penalty: float = -1, no_repeat_ngram_size: int = -1, encoder_input: Optional[Tensor] = None,
+                decoder_prompt: Optional[Tensor] = None, trg_prompt_mask: Optional[Tensor] = None):
+    """beam_search, search.py:345-825 (Transformer branch) -> (ids [B*n_best,L], scores [B*n_best,1])"""
     bos, eos, pad, unk = specials["bos"], specials["eos"], specials["pad"], specials["unk"]
+    tags = list(specials.get("lang_tags", []))
+    excl = list(specials.get("all", [])) + tags
     B = src_mask.size(0)
     V = sd["decoder.output_layer.weight"].size(0)
     enc = enc.repeat_interleave(beam_size, dim=0)
     src_mask = src_mask.repeat_interleave(beam_size, dim=0)
+    if encoder_input is not None:
+        encoder_input = encoder_input.repeat_interleave(beam_size, dim=0)
+    if decoder_prompt is not None:
+        decoder_prompt = decoder_prompt.repeat_interleave(beam_size, dim=0)
+    if trg_prompt_mask is not None:
+        trg_prompt_mask = trg_prompt_mask.repeat_interleave(beam_size, dim=0)
     trg_mask = torch.ones(1, 1, 1, dtype=torch.bool)
     batch_offset = torch.arange(B)
     beam_offset = torch.arange(0, B * beam_size, step=beam_size)
@@ -360,13 +446,31 @@ def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor
     results = {"predictions": [[] for _ in range(B)], "scores": [[] for _ in range(B)]}
     is_finished = torch.zeros(B, beam_size, dtype=torch.bool)
     for step in range(max_output_length):
-        logits, _, _, _ = decoder_forward(sd, cfg, alive_seq, enc, src_mask, trg_mask)
-        log_probs = F.log_softmax(logits[:, -1], dim=-1)
-        _forbid(log_probs, [bos, pad, specials.get("sep")])
-        if not generate_unk:
-            log_probs[:, unk] = float("-inf")
-        if step < min_output_length:
-            log_probs[:, eos] = float("-inf")
+        rows, alive_len = alive_seq.size()
+        forced_token_ids = decoder_prompt[:, step + 1] if decoder_prompt is not None and decoder_prompt.size(1) > step + 1 \
+            else torch.full((rows, ), pad, dtype=torch.long)
+        padding_mask = trg_prompt_mask[:, step + 1].bool() if trg_prompt_mask is not None and trg_prompt_mask.size(1) > step + 1 \
+            else torch.zeros((rows, ), dtype=torch.bool)
+        if torch.any(~padding_mask).item():
+            logits, _, _, _ = decoder_forward(sd, cfg, alive_seq, enc, src_mask, trg_mask,
+                                              trg_prompt_mask=adjust_mask_size(trg_prompt_mask, rows, alive_len))
+            log_probs = F.log_softmax(logits[:, -1], dim=-1)
+            if no_repeat_ngram_size > 0:
+                log_probs = block_repeat_ngrams(alive_seq, log_probs, no_repeat_ngram_size, step, encoder_input, excl)
+            if repetition_penalty > 1.0:
+                log_probs = penalize_repetition(alive_seq, log_probs, repetition_penalty)
+                if encoder_input is not None:
+                    log_probs = penalize_repetition(encoder_input, log_probs, repetition_penalty)
+            _forbid(log_probs, [bos, pad, specials.get("sep")] + tags)
+            if not generate_unk:
+                log_probs[:, unk] = float("-inf")
+            if step < min_output_length:
+                log_probs[:, eos] = float("-inf")
+        else:
+            log_probs = torch.full((rows, V), float("-inf"))
+        forced_rows = padding_mask.nonzero(as_tuple=False).view(-1)
+        if len(forced_rows):
+            log_probs = log_probs.index_put([forced_rows, forced_token_ids[forced_rows]], torch.zeros(len(forced_rows)))
         log_probs += topk_log_probs.view(-1).unsqueeze(1)
         curr_scores = log_probs.clone()
         if alpha > 0:
@@ -377,6 +481,9 @@ def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor
         topk_log_probs = topk_scores * length_penalty if alpha > 0 else topk_scores.clone()
         topk_beam_index = topk_ids.div(V, rounding_mode="floor")
         topk_ids = topk_ids.fmod(V)
+        if len(forced_rows):  # the picks themselves are overwritten too (:648-655)
+            topk_ids = topk_ids.view(-1).index_put((forced_rows, ), forced_token_ids[forced_rows]).view(-1, beam_size)
+            topk_scores = topk_scores.view(-1).index_put((forced_rows, ), torch.zeros(len(forced_rows))).view(-1, beam_size)
         batch_index = topk_beam_index + beam_offset[:topk_ids.size(0)].unsqueeze(1)
         select_indices = batch_index.view(-1)
         alive_seq = torch.cat([alive_seq.index_select(0, select_indices), topk_ids.view(-1, 1)], -1)
@@ -410,6 +517,12 @@ def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor
             is_finished = is_finished.index_select(0, unfinished)
             batch_offset = batch_offset.index_select(0, unfinished)
             alive_seq = predictions.index_select(0, unfinished).view(-1, alive_seq.size(-1))
+            if encoder_input is not None:
+                encoder_input = encoder_input.view(-1, beam_size, encoder_input.size(1)).index_select(0, unfinished).view(-1, encoder_input.size(1))
+            if decoder_prompt is not None:
+                decoder_prompt = decoder_prompt.view(-1, beam_size, decoder_prompt.size(1)).index_select(0, unfinished).view(-1, decoder_prompt.size(1))
+            if trg_prompt_mask is not None:
+                trg_prompt_mask = trg_prompt_mask.view(-1, beam_size, trg_prompt_mask.size(1)).index_select(0, unfinished).view(-1, trg_prompt_mask.size(1))
         select_indices = batch_index.view(-1)
         enc = enc.index_select(0, select_indices)
         src_mask = src_mask.index_select(0, select_indices)

@@ -118,3 +118,49 @@ def test_flat_grad_reducer_matches_manual_average():
     store = ParamStore(net, torch.device("cpu"))
     got = torch.cat([out[0][store.offsets[id(p)]:store.offsets[id(p)] + p.numel()] for p in net.parameters()])
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def _golden_case(rank, world):
+    """The per-rank inputs of tests/golden/ddp.npz through this package's helpers."""
+    from conftest import load_golden
+    from joeys2t_amd.helpers_for_ddp import DistributedSubsetSampler, ddp_merge, ddp_reduce
+    g = load_golden("ddp")
+    pre = f"rank{rank}."
+    a2, a3 = torch.from_numpy(g[pre + "merge2_in"]), torch.from_numpy(g[pre + "merge3_in"])
+    res = {"merge2": ddp_merge(a2, -1).numpy(), "merge2_pad1": ddp_merge(a2, 1).numpy(), "merge3": ddp_merge(a3, 0.0).numpy(),
+           "reduce0": ddp_reduce(torch.tensor(1.5 + rank)).numpy(),
+           "reduce1": ddp_reduce(torch.tensor([1.0 + rank, 2.0, -3.0 * rank])).numpy(),
+           "reduce_int": ddp_reduce(7 + rank, torch.device("cpu"), torch.long).numpy()}
+
+    class DS:
+        def __init__(self, n):
+            self.indices = list(range(n))
+            self.random_subset = -1
+
+        def __len__(self):
+            return len(self.indices)
+
+    for n in (11, 16):
+        sampler = DistributedSubsetSampler(DS(n), shuffle=True, drop_last=True, generator=torch.Generator().manual_seed(42))
+        res[f"sampler{n}_epoch0"] = list(iter(sampler))
+        res[f"sampler{n}_epoch1"] = list(iter(sampler))  # second epoch: the generator has moved on, indices were truncated
+        res[f"sampler{n}_len"] = len(sampler)
+    return res
+
+
+def test_ddp_helpers_match_reference_capture():
+    """ddp_merge / ddp_reduce / DistributedSubsetSampler against outputs of the REFERENCE's functions run under a 2-rank gloo
+    group (oracle/make_golden.py:golden_ddp -> tests/golden/ddp.npz; helpers_for_ddp.py:58-174,244-342)."""
+    import numpy as np
+    from conftest import load_golden
+    g = load_golden("ddp")
+    out = run2(_golden_case)
+    for r in (0, 1):
+        for k, v in out[r].items():
+            ref = g[f"rank{r}.{k}"]
+            got = np.asarray(v)
+            assert got.shape == ref.shape, (r, k, got.shape, ref.shape)
+            if np.issubdtype(ref.dtype, np.floating):
+                np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0, err_msg=f"rank{r}.{k}")
+            else:
+                assert np.array_equal(got, ref), (r, k, got, ref)

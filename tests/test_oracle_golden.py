@@ -185,3 +185,52 @@ def test_ctc_best_path_known_answer():
     assert lens.tolist() == [3, 0, 2]
     assert ids[0, :3].tolist() == [4, 4, 5] and ids[2, :2].tolist() == [3, 4]
     assert (ids[0, 3:] == pad).all() and (ids[1] == pad).all() and (ids[2, 2:] == pad).all()
+
+
+# ---------------------------------------------------------------------------------------------- decoding options
+SEARCH_CFG = {"decoder": {"num_layers": 3, "num_heads": 4, "layer_norm": "pre", "activation": "relu", "alpha": 1.0,
+                          "embeddings": {"scale": False}}}
+SEARCH_SPECIALS = dict(unk=0, pad=1, bos=2, eos=3, sep=4, lang_tags=[5, 6], all=[0, 1, 2, 3, 4])
+
+
+def search_case(g, bs):
+    sd = golden_sd(g, f"bs{bs}.sd.")
+    return sd, torch.from_numpy(g[f"bs{bs}.encoder_output"]), torch.ones(bs, 1, 4, dtype=torch.bool)
+
+
+def _cmp(g, case, ids, scores=None, att=None):
+    assert np.array_equal(np.asarray(ids), g[f"{case}.ids"]), (case, ids, g[f"{case}.ids"])
+    assert np.array_equal(g[f"{case}.ids"], g[f"{case}.exp_ids"])  # the constants of the reference's own test
+    if scores is not None:
+        np.testing.assert_allclose(np.asarray(scores), g[f"{case}.scores"], rtol=1e-4, atol=1e-4, err_msg=case)
+        np.testing.assert_allclose(np.asarray(scores), g[f"{case}.exp_scores"], rtol=1e-4, atol=1e-4, err_msg=case)
+    if att is not None:
+        np.testing.assert_allclose(np.asarray(att), g[f"{case}.att"], rtol=1e-4, atol=1e-4, err_msg=case)
+        np.testing.assert_allclose(np.asarray(att), g[f"{case}.exp_att"], rtol=1e-4, atol=1e-4, err_msg=case)
+
+
+def test_search_options_match_reference_tests():
+    """Forced-decoding prompts, repetition penalty, n-gram blocking, generate_unk, attention export: the oracle's greedy /
+    beam search against the captures AND the hard-coded constants of test/unit/test_search.py:101-500."""
+    g = load_golden("search_options")
+    S, cfg = SEARCH_SPECIALS, SEARCH_CFG
+    sd, enc, mask = search_case(g, 2)
+    prompt, pmask = torch.from_numpy(g["prompt"]), torch.from_numpy(g["prompt_mask"])
+    with torch.no_grad():
+        _cmp(g, "greedy", *O.greedy(sd, cfg, S, enc, mask, 3, return_prob=True))
+        _cmp(g, "greedy_prompt", *O.greedy(sd, cfg, S, enc, mask, 7, return_prob=True, return_attention=True, decoder_prompt=prompt,
+                                           trg_prompt_mask=pmask))
+        _cmp(g, "beam1", *O.beam_search(sd, cfg, S, enc, mask, 1, 3, 0.0, n_best=1))
+        _cmp(g, "beam7", *O.beam_search(sd, cfg, S, enc, mask, 7, 3, 1.0, n_best=5))
+        _cmp(g, "beam7_prompt", *O.beam_search(sd, cfg, S, enc, mask, 7, 10, 1.0, n_best=5, decoder_prompt=prompt, trg_prompt_mask=pmask))
+        _cmp(g, "beam7_penalty", *O.beam_search(sd, cfg, S, enc, mask, 7, 3, 1.0, n_best=5, repetition_penalty=1.5,
+                                                encoder_input=torch.from_numpy(g["beam7_penalty.src_tokens"])))
+        _cmp(g, "greedy_ngram", *O.greedy(sd, cfg, S, enc, mask, 7, return_prob=True, no_repeat_ngram_size=3))
+        _cmp(g, "beam3_ngram", *O.beam_search(sd, cfg, S, enc, mask, 3, 7, 1.0, n_best=3, no_repeat_ngram_size=3))
+        sd, enc, mask = search_case(g, 3)
+        _cmp(g, "greedy_nounk", O.greedy(sd, cfg, S, enc, mask, 3, generate_unk=False)[0])
+        _cmp(g, "greedy_nounk_penalty", O.greedy(sd, cfg, S, enc, mask, 3, generate_unk=False, repetition_penalty=1.5)[0])
+        src = torch.from_numpy(g["greedy_src_penalty.src_tokens"])
+        ids, _, att = O.greedy(sd, cfg, S, enc, (src != 1).unsqueeze(1), 3, generate_unk=False, repetition_penalty=1.5, encoder_input=src,
+                               return_attention=True)
+        _cmp(g, "greedy_src_penalty", ids, att=att)
