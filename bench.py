@@ -257,14 +257,35 @@ def encoder_forward(model, batch, reps=20):
             "what": "subsampler + 16 encoder layers + final LN, forward only, bf16, dropout on"}
 
 
-def cpu_baseline(n_utts=8, threads=None):
-    """The CPU oracle (plain fp32 PyTorch/NumPy restatement of the reference path) timed on the host cores on a
-    bounded sample of the same workload: n_utts utterances of 15 s through fbank -> ... -> loss -> backward -> AdamW."""
+def host_cpu():
+    """(threads this process may use, CPU model string, CPUs online) of the host the baseline is timed on"""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return usable, model, os.cpu_count() or usable
+
+
+def cpu_baseline(n_utts=BATCH, threads=None, timed_steps=2):
+    """The CPU oracle (plain fp32 PyTorch/NumPy restatement of the reference path) timed on the host cores on the SAME
+    workload as the GPU line - one batch of 32 utterances of 15 s through fbank -> ... -> loss -> backward -> clip -> AdamW
+     - with every CPU this process may use (count and model string stated): 1 warm-up + 2 timed
+    steps at ~6 s each.  Plus (ii) of BASELINE.md section 3: beam-5 decode RTF of the oracle's search (full-prefix decoder
+    pass, no KV cache, exactly the reference's algorithm) on a bounded sample."""
     import copy
     from joeys2t_amd.model import build_model
     from joeys2t_amd.vocabulary import Vocabulary
     from oracle import s2t_oracle as O
-    threads = threads or min(16, os.cpu_count() or 1)
+    usable, cpu_model, online = host_cpu()
+    threads = threads or usable
     torch.set_num_threads(threads)
     torch.manual_seed(42)
     cfg = copy.deepcopy(LS100_MODEL)
@@ -294,13 +315,47 @@ def cpu_baseline(n_utts=8, threads=None):
 
     step()  # warm-up
     t0 = time.perf_counter()
-    n = 4
-    for _ in range(n):
+    for _ in range(timed_steps):
         step()
-    dt = (time.perf_counter() - t0) / n
+    dt = (time.perf_counter() - t0) / timed_steps
     frames = n_utts * (1 + (SAMPLES - 400) // 160)
-    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n_utts} utterances x 15 s, LS100 model, full train step (fbank..AdamW), fp32, {n} timed steps"}
+    out = {"value": round(frames / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+           "cpus_online": online, "s_per_step": round(dt, 3),
+           "sample": f"{n_utts} utterances x 15 s (the GPU line's batch), LS100 model, full train step (fbank..AdamW), fp32, "
+                     f"1 warm-up + {timed_steps} timed steps"}
+    try:
+        out["decode_beam5"] = cpu_decode_rtf()
+    except Exception as exc:  # a side figure of a side figure
+        out["decode_beam5"] = {"error": repr(exc)}
+    return out
+
+
+def cpu_decode_rtf(n_utts=4, beam=5, alpha=1.0, max_len=30):
+    """beam-5 decode of the CPU oracle (search.py:345-825 restated: full-prefix decoder pass per
+    step, encoder states tiled beam-fold) on mustc_st.yaml shapes.  Bounded sample: 4 utterances x 15 s, 30 steps."""
+    import copy
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    from oracle import s2t_oracle as O
+    torch.manual_seed(42)
+    cfg = copy.deepcopy(MUSTC_MODEL)
+    n, m = cfg["encoder"]["num_layers"], cfg["decoder"]["num_layers"]
+    cfg["encoder"]["alpha"], cfg["decoder"]["alpha"] = 0.81 * (n**4 * m)**(1 / 16), (3 * m)**(1 / 4)
+    model = build_model(copy.deepcopy(MUSTC_MODEL), None, Vocabulary.synthetic(VOCAB))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    wave = synth_waveforms(n_utts, SAMPLES).numpy()
+    specials = dict(unk=0, pad=1, bos=2, eos=3)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        feats = [O.cmvn(O.fbank(wave[u])).astype(np.float32) for u in range(n_utts)]
+        padded, lengths, _ = O.pad_features(feats)
+        enc, mask, _ = O.encoder_forward(sd, cfg, torch.from_numpy(padded), torch.tensor(lengths))
+        ids, _ = O.beam_search(sd, cfg, specials, enc, mask, beam, max_len, alpha, n_best=1)
+    dt = time.perf_counter() - t0
+    audio_s = n_utts * SAMPLES / 16000.0
+    return {"rtf": round(dt / audio_s, 5), "wall_s": round(dt, 2), "audio_s": audio_s, "beam": beam, "steps": int(ids.shape[1]),
+            "sample": f"{n_utts} utterances x 15 s, beam {beam}, at most {max_len} steps (the GPU leg decodes 32 utterances, 100 steps)",
+            "decoding": "reference algorithm: full-prefix decoder pass per step, no KV cache"}
 
 
 MUSTC_MODEL = {
@@ -469,13 +524,23 @@ def main():
         secs = sum(v[2] for v in fam.values())
         achieved = flops / secs / 1e12
         algo_bytes = sum(v[3] for v in fam.values()) / n
-        traffic = None  # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE)
+        # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE): a committed
+        # measurement, stamped with the kernel source it was taken on - null as soon as csrc/gemm.hip has changed since
+        traffic, traffic_src = None, None
         tfile = ROOT / "profiles" / "gemm_traffic.json"
         if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
+            tj = json.loads(tfile.read_text())
+            import hashlib
+            sha = hashlib.sha256((ROOT / "joeys2t_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()[:16]
+            traffic_src = {"file": "profiles/gemm_traffic.json", "measured_at_commit": tj.get("measured_at_commit"),
+                           "measured_on": tj.get("measured_on"), "gemm_hip_sha16": tj.get("gemm_hip_sha16"),
+                           "current_gemm_hip_sha16": sha, "stale": tj.get("gemm_hip_sha16") != sha}
+            if not traffic_src["stale"]:
+                traffic = tj.get("hbm_bytes_per_launch")
         key = "gemm_bf16_p192_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
         roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo_bytes),
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(algo_bytes),
                     "flop_per_launch": round(flops / n), "launches_per_step": n // 2,
                     "avg_launch_us": round(secs / n * 1e6, 2), "event_pair_overhead_us": round(pair_overhead * 1e6, 2),
                     "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),

@@ -266,7 +266,7 @@ def test_ls960_vocab_xent_ctc_lse(device):
     in_len = torch.tensor([375, 300, 351, 210])
     refs = {}
     for dt in (torch.float32, torch.float64):
-        cr = cl.to(dt).requires_grad_(True)
+        cr = cl.clone().to(dt).requires_grad_(True)  # clone: .to(float32) would hand back cl itself
         rc = F.ctc_loss(torch.log_softmax(cr, -1).transpose(0, 1), ct, in_len, tl, blank=2, reduction="sum", zero_infinity=True)
         rc.backward()
         refs[dt] = (rc.item(), cr.grad)

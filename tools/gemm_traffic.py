@@ -2,8 +2,12 @@
 bytes = FETCH_SIZE [KB] * 1024 * 2 (gfx950 counts 128-byte fabric reads as 64, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE [KB] * 1024
 usage: python tools/gemm_traffic.py <prof dir> <out json>"""
 import csv
+import datetime
+import hashlib
 import json
+import subprocess
 import sys
+from pathlib import Path
 
 d, out = sys.argv[1], sys.argv[2]
 
@@ -22,5 +26,14 @@ res = {"kernel_family": "gemm_bf16_p192_kernel<*> + gemm_bf16_dma_kernel<*> + ge
        "per_kernel": {k: {"launches": fetch[k][0], "fetch_bytes_per_launch": fetch[k][1] * 2048 / fetch[k][0],
                           "write_bytes_per_launch": (write[k][1] * 1024 / write[k][0]) if k in write else None} for k in fam},
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over an eager 3-step bench run; FETCH_SIZE doubled"}
+# provenance: bench.py reports `traffic` only while csrc/gemm.hip is byte-identical to the source this was measured on
+root = Path(__file__).resolve().parent.parent
+res["gemm_hip_sha16"] = hashlib.sha256((root / "joeys2t_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()[:16]
+res["measured_on"] = datetime.date.today().isoformat()
+try:
+    res["measured_at_commit"] = subprocess.run(["git", "-C", str(root), "rev-parse", "--short", "HEAD"], capture_output=True,
+                                               text=True).stdout.strip() or None
+except OSError:
+    res["measured_at_commit"] = None  # the GPU box has no .git: stamped by the caller after copying into profiles/
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("launches_measured", "fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}))
