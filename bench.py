@@ -139,14 +139,35 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     masks_dev = torch.zeros((BATCH, 8), dtype=torch.int32, device=device)
     state = {"batch": None}
 
-    # --host-inputs: the waveforms arrive from (pinned) host memory every step, as a DataLoader would hand them over; the
-    # copy is enqueued on the step's stream in front of it (PCIe-inclusive rate, reported in DESIGN.md, never `value`)
+    # --host-inputs: the waveforms arrive from (pinned) host memory every step, as a DataLoader would hand them over
+    # (PCIe-inclusive rate, reported in DESIGN.md, never `value`).  The transfer of step i + 1 runs on a copy stream while
+    # step i computes (datasets.PrefetchLoader's scheme): H2D into a staging buffer, then a 10 us device copy into the
+    # graph's static input at the head of the step.  JS2T_NO_PREFETCH=1 puts the H2D copy in front of the step instead.
     wave_host = wave.cpu().pin_memory() if host_inputs else None
+    prefetch = host_inputs and os.environ.get("JS2T_NO_PREFETCH", "0") != "1"
+    if prefetch:
+        stage_buf, copy_stream = torch.empty_like(wave), torch.cuda.Stream(device=device)
+        h2d_done, stage_free = torch.cuda.Event(), torch.cuda.Event()
+
+        def start_h2d():
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(stage_free)  # the previous step has read the staging buffer
+                stage_buf.copy_(wave_host, non_blocking=True)
+                h2d_done.record(copy_stream)
+
+        stage_free.record(torch.cuda.current_stream())
+        start_h2d()
 
     def pre_step():
         masks_host.copy_(torch.from_numpy(proc.draw_masks(frames_list)))
         masks_dev.copy_(masks_host, non_blocking=True)
-        if wave_host is not None:
+        if prefetch:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(h2d_done)
+            wave.copy_(stage_buf, non_blocking=True)
+            stage_free.record(cur)
+            start_h2d()  # the next batch travels while this step computes
+        elif wave_host is not None:
             wave.copy_(wave_host, non_blocking=True)
 
     def body():

@@ -80,6 +80,20 @@ def ddp_reduce(data: Union[Tensor, int], device=None, dtype=None) -> Tensor:
     return data
 
 
+class FlatDDP(torch.nn.Module):
+    """What stands where torch's DistributedDataParallel stands in the reference (training.py:131-139): `.module` is the
+    Model, forward passes through.  The gradient exchange itself is not hooked into autograd here - TrainStep drives a
+    FlatGradReducer over the model's flat gradient buffer - so this class only provides the `.module` indirection that
+    model.DataParallelWrapper (and code written against `model.module`) expects."""
+
+    def __init__(self, module: torch.nn.Module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
 class FlatGradReducer:
     """Bucketed, overlapped all-reduce(average) of ParamStore.flat_grad.
 

@@ -1,9 +1,13 @@
-"""SpeechProcessor — the source-side "tokenizer" of the S2T path (reference tokenizers.py:433-508), batched on the GPU.
+"""SpeechProcessor — the source-side "tokenizer" of the S2T path (reference tokenizers.py:433-508), batched on the GPU -
+and the evaluation tail of the target side: `post_process` of the reference's text tokenizers (:133-165,230-260,334-366),
+i.e. hypothesis token lists -> the strings WER is computed on.
 
 Reference per-utterance order (:458-494): length filter (drop if min_length > T > 0; if T > max_length drop in
-training, truncate in evaluation) -> CMVN(before) -> SpecAugment (training only) -> CMVN(after).  Text-side tokenizers
-of the reference are CPU string processing outside the hot path and are not part of this package."""
-from typing import List, Optional, Sequence, Tuple
+training, truncate in evaluation) -> CMVN(before) -> SpecAugment (training only) -> CMVN(after).  Training-side text
+tokenisation (BPE learning / application, Moses) is CPU string processing outside the hot path: `__call__` is provided
+for word / char level and, when the sentencepiece package and a model file are present, for SentencePiece."""
+import re
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -53,3 +57,167 @@ class SpeechProcessor:
     def __repr__(self):
         return (f"{self.__class__.__name__}(level={self.level}, normalize={self.normalize}, "
                 f"filter_by_length=({self.min_length}, {self.max_length}), specaugment={self.specaugment}, cmvn={self.cmvn})")
+
+
+# ------------------------------------------------------------------------------------------------ text side: evaluation tail
+def remove_extra_spaces(s: str) -> str:
+    """helpers.py:409-431 of the reference"""
+    s = re.sub("\u200b", "", s)
+    s = re.sub("[ \u3000]+", " ", s)
+    s = s.replace(" ?", "?")
+    s = s.replace(" !", "!")
+    s = s.replace(" ,", ",")
+    s = s.replace(" .", ".")
+    s = s.replace(" :", ":")
+    return s.strip()
+
+
+class BasicTokenizer:
+    """Word / character level (reference tokenizers.py:24-188): `post_process` undoes it."""
+    SPACE = chr(32)
+    SPACE_ESCAPE = chr(9601)  # the SentencePiece whitespace marker
+
+    def __init__(self, level: str = "word", lowercase: bool = False, normalize: bool = False, max_length: int = -1,
+                 min_length: int = -1, **kwargs):
+        self.level, self.lowercase, self.normalize = level, lowercase, normalize
+        self.max_length, self.min_length = max_length, min_length
+        self.pretokenizer = kwargs.get("pretokenizer", "none").lower()
+        if self.pretokenizer == "moses":
+            raise NotImplementedError("the Moses (de)tokenizer (sacremoses) is not part of this package")
+        self.unk_token = self.eos_token = self.sep_token = None
+        self.specials: List[str] = []
+        self.lang_tags: List[str] = []
+
+    def __call__(self, raw_input: str, is_train: bool = False) -> Optional[List[str]]:
+        if raw_input is None:
+            return None
+        if self.level == "word":
+            sequence = raw_input.split(self.SPACE)
+        elif self.level == "char":
+            sequence = list(raw_input.replace(self.SPACE, self.SPACE_ESCAPE))
+        else:
+            raise NotImplementedError(self.level)
+        if is_train and self._filter_by_length(len(sequence)):
+            return None
+        return sequence
+
+    def _filter_by_length(self, length: int) -> bool:
+        return length > self.max_length > 0 or self.min_length > length > 0
+
+    def _remove_special(self, sequence: List[str], generate_unk: bool = False) -> List[str]:
+        specials = self.specials if generate_unk else self.specials + [self.unk_token]
+        valid = [token for token in sequence if token not in specials]
+        return valid if valid else [self.unk_token]  # never empty
+
+    def _cut_prompt(self, sequence: List[str], keep_sep: bool) -> List[str]:
+        """drop everything up to the prompt marker; the subword tokenizers keep the marker itself (it is a special token and
+        goes in _remove_special): reference :244 / :349 `sequence[sep_pos:]` against :146 `sequence[sep_pos + 1:]`"""
+        try:
+            pos = sequence.index(self.sep_token)
+        except ValueError:
+            return sequence
+        return sequence[pos:] if keep_sep else sequence[pos + 1:]
+
+    def post_process(self, sequence: Union[List[str], str], generate_unk: bool = True, cut_at_sep: bool = True) -> str:
+        if isinstance(sequence, list):
+            if cut_at_sep:
+                sequence = self._cut_prompt(sequence, keep_sep=False)
+            sequence = self._remove_special(sequence, generate_unk=generate_unk)
+            if self.level == "word":
+                sequence = self.SPACE.join(sequence)
+            elif self.level == "char":
+                sequence = "".join(sequence).replace(self.SPACE_ESCAPE, self.SPACE)
+        if self.normalize:
+            sequence = remove_extra_spaces(sequence)
+        assert sequence is not None and len(sequence) > 0, sequence
+        return sequence
+
+    def set_vocab(self, vocab) -> None:
+        """vocab: joeys2t_amd.vocabulary.Vocabulary (reference :167-177)"""
+        self.unk_token = vocab.specials[vocab.unk_index]
+        self.eos_token = vocab.specials[vocab.eos_index]
+        self.sep_token = vocab.specials[vocab.sep_index] if vocab.sep_index else None
+        specials = list(vocab.specials) + list(vocab.lang_tags)
+        self.specials = [token for token in specials if token != self.unk_token]
+        self.lang_tags = list(vocab.lang_tags)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(level={self.level}, lowercase={self.lowercase}, normalize={self.normalize}, "
+                f"filter_by_length=({self.min_length}, {self.max_length}), pretokenizer={self.pretokenizer})")
+
+
+class SentencePieceTokenizer(BasicTokenizer):
+    """reference tokenizers.py:191-288.  Decoding pieces back to text needs no model: SentencePiece's DecodePieces
+    concatenates the pieces, turns the whitespace marker into a space and drops the leading one (byte-fallback and
+    user-defined pieces, which the S2T vocabularies do not contain, would need the model: pass `model_file` then)."""
+
+    def __init__(self, level: str = "bpe", lowercase: bool = False, normalize: bool = False, max_length: int = -1,
+                 min_length: int = -1, **kwargs):
+        super().__init__(level, lowercase, normalize, max_length, min_length, **kwargs)
+        assert self.level == "bpe"
+        self.model_file = kwargs.get("model_file")
+        self.nbest_size, self.alpha = kwargs.get("nbest_size", 5), kwargs.get("alpha", 0.0)
+        self.spm = None
+        if self.model_file is not None:
+            import sentencepiece as sp
+            self.spm = sp.SentencePieceProcessor()
+            self.spm.load(str(self.model_file))
+
+    def __call__(self, raw_input: str, is_train: bool = False) -> Optional[List[str]]:
+        if raw_input is None:
+            return None
+        if self.spm is None:
+            raise RuntimeError("SentencePieceTokenizer needs `model_file` (and the sentencepiece package) to tokenize")
+        if is_train and self.alpha > 0:
+            tokenized = self.spm.sample_encode_as_pieces(raw_input, nbest_size=self.nbest_size, alpha=self.alpha)
+        else:
+            tokenized = self.spm.encode(raw_input, out_type=str)
+        if is_train and self._filter_by_length(len(tokenized)):
+            return None
+        return tokenized
+
+    def _decode(self, pieces: List[str]) -> str:
+        if self.spm is not None:
+            return self.spm.decode(pieces)
+        # the unknown piece is rendered as SentencePiece's default unk surface " \u2047 " (DecodePieces)
+        text = "".join(" \u2047 " if p == self.unk_token else p for p in pieces).replace(self.SPACE_ESCAPE, self.SPACE)
+        return text[1:] if text.startswith(self.SPACE) else text
+
+    def post_process(self, sequence: Union[List[str], str], generate_unk: bool = True, cut_at_sep: bool = True) -> str:
+        if isinstance(sequence, list):
+            if cut_at_sep:
+                sequence = self._cut_prompt(sequence, keep_sep=True)
+            sequence = self._remove_special(sequence, generate_unk=generate_unk)
+            sequence = self._decode(sequence).replace(self.SPACE_ESCAPE, self.SPACE).strip()
+        if self.normalize:
+            sequence = remove_extra_spaces(sequence)
+        assert sequence is not None and len(sequence) > 0, sequence
+        return sequence
+
+
+class SubwordNMTTokenizer(BasicTokenizer):
+    """reference tokenizers.py:291-389: merge markers (`@@ `) are glued back; applying BPE codes (training side) needs the
+    subword-nmt package and is not provided."""
+
+    def __init__(self, level: str = "bpe", lowercase: bool = False, normalize: bool = False, max_length: int = -1,
+                 min_length: int = -1, **kwargs):
+        super().__init__(level, lowercase, normalize, max_length, min_length, **kwargs)
+        assert self.level == "bpe"
+        self.separator: str = kwargs.get("separator", "@@")
+        self.codes = kwargs.get("codes")
+
+    def __call__(self, raw_input: str, is_train: bool = False):
+        raise NotImplementedError("applying BPE merges needs subword-nmt; hypotheses are post-processed without it")
+
+    def post_process(self, sequence: Union[List[str], str], generate_unk: bool = True, cut_at_sep: bool = True) -> str:
+        if isinstance(sequence, list):
+            if cut_at_sep:
+                sequence = self._cut_prompt(sequence, keep_sep=True)
+            sequence = self._remove_special(sequence, generate_unk=generate_unk)
+            sequence = self.SPACE.join(sequence).replace(self.separator + self.SPACE, "")
+            if sequence.endswith(self.separator):
+                sequence = sequence[:-len(self.separator)]
+        if self.normalize:
+            sequence = remove_extra_spaces(sequence)
+        assert sequence is not None and len(sequence) > 0, sequence
+        return sequence

@@ -569,6 +569,113 @@ def golden_ddp(name="ddp", world=2):
     print(name, {k: getattr(v, "shape", v) for k, v in out.items() if k.startswith("rank0.")})
 
 
+class _ToyDataset:
+    """what the batch samplers need of a dataset: `indices`, `__len__`, `__getitem__` -> (idx, src, trg), src None = filtered"""
+
+    def __init__(self, src_len, trg_len, drop):
+        self.src_len, self.trg_len, self.drop = src_len, trg_len, set(drop)
+        self.indices = list(range(len(src_len)))
+        self.random_subset, self.seed, self.split = -1, 0, "train"
+
+    def __len__(self):
+        return len(self.src_len)
+
+    def reset_indices(self):
+        self.indices = list(range(len(self.src_len)))
+
+    def __getitem__(self, idx):
+        if idx in self.drop:
+            return idx, None, None
+        return idx, [0] * self.src_len[idx], [0] * self.trg_len[idx]
+
+
+def golden_text_tail(name="text_tail"):
+    """f1 / f4 captures (JSON, they are strings and index lists):
+    * `post_process` of the reference's SentencePieceTokenizer (its own toy model test/data/toy/sp200.model), SubwordNMTTokenizer
+      and BasicTokenizer (word / char) on hypothesis token lists with special tokens, a prompt marker and unknowns;
+    * the batches its TokenBatchSampler / SentenceBatchSampler cut from a shuffled toy dataset over two epochs."""
+    import json
+
+    from types import SimpleNamespace
+
+    from joeynmt.datasets import SentenceBatchSampler, TokenBatchSampler
+    from joeynmt.helpers_for_ddp import RandomSubsetSampler
+    from joeynmt.tokenizers import BasicTokenizer, SentencePieceTokenizer, SubwordNMTTokenizer
+    from joeynmt.vocabulary import Vocabulary
+    toy = REF / "test" / "data" / "toy"
+    special = SimpleNamespace(unk_token="<unk>", pad_token="<pad>", bos_token="<s>", eos_token="</s>", sep_token="<sep>", unk_id=0,
+                              pad_id=1, bos_id=2, eos_id=3, sep_id=4, lang_tags=["<de>", "<en>"])
+    out = {"specials": special.__dict__}
+    sents = [l.strip() for l in (toy / "dev.en").read_text(encoding="utf-8").splitlines()[:12] if l.strip()]
+    # ---- SentencePiece
+    spt = SentencePieceTokenizer(level="bpe", normalize=True, model_file=str(toy / "sp200.model"))
+    pieces = [spt(x) for x in sents]
+    vocab = Vocabulary(tokens=sorted({p for ps in pieces for p in ps}), cfg=special)
+    BasicTokenizer.set_vocab(spt, vocab)  # SentencePieceTokenizer.set_vocab also calls spm.SetVocabulary (gone in sentencepiece 0.2)
+    cases = []
+    for i, ps in enumerate(pieces):
+        seq = list(ps)
+        if i % 3 == 0:
+            seq = ["<en>"] + seq + ["</s>", "<pad>", "<pad>"]
+        if i % 3 == 1:
+            seq = ["<de>", seq[0], "<sep>"] + seq[1:] + ["<unk>", "</s>"]
+        if i % 4 == 2:
+            seq.insert(len(seq) // 2, "<unk>")
+        for gu in (True, False):
+            for cut in (True, False):
+                cases.append({"seq": seq, "generate_unk": gu, "cut_at_sep": cut,
+                              "out": spt.post_process(list(seq), generate_unk=gu, cut_at_sep=cut)})
+    cases.append({"seq": ["<pad>", "</s>"], "generate_unk": True, "cut_at_sep": True, "out": spt.post_process(["<pad>", "</s>"])})
+    out["sentencepiece"] = {"normalize": True, "cases": cases, "sentences": sents, "pieces": pieces}
+    # ---- subword-nmt (post_process does not touch the BPE object: bypass the constructor, which needs the absent package)
+    bpt = SubwordNMTTokenizer.__new__(SubwordNMTTokenizer)
+    bpt.level, bpt.lowercase, bpt.normalize, bpt.max_length, bpt.min_length = "bpe", False, False, -1, -1
+    bpt.pretokenizer, bpt.separator = "none", "@@"
+    bv = Vocabulary(tokens=["he@@", "llo", "wor@@", "ld", "a", "te@@", "st@@"], cfg=special)
+    BasicTokenizer.set_vocab(bpt, bv)
+    cases = []
+    for seq in (["he@@", "llo", "wor@@", "ld", "</s>"], ["<en>", "a", "<sep>", "te@@", "st@@", "</s>", "<pad>"],
+                ["he@@", "<unk>", "llo", "wor@@"], ["<s>", "</s>"]):
+        for gu in (True, False):
+            for cut in (True, False):
+                cases.append({"seq": seq, "generate_unk": gu, "cut_at_sep": cut,
+                              "out": bpt.post_process(list(seq), generate_unk=gu, cut_at_sep=cut)})
+    out["subword_nmt"] = {"normalize": False, "separator": "@@", "cases": cases}
+    # ---- word / char
+    for level in ("word", "char"):
+        bt = BasicTokenizer(level=level, normalize=True)
+        toks = [bt(x) for x in sents[:4]]
+        wv = Vocabulary(tokens=sorted({t for ts in toks for t in ts}), cfg=special)
+        bt.set_vocab(wv)
+        cases = []
+        for i, ts in enumerate(toks):
+            seq = (["<de>", ts[0], "<sep>"] if i % 2 else []) + list(ts) + ["</s>", "<pad>"]
+            for gu in (True, False):
+                for cut in (True, False):
+                    cases.append({"seq": seq, "generate_unk": gu, "cut_at_sep": cut,
+                                  "out": bt.post_process(list(seq), generate_unk=gu, cut_at_sep=cut)})
+        out[level] = {"normalize": True, "cases": cases, "tokens": toks}
+    # ---- batch samplers
+    g = torch.Generator().manual_seed(5)
+    src_len = torch.randint(50, 1500, (57, ), generator=g).tolist()
+    trg_len = torch.randint(3, 80, (57, ), generator=g).tolist()
+    drop = [3, 17, 40]
+    samplers = {}
+    for kind, cls, bs in (("token", TokenBatchSampler, 6000), ("sentence", SentenceBatchSampler, 8)):
+        for drop_last in (False, True):
+            ds = _ToyDataset(src_len, trg_len, drop)
+            base = RandomSubsetSampler(ds, shuffle=True, generator=torch.Generator().manual_seed(42))
+            bsamp = cls(base, batch_size=bs, drop_last=drop_last, seed=42)
+            epochs = [[list(b) for b in bsamp], [list(b) for b in bsamp]]
+            entry = {"batch_size": bs, "drop_last": drop_last, "epochs": epochs}
+            if kind == "sentence":
+                entry["len"] = len(bsamp)
+            samplers[f"{kind}_{int(drop_last)}"] = entry
+    out["samplers"] = {"src_len": src_len, "trg_len": trg_len, "drop": drop, "cases": samplers}
+    (OUT / f"{name}.json").write_text(json.dumps(out, ensure_ascii=False, indent=0), encoding="utf-8")
+    print(name, "sp cases", len(out["sentencepiece"]["cases"]), "token batches", len(samplers["token_0"]["epochs"][0]))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -578,7 +685,7 @@ def main():
         "model_pre": lambda: golden_model("model_pre", tiny_cfg("pre")),
         "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
-        "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp,
+        "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

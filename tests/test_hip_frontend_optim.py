@@ -171,3 +171,25 @@ def test_wav_manifest_to_gpu_features(device, tmp_path):
         ref = O.cmvn(O.fbank(wavs[b, :n[b]]))
         np.testing.assert_allclose(feats[b, :frames[b]].cpu().numpy(), ref, rtol=2e-3, atol=2e-3)
         assert torch.all(feats[b, frames[b]:] == 1.0)
+
+
+def test_prefetch_loader_copies_one_batch_ahead(device):
+    """datasets.PrefetchLoader: every batch arrives in HBM bit-identical, in order, through pinned staging + a side stream."""
+    from joeys2t_amd.datasets import PrefetchLoader
+    g = torch.Generator().manual_seed(0)
+    data = [torch.randn(4, 24000, generator=g) for _ in range(5)]
+    seen = []
+
+    def load(idx):
+        seen.append(idx[0])
+        return {"wave": data[idx[0]], "n": [24000] * 4, "idx": idx}
+
+    loader = PrefetchLoader([[i] for i in range(5)], load, device)
+    got = []
+    for item in loader:
+        assert item["wave"].is_cuda and item["n"] == [24000] * 4
+        assert len(seen) >= min(5, len(got) + 2) or len(seen) == 5  # the following batch is already being staged
+        got.append((item["idx"][0], item["wave"].sum().item(), item["wave"].clone()))
+    assert [i for i, _, _ in got] == list(range(5))
+    for i, _, w in got:
+        assert torch.equal(w.cpu(), data[i])
