@@ -284,6 +284,19 @@ def host_cpu():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
+    # a container's CPU share is a cgroup quota, not an affinity mask: more threads than that only fight each other
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                usable = max(1, min(usable, int(-(-float(quota) // period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -334,10 +347,16 @@ def cpu_baseline(n_utts=BATCH, threads=None, timed_steps=2):
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         opt.step()
 
-    step()  # warm-up
     t0 = time.perf_counter()
-    for _ in range(timed_steps):
+    step()  # warm-up
+    warm = time.perf_counter() - t0
+    print(f"[bench] cpu baseline: {threads} threads on {cpu_model}; warm-up step {warm:.1f} s", file=sys.stderr, flush=True)
+    if warm > 25.0:  # a slow or over-subscribed host: the bounded sample is the warm-up step plus one timed step at most
+        timed_steps = 1
+    t0 = time.perf_counter()
+    for i in range(timed_steps):
         step()
+        print(f"[bench] cpu baseline: timed step {i + 1}/{timed_steps} done", file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / timed_steps
     frames = n_utts * (1 + (SAMPLES - 400) // 160)
     out = {"value": round(frames / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,

@@ -87,6 +87,8 @@ def lib():
         _lib.js2t_sumsq_partials.argtypes = [C.c_int64]
         if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)
             _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
+        if "JS2T_P192_RING" in os.environ:  # 2 = two blocks per CU with a two-slot ring (js2t_gemm_p192_ring)
+            _lib.js2t_gemm_p192_ring(int(os.environ["JS2T_P192_RING"]))
     return _lib
 
 

@@ -1251,6 +1251,10 @@ int launch_bf16_w256(const js2t_gemm_desc& d, hipStream_t s) {
 //  * B fragment rows are permuted as in dma_gemm_block, so each lane owns 16 consecutive output columns and the tile is
 //    stored from registers (direct_tile_epilogue).
 constexpr int P_BM = 192, P_ATILE = P_BM * 128, P_STAGE = P_ATILE + 16384, P_NST = 3, P_LDS = P_NST * P_STAGE, P_PER = 10;
+// NST = 2 (js2t_gemm_p192_ring(2)): a two-slot ring is 80 KB, so TWO blocks fit a CU and the grid is two blocks per CU.  Each
+// block then has one stage in flight instead of two (its ten requests go out in the second k-half of a stage and must have
+// landed by the middle of the next one) - what one block cannot hide any more (request latency, its epilogue, the switch
+// to the next tile, the prologue of the launch) is the other block's compute time.
 #ifdef JS2T_P192_PROF
 __device__ unsigned long long g_p192_prof2[8];
 #define P192_E(i)                                                   \
@@ -1382,7 +1386,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   }
 }
 
-template <int EPI>
+template <int EPI, int NST = P_NST>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
@@ -1448,7 +1452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       iv += G;
       if (iv < ntiles) set_tile_src(iv);
     }
-    islot = islot == P_NST - 1 ? 0 : islot + 1;
+    islot = islot == NST - 1 ? 0 : islot + 1;
   };
   auto issue_next = [&]() {
     issue_begin();
@@ -1485,10 +1489,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
   set_tile_src(iv);
   issue_next();
   issue_next();
-  issue_begin();
+  if (NST == 3) {
+    issue_begin();
 #pragma unroll
-  for (int q = 0; q < 5; ++q) issue_piece(q);  // pieces 5..9 of stage 2 follow in the first k-half of stage 0
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 5) : "memory");
+    for (int q = 0; q < 5; ++q) issue_piece(q);  // pieces 5..9 of stage 2 follow in the first k-half of stage 0
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 5) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");  // stage 0 landed, stage 1 in flight
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -1522,20 +1530,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
           const int i = q >> 1, j = (q & 1) * 4 + jj;
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(fn0[j]), acc[i][j], 0, 0, 0);
         }
-        if (q < 5) issue_piece(5 + q);
+        if (NST == 3 && q < 5) issue_piece(5 + q);
         read_part(q, cst, aoff1, boff1, fm1, fn1);
       }
-      issue_finish();
-      const int nslot = cslot == P_NST - 1 ? 0 : cslot + 1;
+      if (NST == 3) issue_finish();
+      const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
       P192_T(0);
       // stage s + 1 must have landed: own part by the counted wait (stage s + 2 stays in flight), everybody's by the barrier.
       // Right after a tile whose rows were all stored (12 stores per lane, none skipped) those stores sit between the
       // two stages in the in-order count: letting them stay in flight too saves a write-acknowledge latency per tile.
       // Any other tile keeps the smaller count, which only waits longer.
       if (k == 0 && stores_behind) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER + 12) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST == 3 ? P_PER : 0) + 12) : "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST == 3 ? P_PER : 0) : "memory");
       }
       P192_T(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1553,9 +1561,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
           const int i = q >> 1, j = (q & 1) * 4 + jj;
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(fn1[j]), acc[i][j], 0, 0, 0);
         }
-        if (q < 5) issue_piece(q);
+        if (NST == 3) {
+          if (q < 5) issue_piece(q);
+        } else if (q < 5) {  // the whole of stage s + 2, two requests per MFMA group
+          issue_piece(2 * q);
+          issue_piece(2 * q + 1);
+        }
         read_part(q, nst, aoff0, boff0, fm0, fn0);
       }
+      if (NST == 2) issue_finish();
       cslot = nslot;
       P192_T(5);
     }
@@ -1821,11 +1835,17 @@ inline bool p192_eligible(const js2t_gemm_desc& d) {
   if (g_p192_mode < 0 && (int64_t)cdiv(d.M, P_BM) * (d.N >> 7) < 200) return false;
   return true;
 }
+// ring depth: 3 / 2 forced, -1 (default) by shape: two blocks per CU pay when every CU has at least one and a half tiles
+// (measured on MI355X, tools/p192_ring_ab.py: QKV x1.15, FFN1 x1.20, ReLU-gated input gradient x1.25, CTC projection x1.11;
+// a launch with one tile per CU - N = 512 - loses 3-10 % because each block then has a single stage in flight)
+int g_p192_ring = -1;
 template <int EPI>
 int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   static int n_cu = 0;
   if (n_cu == 0) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1837,8 +1857,13 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     if (n_cu == 0) n_cu = cu;
   }
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
-  const int grid = tm * tn < n_cu ? tm * tn : n_cu;
-  hipLaunchKernelGGL(gemm_bf16_p192_kernel<EPI>, dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
+  if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
+    const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192_kernel<EPI, 2>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
+  } else {
+    const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192_kernel<EPI, 3>), dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
+  }
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -1942,6 +1967,7 @@ extern "C" int js2t_debug_p192_prof2(unsigned long long* out8, int reset) {
   return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof2), 64);
 }
 #endif
+extern "C" void js2t_gemm_p192_ring(int nst) { g_p192_ring = nst == 2 ? 2 : (nst == 3 ? 3 : -1); }
 extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode); }
 
 template <bool SPLITK>

@@ -281,7 +281,10 @@ def test_ls960_vocab_xent_ctc_lse(device):
     err_cpu = (refs[torch.float32][1].double() - g64).abs().max().item()
     print(f"ctc V=10000 gradient, max abs error vs fp64: HIP {err_hip:.2e}, torch CPU fp32 {err_cpu:.2e}")
     assert err_hip <= max(2e-5, 3.0 * err_cpu), (err_hip, err_cpu)
-    assert (cd.grad.cpu().double() - g64).norm().item() <= 1e-4 * g64.norm().item()
+    l2_hip = (cd.grad.cpu().double() - g64).norm().item() / g64.norm().item()
+    l2_cpu = (refs[torch.float32][1].double() - g64).norm().item() / g64.norm().item()
+    print(f"ctc V=10000 gradient, relative L2 error vs fp64: HIP {l2_hip:.2e}, torch CPU fp32 {l2_cpu:.2e}")
+    assert l2_hip <= max(1e-4, 2.0 * l2_cpu), (l2_hip, l2_cpu)
     x = cl[0, :100] * 3
     lse, am = ops.row_lse(x.to(device).contiguous(), want_argmax=True)
     torch.testing.assert_close(lse.cpu(), torch.logsumexp(x, -1), rtol=1e-5, atol=1e-5)
