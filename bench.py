@@ -278,6 +278,76 @@ def encoder_forward(model, batch, reps=20):
             "what": "subsampler + 16 encoder layers + final LN, forward only, bf16, dropout on"}
 
 
+PEAK_FP8_TFLOPS = 5000.0  # dense fp8 MFMA peak (MI355X_MICROARCH.md); the kernel uses the non-scaled K = 32 form, which issues at the bf16 rate
+
+
+def conformer_fp8_forward(device, reps=10):
+    """BASELINE.json configs[4]: Conformer-style encoder (relative-position attention + depthwise convolution module) on
+    librispeech_960h shapes with fp8 MFMA - encoder forward on 32 x 15 s of synthetic features, train mode (dropout on),
+    hipGraph replay; timed with e4m3 forward products (functional.FP8_FORWARD) and, beside it, in plain bf16.
+    An EXTENSION: the reference's ConformerEncoder has no relative-position term and no fp8 path, so there is no parity
+    target; the Conformer layers themselves are pinned by tests/golden/conformer.npz, the fp8 product and the bias by
+    tests/test_hip_ops.py.  FLOP per token and layer: two feed-forward modules 2 x 4 d ff, attention 8 d^2 + 4 T' d,
+    convolution module 2 d (2 d) + 2 d^2 + 2 x 31 d."""
+    from joeys2t_amd import functional as Fn
+    from joeys2t_amd.encoders import ConformerEncoder
+    from joeys2t_amd.runtime import ParamStore, Runtime, install_runtime
+    torch.manual_seed(42)
+    d, ff, layers, heads, k = 512, 2048, 16, 4, 31
+    enc = ConformerEncoder(hidden_size=d, ff_size=ff, num_layers=layers, num_heads=heads, dropout=0.1, emb_dropout=0.1, in_channels=80,
+                           conv_channels=512, conv_kernel_sizes=[5, 5], depthwise_conv_kernel_size=k, alpha=1.0, layer_norm="pre",
+                           rel_pos_clip=64)
+    with torch.no_grad():
+        for layer in enc.layers:
+            layer.src_src_att.rel_pos_bias.normal_(0.0, 0.1)
+    enc.to(device)
+    rt = Runtime(device, torch.bfloat16)
+    rt.store = ParamStore(enc, device)
+    rt.rng.seed(42)
+    install_runtime(enc, rt)
+    rt.store.refresh(force=True)
+    enc.train()
+    frames = 1 + (SAMPLES - 400) // 160
+    src = torch.randn(BATCH, frames, 80, device=device).bfloat16()
+    lengths = torch.full((BATCH, ), frames, device=device)
+    tp = ((frames - 1) // 2) // 2 + 1
+    tokens = BATCH * tp
+    flop = layers * tokens * (2 * 4 * d * ff + 8 * d * d + 4 * tp * d + 4 * d * d + 2 * d * d + 2 * k * d) + 2 * tokens * d * d + 41e9 * (BATCH / 32)
+    out = {}
+    for mode in ("fp8", "bf16"):
+        Fn.FP8_FORWARD = mode == "fp8"
+        try:
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        enc(src, lengths, None)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    enc(src, lengths, None)
+                g.replay()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                s.record()
+                for _ in range(reps):
+                    g.replay()
+                e.record()
+                torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / reps
+            out[mode] = {"ms": round(ms, 3), "achieved": round(flop / (ms * 1e-3) / 1e12, 1)}
+        finally:
+            Fn.FP8_FORWARD = False
+    peak = PEAK_FP8_TFLOPS
+    return {"what": "Conformer encoder forward (16 layers, d 512, ff 2048, 4 heads, depthwise k 31, rel-pos clip 64), 32 x 15 s, "
+                    "dropout on; e4m3 forward products of the nn.Linear layers, everything else bf16",
+            "flop": flop, "unit": "TFLOP/s", "fp8": out.get("fp8"), "bf16": out.get("bf16"), "peak": peak,
+            "frac": round(out["fp8"]["achieved"] / peak, 4) if "fp8" in out else None,
+            "parity": "extension: no reference target (joeynmt has neither rel-pos attention nor fp8)"}
+
+
 def host_cpu():
     """(threads this process may use, CPU model string, CPUs online) of the host the baseline is timed on"""
     try:
@@ -588,6 +658,10 @@ def main():
 
     if roofline is not None:
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
+        try:
+            roofline["conformer_fp8_forward"] = conformer_fp8_forward(device)
+        except Exception as exc:  # a side figure of an extension: never lose the headline line over it
+            roofline["conformer_fp8_forward"] = {"error": repr(exc)}
 
     decode = None
     if rank == 0 and world == 1 and not args.no_decode:

@@ -28,7 +28,7 @@ extern "C" {
 
 typedef void* js2t_stream; /* hipStream_t */
 
-enum { JS2T_F32 = 0, JS2T_BF16 = 1 };
+enum { JS2T_F32 = 0, JS2T_BF16 = 1, JS2T_FP8_E4M3 = 2 /* OCP e4m3fn bytes: js2t_gemm operands, js2t_quantize_fp8 output */ };
 enum { JS2T_ACT_NONE = 0, JS2T_ACT_RELU = 1, JS2T_ACT_GELU = 2, JS2T_ACT_SWISH = 3, JS2T_ACT_TANH = 4, JS2T_ACT_HARDSWISH = 5 };
 enum { JS2T_OK = 0, JS2T_ERR_INVALID = -1, JS2T_ERR_LAUNCH = -2, JS2T_ERR_UNSUPPORTED = -3 };
 
@@ -129,6 +129,16 @@ int js2t_axpby(const void* x, float a, const void* y, float b, void* out, int64_
 
 /* dst[i] = (dst_dt) src[i].  Autocast-style parameter/activation casts (training.py:558 autocast). */
 int js2t_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, js2t_stream stream);
+
+/* fp8 forward mode (BASELINE.json configs[4]: "fp8 MFMA"; the reference has no fp8 path - joeynmt/config.py:223-225 knows
+ * fp16 only - so this is an extension without a parity target).  Per-tensor dynamic scaling, no host sync:
+ *   js2t_absmax:        *out = max |x|                                  (out: device float, reset inside the call)
+ *   js2t_quantize_fp8:  y = e4m3(x * 448 / *amax), clamped to +-448;  *scale_out = *amax / 448 * (*mul or 1)
+ * js2t_gemm with dtype_ab = JS2T_FP8_E4M3 then multiplies the two byte tensors on v_mfma_f32_16x16x32_fp8_fp8 and
+ * applies alpha * *alpha_dev (the product of the two scales), bias, ReLU, dropout, residual like the bf16 kernel. */
+int js2t_absmax(const void* x, int dt, int64_t n, float* out, js2t_stream stream);
+int js2t_quantize_fp8(const void* x, int dt, void* y, int64_t n, const float* amax, const float* mul, float* scale_out,
+                      js2t_stream stream);
 
 /* y[r,c] = x[r,c] * sigmoid(x[r,c+C]) for x[rows,2C] — F.glu(dim=1) of encoders.py:366 in [B,T,C] layout. */
 int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream);
@@ -418,12 +428,16 @@ int js2t_logp_set(float* log_probs, const int64_t* rows, const int64_t* cols, in
                   js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
- * Fused multi-head attention (bf16, head size 128): softmax(mask(q k^T * scale)) [dropout] v without
+ * Fused multi-head attention (bf16, head size 128 or 64): softmax(mask(q k^T * scale [+ rel]))) [dropout] v without
  * materialising the [B,H,Tq,Tk] scores — MultiHeadedAttention.forward, transformer_layers.py:86-105, and its
  * backward.  Head h of token (b,t) lives at ptr[(b*T + t)*ld + h*128 ..]; pointers are pre-offset into fused
  * k|v|q buffers.  mask: uint8, element (b,q,k) at mask[b*mask_sb + q*mask_sq + k] (mask_sq = 0 for key padding),
  * NULL = none.  lse: f32[B*H, Tq] row log-sum-exp (written by fwd, read by bwd); delta: f32[B*H, Tq] workspace.
  * Dropout draws the same masks as js2t_softmax_fwd for equal (rng_state, rng_stream).
+ * rel_bias (extension for BASELINE config 5, "rel-pos attn"; the reference's attention has no relative term,
+ * transformer_layers.py:49-115): f32[H, 2*rel_R + 1], added to the scaled score of (query i, key j) of head h as
+ * rel_bias[h][clamp(j - i, -rel_R, rel_R) + rel_R] (a learned bias per head and clipped distance); d_rel_bias, same
+ * shape, receives the gradient by f32 atomics (+=: zero it first).  NULL = off.
  */
 typedef struct js2t_attn_desc {
   const void* q; const void* k; const void* v;
@@ -437,6 +451,9 @@ typedef struct js2t_attn_desc {
   float scale, dropout_p;
   const uint64_t* rng_state;
   uint32_t rng_stream;
+  int32_t rel_R;            /* clipping distance of the relative-position bias, 1..255 */
+  const float* rel_bias;    /* f32[H, 2 rel_R + 1] or NULL */
+  float* d_rel_bias;        /* bwd: += gradient of rel_bias (NULL: not wanted) */
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);

@@ -58,6 +58,7 @@ class AttnDesc(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("head_dim", C.c_int32),
         ("scale", C.c_float), ("dropout_p", C.c_float),
         ("rng_state", C.c_void_p), ("rng_stream", C.c_uint32),
+        ("rel_R", C.c_int32), ("rel_bias", C.c_void_p), ("d_rel_bias", C.c_void_p),
     ]
 
 

@@ -108,6 +108,7 @@ class FlatAdamW:
                                    _C.c_float(g["betas"][1]), _C.c_float(g["eps"]), _C.c_float(g["weight_decay"]), _C.c_int64(self.t),
                                    ops._p(coef), _C.c_float(grad_scale), int(zero_grad), ops._p(lr_dev), ops._p(step_dev),
                                    ops._stream()), "js2t_adamw")
+        ops.WEIGHT_VERSION += 1  # cached e4m3 copies of the weights (functional.FP8_FORWARD) are stale now
         st.dirty = lp is None and st.dirty
         if lp is not None and st.flat_lp_t is not None:
             st.refresh_t()  # transposed shadows follow the updated weights (one kernel; part of the captured step)

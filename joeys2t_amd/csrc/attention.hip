@@ -49,7 +49,17 @@ struct AttnArgs {
   float scale, p;
   const uint64_t* rng;
   uint32_t stream;
+  const float* rel;  // relative-position bias f32[H, 2R+1] (NULL: none)
+  float* d_rel;
+  int relR;
 };
+constexpr int REL_MAX = 255;  // largest clipping distance: the per-head table (2 * 255 + 1 floats) is staged in LDS
+// the head's bias table in base-2 units, staged once per block
+__device__ __forceinline__ void stage_rel(float* rel_s, const AttnArgs& a, int h, int t) {
+  const int n = 2 * a.relR + 1;
+  for (int i = t; i < n; i += 256) rel_s[i] = a.rel[(int64_t)h * n + i] * 1.4426950408889634f;
+}
+__device__ __forceinline__ int rel_index(int key, int query, int R) { return min(max(key - query, -R), R) + R; }
 
 // HBM -> LDS image of KT rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave
 template <int DH>
@@ -174,12 +184,13 @@ __device__ unsigned long long g_attn_prof[8];
 #endif
 // ------------------------------------------------------------------------------------------------ forward
 // a wave owns 16 queries; a block 64
-template <int DH>
+template <int DH, bool REL>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
 #ifdef JS2T_ATTN_PROF
   const unsigned long long t_start_ = __builtin_readcyclecounter();
 #endif
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kmask(kmask, a, b, nkt * KT, t);
+  if (REL) stage_rel(rel_s, a, h, t);
   img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
   img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
@@ -246,6 +258,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     bf16x8_t pf[NSS];
     {
       uint32_t bits = kbits;
+      if (REL) {  // scores go to base-2 units here, the bias of (query, key) with them: the maximum is taken over the sum
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[tt][r] = fmaf(s[tt][r], scale2, rel_s[rel_index(KT * kt + 16 * tt + 4 * g + r, q0 + m, a.relR)]);
+      }
       if (!tile_clear) {
         const int qc = min(q0 + m, a.Tq - 1);
         if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tt][r]);
-      mx = quad_max(mx) * scale2;  // scale > 0: the max commutes with it
+      mx = quad_max(mx) * (REL ? 1.f : scale2);  // scale > 0: the max commutes with it
       const float mnew = fmaxf(mi, mx);
       const float msafe = mnew == -INFINITY ? 0.f : mnew;
       const float corr = __builtin_amdgcn_exp2f(mi - msafe);  // exp2(-inf) = 0 on the first live tile
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
         const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -msafe));
+          const float pv = __builtin_amdgcn_exp2f(REL ? s[tt][r] - msafe : fmaf(s[tt][r], scale2, -msafe));
           rs += pv;
           s[tt][r] = hv[r] >= thr ? pv : 0.f;
         }
@@ -326,9 +345,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
 // own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
 // dS' of one (own query block, key tile): pv * ((keep ? dp : 0) - delta*(1-p)); the common factor scale/(1-p) is applied to
 // dQ once at the end.  lse2 = lse*log2e, scale2 = scale*log2e.  MASKED = some key of the tile is padded / masked out.
-template <bool MASKED, int NTT>
+template <bool MASKED, int NTT, bool REL = false>
 __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float dl2,
-                                            uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop) {
+                                            uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop,
+                                            const float* rel_s = nullptr, float* drel_s = nullptr, int key0 = 0, int query = 0, int R = 0,
+                                            bool q_live = true) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
@@ -339,21 +360,25 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
     const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -lse2));
+      const int ri = REL ? rel_index(key0 + 16 * tt + r, query, R) : 0;
+      float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, (REL ? rel_s[ri] : 0.f) - lse2));
       if (MASKED) pv = ((bits >> (4 * tt + r)) & 1u) ? pv : 0.f;
       const float tdp = hv[r] >= thr ? dp[tt][r] : 0.f;
       s[tt][r] = pv * (tdp - dl2);
+      // gradient of the bias = dS (before the 1/(1-p) factor, applied when the block's histogram is flushed)
+      if (REL && drel_s && q_live && s[tt][r] != 0.f) atomicAdd(&drel_s[ri], s[tt][r]);
     }
   }
 }
 
 // one own-query block of 16 per wave (two need ~350 registers: one wave per SIMD, slower)
-template <int DH>
+template <int DH, bool REL>
 __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1], drel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int ntile = (a.Tq + 63) / 64;  // XCD-aware 1-D grid, see flash_fwd_kernel
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -395,6 +420,10 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kmask(kmask, a, b, nkt * KT, t);
+  if (REL) {
+    stage_rel(rel_s, a, h, t);
+    for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
+  }
   img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
   img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
@@ -408,7 +437,8 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
     const uint32_t kbits = tile_kbits<DH>(kmask, kt, g);
-    const bool tile_clear = !full_mask && __all(kbits == G::FULL) != 0;  // wave-uniform: every key of the tile is live
+    // with a bias gradient to collect, padded keys beyond Tk must not count: take the masked path for every tile
+    const bool tile_clear = !full_mask && !(REL && a.d_rel) && __all(kbits == G::FULL) != 0;  // wave-uniform: every key is live
     bf16x8_t dsf[NSS];
     {
       f32x4_t s[NTT], dp[NTT];
@@ -426,12 +456,14 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
         }
       const uint32_t c4base = (uint32_t)((KT / 4) * kt + g);
       if (tile_clear) {
-        dq_elements<false, NTT>(s, dp, scale2, lse2, dl2, G::FULL, rowkey, c4base, thr, drop);
+        dq_elements<false, NTT, REL>(s, dp, scale2, lse2, dl2, G::FULL, rowkey, c4base, thr, drop, rel_s, nullptr, KT * kt + 4 * g, q0 + m,
+                                     a.relR);
       } else {
         const int qc = min(q0 + m, a.Tq - 1);
         uint32_t bits = kbits;
         if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
-        dq_elements<true, NTT>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop);
+        dq_elements<true, NTT, REL>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
+                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < a.Tq);
       }
 #pragma unroll
       for (int ss = 0; ss < NSS; ++ss) dsf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
@@ -445,6 +477,13 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
     cur ^= 1;
   }
   const float dq_sc = a.scale * (drop ? 1.f / keep_p : 1.f);
+  if (REL && a.d_rel) {  // the block's histogram of dS over relative distances -> the head's gradient row
+    __syncthreads();
+    const int n = 2 * a.relR + 1;
+    const float sc = drop ? 1.f / keep_p : 1.f;
+    for (int i = t; i < n; i += 256)
+      if (drel_s[i] != 0.f) atomicAdd(a.d_rel + (int64_t)h * n + i, drel_s[i] * sc);
+  }
   {
     const int qrow = q0 + m;
     if (qrow < a.Tq) {
@@ -463,10 +502,11 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
 //   ds' = pv * ((keep ? dp : 0) - delta*(1-p))      (dK gets scale/(1-p) once, at the end)
 // Dropout: the decision of (query row, key) is the half (key & 1) of hash32(rowhash + (key >> 1)) - the same value for
 // the two neighbouring lanes of a key pair, so each lane hashes two of the four rows and swaps with its neighbour (DPP).
-template <bool KEYCHECK, bool FULLMASK, int NTT>
+template <bool KEYCHECK, bool FULLMASK, int NTT, bool REL = false>
 __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NTT], const float* lse2, const float* dl2,
                                              const uint32_t* rkp, float scale2, bool key_ok, int key, uint32_t thr, bool drop, int g,
-                                             int par, const uint8_t* mcol, int64_t msq, int qbase, int Tq) {
+                                             int par, const uint8_t* mcol, int64_t msq, int qbase, int Tq, const float* rel_s = nullptr,
+                                             int R = 0) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     const f32x4_t l4 = *(const f32x4_t*)(lse2 + 16 * tt + 4 * g);
@@ -482,7 +522,8 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NT
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, -l4[r]));
+      float pv = __builtin_amdgcn_exp2f(
+          fmaf(s[tt][r], scale2, (REL ? rel_s[rel_index(key, qbase + 16 * tt + 4 * g + r, R)] : 0.f) - l4[r]));
       if (KEYCHECK) pv = key_ok ? pv : 0.f;
       if (FULLMASK) {
         const int qrow = min(qbase + 16 * tt + 4 * g + r, Tq - 1);
@@ -499,13 +540,14 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NT
 // one own-key block of 16 per wave: with two (32 keys per wave) the dK / dV accumulators, the own K / V fragments and the
 // S / dP tiles need > 400 registers - one wave per SIMD, nothing to overlap the MFMA, exp / dropout VALU work and LDS
 // latency with.  One block per wave fits 256 registers, i.e. two waves per SIMD.
-template <int DH>
+template <int DH, bool REL>
 __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;  // KT = queries per swept tile here
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) float lse_s[2][KT], dl_s[2][KT];
   __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][KT];
+  __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int ntile = (a.Tk + 63) / 64;  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -535,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   const bool key_valid = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
   const bool all_keys = __all(key_valid) != 0;  // wave-uniform: no per-element key test needed
   const int nqt = (a.Tq + KT - 1) / KT;
+  if (REL) stage_rel(rel_s, a, h, t);  // visible after the first barrier of the sweep
   img_dma<DH>(Qb, a.ldq, 0, a.Tq, smem, t);
   img_dma<DH>(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
   // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in registers: fetching
@@ -590,11 +633,14 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
       const uint32_t* rp = rk_s[cur] + 64 * hf;
       const int qbase = qt * KT + 64 * hf;
       if (full_mask)
-        dkv_elements<true, true, 4>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, mcol, a.msq, qbase, a.Tq);
+        dkv_elements<true, true, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, mcol, a.msq, qbase, a.Tq, rel_s,
+                                         a.relR);
       else if (!all_keys)
-        dkv_elements<true, false, 4>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq);
+        dkv_elements<true, false, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq, rel_s,
+                                          a.relR);
       else
-        dkv_elements<false, false, 4>(s, dp, lp, dlp, rp, scale2, true, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq);
+        dkv_elements<false, false, 4, REL>(s, dp, lp, dlp, rp, scale2, true, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq, rel_s,
+                                           a.relR);
       pf[2 * hf] = pack8(s[0], s[1]);
       pf[2 * hf + 1] = pack8(s[2], s[3]);
       dsf[2 * hf] = pack8(dp[0], dp[1]);
@@ -643,6 +689,8 @@ int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "flash_attn: leading dims must be multiples of 8");
   JS2T_CHECK(((((uintptr_t)d->q) | ((uintptr_t)d->k) | ((uintptr_t)d->v)) & 15) == 0, "flash_attn: q/k/v must be 16-byte aligned");
   JS2T_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f && (d->dropout_p == 0.f || d->rng_state), "flash_attn: bad dropout args");
+  JS2T_CHECK(!d->rel_bias || (d->rel_R >= 1 && d->rel_R <= REL_MAX), "flash_attn: rel_R must be 1..%d", REL_MAX);
+  JS2T_CHECK(!d->d_rel_bias || d->rel_bias, "flash_attn: d_rel_bias without rel_bias");
   return JS2T_OK;
 }
 
@@ -656,37 +704,38 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.lddv = d->ld_dv; a.msb = d->mask_sb; a.msq = d->mask_sq;
   a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk;
   a.scale = d->scale; a.p = d->dropout_p; a.rng = d->rng_state; a.stream = d->rng_stream;
+  a.rel = d->rel_bias; a.d_rel = d->d_rel_bias; a.relR = d->rel_bias ? d->rel_R : 0;
   return a;
 }
 
-template <int DH>
+template <int DH, bool REL>
 int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
   if (!once) {
-    const int rc = set_lds(flash_fwd_kernel<DH>, 4 * IMG_BYTES);
+    const int rc = set_lds(flash_fwd_kernel<DH, REL>, 4 * IMG_BYTES);
     if (rc) return rc;
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL(flash_fwd_kernel<DH>, dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  hipLaunchKernelGGL((flash_fwd_kernel<DH, REL>), dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
 
-template <int DH>
+template <int DH, bool REL>
 int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
   if (!once) {
-    int rc = set_lds(flash_dq_kernel<DH>, 4 * IMG_BYTES);
+    int rc = set_lds(flash_dq_kernel<DH, REL>, 4 * IMG_BYTES);
     if (rc) return rc;
-    rc = set_lds(flash_dkv_kernel<DH>, 4 * IMG_BYTES);
+    rc = set_lds(flash_dkv_kernel<DH, REL>, 4 * IMG_BYTES);
     if (rc) return rc;
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL(flash_dq_kernel<DH>, dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+  hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
   JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(flash_dkv_kernel<DH>, dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  hipLaunchKernelGGL((flash_dkv_kernel<DH, REL>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -700,7 +749,9 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
   int rc = check_common(d);
   if (rc) return rc;
   JS2T_CHECK(d->o && (d->ldo % 4) == 0 && ((((uintptr_t)d->o)) & 7) == 0, "flash_attn_fwd: bad output");
-  return d->head_dim == 128 ? launch_fwd<128>(d, (hipStream_t)stream) : launch_fwd<64>(d, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->rel_bias) return d->head_dim == 128 ? launch_fwd<128, true>(d, s) : launch_fwd<64, true>(d, s);
+  return d->head_dim == 128 ? launch_fwd<128, false>(d, s) : launch_fwd<64, false>(d, s);
 }
 
 extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) {
@@ -712,5 +763,7 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
   JS2T_CHECK(((((uintptr_t)d->d_o) | ((uintptr_t)d->o)) & 15) == 0 &&
                  ((((uintptr_t)d->dq) | ((uintptr_t)d->dk) | ((uintptr_t)d->dv)) & 7) == 0,
              "flash_attn_bwd: misaligned gradient buffers");
-  return d->head_dim == 128 ? launch_bwd<128>(d, (hipStream_t)stream) : launch_bwd<64>(d, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->rel_bias) return d->head_dim == 128 ? launch_bwd<128, true>(d, s) : launch_bwd<64, true>(d, s);
+  return d->head_dim == 128 ? launch_bwd<128, false>(d, s) : launch_bwd<64, false>(d, s);
 }

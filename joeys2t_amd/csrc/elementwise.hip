@@ -592,3 +592,92 @@ extern "C" int js2t_transpose_groups(const void* src, void* dst, const int64_t* 
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
+
+// ---------------------------------------------------------------- e4m3 quantisation (fp8 forward mode, BASELINE config 5)
+namespace {
+// max |x| over a tensor: block maxima land in *out through an unsigned atomic max (non-negative floats order like their bits)
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  constexpr int V = 16 / sizeof(T);
+  for (int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * V; i < n; i += (int64_t)gridDim.x * 256 * V) {
+    if (i + V <= n) {
+      const uint4 r = *(const uint4*)(x + i);
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(fabsf(__uint_as_float(wds[k] << 16)), fabsf(__uint_as_float(wds[k] & 0xffff0000u))));
+      } else {
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(__uint_as_float(r.x)), fabsf(__uint_as_float(r.y))),
+                           fmaxf(fabsf(__uint_as_float(r.z)), fabsf(__uint_as_float(r.w)))));
+      }
+    } else {
+      for (int64_t j = i; j < n; ++j) m = fmaxf(m, fabsf(io<T>::ld(x + j)));
+    }
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0) atomicMax((unsigned int*)out, __float_as_uint(m));  // NaN inputs would poison the scale: not handled
+}
+
+// y = e4m3(x * 448 / amax) (round to nearest even, clamped to +-448); scale_out = amax / 448 * (*mul or 1)
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, uint8_t* __restrict__ y, int64_t n,
+                                                          const float* __restrict__ amax, const float* __restrict__ mul,
+                                                          float* __restrict__ scale_out) {
+  const float am = *amax;
+  const float inv = am > 0.f ? 448.f / am : 0.f;
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = (am > 0.f ? am / 448.f : 1.f) * (mul ? *mul : 1.f);
+  for (int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = i + k < n ? fminf(fmaxf(io<T>::ld(x + i + k) * inv, -448.f), 448.f) : 0.f;
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    if (i + 8 <= n) {
+      *(uint2*)(y + i) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    } else {
+      const uint32_t wds[2] = {(uint32_t)lo, (uint32_t)hi};
+      for (int k = 0; i + k < n; ++k) y[i + k] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int js2t_absmax(const void* x, int dt, int64_t n, float* out, js2t_stream stream) {
+  JS2T_CHECK(x && out && n > 0 && (dt == JS2T_F32 || dt == JS2T_BF16), "absmax: bad arguments");
+  JS2T_CHECK((((uintptr_t)x) & 15) == 0, "absmax: input must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  if (e != hipSuccess) {
+    js2t_set_error("absmax: %s", hipGetErrorString(e));
+    return JS2T_ERR_LAUNCH;
+  }
+  const int64_t per = dt == JS2T_BF16 ? 8 : 4;
+  int64_t grid = (n / per + 255) / 256;
+  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  if (dt == JS2T_BF16)
+    hipLaunchKernelGGL(absmax_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)x, n, out);
+  else
+    hipLaunchKernelGGL(absmax_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, (const float*)x, n, out);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_quantize_fp8(const void* x, int dt, void* y, int64_t n, const float* amax, const float* mul, float* scale_out,
+                                 js2t_stream stream) {
+  JS2T_CHECK(x && y && amax && n > 0 && (dt == JS2T_F32 || dt == JS2T_BF16), "quantize_fp8: bad arguments");
+  JS2T_CHECK((((uintptr_t)y) & 7) == 0, "quantize_fp8: output must be 8-byte aligned");
+  int64_t grid = (n / 8 + 255) / 256;
+  grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+  if (dt == JS2T_BF16)
+    hipLaunchKernelGGL(quantize_fp8_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint8_t*)y, n, amax, mul, scale_out);
+  else
+    hipLaunchKernelGGL(quantize_fp8_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (uint8_t*)y, n,
+                       amax, mul, scale_out);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}

@@ -14,6 +14,7 @@
 //
 // Reference call sites replaced: see include/joeys2t_hip.h (js2t_gemm).
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -1386,21 +1387,41 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   }
 }
 
-template <int EPI, int NST = P_NST>
+// one fragment pair -> accumulator: a bf16 MFMA over 32 k, or two e4m3 MFMAs over 32 k each (the fragment's two 8-byte halves)
+template <bool FP8>
+__device__ __forceinline__ f32x4_t p192_mma(const frag_i4& a, const frag_i4& b, f32x4_t c) {
+  if constexpr (FP8) {
+    typedef long l2_t __attribute__((ext_vector_type(2)));
+    const l2_t al = __builtin_bit_cast(l2_t, a), bl = __builtin_bit_cast(l2_t, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(al[0], bl[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(al[1], bl[1], c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+}
+
+// FP8: e4m3 operands (one byte per element).  The stage keeps its 128-byte rows, i.e. 128 k instead of 64; a lane's 16-byte
+// fragment piece then holds the operands of TWO v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each).  Which 8 of the stage's k a
+// lane group supplies to which MFMA is a permutation of k that A and B share (both are read through the same chunk index
+// 4 kk + g), so the sums are unchanged.  Same MFMA rate as bf16, half the L2 -> LDS bytes per flop - and that, not the
+// matrix pipe, is what bounds this kernel.
+template <int EPI, int NST = P_NST, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using elem_t = typename std::conditional<FP8, uint8_t, uint16_t>::type;
+  constexpr int CSH = FP8 ? 4 : 3, KST = FP8 ? 128 : 64;  // log2(elements per 16-byte chunk), k per stage
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform: LDS-DMA destinations (M0) stay on the scalar unit
-  const int M = d.M, N = d.N, K = d.K, nk = (K + 63) >> 6;
+  const int M = d.M, N = d.N, K = d.K, nk = (K + KST - 1) / KST;
   const int ntiles = tiles_m * tiles_n, G = gridDim.x;
-  const uint16_t* Ab = (const uint16_t*)d.A;
-  const uint16_t* Bb = (const uint16_t*)d.B;
+  const elem_t* Ab = (const elem_t*)d.A;
+  const elem_t* Bb = (const elem_t*)d.B;
   const int64_t lda = d.lda, ldb = d.ldb;
 
   // ---- issue side: runs up to three stages ahead of the multiply side, possibly already in the next tile
   int iv = blockIdx.x, ik = 0, islot = 0;
-  const uint16_t* asrc[6];
-  const uint16_t* bsrc[4];
+  const elem_t* asrc[6];
+  const elem_t* bsrc[4];
   const int r8 = lane >> 3, s8 = lane & 7;
   auto set_tile_src = [&](int v) {
     const int lid = xcd_remap(v, ntiles);
@@ -1408,12 +1429,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int row = (w * 6 + q) * 8 + r8;
-      asrc[q] = Ab + (int64_t)min(m0 + row, M - 1) * lda + ((s8 ^ kc_key<false>(row)) << 3);
+      asrc[q] = Ab + (int64_t)min(m0 + row, M - 1) * lda + ((s8 ^ kc_key<false>(row)) << CSH);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // piece P = 4w + q of the B image: fragment index j = P >> 1, lanes r = 8 (P & 1) + r8
       const int P = w * 4 + q, r = (P & 1) * 8 + r8;
-      bsrc[q] = Bb + (int64_t)min(n0 + 8 * r + (P >> 1), N - 1) * ldb + ((s8 ^ (r >> 1)) << 3);
+      bsrc[q] = Bb + (int64_t)min(n0 + 8 * r + (P >> 1), N - 1) * ldb + ((s8 ^ (r >> 1)) << CSH);
     }
   };
   // a stage is requested in ten 1 KB pieces per wave (six of A, four of B); the steady state spreads them between the
@@ -1421,26 +1442,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
   // ~570 cycles (the texture-address path takes ~16 cycles per instruction).
   // Past the block's last stage the requests go on (re-reading k = 0 of the last tile into a free slot): the loop and
   // its vmcnt counts stay branch-free, at the price of three unused stages per block.
-  int p_k0 = 0, p_klim = 64;
+  int p_k0 = 0, p_klim = KST;
   unsigned char* p_st = smem;
   // k offset (inside a stage) of the lane's 8 elements: the same for every A piece, two values for the B pieces
-  const int kofs_a = (s8 ^ (r8 & 7)) << 3, kofs_b0 = (s8 ^ (r8 >> 1)) << 3, kofs_b1 = (s8 ^ ((8 + r8) >> 1)) << 3;
-  const uint16_t* zsrc = (const uint16_t*)&g_zero16;
+  const int kofs_a = (s8 ^ (r8 & 7)) << CSH, kofs_b0 = (s8 ^ (r8 >> 1)) << CSH, kofs_b1 = (s8 ^ ((8 + r8) >> 1)) << CSH;
+  const elem_t* zsrc = (const elem_t*)&g_zero16;
   auto issue_begin = [&]() {
-    p_k0 = iv < ntiles ? ik << 6 : 0;
-    p_klim = K - p_k0;  // < 64 only in the partial last stage of a tile (K % 64 != 0): those k come from a zero constant
+    p_k0 = iv < ntiles ? ik * KST : 0;
+    p_klim = K - p_k0;  // < KST only in the partial last stage of a tile (K % KST != 0): those k come from a zero constant
     p_st = smem + islot * P_STAGE;
   };
   auto issue_piece = [&](int q) {  // q is a compile-time constant at every call site
     if (q < 6) {
-      const uint16_t* sp = asrc[q < 6 ? q : 0] + p_k0;
-      if (p_klim < 64) {
+      const elem_t* sp = asrc[q < 6 ? q : 0] + p_k0;
+      if (p_klim < KST) {
         if (kofs_a >= p_klim) sp = zsrc;
       }
       __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(p_st + (w * 6 + q) * 1024), 16, 0, 0);
     } else {
-      const uint16_t* sp = bsrc[q >= 6 ? q - 6 : 0] + p_k0;
-      if (p_klim < 64) {
+      const elem_t* sp = bsrc[q >= 6 ? q - 6 : 0] + p_k0;
+      if (p_klim < KST) {
         if ((((w * 4 + q - 6) & 1) ? kofs_b1 : kofs_b0) >= p_klim) sp = zsrc;
       }
       __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(p_st + P_ATILE + (w * 4 + q - 6) * 1024), 16, 0, 0);
@@ -1528,7 +1549,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int i = q >> 1, j = (q & 1) * 4 + jj;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm0[i]), as_bf16x8(fn0[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = p192_mma<FP8>(fm0[i], fn0[j], acc[i][j]);
         }
         if (NST == 3 && q < 5) issue_piece(5 + q);
         read_part(q, cst, aoff1, boff1, fm1, fn1);
@@ -1559,7 +1580,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int i = q >> 1, j = (q & 1) * 4 + jj;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fm1[i]), as_bf16x8(fn1[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = p192_mma<FP8>(fm1[i], fn1[j], acc[i][j]);
         }
         if (NST == 3) {
           if (q < 5) issue_piece(q);
@@ -1867,6 +1888,33 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
+// e4m3 operands: generic epilogue only (alpha carries the two per-tensor scales), ring depth by the same rule
+int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<-1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<-1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    int dev = 0, cu = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cu <= 0) {
+      js2t_set_error("gemm fp8 setup: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    n_cu = (cu & ~7) ? (cu & ~7) : cu;
+  }
+  const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
+  if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
+    const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192_kernel<-1, 2, true>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
+  } else {
+    const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192_kernel<-1, 3, true>), dim3(grid), dim3(256), P_LDS, s, d, tm, tn);
+  }
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
 int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
   // the epilogue combinations of the Transformer train step get their own instantiation, anything else the generic one
   if (d.alpha == 1.f && !d.alpha_dev) {
@@ -2066,7 +2114,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
   if (d.M == 0 || d.N == 0 || d.batch == 0) return JS2T_OK;
   JS2T_CHECK(d.A && d.B && d.C, "gemm: null operand");
   JS2T_CHECK(d.batch_inner >= 1, "gemm: batch_inner must be >= 1");
-  JS2T_CHECK(d.dtype_ab == JS2T_F32 || d.dtype_ab == JS2T_BF16, "gemm: bad dtype_ab");
+  JS2T_CHECK(d.dtype_ab == JS2T_F32 || d.dtype_ab == JS2T_BF16 || d.dtype_ab == JS2T_FP8_E4M3, "gemm: bad dtype_ab");
   JS2T_CHECK(d.dtype_c == JS2T_F32 || d.dtype_c == JS2T_BF16, "gemm: bad dtype_c");
   JS2T_CHECK(d.dropout_p >= 0.f && d.dropout_p < 1.f, "gemm: dropout_p out of range");
   JS2T_CHECK(d.dropout_p == 0.f || d.rng_state, "gemm: dropout needs rng_state");
@@ -2084,6 +2132,18 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&
                    !d.gate && d.beta == 0.f,
                "gemm: split_k needs an f32 C and a plain epilogue (C must be zero-filled by the caller)");
+  }
+  if (d.dtype_ab == JS2T_FP8_E4M3) {
+    // e4m3 x e4m3 -> f32 accumulate -> bf16: the persistent 192x128 kernel only (k-contiguous operands, 16-byte rows)
+    JS2T_CHECK(!d.trans_a && !d.trans_b && !d.conv && d.split_k == 1 && d.batch == 1 && d.dtype_c == JS2T_BF16 && !d.preact &&
+                   d.beta == 0.f && !d.a_rowsum && !(d.residual && d.gate) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU),
+               "gemm fp8: plain k-contiguous products with a bf16 result only");
+    JS2T_CHECK((d.N & 7) == 0 && d.N >= 128 && (d.K & 15) == 0 && d.K >= 128 && (d.lda & 15) == 0 && (d.ldb & 15) == 0 && aligned16(d.A) &&
+                   aligned16(d.B) && aligned16(d.C) && (d.ldc & 7) == 0,
+               "gemm fp8: N % 8 == 0, N >= 128, K % 16 == 0, K >= 128, 16-byte aligned rows");
+    JS2T_CHECK(!d.residual || ((d.ldr & 7) == 0 && aligned16(d.residual)), "gemm fp8: misaligned residual");
+    JS2T_CHECK(!d.gate || ((d.ldg & 7) == 0 && aligned16(d.gate)), "gemm fp8: misaligned gate");
+    return launch_fp8_p192(d, s);
   }
   bool fast = d.dtype_ab == JS2T_BF16 && aligned16(d.A) && aligned16(d.B) && (d.lda % 8 == 0) && (d.ldb % 8 == 0) &&
               (d.a_stride_o % 8 == 0) && (d.a_stride_i % 8 == 0) && (d.b_stride_o % 8 == 0) && (d.b_stride_i % 8 == 0) &&

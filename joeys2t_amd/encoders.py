@@ -140,7 +140,8 @@ class ConformerEncoder(TransformerEncoder):
         self.layers = nn.ModuleList([
             ConformerEncoderLayer(size=hidden_size, ff_size=ff_size, num_heads=num_heads, dropout=dropout,
                                   alpha=kwargs.get("alpha", 1.0), layer_norm=kwargs.get("layer_norm", "pre"),
-                                  depthwise_conv_kernel_size=kwargs.get("depthwise_conv_kernel_size", 31)) for _ in range(num_layers)
+                                  depthwise_conv_kernel_size=kwargs.get("depthwise_conv_kernel_size", 31),
+                                  rel_pos_clip=kwargs.get("rel_pos_clip")) for _ in range(num_layers)
         ])
         self.pe = PositionalEncoding(hidden_size)
         self.emb_dropout = nn.Dropout(p=emb_dropout)

@@ -35,6 +35,30 @@ def _row_major_2d(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+# fp8 forward mode (BASELINE config 5, "fp8 MFMA"; an extension - the reference computes in fp32 / fp16 only): the forward
+# product of every eligible nn.Linear runs on e4m3 operands with per-tensor dynamic scales (activations re-quantised per
+# call on the device, weights once per optimizer step); backward keeps the bf16 activations and weights it has anyway.
+FP8_FORWARD = os.environ.get("JS2T_FP8_FORWARD", "0") == "1"
+_FP8_WEIGHTS = {}  # (data_ptr, shape) -> (ops.WEIGHT_VERSION, e4m3 weight, scale f32[1])
+
+
+def _fp8_weight(w):
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _FP8_WEIGHTS.get(key)
+    if hit is None or hit[0] != ops.WEIGHT_VERSION:
+        w8, ws = ops.quantize_fp8(w)
+        hit = _FP8_WEIGHTS[key] = (ops.WEIGHT_VERSION, w8, ws)
+    return hit[1], hit[2]
+
+
+def _fp8_eligible(x2d, w, out_dtype, preact, alpha) -> bool:
+    M, K = x2d.shape
+    N = w.shape[0]
+    return (FP8_FORWARD and x2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (out_dtype in (None, torch.bfloat16)) and
+            preact is None and alpha == 1.0 and x2d.is_contiguous() and w.is_contiguous() and K % 16 == 0 and K >= 128 and
+            N % 8 == 0 and N >= 128 and M >= 1)
+
+
 def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
                out_dtype=None, preact=None, alpha=1.0):
     """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch."""
@@ -42,6 +66,12 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
     M, K = x2d.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    if _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
+        w8, ws = _fp8_weight(w)
+        x8, sc = ops.quantize_fp8(x2d, mul=ws)  # sc = s_x * s_w on the device: the GEMM's alpha_dev
+        ops.gemm(x8, w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
+                 residual=residual, ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha_dev=sc)
+        return y
     ops.gemm(x2d, w, y, M=M, N=N, K=K, lda=x2d.stride(0), ldb=w.stride(0), ldc=N, bias=b, act=act, preact=preact,
              dropout_p=dropout_p, rng=rng, rng_stream=site, residual=residual,
              ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha)
@@ -131,7 +161,7 @@ class AttnShape:
 USE_FLASH = True  # fused attention kernels when the shapes allow (bf16, head size 128); tests flip this to compare
 
 
-def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, site, need_probs=False):
+def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, site, need_probs=False, rel_bias=None):
     """softmax(mask(q k^T / sqrt(dh))) v for all heads; q_t/k_t/v_t are [B*T, ld*] row-major 2-D buffers whose
     head h lives at column off + h*dh.  Returns (ctx[B*Tq, H*dh], P, Pd) on the materialised path and
     (ctx, None, lse) on the fused path (P is None)."""
@@ -140,8 +170,10 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
     Z = B * H
     if USE_FLASH and not need_probs and ops.flash_supported(q_t, k_t, v_t, dh):
         # fused kernel: scores / probabilities stay on chip; the forward keeps (out, lse) for backward
-        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
         return out, None, lse
+    if rel_bias is not None:
+        raise NotImplementedError("relative-position bias: fused attention kernels only (bf16 compute, head size 128 or 64)")
     S = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
     ops.gemm(q_t, k_t, S, M=Tq, N=Tk, K=dh, lda=q_t.stride(0), ldb=k_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
              a_strides=(Tq * q_t.stride(0), dh), b_strides=(Tk * k_t.stride(0), dh), c_strides=(H * Tq * ld, Tq * ld),
@@ -154,13 +186,13 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
 
 
 def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, shp: AttnShape, P, Pd, p,
-             rng, site, ctx_out=None, mask=None):
+             rng, site, ctx_out=None, mask=None, rel_bias=None, d_rel_bias=None):
     """Writes dq/dk/dv into the given (row-major 2-D) gradient buffers at the given column offsets.
     Fused path: P is None, Pd carries the forward's row log-sum-exp and ctx_out its output."""
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
     if P is None:
         ops.flash_attn_bwd(dctx, ctx_out, Pd, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off,
-                           B, H, Tq, Tk, dh, mask, p, rng, site)
+                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias)
         return
     Z = B * H
     dev, dt = dctx.device, dctx.dtype
@@ -276,7 +308,7 @@ class ResidualBlockFn(torch.autograd.Function):
             H, dh = cfg.H, d // cfg.H
             qkv = linear_fwd(n, wts["w_in"], wts["b_in"])  # columns: [k | v | q]
             shp = AttnShape(B, T, T, H, dh)
-            c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0])
+            c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0], rel_bias=wts.get("rel_bias"))
             saved.update(qkv=qkv, P=P, Pd=Pd, shp=shp)
         elif cfg.kind == "cross":
             H, dh = cfg.H, d // cfg.H
@@ -371,8 +403,13 @@ class ResidualBlockFn(torch.autograd.Function):
             dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
+            rel, d_rel = wts.get("rel_bias"), None
+            if rel is not None:
+                d_rel = sk("rel_bias")  # the parameter's slice of the flat gradient: the kernel adds into it
+                if d_rel is None:
+                    d_rel = g["rel_bias"] = torch.zeros_like(rel)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
-                     sites[0], ctx_out=c, mask=ctx.mask)
+                     sites[0], ctx_out=c, mask=ctx.mask, rel_bias=rel, d_rel_bias=d_rel)
             dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"), queue=wq, w_t=wts.get("w_in_t"))
         else:  # cross
             dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
@@ -405,6 +442,8 @@ class ResidualBlockFn(torch.autograd.Function):
             grads = [None] * ctx.nparams
         else:
             grads = _route_param_grads(cfg.kind, g, d, cfg.ln_mode != "none")
+            if "rel_bias" in wts:  # the relative-position table rides last in the parameter list (MultiHeadedAttention.run_block)
+                grads.append(g.get("rel_bias"))
         assert len(grads) == ctx.nparams
         return (None, None, dx2.view(B, T, d), dmem, None, None, *grads)
 

@@ -74,6 +74,7 @@ class Model(nn.Module):
         """As nn.Module.load_state_dict (parameters stay views of the flat store); the compute-dtype shadows are re-derived
         before the next forward."""
         out = super().load_state_dict(state_dict, strict=strict, **kwargs)
+        ops.WEIGHT_VERSION += 1
         if self._rt_obj is not None and self._rt_obj.store is not None:
             self._rt_obj.store.mark_dirty()
         return out

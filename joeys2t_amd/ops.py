@@ -12,7 +12,8 @@ import torch
 
 from joeys2t_amd._lib import ACT_CODES, BF16, F32, AttnDesc, GemmDesc, Js2tError, check, lib
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+FP8 = 2  # JS2T_FP8_E4M3: OCP e4m3fn bytes (js2t_gemm operands only)
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
 
 def dt_code(t_or_dtype) -> int:
@@ -147,7 +148,9 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     d.split_k = int(split_k)
     d.a_rowsum = None if a_rowsum is None else a_rowsum.data_ptr()
     if GEMM_TIMER is not None:
-        if d.dtype_ab == BF16:
+        if d.dtype_ab == FP8:
+            key = "gemm_fp8_p192_kernel<0,0,0>"
+        elif d.dtype_ab == BF16:
             fam = "gemm_bf16_kernel" if d.conv else ("gemm_bf16_p192_kernel" if _takes_p192(d) else "gemm_bf16_dma_kernel")
             key = f"{fam}<{int(d.trans_a)},{int(d.trans_b)},{int(d.split_k > 1)}>"
         else:
@@ -644,6 +647,26 @@ def attn_decode(q2d, k_view, v_view, ldkv: int, idx, idx_ld: int, Tmax: int, len
 
 
 # ----------------------------------------------------------------------------------------- beam search
+# ----------------------------------------------------------------------------------------- fp8 (e4m3) forward mode
+WEIGHT_VERSION = 0  # bumped whenever parameters change (optimizer step, load_state_dict): invalidates cached e4m3 weights
+
+
+def quantize_fp8(x: torch.Tensor, mul: Optional[torch.Tensor] = None):
+    """Per-tensor dynamic e4m3 quantisation without a host sync: amax on the device (js2t_absmax), y = e4m3(x * 448 / amax)
+    (js2t_quantize_fp8).  Returns (y float8_e4m3fn like x, scale f32[1] = amax / 448 [* mul]); the fp8 GEMM takes `scale`
+    as alpha_dev, so passing the weight's scale as `mul` folds both dequantisation factors into one device scalar."""
+    _dev(x, mul)
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous():
+        raise Js2tError("quantize_fp8: contiguous float32 / bfloat16 input")
+    y = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    amax = torch.empty((1, ), dtype=torch.float32, device=x.device)
+    scale = torch.empty((1, ), dtype=torch.float32, device=x.device)
+    check(lib().js2t_absmax(_p(x), dt_code(x), C.c_int64(x.numel()), _p(amax), _stream()), "js2t_absmax")
+    check(lib().js2t_quantize_fp8(_p(x), dt_code(x), _p(y), C.c_int64(x.numel()), _p(amax), _p(mul), _p(scale), _stream()),
+          "js2t_quantize_fp8")
+    return y, scale
+
+
 def rep_penalty(log_probs: torch.Tensor, tokens: torch.Tensor, penalty: float):
     """penalize_repetition (search.py:972-1001) in place on f32 [rows, V]; tokens int64 [rows, L] with ids in [0, V)."""
     _dev(log_probs, tokens)
@@ -714,8 +737,13 @@ def flash_supported(q_t, k_t, v_t, dh: int) -> bool:
     return ok
 
 
-def _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site):
+def _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None):
     d = AttnDesc()
+    if rel_bias is not None:
+        if rel_bias.dtype != torch.float32 or rel_bias.dim() != 2 or rel_bias.shape[0] != H or rel_bias.shape[1] % 2 != 1 or \
+                not rel_bias.is_contiguous():
+            raise Js2tError(f"relative-position bias must be contiguous float32 [H, 2R+1], got {tuple(rel_bias.shape)} {rel_bias.dtype}")
+        d.rel_bias, d.rel_R = rel_bias.data_ptr(), (rel_bias.shape[1] - 1) // 2
     es = q_t.element_size()
     d.q, d.k, d.v = q_t.data_ptr() + q_off * es, k_t.data_ptr() + k_off * es, v_t.data_ptr() + v_off * es
     d.ldq, d.ldk, d.ldv = q_t.stride(0), k_t.stride(0), v_t.stride(0)
@@ -729,20 +757,25 @@ def _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rn
     return d
 
 
-def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site):
-    _dev(q_t, k_t, v_t, mask)
+def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None):
+    _dev(q_t, k_t, v_t, mask, rel_bias)
     out = torch.empty((B * Tq, H * dh), dtype=q_t.dtype, device=q_t.device)
     lse = torch.empty((B * H, Tq), dtype=torch.float32, device=q_t.device)
-    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
     check(lib().js2t_flash_attn_fwd(C.byref(d), _stream()), "js2t_flash_attn_fwd")
     return out, lse
 
 
 def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
-                   dh, mask, p, rng, site):
-    _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask)
-    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site)
+                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None):
+    """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating."""
+    _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask, rel_bias, d_rel_bias)
+    d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
+    if d_rel_bias is not None:
+        if rel_bias is None or d_rel_bias.shape != rel_bias.shape or d_rel_bias.dtype != torch.float32 or not d_rel_bias.is_contiguous():
+            raise Js2tError("d_rel_bias must be a contiguous float32 tensor shaped like rel_bias")
+        d.d_rel_bias = d_rel_bias.data_ptr()
     delta = torch.empty_like(lse)
     es = q_t.element_size()
     d.o, d.ldo, d.lse, d.delta = out.data_ptr(), out.stride(0), lse.data_ptr(), delta.data_ptr()

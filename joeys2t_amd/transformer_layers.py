@@ -27,9 +27,15 @@ def _rng(rt, x: Tensor):
 class MultiHeadedAttention(nn.Module):
     """Multi-head attention; argument order of forward is (k, v, q, mask) as in the reference (:49-56)."""
 
-    def __init__(self, num_heads: int, size: int, dropout: float = 0.1) -> None:
+    def __init__(self, num_heads: int, size: int, dropout: float = 0.1, rel_pos_clip: Optional[int] = None) -> None:
+        """rel_pos_clip (extension, BASELINE config 5 "rel-pos attn"; not in the reference): a learned bias per head and
+        clipped relative distance, rel_pos_bias[h, clamp(j - i, -R, R) + R], added to the scaled self-attention scores
+        inside the fused attention kernels (bf16 compute only).  Zero-initialised: the module then equals the reference's."""
         super().__init__()
         assert size % num_heads == 0
+        self.rel_pos_bias = None
+        if rel_pos_clip:
+            self.rel_pos_bias = nn.Parameter(torch.zeros(num_heads, 2 * int(rel_pos_clip) + 1))
         self.head_size = size // num_heads
         self.model_size = size
         self.num_heads = num_heads
@@ -87,6 +93,12 @@ class MultiHeadedAttention(nn.Module):
             wts["ln_g"], wts["ln_b"] = ln.weight.data, ln.bias.data
             params = params + [ln.weight, ln.bias]
             smap.update(ln_g=[ln.weight], ln_b=[ln.bias])
+        if self.rel_pos_bias is not None:
+            if kind != "self":
+                raise NotImplementedError("relative-position bias is defined for self-attention")
+            wts["rel_bias"] = self.rel_pos_bias.data
+            params = params + [self.rel_pos_bias]
+            smap.update(rel_bias=[self.rel_pos_bias])
         wts["sink"], wts["notify"] = rt.sinks(smap), rt.grads_ready
         rng = _rng(rt, x) if cfg.any_dropout else None
         if mask is not None and not mask.is_contiguous():
@@ -264,12 +276,13 @@ class ConformerEncoderLayer(nn.Module):
     (which carry their own LayerNorm and residual), self-attention, the convolution module, final LayerNorm."""
 
     def __init__(self, size: int = 512, ff_size: int = 2048, num_heads: int = 4, dropout: float = 0.1,
-                 depthwise_conv_kernel_size: int = 31, alpha: float = 1.0, layer_norm: str = "pre"):
+                 depthwise_conv_kernel_size: int = 31, alpha: float = 1.0, layer_norm: str = "pre",
+                 rel_pos_clip: Optional[int] = None):
         super().__init__()
         self.initial_feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha, layer_norm=layer_norm)
         self.src_att_layer_norm = nn.LayerNorm(size, eps=1e-6)
         self.src_att_dropout = nn.Dropout(dropout)
-        self.src_src_att = MultiHeadedAttention(num_heads, size, dropout=dropout)
+        self.src_src_att = MultiHeadedAttention(num_heads, size, dropout=dropout, rel_pos_clip=rel_pos_clip)
         self.conv_module = ConvolutionModule(hidden_size=size, channels=size, depthwise_kernel_size=depthwise_conv_kernel_size,
                                              dropout=dropout)
         self.final_feed_forward = PositionwiseFeedForward(size, ff_size=ff_size, dropout=dropout, alpha=alpha, layer_norm=layer_norm)

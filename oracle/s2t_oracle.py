@@ -74,9 +74,18 @@ def layer_norm(sd: SD, prefix: str, x: Tensor) -> Tensor:
     return F.layer_norm(x, (x.size(-1), ), sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-6)
 
 
+def rel_pos_scores(rel_bias: Tensor, Tq: int, Tk: int) -> Tensor:
+    """EXTENSION (BASELINE config 5 "rel-pos attn"; the reference's attention has no relative term): the additive score
+    term [H, Tq, Tk] of a learned bias per head and clipped distance, rel_bias[h, clamp(j - i, -R, R) + R], R = (cols-1)/2."""
+    R = (rel_bias.size(1) - 1) // 2
+    idx = (torch.arange(Tk)[None, :] - torch.arange(Tq)[:, None]).clamp(-R, R) + R
+    return rel_bias[:, idx]
+
+
 def mha(sd: SD, prefix: str, k: Tensor, v: Tensor, q: Tensor, mask: Optional[Tensor], num_heads: int,
         return_weights: bool = False):
-    """MultiHeadedAttention.forward, transformer_layers.py:49-115 (eval mode: dropout is the identity)."""
+    """MultiHeadedAttention.forward, transformer_layers.py:49-115 (eval mode: dropout is the identity).  A
+    `<prefix>.rel_pos_bias` entry in sd adds rel_pos_scores() to the scaled scores (extension, see there)."""
     B, d = k.size(0), q.size(-1)
     dh = d // num_heads
     k = linear(sd, prefix + ".k_layer", k).view(B, -1, num_heads, dh).transpose(1, 2)
@@ -84,6 +93,8 @@ def mha(sd: SD, prefix: str, k: Tensor, v: Tensor, q: Tensor, mask: Optional[Ten
     q = linear(sd, prefix + ".q_layer", q).view(B, -1, num_heads, dh).transpose(1, 2)
     q = q / math.sqrt(dh)  # scaled BEFORE the product (:86)
     scores = torch.matmul(q, k.transpose(2, 3))
+    if prefix + ".rel_pos_bias" in sd:
+        scores = scores + rel_pos_scores(sd[prefix + ".rel_pos_bias"], scores.size(2), scores.size(3)).unsqueeze(0)
     if mask is not None:
         scores = scores.masked_fill(~mask.unsqueeze(1), float("-inf"))
     weights = torch.softmax(scores, dim=-1)

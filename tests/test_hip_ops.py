@@ -715,3 +715,105 @@ def test_layernorm_bwd_gradient_copies_fold(device):
         torch.testing.assert_close(g1 - base_g, 2 * (g0 - base_g), rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(b1 - base_b, 2 * (b0 - base_b), rtol=1e-4, atol=1e-3)
     assert float(ws.ws.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (e4m3) forward mode
+def test_quantize_fp8_matches_torch(device):
+    """js2t_absmax + js2t_quantize_fp8 against torch's own float8_e4m3fn conversion of x * 448 / amax (round to nearest even)."""
+    x = rnd(777, 130, seed=5, scale=3.0)
+    x[5, 7] = -41.5  # the maximum: lands on -448 exactly
+    for dt in (torch.float32, torch.bfloat16):
+        xs = x.to(dt)
+        y, scale = ops.quantize_fp8(xs.to(device))
+        amax = xs.float().abs().max()
+        assert scale.item() == pytest.approx((amax / 448.0).item(), rel=1e-6)
+        ref = (xs.float() * (torch.tensor(448.0) / amax)).clamp(-448, 448).to(torch.float8_e4m3fn)
+        assert torch.equal(y.cpu().view(torch.uint8), ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 256, "plain"), (12000, 1536, 512, "bias"), (2000, 2048, 512, "relu"),
+                                       (1000, 512, 2048, "res"), (193, 136, 144, "bias")])
+def test_gemm_fp8_e4m3_matches_fp32_math_on_rounded_inputs(device, M, N, K, epi):
+    """e4m3 x e4m3 GEMM (v_mfma_f32_16x16x32_fp8_fp8, per-tensor scales folded into alpha_dev) against fp32 math on the
+    SAME fp8-rounded operands: only the accumulation order and the bf16 rounding of the result differ.  Extension for
+    BASELINE config 5 - the reference has no fp8 path (joeynmt/config.py:223-225), so there is no parity target."""
+    A = rnd(M, K, seed=1).bfloat16()
+    W = (rnd(N, K, seed=2) * 0.05).bfloat16()
+    w8, ws = ops.quantize_fp8(W.to(device))
+    a8, sc = ops.quantize_fp8(A.to(device), mul=ws)
+    ref = (a8.cpu().float() @ w8.cpu().float().t()) * sc.item()
+    kw = {}
+    if epi in ("bias", "relu", "res"):
+        bias = rnd(N, seed=3)
+        kw["bias"] = bias.to(device)
+        ref = ref + bias
+    if epi == "relu":
+        kw["act"] = "relu"
+        ref = ref.clamp_min(0)
+    if epi == "res":
+        R = rnd(M, N, seed=4).bfloat16()
+        kw.update(residual=R.to(device), ldr=N, res_scale=1.0)
+        ref = ref + R.float()
+    Cd = torch.zeros(M, N, dtype=torch.bfloat16, device=device)
+    ops.gemm(a8, w8, Cd, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha_dev=sc, **kw)
+    bf16_close(Cd, ref, 1e-2)
+    # and the quantisation error itself stays where e4m3 puts it (3 mantissa bits, ~4 % per element before averaging over K)
+    full = A.float() @ W.float().t()
+    q = (a8.cpu().float() @ w8.cpu().float().t()) * sc.item()
+    assert (q - full).norm() / full.norm() < 6e-2
+
+
+@pytest.mark.parametrize("dh,H,R", [(128, 2, 8), (64, 4, 40), (128, 3, 255)])
+@pytest.mark.parametrize("p", [0.0, 0.15])
+def test_flash_attention_relative_position_bias(device, dh, H, R, p):
+    """EXTENSION (BASELINE config 5): learned relative-position bias inside the fused kernels, forward and all gradients
+    (q, k, v, bias table) against the oracle's rel_pos_scores() in fp32 on the bf16-rounded inputs.  With dropout the fused
+    forward is checked against the unfused softmax path's masks indirectly: the no-bias kernels are (test above), and the
+    bias only shifts the scores - here p > 0 checks that the gradient scaling 1/(1-p) reaches the table (expectation)."""
+    from oracle import s2t_oracle as O
+    B, Tq, Tk = 2, 150, 150
+    d = H * dh
+    q = rnd(B, Tq, d, seed=1).bfloat16()
+    kv = rnd(B, Tk, 2 * d, seed=2).bfloat16()
+    rel = (rnd(H, 2 * R + 1, seed=5) * 0.7).contiguous()
+    lens = torch.tensor([150, 101])
+    mask = (torch.arange(Tk)[None, :] < lens[:, None]).unsqueeze(1)
+    qr = q.float().requires_grad_(True)
+    kr = kv.float()[..., :d].clone().requires_grad_(True)
+    vr = kv.float()[..., d:].clone().requires_grad_(True)
+    rr = rel.clone().requires_grad_(True)
+    qh = qr.view(B, Tq, H, dh).transpose(1, 2) / math.sqrt(dh)
+    s = qh @ kr.view(B, Tk, H, dh).transpose(1, 2).transpose(2, 3) + O.rel_pos_scores(rr, Tq, Tk).unsqueeze(0)
+    s = s.masked_fill(~mask.unsqueeze(1), float("-inf"))
+    ref = (torch.softmax(s, -1) @ vr.view(B, Tk, H, dh).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, d)
+    gy = rnd(B, Tq, d, seed=4).bfloat16()
+    ref.backward(gy.float())
+    qd, kvd, reld, md = q.view(B * Tq, d).to(device), kv.view(B * Tk, 2 * d).to(device), rel.to(device), mask.to(device)
+    if p == 0.0:
+        out, lse = ops.flash_attn_fwd(qd, 0, kvd, 0, kvd, d, B, H, Tq, Tk, dh, md, 0.0, None, 0, rel_bias=reld)
+        bf16_close(out.view(B, Tq, d), ref.detach(), 2e-2)
+        dq, dkv, drel = torch.empty_like(qd), torch.empty_like(kvd), torch.zeros_like(reld)
+        ops.flash_attn_bwd(gy.view(B * Tq, d).to(device), out, lse, qd, 0, kvd, 0, kvd, d, dq, 0, dkv, 0, dkv, d, B, H, Tq, Tk, dh, md,
+                           0.0, None, 0, rel_bias=reld, d_rel_bias=drel)
+        bf16_close(dq.view(B, Tq, d), qr.grad, 3e-2)
+        bf16_close(dkv.view(B, Tk, 2 * d)[..., :d], kr.grad, 3e-2)
+        bf16_close(dkv.view(B, Tk, 2 * d)[..., d:], vr.grad, 3e-2)
+        bf16_close(drel, rr.grad, 3e-2)
+        # adding twice accumulates (+=)
+        ops.flash_attn_bwd(gy.view(B * Tq, d).to(device), out, lse, qd, 0, kvd, 0, kvd, d, dq, 0, dkv, 0, dkv, d, B, H, Tq, Tk, dh, md,
+                           0.0, None, 0, rel_bias=reld, d_rel_bias=drel)
+        bf16_close(drel, 2 * rr.grad, 3e-2)
+    else:
+        rng = ops.DropoutRng(device, seed=3)
+        acc = torch.zeros_like(reld)
+        n = 24
+        for i in range(n):  # E[dropout gradient] = gradient without dropout
+            rng.advance()
+            out, lse = ops.flash_attn_fwd(qd, 0, kvd, 0, kvd, d, B, H, Tq, Tk, dh, md, p, rng, 7, rel_bias=reld)
+            dq, dkv = torch.empty_like(qd), torch.empty_like(kvd)
+            ops.flash_attn_bwd(gy.view(B * Tq, d).to(device), out, lse, qd, 0, kvd, 0, kvd, d, dq, 0, dkv, 0, dkv, d, B, H, Tq, Tk, dh,
+                               md, p, rng, 7, rel_bias=reld, d_rel_bias=acc)
+        mean = acc.cpu() / n
+        cos = torch.nn.functional.cosine_similarity(mean.flatten(), rr.grad.flatten(), dim=0).item()
+        assert cos > 0.9, cos
+        assert 0.6 < mean.norm().item() / rr.grad.norm().item() < 1.6
