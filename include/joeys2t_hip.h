@@ -139,6 +139,12 @@ int js2t_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, js2
 int js2t_absmax(const void* x, int dt, int64_t n, float* out, js2t_stream stream);
 int js2t_quantize_fp8(const void* x, int dt, void* y, int64_t n, const float* amax, const float* mul, float* scale_out,
                       js2t_stream stream);
+/* The same in ONE pass with delayed scaling: state f32[4] (16-byte aligned, device) = {scale in use, running max of this
+ * call (bits), arrival ticket, unused}.  y = e4m3(clamp(x / state[0])), *scale_out = state[0] * (*mul or 1); the last
+ * block to finish replaces state[0] by this call's max |x| / 448 for the NEXT call and clears the counters - a captured
+ * hipGraph keeps adapting the scale by itself.  Initialise state = {max|x| / 448 of a calibration tensor, 0, 0, 0}. */
+int js2t_quantize_fp8_delayed(const void* x, int dt, void* y, int64_t n, float* state, const float* mul, float* scale_out,
+                              js2t_stream stream);
 
 /* y[r,c] = x[r,c] * sigmoid(x[r,c+C]) for x[rows,2C] — F.glu(dim=1) of encoders.py:366 in [B,T,C] layout. */
 int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream);

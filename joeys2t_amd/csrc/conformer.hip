@@ -25,6 +25,70 @@ __global__ __launch_bounds__(256) void dwconv_outer_fwd_kernel(const T* __restri
   io<T>::st(y + i, acc);
 }
 
+// The same convolution for bf16 with C % 128 == 0 and L <= 64 (L is the BATCH size here, see the header): a block stages
+// the slab x[0..L, 4 n, 128 c] (at most 64 KB) and the 128 channels' taps in LDS; a thread then owns one channel PAIR of one
+// n for every l - its reads walk consecutive 4-byte LDS words (conflict-free), every global byte is read exactly once in
+// 256-byte runs.  The one-output-per-thread kernel above issues 31 scattered 2-byte loads and 31 strided tap loads per
+// output and ran at 2 % of the HBM rate (322 us for 12 MB at L = 32, K = 31).  FLIP: taps reversed (input gradient).
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_outer_lds_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ y, int L, int64_t N,
+                                                               int64_t C, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  uint32_t* xs = (uint32_t*)dsm;                    // [L][4][64] channel pairs
+  float2* ws = (float2*)(dsm + (size_t)L * 1024);  // [K][64] taps of the pair
+  const int t = threadIdx.x, cp = t & 63, nn = t >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * 128, n = (int64_t)blockIdx.y * 4 + nn;
+  const bool live = n < N;
+  for (int l = 0; l < L; ++l)
+    xs[(l * 4 + nn) * 64 + cp] = live ? *(const uint32_t*)(x + ((int64_t)l * N + n) * C + c0 + 2 * cp) : 0u;
+  for (int i = t; i < K * 64; i += 256) {
+    const int k = i >> 6, p = i & 63;
+    ws[i] = make_float2(w[(c0 + 2 * p) * K + k], w[(c0 + 2 * p + 1) * K + k]);
+  }
+  __syncthreads();
+  if (!live) return;
+  const int pad = (K - 1) / 2;
+  const float b0 = bias ? bias[c0 + 2 * cp] : 0.f, b1 = bias ? bias[c0 + 2 * cp + 1] : 0.f;
+  for (int lb = 0; lb < L; lb += 8) {
+    float a0[8], a1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = b0, a1[j] = b1;
+    for (int k = 0; k < K; ++k) {
+      const float2 wk = ws[k * 64 + cp];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int li = FLIP ? lb + j - k + pad : lb + j + k - pad;
+        const uint32_t v = xs[(min(max(li, 0), L - 1) * 4 + nn) * 64 + cp];
+        const bool in = li >= 0 && li < L;
+        a0[j] = fmaf(wk.x, in ? __uint_as_float(v << 16) : 0.f, a0[j]);
+        a1[j] = fmaf(wk.y, in ? __uint_as_float(v & 0xffff0000u) : 0.f, a1[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (lb + j < L)
+        *(uint32_t*)(y + ((int64_t)(lb + j) * N + n) * C + c0 + 2 * cp) =
+            (uint32_t)f32_to_bf16_bits(a0[j]) | ((uint32_t)f32_to_bf16_bits(a1[j]) << 16);
+  }
+}
+template <bool FLIP>
+bool dwconv_outer_lds_launch(const void* x, const float* w, const float* bias, void* y, int64_t L, int64_t N, int64_t C, int K, int dt,
+                             hipStream_t s) {
+  if (dt != JS2T_BF16 || (C & 127) || L > 64 || L < 1 || ((((uintptr_t)x) | ((uintptr_t)y)) & 3) || (N + 3) / 4 > 65535) return false;
+  const size_t lds = (size_t)L * 1024 + (size_t)K * 64 * sizeof(float2);
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute((const void*)dwconv_outer_lds_kernel<FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 63 * 512) !=
+        hipSuccess)
+      return false;
+    once = true;
+  }
+  hipLaunchKernelGGL(dwconv_outer_lds_kernel<FLIP>, dim3((unsigned)(C / 128), (unsigned)((N + 3) / 4)), dim3(256), lds, s,
+                     (const uint16_t*)x, w, bias, (uint16_t*)y, (int)L, N, C, K);
+  return true;
+}
+
 // dx[l,n,c] = sum_k w[c,k] * dy[l - k + pad, n, c]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_outer_dx_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
@@ -195,6 +259,10 @@ extern "C" int js2t_dwconv_outer_fwd(const void* x, const float* w, const float*
   if (L * N * C == 0) return JS2T_OK;
   JS2T_CHECK(x && w && y, "dwconv_outer_fwd: null pointer");
   JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_fwd: kernel size must be odd and <= %d", DW_MAXK);
+  if (dwconv_outer_lds_launch<false>(x, w, bias, y, L, N, C, K, dt, (hipStream_t)stream)) {
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_fwd_kernel<T>), dim3((unsigned)cdiv(L * N * C, 256)), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)x, w, bias, (T*)y, L, N, C, K));
   JS2T_LAUNCH_CHECK();
@@ -207,7 +275,9 @@ extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float*
   JS2T_CHECK(dy && w, "dwconv_outer_bwd: null pointer");
   JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_bwd: kernel size must be odd and <= %d", DW_MAXK);
   hipStream_t s = (hipStream_t)stream;
-  if (dx) {
+  if (dx && dwconv_outer_lds_launch<true>(dy, w, nullptr, dx, L, N, C, K, dt, s)) {
+    JS2T_LAUNCH_CHECK();
+  } else if (dx) {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dx_kernel<T>), dim3((unsigned)cdiv(L * N * C, 256)), dim3(256), 0, s,
                                           (const T*)dy, w, (T*)dx, L, N, C, K));
     JS2T_LAUNCH_CHECK();

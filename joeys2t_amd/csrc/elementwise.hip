@@ -617,7 +617,31 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, in
     }
   }
   m = block_max(m, red);
-  if (threadIdx.x == 0) atomicMax((unsigned int*)out, __float_as_uint(m));  // NaN inputs would poison the scale: not handled
+  // same-address atomics retire one per ~12 ns chip-wide: post only maxima that beat what is already there (a stale read is
+  // fine, the atomic decides).  NaN inputs would poison the scale: not handled
+  if (threadIdx.x == 0 && __float_as_uint(m) > *(volatile unsigned int*)out) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+
+// 8 consecutive elements as floats: one 16-byte (bf16) or two 16-byte (f32) loads when the whole group is in range and aligned
+template <typename T>
+__device__ __forceinline__ void load8f(const T* __restrict__ x, int64_t i, int64_t n, float (&v)[8]) {
+  if (i + 8 <= n && (((uintptr_t)(x + i)) & 15) == 0) {
+    if constexpr (sizeof(T) == 2) {
+      const uint4 r = *(const uint4*)(x + i);
+      const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] = __uint_as_float(wds[k] << 16);
+        v[2 * k + 1] = __uint_as_float(wds[k] & 0xffff0000u);
+      }
+    } else {
+      const float4 a = *(const float4*)(x + i), b = *(const float4*)(x + i + 4);
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = i + k < n ? io<T>::ld(x + i + k) : 0.f;
+  }
 }
 
 // y = e4m3(x * 448 / amax) (round to nearest even, clamped to +-448); scale_out = amax / 448 * (*mul or 1)
@@ -630,8 +654,9 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = (am > 0.f ? am / 448.f : 1.f) * (mul ? *mul : 1.f);
   for (int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
     float v[8];
+    load8f(x, i, n, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = i + k < n ? fminf(fmaxf(io<T>::ld(x + i + k) * inv, -448.f), 448.f) : 0.f;
+    for (int k = 0; k < 8; ++k) v[k] = fminf(fmaxf(v[k] * inv, -448.f), 448.f);
     int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
     int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
@@ -657,7 +682,7 @@ extern "C" int js2t_absmax(const void* x, int dt, int64_t n, float* out, js2t_st
   }
   const int64_t per = dt == JS2T_BF16 ? 8 : 4;
   int64_t grid = (n / per + 255) / 256;
-  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
   if (dt == JS2T_BF16)
     hipLaunchKernelGGL(absmax_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)x, n, out);
   else
@@ -678,6 +703,74 @@ extern "C" int js2t_quantize_fp8(const void* x, int dt, void* y, int64_t n, cons
   else
     hipLaunchKernelGGL(quantize_fp8_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, (uint8_t*)y, n,
                        amax, mul, scale_out);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+// ---------------------------------------------------------------- e4m3 quantisation with DELAYED scaling: one pass
+// state[0] = scale S in use (amax / 448 of an earlier call), state[1] = running max |x| of this call (uint bits),
+// state[2] = arrival ticket.  y = e4m3(clamp(x / S)); the block that finishes last turns the collected maximum into the
+// next call's scale and clears the two counters - every other block has read S by then.  Replays of a captured hipGraph
+// therefore keep adapting the scale with no host involvement.  Values beyond the stale maximum saturate at +-448.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_delayed_kernel(const T* __restrict__ x, uint8_t* __restrict__ y, int64_t n,
+                                                                  float* __restrict__ state, const float* __restrict__ mul,
+                                                                  float* __restrict__ scale_out) {
+  __shared__ float red[4];
+  const float S = state[0];
+  const float inv = S > 0.f ? 1.f / S : 0.f;
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = (S > 0.f ? S : 1.f) * (mul ? *mul : 1.f);
+  float m = 0.f;
+  for (int64_t i = (blockIdx.x * (int64_t)256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
+    float v[8];
+    load8f(x, i, n, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      m = fmaxf(m, fabsf(v[k]));
+      v[k] = fminf(fmaxf(v[k] * inv, -448.f), 448.f);
+    }
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    if (i + 8 <= n) {
+      *(uint2*)(y + i) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    } else {
+      const uint32_t wds[2] = {(uint32_t)lo, (uint32_t)hi};
+      for (int k = 0; i + k < n; ++k) y[i + k] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
+    }
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0) {
+    unsigned int* st = (unsigned int*)state;
+    // post the maximum (only if it beats what is there: see absmax_kernel) with a RETURNING atomic whose result is consumed: it
+    // has been performed at the L2 before the ticket below is drawn, so no fence (buffer_wbl2 + invalidate, ~3.5 us per
+    // block) is needed - both words are only ever touched by device-scope atomics
+    unsigned int seen = 0u;
+    if (__float_as_uint(m) > *(volatile unsigned int*)(st + 1)) seen = atomicMax(st + 1, __float_as_uint(m));
+    asm volatile("" ::"v"(seen));
+    if (atomicAdd(st + 2, 1u) == gridDim.x - 1) {  // last block: every other one has read S and posted its maximum
+      const float am = __uint_as_float(atomicExch(st + 1, 0u));
+      if (am > 0.f) state[0] = am / 448.f;
+      st[2] = 0u;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int js2t_quantize_fp8_delayed(const void* x, int dt, void* y, int64_t n, float* state, const float* mul, float* scale_out,
+                                         js2t_stream stream) {
+  JS2T_CHECK(x && y && state && n > 0 && (dt == JS2T_F32 || dt == JS2T_BF16), "quantize_fp8_delayed: bad arguments");
+  JS2T_CHECK((((uintptr_t)y) & 7) == 0 && (((uintptr_t)state) & 15) == 0, "quantize_fp8_delayed: misaligned output / state");
+  int64_t grid = (n / 8 + 255) / 256;
+  grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);  // one arrival-ticket atomic per block: keep the blocks few
+  if (dt == JS2T_BF16)
+    hipLaunchKernelGGL(quantize_fp8_delayed_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint8_t*)y, n, state, mul, scale_out);
+  else
+    hipLaunchKernelGGL(quantize_fp8_delayed_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (uint8_t*)y, n, state, mul, scale_out);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

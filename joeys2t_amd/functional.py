@@ -40,6 +40,8 @@ def _row_major_2d(t: torch.Tensor) -> torch.Tensor:
 # call on the device, weights once per optimizer step); backward keeps the bf16 activations and weights it has anyway.
 FP8_FORWARD = os.environ.get("JS2T_FP8_FORWARD", "0") == "1"
 _FP8_WEIGHTS = {}  # (data_ptr, shape) -> (ops.WEIGHT_VERSION, e4m3 weight, scale f32[1])
+_FP8_STATES = {}   # (weight data_ptr, shape) -> delayed-scaling state of the activations that meet this weight
+FP8_DELAYED = os.environ.get("JS2T_FP8_DELAYED", "1") != "0"  # one quantisation pass with the previous call's scale
 
 
 def _fp8_weight(w):
@@ -68,7 +70,16 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
     if _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
         w8, ws = _fp8_weight(w)
-        x8, sc = ops.quantize_fp8(x2d, mul=ws)  # sc = s_x * s_w on the device: the GEMM's alpha_dev
+        if FP8_DELAYED:
+            key = (w.data_ptr(), tuple(w.shape))
+            st = _FP8_STATES.get(key)
+            if st is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise ops.Js2tError("fp8 forward: run one eager step before capturing (activation scales are calibrated on first use)")
+                st = _FP8_STATES[key] = ops.new_fp8_state(x2d)
+            x8, sc = ops.quantize_fp8_delayed(x2d, st, mul=ws)
+        else:
+            x8, sc = ops.quantize_fp8(x2d, mul=ws)  # sc = s_x * s_w on the device: the GEMM's alpha_dev
         ops.gemm(x8, w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
                  residual=residual, ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha_dev=sc)
         return y
@@ -590,14 +601,19 @@ class ConvModuleFn(torch.autograd.Function):
     parameter gradients come back through autograd (this module is off the LS100 hot path)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, wd, bd, gamma, beta, running_mean, running_var, w2, b2, p, rng, training, compute_dtype):
+    def forward(ctx, x, w1, b1, wd, bd, gamma, beta, running_mean, running_var, w2, b2, p, rng, training, compute_dtype,
+                w1_lp=None, w2_lp=None):
+        """w1_lp / w2_lp: the two pointwise weights in the compute dtype when the flat store keeps such a shadow (stable
+        addresses: the e4m3 copies of the fp8 forward mode are cached by address); otherwise they are cast here."""
         B, T, Cc = x.shape
         x2 = x.reshape(B * T, Cc)
         if x2.dtype != compute_dtype:
             x2 = ops.cast(x2, compute_dtype)
         w1c = w1.reshape(w1.shape[0], Cc)
         w2c = w2.reshape(w2.shape[0], -1)
-        w1c, w2c = (w1c, w2c) if compute_dtype == torch.float32 else (ops.cast(w1c, compute_dtype), ops.cast(w2c, compute_dtype))
+        if compute_dtype != torch.float32:
+            w1c = w1_lp.reshape(w1.shape[0], Cc) if w1_lp is not None else ops.cast(w1c, compute_dtype)
+            w2c = w2_lp.reshape(w2.shape[0], -1) if w2_lp is not None else ops.cast(w2c, compute_dtype)
         h = linear_fwd(x2, w1c, b1)                                   # [B*T, 2C]
         u = ops.glu_fwd(h)                                            # [B*T, C]
         wd2 = wd.reshape(wd.shape[0], wd.shape[-1]).contiguous()
@@ -631,7 +647,7 @@ class ConvModuleFn(torch.autograd.Function):
         if dx.dtype != in_dtype:
             dx = dx.to(in_dtype)
         return (dx, dw1.view(dw1.shape[0], Cc, 1), db1, dwd.view(dwd.shape[0], 1, -1), dbd, dgamma, dbeta, None, None,
-                dw2.view(dw2.shape[0], -1, 1), db2, None, None, None, None)
+                dw2.view(dw2.shape[0], -1, 1), db2, None, None, None, None, None, None)
 
 
 def conv_out_len(t_in: int, k: int, stride: int = 2) -> int:

@@ -667,6 +667,29 @@ def quantize_fp8(x: torch.Tensor, mul: Optional[torch.Tensor] = None):
     return y, scale
 
 
+def quantize_fp8_delayed(x: torch.Tensor, state: torch.Tensor, mul: Optional[torch.Tensor] = None):
+    """One-pass e4m3 quantisation with the scale of an earlier call (js2t_quantize_fp8_delayed); `state` f32[4] on the device
+    lives with the call site (new_fp8_state()).  Returns (y, scale f32[1])."""
+    _dev(x, state, mul)
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous():
+        raise Js2tError("quantize_fp8_delayed: contiguous float32 / bfloat16 input")
+    y = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((1, ), dtype=torch.float32, device=x.device)
+    check(lib().js2t_quantize_fp8_delayed(_p(x), dt_code(x), _p(y), C.c_int64(x.numel()), _p(state), _p(mul), _p(scale), _stream()),
+          "js2t_quantize_fp8_delayed")
+    return y, scale
+
+
+def new_fp8_state(x: torch.Tensor) -> torch.Tensor:
+    """Calibrate a delayed-scaling state on x: {max|x| / 448, 0, 0, 0}."""
+    _dev(x)
+    amax = torch.empty((1, ), dtype=torch.float32, device=x.device)
+    check(lib().js2t_absmax(_p(x), dt_code(x), C.c_int64(x.numel()), _p(amax), _stream()), "js2t_absmax")
+    state = torch.zeros((4, ), dtype=torch.float32, device=x.device)
+    state[0:1] = amax / 448.0
+    return state
+
+
 def rep_penalty(log_probs: torch.Tensor, tokens: torch.Tensor, penalty: float):
     """penalize_repetition (search.py:972-1001) in place on f32 [rows, V]; tokens int64 [rows, L] with ids in [0, V)."""
     _dev(log_probs, tokens)

@@ -266,9 +266,12 @@ class ConvolutionModule(nn.Module):
         rng = _rng(rt, x) if (self.training and p > 0) else None
         if self.training:
             bn.num_batches_tracked += 1
+        lp = rt.store is not None and rt.compute_dtype != torch.float32  # the flat store's bf16 shadow: stable addresses
         return Fn.ConvModuleFn.apply(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias, self.depthwise_conv.weight,
                                      self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     self.pointwise_conv2.weight, self.pointwise_conv2.bias, p, rng, self.training, rt.compute_dtype)
+                                     self.pointwise_conv2.weight, self.pointwise_conv2.bias, p, rng, self.training, rt.compute_dtype,
+                                     rt.weight([self.pointwise_conv1.weight]) if lp else None,
+                                     rt.weight([self.pointwise_conv2.weight]) if lp else None)
 
 
 class ConformerEncoderLayer(nn.Module):

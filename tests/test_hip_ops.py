@@ -817,3 +817,44 @@ def test_flash_attention_relative_position_bias(device, dh, H, R, p):
         cos = torch.nn.functional.cosine_similarity(mean.flatten(), rr.grad.flatten(), dim=0).item()
         assert cos > 0.9, cos
         assert 0.6 < mean.norm().item() / rr.grad.norm().item() < 1.6
+
+
+def test_quantize_fp8_delayed_scaling(device):
+    """One-pass quantisation with the previous call's scale: the first call uses the calibrated scale, the state then carries
+    THIS call's max |x| / 448 for the next one (also through a hipGraph replay), out-of-range values saturate at +-448."""
+    x1 = rnd(3000, 130, seed=5, scale=2.0).bfloat16()
+    x2 = (rnd(3000, 130, seed=6, scale=2.0) * 5).bfloat16()
+    d1, d2 = x1.to(device), x2.to(device)
+    st = ops.new_fp8_state(d1)
+    s1 = x1.float().abs().max().item() / 448.0
+    assert st[0].item() == pytest.approx(s1, rel=1e-6)
+    y1, sc1 = ops.quantize_fp8_delayed(d1, st)
+    assert sc1.item() == pytest.approx(s1, rel=1e-6) and st[0].item() == pytest.approx(s1, rel=1e-6)
+    ref1 = (x1.float() * (1.0 / torch.tensor(s1))).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert (y1.cpu().view(torch.uint8) != ref1.view(torch.uint8)).float().mean().item() < 1e-3  # 1/S vs 448/amax: last-bit ties only
+    y2, sc2 = ops.quantize_fp8_delayed(d2, st)  # still quantised with scale 1: saturates
+    assert sc2.item() == pytest.approx(s1, rel=1e-6)
+    assert st[0].item() == pytest.approx(x2.float().abs().max().item() / 448.0, rel=1e-6) and st[1].item() == 0 and st[2].item() == 0
+    assert y2.cpu().float().abs().max().item() == 448.0
+    y3, sc3 = ops.quantize_fp8_delayed(d2, st)  # now with its own scale
+    assert sc3.item() == pytest.approx(x2.float().abs().max().item() / 448.0, rel=1e-6)
+    err = (y3.cpu().float() * sc3.item() - x2.float()).norm() / x2.float().norm()
+    assert err < 4e-2
+
+
+@pytest.mark.parametrize("L,N,C,K", [(32, 375, 512, 31), (13, 10, 128, 5), (64, 7, 256, 31), (3, 5, 128, 7)])
+def test_dwconv_outer_lds_kernel(device, L, N, C, K):
+    """The LDS-staged depthwise convolution over the outer (batch) index - bf16, C % 128 == 0, L <= 64 - forward and input
+    gradient against F.conv1d (the one-output-per-thread kernel it replaces is still the fallback, tested in test_hip_conformer)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(L, N, C, generator=gen).bfloat16()
+    w, b = torch.randn(C, K, generator=gen) * 0.2, torch.randn(C, generator=gen)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.conv1d(xr.permute(1, 2, 0), w.unsqueeze(1), b, padding=(K - 1) // 2, groups=C).permute(2, 0, 1)
+    y = ops.dwconv_outer_fwd(x.to(device), w.to(device), b.to(device))
+    torch.testing.assert_close(y.float().cpu(), ref.detach(), rtol=2e-2, atol=2e-2)
+    dy = torch.randn(L, N, C, generator=gen).bfloat16()
+    ref.backward(dy.float())
+    dx, dw = ops.dwconv_outer_bwd(dy.to(device), x.to(device), w.to(device))
+    torch.testing.assert_close(dx.float().cpu(), xr.grad, rtol=2e-2, atol=2e-2)
