@@ -367,8 +367,11 @@ class GradCopies:
         self.stride = 2 * self.MAX_D  # floats per copy: [gamma | beta]
         self.ws = torch.zeros(self.MAX_SLOTS * self.COPIES * self.stride, dtype=torch.float32, device=device)
         self.slots = {}   # (dgamma ptr, dbeta ptr) -> slot
-        self.rows = []    # table rows
-        self.table = None
+        # the fold kernel's table lives at ONE address for the object's lifetime (a captured hipGraph keeps that pointer):
+        # allocated at full capacity, rows are written in place, the launch passes the number of rows in use
+        self.table = torch.zeros((2 * self.MAX_SLOTS, 3), dtype=torch.int64, device=device)
+        self.n_rows = 0
+        self.captured_rows = None  # rows in use when a capture last saw fold(): later registrations would be missed by it
 
     def lookup(self, dg: torch.Tensor, db: torch.Tensor):
         """-> (ws view for gamma, ws view for beta) of the slot registered for these gradient views, or None."""
@@ -378,19 +381,33 @@ class GradCopies:
         key = (dg.data_ptr(), db.data_ptr())
         slot = self.slots.get(key)
         if slot is None:
-            if len(self.slots) >= self.MAX_SLOTS or torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
+                raise Js2tError("GradCopies: a LayerNorm gradient slot was first seen during hipGraph capture - run one eager "
+                                "step first (the captured fold launch would never sum this slot's copies)")
+            if len(self.slots) >= self.MAX_SLOTS:
                 return None
             slot = len(self.slots)
             self.slots[key] = slot
             base = slot * self.COPIES * self.stride
-            self.rows += [[base, dg.data_ptr(), D], [base + self.MAX_D, db.data_ptr(), D]]
-            self.table = torch.tensor(self.rows, dtype=torch.int64, device=self.ws.device)
+            rows = torch.tensor([[base, dg.data_ptr(), D], [base + self.MAX_D, db.data_ptr(), D]], dtype=torch.int64)
+            self.table[self.n_rows:self.n_rows + 2].copy_(rows)
+            self.n_rows += 2
         base = slot * self.COPIES * self.stride
         return self.ws[base:base + D], self.ws[base + self.MAX_D:base + self.MAX_D + D]
 
+    def invalidate(self):
+        """Forget every registration (the flat gradient buffer was re-allocated: the stored destination addresses are stale)."""
+        self.slots.clear()
+        self.n_rows = 0
+        self.ws.zero_()
+
     def fold(self):
-        if self.table is not None:
-            check(lib().js2t_fold_copies(_p(self.ws), _p(self.table), C.c_int32(self.table.shape[0]), C.c_int32(self.COPIES),
+        if self.n_rows:
+            if torch.cuda.is_current_stream_capturing():
+                self.captured_rows = self.n_rows
+            elif self.captured_rows is not None and self.n_rows != self.captured_rows:
+                raise Js2tError("GradCopies: slots were registered after a hipGraph captured fold(); re-capture the step")
+            check(lib().js2t_fold_copies(_p(self.ws), _p(self.table), C.c_int32(self.n_rows), C.c_int32(self.COPIES),
                                          C.c_int64(self.stride), _stream()), "js2t_fold_copies")
 
 

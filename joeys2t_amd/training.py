@@ -136,10 +136,17 @@ class TrainStep:
 
     # ---- checkpoints in the reference's layout (training.py:149-190,220-285) ---------------------------------------------
     def state_for_checkpoint(self) -> Dict:
+        """The reference's checkpoint layout (training.py:166-177), readable by ITS loader too: TrainStatistics.load_state_dict
+        indexes all six stats keys (:819-826) and `train_iter_state` gets `.cpu()` called on it (:287) - a generator state
+        tensor, here of a fresh torch.Generator (this driver owns no sampler; pass `train_iter_state` to save a real one)."""
         params = list(self.model.parameters())
+        stats = dict(zip(["loss", "nll", "ctc", "n_correct", "nseqs", "ntokens"], self.stats.tolist()))  # local: no collective here
         return {"model_state": self.model.state_dict(), "optimizer_state": self.optimizer.torch_state_dict(params), "scaler_state": None,
                 "scheduler_state": None if self.scheduler is None else {"step": self.scheduler._step, "rate": self.scheduler._rate},
-                "train_iter_state": None, "stats_state": {"steps": self.steps}}
+                "train_iter_state": getattr(self, "train_iter_state", None) if getattr(self, "train_iter_state", None) is not None
+                else torch.Generator().get_state(),
+                "stats_state": {"epochs": getattr(self, "epochs", 1), "steps": self.steps, "total_tokens": int(stats.get("ntokens", 0)),
+                                "total_correct": int(stats.get("n_correct", 0)), "best_ckpt_score": float("inf"), "best_ckpt_iter": 0}}
 
     def save_checkpoint(self, path):
         torch.save(self.state_for_checkpoint(), str(path))

@@ -103,3 +103,25 @@ def test_resume_from_reference_checkpoint(device, tmp_path):
             if "k_layer.bias" in n:
                 continue
             assert (p.detach().cpu() - ref[n]).abs().max().item() <= 3e-4, n
+
+
+def test_checkpoint_written_here_has_the_reference_loaders_keys(device, tmp_path):
+    """Two-way compatibility: the reference's loader indexes six stats keys (training.py:819-826) and calls .cpu() on
+    train_iter_state (:287); a checkpoint written by TrainStep must carry them in the reference's types."""
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    model = build_model(copy.deepcopy(tiny_cfg("pre")), None, Vocabulary.synthetic(20))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.finalize(device, torch.float32)
+    step = TrainStep(model, batch_multiplier=1)
+    path = tmp_path / "ours.ckpt"
+    step.save_checkpoint(path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    st = ck["stats_state"]
+    for key in ("epochs", "steps", "total_tokens", "total_correct", "best_ckpt_score", "best_ckpt_iter"):
+        assert key in st, key  # TrainStatistics.load_state_dict reads exactly these
+    assert isinstance(st["steps"], int) and isinstance(st["total_tokens"], int) and isinstance(st["best_ckpt_score"], float)
+    assert torch.is_tensor(ck["train_iter_state"]) and ck["train_iter_state"].cpu().dtype == torch.uint8  # a generator state
+    torch.Generator().set_state(ck["train_iter_state"])  # what batch_sampler.set_state does with it (datasets.py:1243-1246)
+    assert set(ck) == {"model_state", "optimizer_state", "scaler_state", "scheduler_state", "train_iter_state", "stats_state"}
