@@ -360,7 +360,8 @@ int js2t_bn_act_bwd(const void* dy, const void* x, const float* gamma, const flo
  *   frame_off   int64[U+1] prefix sums of frames per utterance (T_u = 1 + (N_u - win_len)/shift); out is
  *               f32[frame_off[U], n_mel], utterance u occupying rows frame_off[u] .. frame_off[u+1]-1
  *   window      f32[win_len] (Povey);  tw_re/tw_im f32[n_fft/2] = cos/-sin(2 pi k / n_fft)
- *   mel bin m   = sum_{k < mel_len[m]} power[mel_start[m]+k] * mel_w[mel_woff[m]+k]
+ *   mel bin m   = sum_{k < mel_len[m]} power[mel_start[m]+k] * mel_w[mel_woff[m]+k]; the weights of bin m + 1 follow those
+ *               of bin m in mel_w (mel_woff[n_mel-1] + mel_len[n_mel-1] = number of weights)
  *   scale       multiplies the samples first (2**15);  log_floor = FLT_EPSILON. */
 int js2t_fbank(const float* wave, const int64_t* sample_off, const int64_t* frame_off, int32_t U,
                int64_t total_frames, const float* window, const float* tw_re, const float* tw_im,

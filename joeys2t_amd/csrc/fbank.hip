@@ -122,6 +122,213 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
   }
 }
 
+
+// ---------------------------------------------------------------- 512-point frames: the FFT lives in registers
+// The kernel above keeps a frame's 512 complex points in LDS and makes nine radix-2 passes over them: ~500 LDS
+// wave-instructions per frame, most of them 2- to 8-way bank-conflicted (strided butterflies, strided twiddles) - the CU's
+// LDS pipe is what bounds it (228 us for 47,936 frames, 2 % of the HBM rate it is nominally bound by).  Here a lane holds 8
+// points; a decimation-in-frequency FFT does three radix-2 stages in registers, transposes through LDS (conflict-free padded
+// images), three more stages, a second transpose, the last three stages: 2 x 16 LDS stores + loads per lane instead of ~500,
+// twiddles of the first six stages in registers for the whole kernel (they depend on the lane, not on the frame), those of
+// the last three are constants.  A wave walks over frames with a grid stride.
+//   position n = 64 j + l (lane l, register j)  --T1-->  n = 64 j' + 8 m + r (lane 8 j' + r, register m)  --T2-->  lane 8 j' + m,
+//   register r.  DIF leaves X[bitrev9(n)] at position n: bins below Nyquist are the even r.
+struct cplx { float re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// DIF butterfly: (a, b) -> (a + b, (a - b) * w)
+__device__ __forceinline__ void bfly(cplx& a, cplx& b, cplx w) {
+  const cplx d = {a.re - b.re, a.im - b.im};
+  a = {a.re + b.re, a.im + b.im};
+  b = cmul(d, w);
+}
+__device__ __forceinline__ void bfly1(cplx& a, cplx& b) {  // w = 1
+  const cplx d = {a.re - b.re, a.im - b.im};
+  a = {a.re + b.re, a.im + b.im};
+  b = d;
+}
+__device__ __forceinline__ int rev3(int v) { return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1); }
+
+constexpr int FB5_T1 = 72, FB5_T2 = 9;  // padded strides (float2 elements) of the two transpose images
+constexpr int FB5_MELW = 2048;          // filter weights kept in LDS (80 bins over 256 FFT bins have ~1000)
+__global__ __launch_bounds__(256) void fbank512_kernel(const float* __restrict__ wave, const int64_t* __restrict__ sample_off,
+                                                       const int64_t* __restrict__ frame_off, int U,
+                                                       const float* __restrict__ window, const float* __restrict__ tw_re,
+                                                       const float* __restrict__ tw_im, const int32_t* __restrict__ mel_start,
+                                                       const int32_t* __restrict__ mel_len, const int32_t* __restrict__ mel_woff,
+                                                       const float* __restrict__ mel_w, float* __restrict__ out, int win_len,
+                                                       int shift, int n_mel, float scale, float preemph, float log_floor) {
+  __shared__ float2 simg[FB_WAVES][8 * FB5_T1];  // 576 float2 >= 64 * FB5_T2
+  __shared__ float spw[FB_WAVES][256];
+  __shared__ float smw[FB5_MELW];  // the sparse filter weights: read by every frame, fetched once per block
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float2* img = simg[w];
+  float* pw = spw[w];
+  const int n_mel_w = mel_woff[n_mel - 1] + mel_len[n_mel - 1];  // the filters' weights are stored back to back, in bin order
+  const bool mw_lds = n_mel_w <= FB5_MELW;
+  if (mw_lds)
+    for (int i = threadIdx.x; i < n_mel_w; i += 256) smw[i] = mel_w[i];
+  __syncthreads();
+  // this lane's (at most two) mel bins: bin lane and bin lane + 64
+  int mst[2], mln[2], mwo[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int mb = lane + 64 * q;
+    mst[q] = mb < n_mel ? mel_start[mb] : 0;
+    mln[q] = mb < n_mel ? mel_len[mb] : 0;
+    mwo[q] = mb < n_mel ? mel_woff[mb] : 0;
+  }
+  auto tw = [&](int t) -> cplx { return {tw_re[t], tw_im[t]}; };  // exp(-2 pi i t / 512), t < 256
+  // twiddles of stages 1-6 (W_512^t): they depend on the lane and the register index only
+  const int r = lane & 7;
+  cplx w1[4], w2[2], w3, w4[4], w5[2], w6;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w1[j] = tw(lane + 64 * j);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w2[j] = tw(2 * (lane + 64 * j));
+  w3 = tw(4 * lane);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) w4[m] = tw(8 * (r + 8 * m));
+#pragma unroll
+  for (int m = 0; m < 2; ++m) w5[m] = tw(16 * (r + 8 * m));
+  w6 = tw(32 * r);
+  const cplx c8[4] = {{1.f, 0.f}, {0.70710678118654752f, -0.70710678118654752f}, {0.f, -1.f}, {-0.70710678118654752f, -0.70710678118654752f}};
+  float win[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) win[j] = lane + 64 * j < win_len ? window[lane + 64 * j] : 0.f;
+  // a wave takes a run of consecutive frames: one utterance search per run, neighbouring frames share 60 % of their samples
+  const int64_t total = frame_off[U];
+  const int64_t n_waves = (int64_t)gridDim.x * FB_WAVES, per = (total + n_waves - 1) / n_waves;
+  const int64_t f0 = ((int64_t)blockIdx.x * FB_WAVES + w) * per, f1 = min(total, f0 + per);
+  int u = f0 < total ? find_utt(frame_off, U, f0) : 0;
+  int64_t u_end = f0 < total ? frame_off[u + 1] : 0, u_beg = f0 < total ? frame_off[u] : 0, s_off = f0 < total ? sample_off[u] : 0;
+  // samples of the NEXT frame are requested while the current one is transformed (three waves per SIMD do not cover an HBM
+  // round trip on their own); a lane's predecessor sample sits in the neighbouring lane (DPP wave shift), lane 0's in lane
+  // 63 of the previous register
+  auto frame_ptr = [&](int64_t f) -> const float* {
+    while (f >= u_end) {  // next utterance (empty ones are skipped)
+      ++u;
+      u_beg = u_end;
+      u_end = frame_off[u + 1];
+      s_off = sample_off[u];
+    }
+    return wave + s_off + (f - u_beg) * shift;
+  };
+  float nxt[8];
+  if (f0 < f1) {
+    const float* x0 = frame_ptr(f0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nxt[j] = lane + 64 * j < win_len ? x0[lane + 64 * j] : 0.f;
+  }
+  for (int64_t f = f0; f < f1; ++f) {
+    // 1. scale, DC removal, pre-emphasis (x[-1] := x[0]), window
+    float cur[8], prv[8], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cur[j] = nxt[j] * scale;
+      sum += cur[j];
+    }
+    if (f + 1 < f1) {
+      const float* xn = frame_ptr(f + 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nxt[j] = lane + 64 * j < win_len ? xn[lane + 64 * j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur[j]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      // lane 0: sample 64 j - 1 is lane 63's register j - 1; for the very first sample x[-1] := x[0] (bit patterns travel
+      // through the scalar unit: the readlane builtins take integers)
+      const int edge = j == 0 ? __builtin_amdgcn_readfirstlane(__float_as_int(cur[0]))
+                              : __builtin_amdgcn_readlane(__float_as_int(cur[j > 0 ? j - 1 : 0]), 63);
+      prv[j] = lane == 0 ? __int_as_float(edge) : up;
+    }
+    const float mean = wave_sum(sum) / (float)win_len;
+    cplx a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = {lane + 64 * j < win_len ? ((cur[j] - mean) - preemph * (prv[j] - mean)) * win[j] : 0.f, 0.f};
+    // 2. stages 1-3 (spans 256, 128, 64): register pairs (j, j+4), (j, j+2), (j, j+1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfly(a[j], a[j + 4], w1[j]);
+#pragma unroll
+    for (int hlf = 0; hlf < 8; hlf += 4)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfly(a[hlf + j], a[hlf + j + 2], w2[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) bfly(a[j], a[j + 1], w3);
+    // 3. transpose 1: (j, l) -> lane 8 j' + r holds positions r + 8 m of sub-transform j'
+#pragma unroll
+    for (int j = 0; j < 8; ++j) img[j * FB5_T1 + lane] = make_float2(a[j].re, a[j].im);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int jp = lane >> 3;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float2 v = img[jp * FB5_T1 + r + 8 * m];
+      a[m] = {v.x, v.y};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 4. stages 4-6 (spans 32, 16, 8 inside a 64-point sub-transform): register pairs (m, m+4), (m, m+2), (m, m+1)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bfly(a[m], a[m + 4], w4[m]);
+#pragma unroll
+    for (int hlf = 0; hlf < 8; hlf += 4)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) bfly(a[hlf + m], a[hlf + m + 2], w5[m]);
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) bfly(a[m], a[m + 1], w6);
+    // 5. transpose 2: lane 8 j' + m gathers r = 0..7 of its 8-point block
+#pragma unroll
+    for (int m = 0; m < 8; ++m) img[(8 * jp + m) * FB5_T2 + r] = make_float2(a[m].re, a[m].im);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float2 v = img[lane * FB5_T2 + q];
+      a[q] = {v.x, v.y};
+    }
+    // 6. stages 7-9 (spans 4, 2, 1): constants W_8^q, W_4^q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfly(a[q], a[q + 4], c8[q]);
+#pragma unroll
+    for (int hlf = 0; hlf < 8; hlf += 4) {
+      bfly1(a[hlf], a[hlf + 2]);
+      bfly(a[hlf + 1], a[hlf + 3], c8[2]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) bfly1(a[q], a[q + 1]);
+    // 7. power spectrum of the bins below Nyquist: position n = 64 j' + 8 m + q holds X[bitrev9(n)]; bit 8 of the bin is q & 1
+    const int mm = lane & 7, base = 8 * rev3(mm) + rev3(jp);
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) pw[64 * rev3(q) + base] = a[q].re * a[q].re + a[q].im * a[q].im;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 8. mel bins + log: bins lane and lane + 64 from registers-resident filter descriptors, weights in LDS; four partial
+    //    sums per bin (the order of the additions inside a bin is fixed: results do not depend on the launch)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int mb = lane + 64 * q;
+      if (mb < n_mel) {
+        const float* wt = mw_lds ? smw + mwo[q] : mel_w + mwo[q];
+        const float* pp = pw + mst[q];
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= mln[q]; k += 4) {
+          e0 += pp[k] * wt[k];
+          e1 += pp[k + 1] * wt[k + 1];
+          e2 += pp[k + 2] * wt[k + 2];
+          e3 += pp[k + 3] * wt[k + 3];
+        }
+        for (; k < mln[q]; ++k) e0 += pp[k] * wt[k];
+        out[f * n_mel + mb] = __logf(fmaxf((e0 + e1) + (e2 + e3), log_floor));
+      }
+    }
+    for (int mb = lane + 128; mb < n_mel; mb += 64) {  // more than 128 bins: the plain loop
+      const int st = mel_start[mb], ln = mel_len[mb];
+      const float* wt = mel_w + mel_woff[mb];
+      float e = 0.f;
+      for (int k = 0; k < ln; ++k) e += pw[st + k] * wt[k];
+      out[f * n_mel + mb] = __logf(fmaxf(e, log_floor));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // pw / img are rewritten by the next frame
+  }
+}
+
 // ---------------------------------------------------------------- CMVN statistics (one block per utterance)
 // mean[u,c] = mean_t x ; istd[u,c] = 1/sqrt(max(sum x^2 / T - mean^2, 1e-10)) ; fill[u] = mean of the normalised
 // spectrogram (SpecAugment's mask value).  Accumulated in f64.
@@ -209,6 +416,14 @@ extern "C" int js2t_fbank(const float* wave, const int64_t* sample_off, const in
   JS2T_CHECK(n_fft >= 64 && n_fft <= FB_MAX_FFT && (n_fft & (n_fft - 1)) == 0, "fbank: n_fft must be a power of two in [64,%d]",
              FB_MAX_FFT);
   JS2T_CHECK(win_len > 0 && win_len <= n_fft && shift > 0 && n_mel > 0, "fbank: bad frame geometry");
+  if (n_fft == 512 && win_len <= 512 && n_mel <= 1024) {  // the Kaldi defaults at 16 kHz: FFT in registers
+    int64_t grid = cdiv(total_frames, FB_WAVES);
+    if (grid > 2048) grid = 2048;  // 8 blocks per CU; waves walk the frames with a grid stride
+    hipLaunchKernelGGL(fbank512_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wave, sample_off, frame_off, U, window,
+                       tw_re, tw_im, mel_start, mel_len, mel_woff, mel_w, out, win_len, shift, n_mel, scale, preemph, log_floor);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   int lg = 0;
   while ((1 << lg) < n_fft) ++lg;
   hipLaunchKernelGGL(fbank_kernel, dim3(cdiv(total_frames, FB_WAVES)), dim3(256), 0, (hipStream_t)stream, wave, sample_off,
