@@ -58,15 +58,26 @@ __device__ __forceinline__ void st_elem(void* p, int64_t i, int dt, float v) {
 }
 
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
+// All-lanes butterfly reductions in the VALU: __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), i.e. six LDS
+// round trips per reduction on the critical path of every row-wise kernel (LayerNorm: two per row).  Inside a row of 16
+// lanes DPP does the exchange (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: each a symmetric pairing, so every
+// lane ends with the row's value); across the four rows gfx950's v_permlane16_swap / v_permlane32_swap trade whole rows.
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false)));  // row_mirror
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = op(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return op(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
 // block-wide sum; `red` is a __shared__ float[>= blockDim/64]; all threads get the result
 __device__ __forceinline__ float block_sum(float v, float* red) {
