@@ -538,6 +538,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-5 decode RTF measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side figures (encoder-forward and Conformer fp8 timings): a kernel trace of the train step alone")
     ap.add_argument("--ragged", action="store_true", help="utterances of 10-17 s instead of 32 x 15 s (value counts un-padded frames)")
     ap.add_argument("--host-inputs", action="store_true", help="copy the waveforms from pinned host memory every step (PCIe-inclusive rate; not the headline value)")
     args = ap.parse_args()
@@ -656,7 +658,7 @@ def main():
                     "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
                                              "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
 
-    if roofline is not None:
+    if roofline is not None and not args.no_extras:
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
         try:
             roofline["conformer_fp8_forward"] = conformer_fp8_forward(device)

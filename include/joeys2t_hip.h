@@ -114,9 +114,10 @@ void js2t_gemm_force_w256(int on);
  * js2t_gemm_grouped (f32 result, N % 128 == 0, M % 8 == 0, no split-K; only in mode 1): 0 = never, 1 = every product
  * that qualifies (test hook), -1 = k-contiguous products that qualify and have >= 200 tiles (default). */
 void js2t_gemm_p192_mode(int mode);
-/* Ring depth of the persistent 192x128 kernel: 3 = one block per CU with two stages in flight, 2 = two blocks per CU
- * with one stage in flight each (80 KB of LDS per block), anything else = chosen per launch (default: 2 when the
- * product has at least 1.5 tiles per CU). */
+/* Variant of the persistent 192x128 kernel: 3 = one block per CU with two stages in flight, 2 = two blocks per CU
+ * with one stage in flight each (80 KB of LDS per block), 4 = one block per CU of eight multiplying and four
+ * requesting waves, anything else = chosen per launch (default: 2 when the product has at least 1.5 tiles per CU,
+ * else 4).  All variants produce bit-identical results. */
 void js2t_gemm_p192_ring(int nst);
 
 /* --------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ import re
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libjoeys2t_hip.so"
+LIB_PATH = Path(os.environ.get("JS2T_LIB", PKG_DIR / "libjoeys2t_hip.so"))  # JS2T_LIB: instrumented builds of tools/
 HEADER_PATH = PKG_DIR.parent / "include" / "joeys2t_hip.h"
 
 F32, BF16 = 0, 1

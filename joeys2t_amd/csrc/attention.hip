@@ -164,13 +164,15 @@ __device__ __forceinline__ uint32_t tile_kbits(const uint8_t* kmask, int kt, int
 // per-query full mask (mask_sq != 0): AND the row's bytes into the key bits
 template <int DH>
 __device__ __forceinline__ uint32_t row_kbits(uint32_t bits, const uint8_t* mrow, int kt, int g, int Tk) {
+  // all bytes are requested before the first is looked at (clamped addresses, no branch): written as
+  // `if (key < Tk && !mrow[key])` this compiled to 16-32 byte loads each waited for in turn
+  uint8_t mv[4 * Geo<DH>::NTT];
 #pragma unroll
   for (int tt = 0; tt < Geo<DH>::NTT; ++tt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = Geo<DH>::KT * kt + 16 * tt + 4 * g + r;
-      if (key < Tk && !mrow[key]) bits &= ~(1u << (4 * tt + r));
-    }
+    for (int r = 0; r < 4; ++r) mv[4 * tt + r] = mrow[min(Geo<DH>::KT * kt + 16 * tt + 4 * g + r, Tk - 1)];
+#pragma unroll
+  for (int i = 0; i < 4 * Geo<DH>::NTT; ++i) bits &= mv[i] ? 0xffffffffu : ~(1u << i);
   return bits;
 }
 

@@ -1606,6 +1606,290 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same tile and stage image with the work split between waves (js2t_gemm_p192_ring(4))
+// ------------------------------------------------------------------------------------------------
+// Two measurements behind this variant (tools/l2_feed_probe.hip, tools/mfma_rate_probe.hip, MI355X):
+//  * a CU pulls a 40 KB stage out of its L2 in ~410-490 ns by LDS-DMA when nothing else is going on (fragments loaded
+//    straight into registers are 2.7x slower: 16 rows x 64 B per instruction) - but a wave that meets a DMA request while
+//    the texture path's queue is full stalls IN ORDER, and its MFMAs stall with it;
+//  * ONE wave per SIMD issuing v_mfma_f32_16x16x32_bf16 with its fragment reads in between reaches 1.76 PFLOP/s chip-wide
+//    (~20 cycles per MFMA), TWO waves per SIMD 2.1-2.2 (16 cycles, the pipe's rate at the ~2.1 GHz it runs at).
+// So a block is 12 waves: waves 0-7 (two per SIMD) only read fragments, multiply and store - wave (wm, wn) owns rows
+// 48 wm .. +47 and columns 64 wn .. +63 of the tile - and waves 8-11 only issue the requests, each the pieces wave w - 8
+// of the kernel above issues.  Same 3-slot ring, one s_barrier per stage for all twelve waves:
+//   loader   : [stage s+1 landed: counted vmcnt, stage s+2 stays in flight] -> barrier s -> request stage s+3 (slot of s)
+//   consumer : MFMAs of k-half 0 of stage s + reads of its k-half 1 -> lgkmcnt(0) -> barrier s -> MFMAs of k-half 1 +
+//              reads of k-half 0 of stage s+1
+// B image: granule (j, r, c) as in p192_b_granule, but fragment j of lane r is column 64 (j >> 2) + 4 r + (j & 3): after
+// its four MFMAs along N a lane holds 4 CONSECUTIVE columns and the 16 lanes of a row group store one 128-byte run.
+// One block per CU (120 KB of LDS, 168 registers per wave).
+template <int EPI>
+__device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][4], int mw, int n0, int lane,
+                                                 const float (&bias_r)[4], uint32_t drop_key) {
+  const int g = lane >> 4, r = lane & 15;
+  const int M = d.M, n = n0 + 4 * r;
+  if (n >= d.N) return;  // N is a multiple of 8 (hence of 4): a lane's column group lies inside or outside as a whole
+  const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
+  const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
+  const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
+  const bool has_res = EPI < 0 ? d.residual != nullptr : (EPI & PE_RES) != 0;
+  const bool has_gate = EPI < 0 ? d.gate != nullptr : (EPI & PE_GATE) != 0;
+  const bool has_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
+  const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
+  const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
+  const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
+  const int64_t rld = has_res ? d.ldr : d.ldg;
+  uint2 rg[3][4];
+  if (has_res || has_gate) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rg[i][e] = *(const uint2*)(rsrc + (int64_t)min(mw + 16 * i + 4 * g + e, M - 1) * rld);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = mw + 16 * i + 4 * g + e;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
+      if (relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, n / 4)
+        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
+        const uint32_t h0 = hash32(rowkey), h1 = hash32(rowkey + 1u);
+        v[0] = (h0 & 0xffffu) >= thr ? v[0] * keep_scale : 0.f;
+        v[1] = (h0 >> 16) >= thr ? v[1] * keep_scale : 0.f;
+        v[2] = (h1 & 0xffffu) >= thr ? v[2] * keep_scale : 0.f;
+        v[3] = (h1 >> 16) >= thr ? v[3] * keep_scale : 0.f;
+      }
+      if (has_res || has_gate) {
+        const uint2 q = rg[i][e];
+        const float rr[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                             __uint_as_float(q.y & 0xffff0000u)};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = has_res ? v[c] + res_scale * rr[c] : (rr[c] > 0.f ? v[c] * gate_scale : 0.f);
+      }
+      if (m < M) {
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+        *(uint2*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
+      }
+    }
+  }
+}
+
+#ifdef JS2T_P192S_DBG
+// [0] ticks of block 0's consumer wave 0 from first to last instruction, [1] of those spent between lgkmcnt(0) and the end
+// of the barrier, [2] loader wave 8: ticks in vmcnt wait, [3] in barrier, [4] issuing, [5] stages
+__device__ unsigned long long g_p192s_prof[8];
+extern "C" int js2t_debug_p192s_prof(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192s_prof), 64); }
+#endif
+template <int EPI, bool FP8 = false>
+__global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using elem_t = typename std::conditional<FP8, uint8_t, uint16_t>::type;
+  constexpr int CSH = FP8 ? 4 : 3, KST = FP8 ? 128 : 64, NST = 3;
+  const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
+  const int w12 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = d.M, N = d.N, K = d.K, nk = (K + KST - 1) / KST;
+  const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+  const int nstages = my_tiles * nk;  // every wave of the block passes 1 + nstages barriers
+
+  if (w12 >= 8) {
+    // ------------------------------------------------------------------------------------------ loader waves
+    const int w = w12 - 8;
+    const elem_t* Ab = (const elem_t*)d.A;
+    const elem_t* Bb = (const elem_t*)d.B;
+    const int64_t lda = d.lda, ldb = d.ldb;
+    int iv = blockIdx.x, ik = 0, islot = 0;
+    const elem_t* asrc[6];
+    const elem_t* bsrc[4];
+    const int r8 = lane >> 3, s8 = lane & 7;
+    auto set_tile_src = [&](int v) {
+      const int lid = xcd_remap(v, ntiles);
+      const int m0 = (lid / tiles_n) * P_BM, n0 = (lid % tiles_n) * 128;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int row = (w * 6 + q) * 8 + r8;
+        asrc[q] = Ab + (int64_t)min(m0 + row, M - 1) * lda + ((s8 ^ kc_key<false>(row)) << CSH);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // piece P = 4w + q of the B image: fragment index j = P >> 1, lanes r = 8 (P & 1) + r8
+        const int P = w * 4 + q, r = (P & 1) * 8 + r8, jf = P >> 1;
+        bsrc[q] = Bb + (int64_t)min(n0 + 64 * (jf >> 2) + 4 * r + (jf & 3), N - 1) * ldb + ((s8 ^ (r >> 1)) << CSH);
+      }
+    };
+    const int kofs_a = (s8 ^ (r8 & 7)) << CSH, kofs_b0 = (s8 ^ (r8 >> 1)) << CSH, kofs_b1 = (s8 ^ ((8 + r8) >> 1)) << CSH;
+    const elem_t* zsrc = (const elem_t*)&g_zero16;
+    // past the block's last stage the requests go on (k = 0 of its last tile into a free slot): branch-free counts
+    auto issue_next = [&]() {
+      const int k0 = iv < ntiles ? ik * KST : 0, klim = K - k0;
+      unsigned char* st = smem + islot * P_STAGE;
+#if defined(JS2T_P192S_DBG) && (JS2T_P192S_DBG & 1)  // measurement only: no requests, the consumers multiply stale LDS
+      return;
+#endif
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const elem_t* sp = asrc[q] + k0;
+        if (klim < KST && kofs_a >= klim) sp = zsrc;
+        __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(st + (w * 6 + q) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const elem_t* sp = bsrc[q] + k0;
+        if (klim < KST && (((w * 4 + q) & 1) ? kofs_b1 : kofs_b0) >= klim) sp = zsrc;
+        __builtin_amdgcn_global_load_lds((g_cvoid*)sp, (l_void*)(st + P_ATILE + (w * 4 + q) * 1024), 16, 0, 0);
+      }
+      if (iv < ntiles && ++ik == nk) {
+        ik = 0;
+        iv += G;
+        if (iv < ntiles) set_tile_src(iv);
+      }
+      islot = islot == NST - 1 ? 0 : islot + 1;
+    };
+    set_tile_src(min(iv, ntiles - 1));
+    issue_next();
+    issue_next();
+    issue_next();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_PER) : "memory");  // stage 0 landed
+    __builtin_amdgcn_s_barrier();
+#ifdef JS2T_P192S_DBG
+    unsigned long long pw = 0, pb = 0, pi = 0, c0 = __builtin_readcyclecounter(), c1;
+#define P192S_L(acc) do { c1 = __builtin_readcyclecounter(); acc += c1 - c0; c0 = c1; } while (0)
+#else
+#define P192S_L(acc)
+#endif
+    for (int sidx = 0; sidx < nstages; ++sidx) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");  // stage sidx + 1 landed, sidx + 2 in flight
+      P192S_L(pw);
+      __builtin_amdgcn_s_barrier();                                  // ... and every consumer holds stage sidx in registers
+      P192S_L(pb);
+      issue_next();                                                  // stage sidx + 3 into the slot of stage sidx
+      P192S_L(pi);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
+#ifdef JS2T_P192S_DBG
+    if (blockIdx.x == 0 && t == 512) g_p192s_prof[2] = pw, g_p192s_prof[3] = pb, g_p192s_prof[4] = pi, g_p192s_prof[5] = nstages;
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------- consumer waves
+  const int wm = w12 & 3, wn = w12 >> 2;
+  const int arow = wm * 48 + (lane & 15);
+  const int br = lane & 15;
+  const int aoff0 = arow * 128 + ((g ^ kc_key<false>(arow)) << 4), aoff1 = arow * 128 + (((4 + g) ^ kc_key<false>(arow)) << 4);
+  const int boff0 = P_ATILE + wn * 8192 + p192_b_granule(8 * br, g) * 16, boff1 = P_ATILE + wn * 8192 + p192_b_granule(8 * br, 4 + g) * 16;
+  auto read_half = [&](const unsigned char* st, int ao, int bo, frag_i4 (&fm)[3], frag_i4 (&fn)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fn[j] = *(const frag_i4*)(st + bo + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fm[i] = *(const frag_i4*)(st + ao + i * 2048);
+  };
+  // the seven reads of the next k-half ride behind the first two of the three MFMA groups: the third group (and the other
+  // wave of the SIMD) covers the latency of the last read, so neither the lgkmcnt(0) in front of the barrier nor the wait
+  // in front of the next half's first MFMA finds anything outstanding
+  auto read_part = [&](int q, const unsigned char* st, int ao, int bo, frag_i4 (&fm)[3], frag_i4 (&fn)[4]) {
+#if defined(JS2T_P192S_DBG) && (JS2T_P192S_DBG & 4)  // measurement only: MFMAs on stale fragments, no LDS reads
+    return;
+#endif
+    auto rn = [&](int j) { fn[j] = *(const frag_i4*)(st + bo + j * 2048); };
+    auto rm = [&](int i) { fm[i] = *(const frag_i4*)(st + ao + i * 2048); };
+    if (q == 0) { rm(0); rn(0); rn(1); rn(2); }
+    if (q == 1) { rn(3); rm(1); rm(2); }
+  };
+  const bool any_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
+  const uint32_t drop_key = any_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
+  __builtin_amdgcn_s_barrier();  // stage 0 landed
+  asm volatile("" ::: "memory");
+  frag_i4 fm0[3], fn0[4], fm1[3], fn1[4];
+  f32x4_t acc[3][4];
+  read_half(smem, aoff0, boff0, fm0, fn0);
+  int cslot = 0;
+#ifdef JS2T_P192S_DBG
+  unsigned long long cons_bar = 0, cons_epi = 0;
+  const unsigned long long cons_t0 = __builtin_readcyclecounter();
+#endif
+  for (int v = blockIdx.x; v < ntiles; v += G) {
+    const int lid = xcd_remap(v, ntiles);
+    const int tm0 = (lid / tiles_n) * P_BM, tn0 = (lid % tiles_n) * 128 + 64 * wn;
+    float bias_r[4];
+    {
+      const int n = tn0 + 4 * br;
+      const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < N;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nk; ++k) {
+      const unsigned char* cst = smem + cslot * P_STAGE;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#if defined(JS2T_P192S_DBG) && (JS2T_P192S_DBG & 2)  // measurement only: reads without MFMAs
+          asm volatile("" ::"v"(fm0[i]), "v"(fn0[j]));
+#else
+          acc[i][j] = p192_mma<FP8>(fm0[i], fn0[j], acc[i][j]);
+#endif
+        }
+        // scheduling fences: the reads stay behind their MFMA group (the scheduler would sink them into one burst, or hoist
+        // them above the group - and then the wait for this group's operands also waits for them)
+        __builtin_amdgcn_sched_barrier(0);
+        read_part(i, cst, aoff1, boff1, fm1, fn1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
+#ifdef JS2T_P192S_DBG
+      const unsigned long long cb0 = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last read of this slot has returned
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#ifdef JS2T_P192S_DBG
+      cons_bar += __builtin_readcyclecounter() - cb0;
+#endif
+      const unsigned char* nst = smem + nslot * P_STAGE;  // after the block's last stage: unused reads of a stale slot
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#if defined(JS2T_P192S_DBG) && (JS2T_P192S_DBG & 2)
+          asm volatile("" ::"v"(fm1[i]), "v"(fn1[j]));
+#else
+          acc[i][j] = p192_mma<FP8>(fm1[i], fn1[j], acc[i][j]);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_part(i, nst, aoff0, boff0, fm0, fn0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cslot = nslot;
+    }
+#ifdef JS2T_P192S_DBG
+    const unsigned long long ce0 = __builtin_readcyclecounter();
+#endif
+    p192s_store_tile<EPI>(d, acc, tm0 + wm * 48, tn0, lane, bias_r, drop_key);
+#ifdef JS2T_P192S_DBG
+    cons_epi += __builtin_readcyclecounter() - ce0;
+#endif
+  }
+#ifdef JS2T_P192S_DBG
+  if (blockIdx.x == 0 && t == 0)
+    g_p192s_prof[0] = __builtin_readcyclecounter() - cons_t0, g_p192s_prof[1] = cons_bar, g_p192s_prof[6] = cons_epi;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same persistent 192x128 pipeline for reduction-major operands: grouped weight gradients
 // C_g[M,N] (f32) = alpha * A_g[K,M]^T B_g[K,N] + beta * C_g, optional row sums of A_g^T (bias gradients)
 // ------------------------------------------------------------------------------------------------
@@ -1856,9 +2140,11 @@ inline bool p192_eligible(const js2t_gemm_desc& d) {
   if (g_p192_mode < 0 && (int64_t)cdiv(d.M, P_BM) * (d.N >> 7) < 200) return false;
   return true;
 }
-// ring depth: 3 / 2 forced, -1 (default) by shape: two blocks per CU pay when every CU has at least one and a half tiles
-// (measured on MI355X, tools/p192_ring_ab.py: QKV x1.15, FFN1 x1.20, ReLU-gated input gradient x1.25, CTC projection x1.11;
-// a launch with one tile per CU - N = 512 - loses 3-10 % because each block then has a single stage in flight)
+// variant: 3 / 2 / 4 forced, -1 (default) by shape (measured on MI355X, tools/p192_ring_ab.py):
+//  * at least one and a half tiles per CU -> two blocks per CU on two-slot rings (QKV x1.15, FFN1 x1.23, ReLU-gated input
+//    gradient x1.23, CTC projection x1.11 over the single block with a three-slot ring);
+//  * fewer (N = 512: one tile per CU) -> ONE block of eight multiplying + four requesting waves (gemm_bf16_p192s_kernel:
+//    FFN2 x1.15, dQKV x1.16, dFFN1 x1.16, output projection x1.15); two blocks per CU lose 3-10 % there.
 int g_p192_ring = -1;
 template <int EPI>
 int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
@@ -1867,6 +2153,8 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1878,7 +2166,10 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     if (n_cu == 0) n_cu = cu;
   }
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
-  if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
+  if (g_p192_ring == 4 || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
+    const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
+  } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
     const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192_kernel<EPI, 2>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
   } else {
@@ -2015,7 +2306,7 @@ extern "C" int js2t_debug_p192_prof2(unsigned long long* out8, int reset) {
   return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof2), 64);
 }
 #endif
-extern "C" void js2t_gemm_p192_ring(int nst) { g_p192_ring = nst == 2 ? 2 : (nst == 3 ? 3 : -1); }
+extern "C" void js2t_gemm_p192_ring(int nst) { g_p192_ring = (nst >= 2 && nst <= 4) ? nst : -1; }
 extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode); }
 
 template <bool SPLITK>

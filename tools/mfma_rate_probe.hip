@@ -1,0 +1,115 @@
+// What the consumer side of the persistent GEMM can reach on this part (tools/, not part of the library): one wave per
+// SIMD (or two), a loop of 48 v_mfma_f32_16x16x32_bf16 on 24 accumulators =
+//   mode 0  MFMAs only
+//   mode 1  + 22 ds_read_b128 of a resident 40 KB stage image, in the GEMM's order (3,3,3,2 behind the first four groups)
+//   mode 2  + lgkmcnt(0) and an s_barrier per 48 MFMAs
+// each with a near-constant operand pattern and with random bf16 operands: the clock the part sustains depends on how
+// many multiplier inputs toggle (power), so "peak" has to be quoted for random data
+// prints ns per 48-MFMA "stage" and the TFLOP/s of the whole chip.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(int iters, float* out, int random_data) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int i = t; i < 40960 / 4; i += blockDim.x) {
+    uint32_t x = (uint32_t)i * 0x9E3779B9u + blockIdx.x;
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    // random_data: bf16 pairs with random sign / mantissa and exponents around 1 (what a GEMM operand looks like to the
+    // multipliers); otherwise a near-constant pattern
+    ((uint32_t*)smem)[i] = random_data ? ((x & 0x807f807fu) | 0x3f003f00u) : 0x3c003c00u + i;
+  }
+  __syncthreads();
+  f32x4_t acc[3][8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0, 0, 0, 0};
+  i4 fm[2][3], fn[2][8];
+  const int ao = (w * 48 + (lane & 15)) * 128 + ((lane >> 4) ^ (lane & 7)) * 16, bo = 24576 + (lane & 15) * 128 + ((lane >> 4) ^ (lane & 7)) * 16;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fn[h][j] = *(const i4*)(smem + bo + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fm[h][i] = *(const i4*)(smem + ao + i * 2048);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int i = q >> 1, j = (q & 1) * 4 + jj;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fm[h][i]), __builtin_bit_cast(bf16x8_t, fn[h][j]),
+                                                              acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE >= 1) {
+          const unsigned char* st = smem + ((it + h) & 1) * 64;
+          auto rn = [&](int j) { fn[h ^ 1][j] = *(const i4*)(st + bo + j * 2048); };
+          auto rm = [&](int i) { fm[h ^ 1][i] = *(const i4*)(st + ao + i * 2048); };
+          if (q == 0) { rm(0); rn(0); rn(1); }
+          if (q == 1) { rn(2); rn(3); rn(4); }
+          if (q == 2) { rn(5); rn(6); rn(7); }
+          if (q == 3) { rm(1); rm(2); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (MODE >= 2 && h == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 12345.f) out[0] = s;
+}
+
+template <int MODE>
+static void run(const char* name, int blocks_per_cu, float* out, int random_data) {
+  const int iters = 2000, grid = 256 * blocks_per_cu;
+  CK(hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 + 256));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < 4; ++r) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 40960 + 256, 0, iters, out, random_data);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    if (r && ms < best) best = ms;
+  }
+  const double flop = (double)grid * 4 * iters * 48 * 16384.0;
+  printf("%s %-44s %d block(s)/CU  %7.1f ns per 48 MFMAs per wave  %7.1f TFLOP/s  -> %.2f GHz if MFMA-bound at 16 cycles\n", random_data ? "random  " : "constant", name,
+         blocks_per_cu, best * 1e6 / iters / blocks_per_cu * blocks_per_cu, flop / (best * 1e-3) / 1e12,
+         (double)blocks_per_cu * iters * 48 * 16 / (best * 1e-3) / 1e9);
+}
+
+int main() {
+  float* out;
+  CK(hipMalloc(&out, 64));
+  for (int rnd : {0, 1})
+    for (int b : {1, 2}) {
+      run<0>("0 MFMAs only", b, out, rnd);
+      run<1>("1 + 22 ds_read_b128 per 48 MFMAs", b, out, rnd);
+      run<2>("2 + lgkmcnt(0) + s_barrier per 48 MFMAs", b, out, rnd);
+    }
+  return 0;
+}

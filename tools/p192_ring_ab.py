@@ -1,5 +1,6 @@
-"""A/B of the persistent 192x128 GEMM's ring depth on the LS100 train-step shapes, interleaved in one process:
-ring 3 = one block per CU, two stages in flight; ring 2 = two blocks per CU, one stage in flight each.
+"""A/B of the persistent 192x128 GEMM's variants on the LS100 train-step shapes, interleaved in one process:
+ring 3 = one block per CU, two stages in flight; ring 2 = two blocks per CU, one stage in flight each; 4 = one block of
+four consumer + four loader waves per CU (3-slot ring).
 usage: python tools/p192_ring_ab.py [reps]"""
 import sys
 from pathlib import Path
@@ -51,17 +52,17 @@ def timed(run):
 lib().js2t_gemm_p192_mode(1)
 for name, M, N, K, kw in SHAPES:
     run, C = make(M, N, K, **kw)
-    res, outs = {2: [], 3: []}, {}
+    res, outs = {2: [], 3: [], 4: []}, {}
     for rnd in range(4):
-        for ring in (3, 2):
+        for ring in (3, 2, 4):
             lib().js2t_gemm_p192_ring(ring)
             run()
             torch.cuda.synchronize()
             if rnd == 0:
                 outs[ring] = C.clone()
             res[ring].append(timed(run))
-    same = torch.equal(outs[2], outs[3])
+    same = torch.equal(outs[2], outs[3]) and torch.equal(outs[4], outs[3])
     fl = 2.0 * M * N * K
-    a, b = min(res[3]), min(res[2])
+    a, b, c = min(res[3]), min(res[2]), min(res[4])
     print(f"{name:30s} M={M} N={N:5d} K={K:5d}  ring3 {a:7.1f} us {fl / a / 1e6:6.0f} TF | ring2 {b:7.1f} us {fl / b / 1e6:6.0f} TF  "
-          f"x{a / b:5.2f}  identical={same}", flush=True)
+          f"x{a / b:5.2f} | split {c:7.1f} us {fl / c / 1e6:6.0f} TF x{a / c:5.2f}  identical={same}", flush=True)
