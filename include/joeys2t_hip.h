@@ -288,6 +288,13 @@ int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, const float* l
                   float scale, void* dlogits, int64_t rows, int64_t V, int64_t pad_idx, float smoothing,
                   js2t_stream stream);
 
+/* Running statistics of TrainManager._train_step (training.py:566-586: loss, nll, ctc are normalised by
+ * batch.normalize(), batch.py:135-175; n_correct, nseqs, ntokens are counts) in one launch instead of a dozen scalar
+ * kernels: stats6 (f64) += [total*inv_norm, nll*inv_norm, ctc*inv_norm, n_correct, nseqs, ntokens]; nll / ctc /
+ * n_correct may be NULL; norm_out (optional f32) receives total*inv_norm, the value _train_step returns. */
+int js2t_train_stats(double* stats6, const float* total, const float* nll, const float* ctc, const int64_t* n_correct,
+                     double inv_norm, double nseqs, double ntokens, float* norm_out, js2t_stream stream);
+
 /* out[0] = sum_i x[i] (single block, fixed order => bit-reproducible). */
 int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream);
 

@@ -601,6 +601,28 @@ extern "C" int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, con
   return JS2T_OK;
 }
 
+// running statistics of the train step in one launch (the reference adds six Python scalars, training.py:566-586)
+__global__ void train_stats_kernel(double* __restrict__ stats, const float* total, const float* nll, const float* ctc,
+                                   const int64_t* n_correct, double inv_norm, double nseqs, double ntokens, float* norm_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double t = (double)total[0] * inv_norm;
+  stats[0] += t;
+  if (nll) stats[1] += (double)nll[0] * inv_norm;
+  if (ctc) stats[2] += (double)ctc[0] * inv_norm;
+  if (n_correct) stats[3] += (double)n_correct[0];
+  stats[4] += nseqs;
+  stats[5] += ntokens;
+  if (norm_out) norm_out[0] = (float)t;
+}
+extern "C" int js2t_train_stats(double* stats6, const float* total, const float* nll, const float* ctc, const int64_t* n_correct,
+                                double inv_norm, double nseqs, double ntokens, float* norm_out, js2t_stream stream) {
+  JS2T_CHECK(stats6 && total, "train_stats: null pointer");
+  hipLaunchKernelGGL(train_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats6, total, nll, ctc, n_correct, inv_norm, nseqs,
+                     ntokens, norm_out);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 extern "C" int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream) {
   JS2T_CHECK(x && out && n >= 0, "sum_f32: bad arguments");
   hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);

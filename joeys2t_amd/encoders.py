@@ -64,6 +64,9 @@ class Conv1dSubsampler(nn.Module):
             x = Fn.Conv1dGluFn.apply(x, conv.weight, conv.bias, rt.compute_dtype,
                                      rt.sinks({"w": [conv.weight], "b": [conv.bias]}), rt.grads_ready)
         out_lens, mask = ops.subsample_lengths_mask(src_lengths, x.size(1), self.kernel_sizes)
+        # the mask's row sums, which the CTC loss asks for (model.py:125): = min(out_lens, T'), and T' is the sub-sampled
+        # length of the longest utterance, so out_lens itself; saves a cast + reduction per step
+        mask.js2t_row_sums = out_lens
         return x, out_lens, mask
 
 

@@ -90,7 +90,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
 
 
 def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None,
-               dw_out=None, db_out=None, queue=None, w_t=None):
+               dw_out=None, db_out=None, queue=None, w_t=None, dx_add=None):
     """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32).
     dw_out / db_out: fp32 gradient buffers (views of the flat gradient store) to ACCUMULATE into; the corresponding
     return value is then None (nothing left for autograd to add)."""
@@ -101,13 +101,17 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
     if need_dx:
         # dx[M,K] = dz[M,N] . W[N,K]   (B(n'=k, red=n) lives at W[n*ldw + k] -> trans_b)
         dx = torch.empty((M, K), dtype=dx_dtype or x2d.dtype, device=x2d.device)
+        extra = {}
+        if dx_add is not None:  # dx = dz . W + dx_add in the product's epilogue (a gradient that accumulates over several users of x)
+            assert gate is None and dx_add.shape == dx.shape and dx_add.dtype == dx.dtype
+            extra = dict(residual=dx_add, ldr=dx_add.stride(0), res_scale=1.0)
         if w_t is not None and w_t.dtype == dz2d.dtype:
             # W^T [K, N] is at hand (ParamStore.view_t): both operands k-contiguous -> plain product, register-direct epilogue
             ops.gemm(dz2d, w_t, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w_t.stride(0), ldc=K, gate=gate,
-                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale, **extra)
         else:
             ops.gemm(dz2d, w, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w.stride(0), ldc=K, trans_b=True, gate=gate,
-                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale)
+                     ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale, **extra)
     # the bias gradient (column sums of dz) rides on the weight-gradient product when that runs on the bf16 LDS-DMA
     # kernel: its dz tiles are already in LDS, so no separate pass over dz is needed
     fuse_db = need_dw and need_db and _mfma_operand(dz2d) and _mfma_operand(x2d)
@@ -275,9 +279,40 @@ _DROP_READY = {}
 FUSE_LN_DROPOUT_BWD = os.environ.get("JS2T_LN_DROPOUT_HANDOVER", "1") != "0"  # tests flip this to compare with the separate kernel
 
 
+# Gradient of the encoder states ("memory"): every decoder layer's cross-attention block contributes dkv . W_kv, and
+# autograd would add the six [B*S, d] tensors one launch at a time.  Instead the blocks chain them: forward counts the
+# blocks that took a given memory tensor, each block's backward adds the running sum in its product's epilogue
+# (linear_bwd(dx_add=...)) and returns None - except the last one to run, which hands the sum to autograd.
+# Only between begin_memory_chain() and end_memory_chain() - i.e. inside TrainStep.micro_step(), which runs exactly one
+# forward and one backward in between; end_memory_chain() fails loudly if a block that was counted never ran (its share
+# and everything chained behind it would be lost).  Anywhere else autograd adds the tensors as usual.
+_MEM_USERS = {}  # (data_ptr, shape) -> number of cross blocks whose backward is still to come
+_MEM_ACC = {}    # (data_ptr, shape) -> running sum
+CHAIN_MEMORY_GRADS = os.environ.get("JS2T_CHAIN_MEMORY_GRADS", "1") != "0"
+_CHAIN_ACTIVE = False
+
+
 def reset_handover():
     _DROP_HINT.clear()
     _DROP_READY.clear()
+
+
+def begin_memory_chain():
+    global _CHAIN_ACTIVE
+    _MEM_USERS.clear()
+    _MEM_ACC.clear()
+    _CHAIN_ACTIVE = CHAIN_MEMORY_GRADS
+
+
+def end_memory_chain(check: bool = True):
+    global _CHAIN_ACTIVE
+    _CHAIN_ACTIVE = False
+    left = sum(v for v in _MEM_USERS.values() if v != 0)
+    _MEM_USERS.clear()
+    _MEM_ACC.clear()
+    if check and left:
+        raise RuntimeError(f"encoder-state gradient chain incomplete: {left} cross-attention backward pass(es) never ran, their "
+                           "share of the gradient is lost; set JS2T_CHAIN_MEMORY_GRADS=0")
 
 
 class ResidualBlockFn(torch.autograd.Function):
@@ -332,6 +367,10 @@ class ResidualBlockFn(torch.autograd.Function):
             if cfg.need_weights:
                 att_w = ops.attn_head_mean(P, B, H, T, S, shp.ld)
             saved.update(q=q, kv=kv, m2=m2, P=P, Pd=Pd, shp=shp)
+            if _CHAIN_ACTIVE and memory.requires_grad and _mfma_operand(m2):
+                key = (m2.data_ptr(), tuple(m2.shape))
+                _MEM_USERS[key] = _MEM_USERS.get(key, 0) + 1
+                saved["mem_key"] = key
         else:  # ffn
             pre = None
             if cfg.act != "relu" and cfg.act is not None:
@@ -429,8 +468,17 @@ class ResidualBlockFn(torch.autograd.Function):
             attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
                      ctx_out=c, mask=ctx.mask)
             dn, g["w_q"], g["b_q"] = linear_bwd(dq, n, wts["w_q"], dw_out=sk("w_q"), db_out=sk("b_q"), queue=wq, w_t=wts.get("w_q_t"))
+            key = sv.get("mem_key") if ctx.needs_input_grad[3] else None
             dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
-                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq, w_t=wts.get("w_kv_t"))
+                                                     dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq, w_t=wts.get("w_kv_t"),
+                                                     dx_add=None if key is None else _MEM_ACC.get(key))
+            if key is not None:
+                _MEM_USERS[key] -= 1
+                if _MEM_USERS[key] > 0:  # more cross blocks to come: keep the sum, nothing for autograd yet
+                    _MEM_ACC[key] = dmem2
+                    dmem2 = None
+                else:
+                    _MEM_ACC.pop(key, None)
             dmem = None if dmem2 is None else dmem2.view(ctx.mem_shape)
         if cfg.ln_mode == "pre":
             if ctx.prev_drop is not None:

@@ -11,9 +11,19 @@ import torch
 from torch import Tensor, nn
 
 
+_SUBSEQUENT_MASKS = {}
+
+
 def subsequent_mask(size: int, device=None) -> Tensor:
-    """Lower-triangular bool mask of shape (1, size, size)."""
-    return torch.ones(size, size, dtype=torch.bool, device=device).tril_().unsqueeze(0)
+    """Lower-triangular bool mask of shape (1, size, size).  A constant per (size, device): built once (two launches per
+    decoder pass otherwise) and handed out read-only - callers combine it with `&`, none writes into it."""
+    key = (int(size), str(device))
+    m = _SUBSEQUENT_MASKS.get(key)
+    if m is None:
+        if len(_SUBSEQUENT_MASKS) > 256:
+            _SUBSEQUENT_MASKS.clear()
+        m = _SUBSEQUENT_MASKS[key] = torch.ones(size, size, dtype=torch.bool, device=device).tril_().unsqueeze(0)
+    return m
 
 
 def set_seed(seed: int) -> None:

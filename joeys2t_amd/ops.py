@@ -589,6 +589,32 @@ def log_softmax(x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
     return y
 
 
+def train_stats(stats6, total, nll, ctc, n_correct, inv_norm: float, nseqs: float, ntokens: float):
+    """stats6 += [total, nll, ctc] * inv_norm, n_correct, nseqs, ntokens; returns total * inv_norm (0-d f32)."""
+    _dev(stats6, total, nll, ctc, n_correct)
+    assert stats6.dtype == torch.float64 and stats6.numel() == 6 and total.dtype == torch.float32
+    assert n_correct is None or n_correct.dtype == torch.int64
+    norm = torch.empty((), dtype=torch.float32, device=total.device)
+    check(lib().js2t_train_stats(_p(stats6), _p(total), _p(nll), _p(ctc), _p(n_correct), C.c_double(inv_norm), C.c_double(nseqs),
+                                 C.c_double(ntokens), _p(norm), _stream()), "js2t_train_stats")
+    return norm
+
+
+class LinComb2Fn(torch.autograd.Function):
+    """a*x + b*y of two 0-d (or same-shaped) f32 tensors as ONE launch (loss interpolation, loss.py:164); the backward is two."""
+
+    @staticmethod
+    def forward(ctx, x, y, a: float, b: float):
+        ctx.ab = (a, b)
+        return axpby(x, a, y, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        g = g.contiguous()
+        return axpby(g, a), axpby(g, b), None, None
+
+
 def sum_f32(x: torch.Tensor) -> torch.Tensor:
     _dev(x)
     out = torch.empty((), dtype=torch.float32, device=x.device)

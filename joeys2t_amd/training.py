@@ -62,6 +62,7 @@ class TrainStep:
         self.rt.on_grads_ready = self.reducer.params_ready if (self.reducer is not None and self.rt.wgrad_queue is None) else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
+        self._grad_seeds: Dict[float, torch.Tensor] = {}  # device constants seeding backward, by normalisation factor
 
     def exchange_and_flush(self, plan=None):
         """Deferred weight-gradient products + gradient exchange of one optimizer step, overlapped: each range of the flat
@@ -94,9 +95,24 @@ class TrainStep:
         use_hooks = exchange and self.rt.wgrad_queue is None  # without the queue: bucket hooks fire during backward
         if use_hooks:
             self.reducer.begin(armed=True)
-        total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
-        norm = batch.normalize(total, self.normalization, self.n_gpu, self.batch_multiplier)
-        norm.backward()
+        functional.begin_memory_chain()
+        try:
+            total, nll, ctc, n_correct = model(return_type="loss", **vars(batch))
+        except BaseException:
+            functional.end_memory_chain(check=False)
+            raise
+        # batch.normalize() (batch.py:135-175) is a multiplication by a host constant: it seeds the backward pass instead of
+        # running as a chain of scalar kernels (division forward + backward, then the same division for every statistic)
+        inv_norm = self._inv_normalizer(batch)
+        seed = self._grad_seeds.get(inv_norm)
+        if seed is None:
+            seed = self._grad_seeds[inv_norm] = torch.full((), inv_norm, dtype=torch.float32, device=total.device)
+        try:
+            total.backward(gradient=seed)
+        except BaseException:
+            functional.end_memory_chain(check=False)
+            raise
+        functional.end_memory_chain()
         if self.rt.grad_copies is not None:
             self.rt.grad_copies.fold()
         if use_hooks:
@@ -105,21 +121,26 @@ class TrainStep:
             self.exchange_and_flush()
         elif flush:
             self.rt.flush_wgrads()
-        with torch.no_grad():
-            s = self.stats
-            s[0] += norm.detach()
-            if nll is not None:
-                s[1] += batch.normalize(nll.detach(), self.normalization, self.n_gpu, self.batch_multiplier)
-            if ctc is not None:
-                s[2] += batch.normalize(ctc.detach(), self.normalization, self.n_gpu, self.batch_multiplier)
-            s[3] += n_correct
-            s[4] += batch.nseqs
-            s[5] += batch.ntokens or 0
+        with torch.no_grad():  # one launch: stats += [total, nll, ctc] * inv_norm, n_correct, nseqs, ntokens
+            norm = ops.train_stats(self.stats, total.detach(), None if nll is None else nll.detach(), None if ctc is None else ctc.detach(),
+                                   n_correct, inv_norm, batch.nseqs, batch.ntokens or 0)
         self.rt.rng.advance()
         self.micro += 1
         if last and update:
             self.update()
-        return norm.detach()
+        return norm
+
+    def _inv_normalizer(self, batch: Batch) -> float:
+        """The factor batch.normalize(x, normalization, n_gpu, batch_multiplier) multiplies a 0-d loss by (batch.py:135-175:
+        "sum" returns the tensor untouched, otherwise / normalizer, / n_gpu, / n_accumulation)."""
+        if self.normalization == "sum":
+            return 1.0
+        f = 1.0 / {"batch": batch.nseqs, "tokens": batch.ntokens, "none": 1}[self.normalization]
+        if self.n_gpu > 1:
+            f /= self.n_gpu
+        if self.batch_multiplier > 1:
+            f /= self.batch_multiplier
+        return f
 
     def update(self):
         """clip -> AdamW -> scheduler.step(steps) -> (grads cleared in the kernel) -> steps += 1."""

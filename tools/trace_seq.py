@@ -7,7 +7,7 @@ d = sys.argv[1]
 f = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # last step = from the last fbank_kernel on
-idx = max(i for i, r in enumerate(rows) if "fbank_kernel" in r["Kernel_Name"])
+idx = max(i for i, r in enumerate(rows) if "fbank" in r["Kernel_Name"])
 t0 = int(rows[idx]["Start_Timestamp"])
 for r in rows[idx:]:
     name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
