@@ -649,7 +649,7 @@ def main():
                            "current_gemm_hip_sha16": sha, "stale": tj.get("gemm_hip_sha16") != sha}
             if not traffic_src["stale"]:
                 traffic = tj.get("hbm_bytes_per_launch")
-        key = "gemm_bf16_p192_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
+        key = "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
         roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": round(algo_bytes),
