@@ -573,9 +573,27 @@ def main():
         device, world, ragged=args.ragged, host_inputs=args.host_inputs, ddp=(world > 1 or force_ddp))
     use_graph = not args.no_graph
     one_step = eager_step
+    capture_error = None
     if use_graph:
-        capture()
-        one_step = graph_step
+        # Data parallel: a capture that fails on this node (the graph pieces around the RCCL calls have only been rehearsed on
+        # one card) must not cost the whole line - every rank then times the same kernels launched eagerly, and says so.
+        try:
+            capture()
+        except Exception as exc:  # noqa: BLE001
+            if world == 1 and not force_ddp:
+                raise
+            capture_error = repr(exc)[:300]
+            torch.cuda.synchronize()
+        if world > 1:
+            flag = torch.tensor([1.0 if capture_error else 0.0], device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if flag.item() > 0 and capture_error is None:
+                capture_error = "capture failed on another rank"
+        if capture_error is None:
+            one_step = graph_step
+        else:
+            use_graph = False
+            print(f"bench.py: rank {rank}: graph capture failed, timing the eager step instead: {capture_error}", file=sys.stderr, flush=True)
 
     def barrier():
         if world > 1:
@@ -691,6 +709,7 @@ def main():
                        "launch": ("hipGraph replay" if world == 1 and not force_ddp else
                                   "hipGraph replay in pieces (fwd+bwd | weight-gradient groups | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
+                       "capture_error": capture_error,
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode,
         }
