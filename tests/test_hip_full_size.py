@@ -94,3 +94,63 @@ def test_full_size_batch_normalisation_is_an_exact_scale(device, full_case, over
     torch.cuda.synchronize()
     assert torch.isfinite(step.store.flat).all()
     assert float(step.optimizer.norm_clip[0]) == pytest.approx(float(gb.double().norm()), rel=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ decoding at full size
+def _mustc_decode_case(device, dtype):
+    """configs/mustc_st.yaml shapes (12 + 6 layers, d 512, 8 heads of 64), 32 ragged utterances of up to 1498 frames"""
+    from test_hip_config_width import MUSTC_ALPHA, set_alpha
+    cfg = width_cfg(8, 12, 6, "xavier_normal")
+    torch.manual_seed(17)
+    model = make_model(cfg, V, None, None, None, 0.1)
+    set_alpha(model, *MUSTC_ALPHA)
+    model.finalize(device, dtype).eval()
+    g = torch.Generator().manual_seed(4)
+    lengths = torch.tensor([1498] + torch.randint(700, 1499, (B - 1, ), generator=g).tolist())
+    src = torch.randn(B, 1498, 80, generator=g)
+    for b in range(B):
+        src[b, lengths[b]:] = 1.0
+    return model, src, lengths
+
+
+def _decode_batch(src, lengths, idx, device):
+    from joeys2t_amd.batch import Batch
+    idx = torch.as_tensor(idx)
+    T = int(lengths[idx].max())
+    return Batch(src=src[idx][:, :T].contiguous(), src_length=lengths[idx], src_prompt_mask=None, trg=None, trg_length=None,
+                 trg_prompt_mask=None, indices=torch.arange(len(idx)), device=device, pad_index=1, eos_index=3, is_train=False, task="S2T",
+                 n_gpu=1)
+
+
+def test_full_size_decoding_properties(device):
+    """Beam search / greedy / CTC best path at full size in fp32 (reference search.py:345-912): hypotheses do not depend on
+    the order of the utterances in the batch, a beam of one is greedy search, and the key/value-cached step produces the
+    hypotheses of the reference's full-prefix decoder pass."""
+    import numpy as np
+    from joeys2t_amd.search import ctc_greedy, search
+    model, src, lengths = _mustc_decode_case(device, torch.float32)
+    order = list(range(B))
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(8)).tolist()
+    kw = dict(max_output_length=12, beam_alpha=1.0, n_best=1, return_prob="hyp")
+    ids0, sc0, _ = search(model, _decode_batch(src, lengths, order, device), beam_size=5, **kw)
+    idsp, scp, _ = search(model, _decode_batch(src, lengths, perm, device), beam_size=5, **kw)
+    assert np.array_equal(ids0[perm], idsp)  # row i of the permuted batch is utterance perm[i]
+    np.testing.assert_allclose(np.asarray(sc0)[perm], np.asarray(scp), rtol=1e-4, atol=1e-4)
+    # beam size 1 takes the greedy path in search() (search.py:891-900); the beam machinery with a single hypothesis agrees
+    from joeys2t_amd.search import beam_search
+    b = _decode_batch(src, lengths, order[:8], device)
+    with torch.no_grad():
+        enc, hid, mask, _ = model(return_type="encode", **vars(b))
+    gids, _, _ = search(model, b, beam_size=1, **kw)
+    bids, _, _ = beam_search(model, 1, enc, hid, mask, max_output_length=12, alpha=1.0, n_best=1)
+    L = min(gids.shape[1], bids.shape[1])
+    assert np.array_equal(np.asarray(gids)[:, :L], np.asarray(bids)[:, :L])
+    # KV-cached step against the full-prefix pass
+    fids, fsc, _ = search(model, b, beam_size=5, incremental=False, **kw)
+    assert np.array_equal(ids0[:8], fids)
+    np.testing.assert_allclose(np.asarray(sc0)[:8], np.asarray(fsc), rtol=1e-4, atol=1e-4)
+    # CTC best path
+    c0, n0 = ctc_greedy(model, _decode_batch(src, lengths, order, device))
+    cp, n1 = ctc_greedy(model, _decode_batch(src, lengths, perm, device))
+    for i, u in enumerate(perm):
+        assert list(cp[i][:n1[i]]) == list(c0[u][:n0[u]]), (i, u)
