@@ -186,12 +186,17 @@ __device__ unsigned long long g_attn_prof[8];
 #endif
 // ------------------------------------------------------------------------------------------------ forward
 // a wave owns 16 queries; a block 64
-template <int DH, bool REL>
-__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
+// SB (single-buffered): ONE K image and ONE V image per block (32 KB) and the key mask in dynamic LDS, so that three
+// blocks fit a CU (three waves per SIMD at <= 168 registers) and the 768 blocks of an encoder layer are resident at once.
+// V(kt) is requested when K(kt) has landed and lands under QK^T + softmax; K(kt+1) is requested when every wave is through
+// with QK^T and lands under PV (what of it is exposed, the other two blocks of the CU cover): two barriers per tile.
+template <int DH, bool REL, bool SB = false>
+__global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}
-  __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}; SB: K, V, key mask
+  __shared__ __attribute__((aligned(16))) uint8_t kmask_st[SB ? 16 : KMASK_MAX];
+  uint8_t* kmask = SB ? (uint8_t*)(smem + 2 * IMG_BYTES) : kmask_st;
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
 #ifdef JS2T_ATTN_PROF
   const unsigned long long t_start_ = __builtin_readcyclecounter();
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
   stage_kmask(kmask, a, b, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
   img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
-  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  if (!SB) img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = t_start_;
@@ -235,12 +240,14 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     ATT_T(0);
     __syncthreads();
     ATT_T(1);
-    if (kt + 1 < nkt) {
+    if (SB) {
+      img_dma<DH>(Vb, a.ldv, kt * KT, a.Tk, smem + IMG_BYTES, t);  // every wave is through with PV of the previous tile
+    } else if (kt + 1 < nkt) {
       img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
       img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
     ATT_T(2);
-    const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
+    const unsigned char* Ki = SB ? smem : smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
     const uint32_t kbits = tile_kbits<DH>(kmask, kt, g);
     // S^T = K Q^T : s[tt][r] = score(query q0+m, key KT*kt + 16tt + 4g + r)
@@ -314,6 +321,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(AttnArgs a) {
     }
     ATT_PIN(pf[NSS - 1]);
     ATT_T(4);
+    if (SB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of V(kt)
+      __syncthreads();                                   // V(kt) complete; every wave is through with the K image
+      if (kt + 1 < nkt) img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem, t);
+    }
     // O^T += V^T P^T
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -710,16 +722,25 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   return a;
 }
 
+int g_attn_fwd_sb = -1;  // -1: by shape, 0 / 1: forced (js2t_debug_attn_fwd_sb; measurements)
 template <int DH, bool REL>
 int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
   if (!once) {
-    const int rc = set_lds(flash_fwd_kernel<DH, REL>, 4 * IMG_BYTES);
+    int rc = set_lds(flash_fwd_kernel<DH, REL, false>, 4 * IMG_BYTES);
+    if (rc) return rc;
+    rc = set_lds(flash_fwd_kernel<DH, REL, true>, 2 * IMG_BYTES + KMASK_MAX);
     if (rc) return rc;
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL((flash_fwd_kernel<DH, REL>), dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+  const int nblk = cdiv(d->Tq, 64) * d->B * d->H;
+  constexpr int KT = Geo<DH>::KT;
+  const int kmask_bytes = (cdiv(d->Tk, KT) * KT + 15) & ~15;
+  // three single-buffered blocks per CU when the grid does not fit two per CU (and the key mask leaves room for three)
+  const bool sb = g_attn_fwd_sb >= 0 ? g_attn_fwd_sb != 0 : (nblk > 512 && kmask_bytes <= 4096);
+  if (sb) hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, true>), dim3(nblk), dim3(256), 2 * IMG_BYTES + kmask_bytes, s, a);
+  else hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, false>), dim3(nblk), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -747,6 +768,7 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
 #ifdef JS2T_ATTN_PROF
 extern "C" int js2t_debug_attn_prof(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 64); }
 #endif
+extern "C" void js2t_debug_attn_fwd_sb(int mode) { g_attn_fwd_sb = mode; }
 extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) {
   int rc = check_common(d);
   if (rc) return rc;

@@ -475,6 +475,36 @@ def test_flash_attention_dropout_matches_unfused(device, dh):
         bf16_close(a, b, 3e-2)
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,p,mask_kind,R", [(32, 4, 375, 375, 128, 0.1, "pad", 0), (4, 8, 200, 333, 64, 0.1, None, 0),
+                                                       (3, 2, 130, 129, 128, 0.0, "full", 0), (2, 2, 96, 300, 128, 0.2, "pad", 16),
+                                                       (1, 1, 64, 1000, 64, 0.1, "pad", 0)])
+def test_flash_attention_forward_single_buffered_variant(device, B, H, Tq, Tk, dh, p, mask_kind, R):
+    """The forward kernel's three-blocks-per-CU form (one K and one V image per block, requested one after the other; taken
+    for grids that do not fit two blocks per CU) computes the bits of the double-buffered form: same tiles, same order."""
+    from joeys2t_amd._lib import lib
+    d = H * dh
+    rng = ops.DropoutRng(device, seed=5)
+    q = rnd(B * Tq, d, seed=1).bfloat16().to(device)
+    kv = rnd(B * Tk, 2 * d, seed=2).bfloat16().to(device)
+    mask = None
+    if mask_kind == "pad":
+        lens = torch.randint(Tk // 2, Tk + 1, (B, ), generator=torch.Generator().manual_seed(3))
+        mask = (torch.arange(Tk)[None, :] < lens[:, None]).unsqueeze(1).to(device)
+    elif mask_kind == "full":
+        mask = torch.tril(torch.ones(Tq, Tk, dtype=torch.bool)).unsqueeze(0).expand(B, -1, -1).contiguous().to(device)
+    rel = (0.3 * rnd(H, 2 * R + 1, seed=4)).to(device) if R else None
+    res = []
+    try:
+        for mode in (0, 1):
+            lib().js2t_debug_attn_fwd_sb(mode)
+            out, lse = ops.flash_attn_fwd(q, 0, kv, 0, kv, d, B, H, Tq, Tk, dh, mask, p, rng, 9, rel_bias=rel)
+            torch.cuda.synchronize()
+            res.append((out, lse))
+    finally:
+        lib().js2t_debug_attn_fwd_sb(-1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("split", [1, 4])
 def test_gemm_a_rowsum_bias_grad(device, split):
     """a_rowsum: the bias gradient taken inside the weight-gradient product equals the column sums of dz (added onto

@@ -8,6 +8,10 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from joeys2t_amd import ops  # noqa: E402
 
+import os
+from joeys2t_amd._lib import lib  # noqa: E402
+if "ATTN_FWD_SB" in os.environ:  # 0 / 1: force the double- / single-buffered forward kernel (default: by grid size)
+    lib().js2t_debug_attn_fwd_sb(int(os.environ["ATTN_FWD_SB"]))
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 P_DROP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
