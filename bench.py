@@ -480,7 +480,7 @@ MUSTC_MODEL = {
 }
 
 
-def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100):
+def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos_scale=0.0):
     """Second half of BASELINE.json's metric: beam-5 decode real-time factor on configs/mustc_st.yaml shapes
     (12+6 layers, H=8, beam 5, alpha 1.0, max_output_length 100), 32 synthetic 15 s utterances resident in HBM.
     RTF = wall time of front-end + encode + beam search / seconds of audio."""
@@ -492,6 +492,14 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100):
     from joeys2t_amd.vocabulary import Vocabulary
     torch.manual_seed(42)
     model = build_model(copy.deepcopy(MUSTC_MODEL), None, Vocabulary.synthetic(VOCAB))
+    if eos_scale > 0:
+        # a random-init model never emits EOS: every hypothesis runs the full max_output_length, the best case for the replayed
+        # step and the only case in which nothing finishes, nothing is compacted and the host never looks at the device.  A
+        # larger EOS row in the output layer makes EOS win with a few per cent probability per step, so hypotheses finish at
+        # scattered steps (geometric lengths) as they do for a trained model - the bookkeeping of search.py:640-700 then runs.
+        with torch.no_grad():
+            w = model.decoder.output_layer.weight
+            w[3] = torch.nn.functional.normalize(torch.randn(w.shape[1]), dim=0) * eos_scale
     model.finalize(device, dtype).eval()
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=5000, cmvn=dict(norm_means=True, norm_vars=True, before=True))
     wave = synth_waveforms(BATCH, SAMPLES).to(device)
@@ -523,8 +531,10 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100):
     cached = sum(rows * (per_pos + nl * 4 * d * (t + 1 + S) + 2 * d * VOCAB) for t in range(steps)) + BATCH * S * nl * 4 * d * d
     uncached = sum(rows * ((t + 1) * per_pos + nl * (4 * d * (t + 1) * (t + 2) // 2 + 4 * d * S * (t + 1)) + nl * S * 4 * d * d + 2 * d * VOCAB)
                    for t in range(steps))
+    hyp_len = [int((row != 1).sum()) for row in np.asarray(ids)]  # non-pad tokens per best hypothesis (EOS cut by the search)
     return {"rtf": round(dt / audio_s, 6), "wall_s": round(dt, 3), "audio_s": audio_s, "beam": beam, "alpha": alpha,
-            "steps": steps, "steps_per_s": round(steps / dt, 1), "decoder_tflop_kv_cached": round(cached / 1e12, 3),
+            "steps": steps, "steps_per_s": round(steps / dt, 1),
+            "hyp_len_min_median_max": [int(np.min(hyp_len)), int(np.median(hyp_len)), int(np.max(hyp_len))], "decoder_tflop_kv_cached": round(cached / 1e12, 3),
             "decoder_tflop_full_prefix": round(uncached / 1e12, 3), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16",
             "decoding": "KV-cached, hipGraph-replayed step"}
 
@@ -687,6 +697,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_decode:
         try:
             decode = decode_rtf(device)
+            # the same decode with a model whose lower beams end in EOS at every step while the best one goes on: the
+            # host-side bookkeeping of finished hypotheses (search.py:683-717) then runs in all 100 steps
+            fin = decode_rtf(device, eos_scale=0.2)
+            decode["with_hypotheses_finishing_every_step"] = {k: fin[k] for k in ("rtf", "wall_s", "steps", "hyp_len_min_median_max")}
         except Exception as exc:
             decode = {"error": repr(exc)}
     if rank == 0:

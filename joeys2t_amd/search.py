@@ -19,6 +19,7 @@ between those stages, so with any of them on the step runs as js2t_log_softmax -
   * `return_attention` (greedy only, :318-325): cross-attention weights of the last layer, full-prefix pass."""
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -269,25 +270,26 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
 
         if bool(is_finished.any()):
             # one device->host transfer per step for the bookkeeping below (the reference syncs per hypothesis, :683-717)
+            # and the tests of :683-717 for all (utterance, beam) pairs at once: with a trained model some hypothesis ends at
+            # most steps, and a Python loop of small tensor operations per pair (~1 ms per step at 32 x 5) costs more than the
+            # replayed decoder step itself
             fin_h, end_h = is_finished.cpu(), end_condition.cpu()
             pred_h = alive_seq.view(-1, beam_size, alive_seq.size(-1)).cpu()
             score_h = topk_scores.cpu()
-            for i in range(fin_h.size(0)):
-                b = int(batch_offset[i])
-                if end_h[i]:
-                    fin_h[i].fill_(True)
-                for j in fin_h[i].nonzero(as_tuple=False).view(-1).tolist():
-                    n_eos = int((pred_h[i, j, 1:] == eos).count_nonzero())
-                    if n_eos > 1:
-                        continue  # already collected at an earlier step
-                    if (n_eos == 0 and step + 1 == max_output_length) or (n_eos == 1 and pred_h[i, j, -1] == eos):
-                        hypotheses[b].append((score_h[i, j], pred_h[i, j, 1:]))
-                if end_h[i]:
-                    for n, (score, pred) in enumerate(sorted(hypotheses[b], key=lambda x: x[0], reverse=True)):
-                        if n >= n_best:
-                            break
-                        results["scores"][b].append(score)
-                        results["predictions"][b].append(pred)
+            fin_h[end_h] = True
+            pred_np = pred_h.numpy()
+            n_eos = (pred_np[:, :, 1:] == eos).sum(-1)  # 0: still open, 1: ends here or ended earlier, > 1: collected earlier
+            take = fin_h.numpy() & (((n_eos == 0) & (step + 1 == max_output_length)) | ((n_eos == 1) & (pred_np[:, :, -1] == eos)))
+            offs = batch_offset.tolist()
+            for i, j in zip(*np.nonzero(take)):  # row-major: utterances ascending, beams ascending, as the reference's loops
+                hypotheses[offs[i]].append((score_h[i, j], pred_h[i, j, 1:]))
+            for i in np.nonzero(end_h.numpy())[0]:
+                b = offs[i]
+                for n, (score, pred) in enumerate(sorted(hypotheses[b], key=lambda x: x[0], reverse=True)):
+                    if n >= n_best:
+                        break
+                    results["scores"][b].append(score)
+                    results["predictions"][b].append(pred)
             unfinished_h = end_h.eq(False).nonzero(as_tuple=False).view(-1)
             if len(unfinished_h) == 0:
                 break
