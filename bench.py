@@ -216,11 +216,31 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
             # group (one grouped launch per Linear shape = one range of the flat gradient) becomes a graph of its own, so
             # that the range's all-reduce can be handed to RCCL between two replays; the update is the last piece.
             plan = step.rt.wgrad_queue.take()
-            state["plan"], graphs["wgrad"] = plan, []
+            # one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start): groups
+            # that finish no range ride with the next one that does - eleven groups, four or five pieces
+            red = step.reducer
+            pend = [0] * len(red.ranges)
+            for _, items in plan:
+                for it in items:
+                    pend[red.bucket_of_tensor(it[2])] += 1
+            pieces, cur = [], []
             for entry in plan:
+                cur.append(entry)
+                done = False
+                for it in entry[1]:
+                    bi = red.bucket_of_tensor(it[2])
+                    pend[bi] -= 1
+                    done = done or pend[bi] == 0
+                if done:
+                    pieces.append(cur)
+                    cur = []
+            if cur:
+                pieces.append(cur)
+            state["plan"], state["pieces"], graphs["wgrad"] = plan, pieces, []
+            for piece in pieces:
                 gw = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
-                    WgradQueue.run([entry])
+                    WgradQueue.run(piece)
                 graphs["wgrad"].append(gw)
             gu = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
@@ -235,10 +255,17 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         graphs["step"].replay()
         if ddp:
             plan, red = state["plan"], step.reducer
+            if os.environ.get("JS2T_BENCH_NO_EXCHANGE") == "1":  # measurement only: the price of the cut without the collectives
+                for gw in graphs["wgrad"]:
+                    gw.replay()
+                graphs["update"].replay()
+                step.after_update()
+                return
             red.exchange_begin(plan)
-            for (_, items), gw in zip(plan, graphs["wgrad"]):
+            for piece, gw in zip(state["pieces"], graphs["wgrad"]):
                 gw.replay()
-                red.entries_done(items)
+                for _, items in piece:
+                    red.entries_done(items)
             red.finish()
             graphs["update"].replay()
         step.after_update()
@@ -721,7 +748,7 @@ def main():
                        "lengths": "ragged 10-17 s, un-padded frames counted" if args.ragged else "fixed 15 s",
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
                        "launch": ("hipGraph replay" if world == 1 and not force_ddp else
-                                  "hipGraph replay in pieces (fwd+bwd | weight-gradient groups | update) around the RCCL calls") if use_graph else "eager",
+                                  "hipGraph replay in pieces (fwd+bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
                        "capture_error": capture_error,
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
