@@ -107,9 +107,13 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
     model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
     model.finalize(device, dtype, seed=seed)
+    # gradient exchange: bf16 over RCCL by default (JS2T_COMM_DTYPE=fp32 for the reference's fp32 all-reduce); gloo: fp32
+    comm_dtype = None
+    if ddp and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and os.environ.get("JS2T_COMM_DTYPE", "bf16") == "bf16":
+        comm_dtype = torch.bfloat16
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
                      learning_rate_warmup=10000, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1,
-                     n_gpu=world,
+                     n_gpu=world, comm_dtype=comm_dtype,
                      # second stream for the CTC branch - except in the gloo rehearsal, where several ranks time-slice ONE card
                      # and its cross-stream waits turn into a 13x slowdown (an artefact of that set-up, not of RCCL)
                      overlap_ctc=(world == 1 or torch.distributed.get_backend() == "nccl") and os.environ.get("JS2T_OVERLAP_CTC", "1") != "0")
@@ -751,6 +755,7 @@ def main():
                                   "hipGraph replay in pieces (fwd+bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
                        "capture_error": capture_error,
+                       "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else ("bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32"),
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode,
         }

@@ -103,9 +103,15 @@ class FlatGradReducer:
     no_sync() after the forward, which does not disarm the reducer) — the summed gradient is identical."""
 
     def __init__(self, store, n_buckets: int = 4, average: bool = True, comm_stream: Optional["torch.cuda.Stream"] = None,
-                 ranges=None):
+                 ranges=None, comm_dtype: Optional[torch.dtype] = None):
         self.store = store
         self.average = average
+        # comm_dtype=torch.bfloat16 (GPU + RCCL only): a range goes over the links as bf16 - cast into a staging buffer, averaged
+        # there, cast back into the fp32 flat gradient, all on the communication stream.  Half the bytes on xGMI (point-to-point
+        # links: a ring all-reduce is bound by one of them) for a rounding of 2^-9 relative on gradients that come out of bf16
+        # products anyway.  None (default): the fp32 exchange of torch's DistributedDataParallel (prediction.py:508-515).
+        self.comm_dtype = comm_dtype
+        self._stage = None
         self.world = dist.get_world_size() if use_ddp() else 1
         total = store.total
         # buckets are contiguous flat ranges cut at parameter boundaries, in REVERSE flat order (backward order)
@@ -172,7 +178,20 @@ class FlatGradReducer:
         lo, hi = self.ranges[bi]
         buf = self.store.flat_grad[lo:hi]
         op = dist.ReduceOp.AVG if (self.average and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
-        if self.on_gpu:
+        if self.on_gpu and self.comm_dtype is not None and self.comm_dtype != torch.float32 and dist.get_backend() == "nccl":
+            from joeys2t_amd import ops
+            if self._stage is None:
+                self._stage = torch.empty(self.store.total, dtype=self.comm_dtype, device=self.store.device)
+            st = self._stage[lo:hi]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                ops.cast(buf, self.comm_dtype, out=st)
+                w = dist.all_reduce(st, op=op, async_op=True)
+                w.wait()  # a stream-side wait: the cast back is ordered behind the collective, the host goes on
+                ops.cast(st, torch.float32, out=buf)
+        elif self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):

@@ -30,7 +30,7 @@ class TrainStep:
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
                  learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
                  batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False,
-                 defer_wgrads: bool = True, overlap_ctc: bool = False):
+                 defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None):
         self.model = model
         model.overlap_ctc = bool(overlap_ctc)
         self.rt = model.runtime
@@ -57,7 +57,8 @@ class TrainStep:
         self.rt.grad_copies = ops.GradCopies(self.store.device) if defer_wgrads else None
         self.reducer = None
         if use_ddp():
-            self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None)
+            self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None,
+                                           comm_dtype=comm_dtype)
         # bucket bookkeeping by per-parameter notifications only without the queue (with it: exchange_and_flush)
         self.rt.on_grads_ready = self.reducer.params_ready if (self.reducer is not None and self.rt.wgrad_queue is None) else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]

@@ -67,3 +67,47 @@ def test_overlapped_exchange_averages_gradients(device):
         err, ref, differs = ret[r]
         assert differs > 1e-3 * ref
         assert err <= 2e-3 * ref, (err, ref)  # split-K atomics / bf16 products: not bit-reproducible run to run
+
+
+def _rccl_bf16_worker(rank, port, ret):
+    """One rank, RCCL: the bf16 staging path of the exchange (cast -> all-reduce(avg) -> cast back on the communication stream)."""
+    import torch.distributed as dist
+    from joeys2t_amd.helpers_for_ddp import FlatGradReducer
+    from joeys2t_amd.runtime import ParamStore
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["JS2T_DDP_SINGLE"] = "1"  # a one-rank communicator exchanges nothing unless asked to
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 32)).to(dev)
+        store = ParamStore(net, dev)
+        store.attach_grads()
+        out = {}
+        for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
+            red = FlatGradReducer(store, n_buckets=3, comm_dtype=dt)
+            store.flat_grad.copy_(torch.randn(store.total, generator=torch.Generator().manual_seed(5)).to(dev))
+            before = store.flat_grad.clone()
+            red.begin(armed=True)
+            red.finish()
+            torch.cuda.synchronize()
+            out[name] = (before.cpu(), store.flat_grad.clone().cpu())
+            for h in red._hooks:
+                h.remove()
+        ret["res"] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_over_rccl_single_rank(device):
+    """FlatGradReducer(comm_dtype=bf16) on a real (one-rank) RCCL communicator: the flat gradient comes back as its own
+    bf16 rounding (mean over one rank), the fp32 exchange leaves it untouched."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_bf16_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    res = ret["res"]
+    before, after = res["fp32"]
+    assert torch.equal(before, after)
+    before, after = res["bf16"]
+    assert torch.equal(after, before.bfloat16().float()) and not torch.equal(after, before)
