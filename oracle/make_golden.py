@@ -676,6 +676,58 @@ def golden_text_tail(name="text_tail"):
     print(name, "sp cases", len(out["sentencepiece"]["cases"]), "token batches", len(samplers["token_0"]["epochs"][0]))
 
 
+def golden_ref_unit_tests(name="ref_unit_tests"):
+    """The known-answer tests of the reference's own suite for the Transformer stacks, replayed with the reference's classes:
+    test/unit/test_transformer_encoder.py:31-90 (3 layers, 4 heads of 3, pre-LN, parameters ~ U(-0.5, 0.5) under seed 42) and
+    test/unit/test_transformer_decoder.py:45-172 (logits, last-layer cross-attention, hidden states).  Stored: parameters, inputs,
+    the reference's outputs - and the first rows of the constants the tests hard-code, which the outputs are asserted to match
+    here (the tests' tolerance 1e-4), so the fixture is tied to those constants and not only to this replay."""
+    from joeynmt.decoders import TransformerDecoder
+    from joeynmt.encoders import TransformerEncoder
+    out = {}
+    torch.manual_seed(42)  # setUp
+    torch.manual_seed(42)  # test_transformer_encoder_forward
+    enc = TransformerEncoder(hidden_size=12, ff_size=24, num_layers=3, num_heads=4, dropout=0.0, emb_dropout=0.0, alpha=1.0, layer_norm="pre")
+    for p in enc.parameters():
+        torch.nn.init.uniform_(p, -0.5, 0.5)
+    x = torch.rand(size=(2, 4, 12))
+    x_length = torch.Tensor([4, 4]).int()
+    mask = torch.ones([2, 1, 4]) == 1
+    y, hidden, _ = enc(x, x_length, mask)
+    assert hidden is None
+    enc_row0 = torch.tensor([1.9728e-01, -1.2042e-01, 8.0998e-02, 1.3411e-03, -3.5960e-01, -5.2988e-01, -5.6056e-01, -3.5297e-01,
+                             2.6680e-01, 2.8343e-01, -3.7342e-01, -5.9112e-03])  # output_target[0, 0] of the reference test
+    torch.testing.assert_close(y[0, 0].detach(), enc_row0, rtol=1e-4, atol=1e-4)
+    out.update({"enc.sd." + k: v.detach().numpy() for k, v in enc.state_dict().items()})
+    out.update({"enc.x": x.numpy(), "enc.out": y.detach().numpy(), "enc.test_const_row0": enc_row0.numpy()})
+
+    torch.manual_seed(42)  # setUp of test_transformer_decoder.py
+    trg_embed = torch.rand(size=(2, 5, 12))
+    dec = TransformerDecoder(num_layers=3, num_heads=4, hidden_size=12, ff_size=24, dropout=0.0, emb_dropout=0.0, vocab_size=7, alpha=1.0,
+                             layer_norm="pre")
+    encoder_output = torch.rand(size=(2, 4, 12))
+    for p in dec.parameters():
+        torch.nn.init.uniform_(p, -0.5, 0.5)
+    src_mask = torch.ones(size=(2, 1, 4)) == 1
+    trg_mask = torch.ones(size=(2, 5, 1)) == 1
+    logits, states, att, _, _ = dec(trg_embed, encoder_output, None, src_mask, None, None, trg_mask, return_attention=True)
+    dec_row0 = torch.tensor([0.1718, 0.5595, -0.1996, -0.6924, 0.4351, -0.0850, 0.2805])  # output_target[0, 0]
+    att_row0 = torch.tensor([0.2494, 0.2482, 0.2419, 0.2605])  # att_target[0, 0]
+    st_row0 = torch.tensor([3.7535e-02, 5.3508e-01, 4.9478e-02, -9.1961e-01, -5.3966e-01, -1.0065e-01, 4.3053e-01, -3.0671e-01,
+                            -1.2724e-02, -4.1879e-01, 5.9625e-01, 1.1887e-01])  # states_target[0, 0]
+    torch.testing.assert_close(logits[0, 0].detach(), dec_row0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(att[0, 0].detach(), att_row0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(states[0, 0].detach(), st_row0, rtol=1e-4, atol=1e-4)
+    out.update({"dec.sd." + k: v.detach().numpy() for k, v in dec.state_dict().items()})
+    out.update({"dec.trg_embed": trg_embed.numpy(), "dec.memory": encoder_output.numpy(), "dec.logits": logits.detach().numpy(),
+                "dec.att": att.detach().numpy(), "dec.states": states.detach().numpy(), "dec.test_const_logits_row0": dec_row0.numpy(),
+                "dec.test_const_att_row0": att_row0.numpy(), "dec.test_const_states_row0": st_row0.numpy()})
+    # test_model_init.py:81-117: DeepNet residual scale of a 6 + 6 stack under `xavier_normal`
+    out["deepnet_alpha_6_6"] = np.array([1.417938140685523, 2.0597671439071177])
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print("wrote", name, len(out), "arrays")
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -686,6 +738,7 @@ def main():
         "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
         "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
+        "ref_unit_tests": golden_ref_unit_tests,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

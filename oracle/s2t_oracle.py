@@ -255,12 +255,20 @@ def decoder_forward(sd: SD, cfg: dict, trg_input: Tensor, memory: Tensor, src_ma
     """TransformerDecoder.forward, decoders.py:567-625 (eval mode) -> (logits, hidden, att, ctc_logits|None).
     trg_prompt_mask (0/1 ids [B, L]): embedded with the target table and added after the positional encoding
     (model.py:271-282, decoders.py:600-602)."""
-    dcfg = cfg["decoder"]
     x = embed(sd, cfg, trg_input)
-    x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
-    if trg_prompt_mask is not None:
-        x = x + embed(sd, cfg, trg_prompt_mask)
-    tmask = trg_mask & subsequent_mask(trg_input.size(1))
+    return decoder_forward_embedded(sd, cfg, x, memory, src_mask, trg_mask, return_attention, prefix,
+                                    None if trg_prompt_mask is None else embed(sd, cfg, trg_prompt_mask))
+
+
+def decoder_forward_embedded(sd: SD, cfg: dict, trg_embed: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor,
+                             return_attention: bool = False, prefix: str = "decoder", prompt_embed: Optional[Tensor] = None):
+    """TransformerDecoder.forward proper (decoders.py:567-625): takes the embedded targets, as the reference's own
+    known-answer test does (test/unit/test_transformer_decoder.py:45-172)."""
+    dcfg = cfg["decoder"]
+    x = trg_embed + positional_table(5000, trg_embed.size(-1))[: trg_embed.size(1)].unsqueeze(0)
+    if prompt_embed is not None:
+        x = x + prompt_embed
+    tmask = trg_mask & subsequent_mask(trg_embed.size(1))
     att = None
     n = dcfg["num_layers"]
     for i in range(n):

@@ -255,3 +255,36 @@ def test_full_width_model_matches_oracle(device):
     assert abs(f32[1] - rx.item()) <= 1e-4 * abs(rx.item()) and abs(f32[2] - rc.item()) <= 1e-4 * abs(rc.item())
     assert f32[3] == int(rn)
     assert abs(bf[0] - rt.item()) <= 2e-2 * abs(rt.item()), (bf, rt.item())
+
+
+def test_reference_unit_test_known_answers_on_the_hip_path(device):
+    """The reference's own known-answer tests for the Transformer stacks (test/unit/test_transformer_encoder.py:31-90,
+    test/unit/test_transformer_decoder.py:45-172; captured with the constants they hard-code in tests/golden/ref_unit_tests.npz),
+    run the way those tests run them: the encoder / decoder classes constructed directly, parameters loaded, fp32, 1e-4."""
+    from conftest import load_golden
+    from joeys2t_amd.decoders import TransformerDecoder
+    from joeys2t_amd.encoders import TransformerEncoder
+    from joeys2t_amd.runtime import Runtime, install_runtime
+    g = load_golden("ref_unit_tests")
+    enc = TransformerEncoder(hidden_size=12, ff_size=24, num_layers=3, num_heads=4, dropout=0.0, emb_dropout=0.0, alpha=1.0, layer_norm="pre")
+    enc.load_state_dict({k[len("enc.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("enc.sd.")})
+    enc.to(device)
+    install_runtime(enc, Runtime(device, torch.float32))
+    x = torch.from_numpy(g["enc.x"]).to(device)
+    y, hidden, _ = enc(x, torch.tensor([4, 4], device=device), torch.ones(2, 1, 4, dtype=torch.bool, device=device))
+    assert hidden is None
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["enc.out"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y[0, 0].detach().cpu().numpy(), g["enc.test_const_row0"], rtol=1e-4, atol=1e-4)
+
+    dec = TransformerDecoder(num_layers=3, num_heads=4, hidden_size=12, ff_size=24, dropout=0.0, emb_dropout=0.0, vocab_size=7, alpha=1.0,
+                             layer_norm="pre")
+    dec.load_state_dict({k[len("dec.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dec.sd.")})
+    dec.to(device)
+    install_runtime(dec, Runtime(device, torch.float32))
+    src_mask = torch.ones(2, 1, 4, dtype=torch.bool, device=device)
+    trg_mask = torch.ones(2, 5, 1, dtype=torch.bool, device=device)
+    logits, states, att, _, _ = dec(torch.from_numpy(g["dec.trg_embed"]).to(device), torch.from_numpy(g["dec.memory"]).to(device), None,
+                                    src_mask, None, None, trg_mask, return_attention=True)
+    for got, key in ((logits, "logits"), (att, "att"), (states, "states")):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), g["dec." + key], rtol=1e-4, atol=1e-4, err_msg=key)
+        np.testing.assert_allclose(got[0, 0].detach().cpu().numpy(), g[f"dec.test_const_{key}_row0"], rtol=1e-4, atol=1e-4, err_msg=key)

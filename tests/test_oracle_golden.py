@@ -234,3 +234,38 @@ def test_search_options_match_reference_tests():
         ids, _, att = O.greedy(sd, cfg, S, enc, (src != 1).unsqueeze(1), 3, generate_unk=False, repetition_penalty=1.5, encoder_input=src,
                                return_attention=True)
         _cmp(g, "greedy_src_penalty", ids, att=att)
+
+
+REF_UNIT_CFG = {"encoder": {"num_layers": 3, "num_heads": 4, "layer_norm": "pre", "activation": "relu", "alpha": 1.0, "subsample": False},
+                "decoder": {"num_layers": 3, "num_heads": 4, "layer_norm": "pre", "activation": "relu", "alpha": 1.0,
+                            "embeddings": {"scale": False}}}
+
+
+def test_reference_unit_test_known_answers():
+    """The oracle against the known-answer tests of the reference's own suite (tests/golden/ref_unit_tests.npz, written by
+    oracle/make_golden.py:golden_ref_unit_tests from the reference's classes and tied there to the constants the tests
+    hard-code): test/unit/test_transformer_encoder.py:31-90 and test/unit/test_transformer_decoder.py:45-172, tolerance 1e-4
+    as in those tests; the DeepNet residual scales of test/unit/test_model_init.py:104-107."""
+    g = load_golden("ref_unit_tests")
+    sd = {"encoder." + k[len("enc.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("enc.sd.")}
+    x = torch.from_numpy(g["enc.x"])
+    y, mask, _ = O.encoder_forward(sd, REF_UNIT_CFG, x, torch.tensor([4, 4]))
+    torch.testing.assert_close(y, torch.from_numpy(g["enc.out"]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y[0, 0], torch.from_numpy(g["enc.test_const_row0"]), rtol=1e-4, atol=1e-4)
+    sd = {"decoder." + k[len("dec.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dec.sd.")}
+    src_mask, trg_mask = torch.ones(2, 1, 4, dtype=torch.bool), torch.ones(2, 5, 1, dtype=torch.bool)
+    logits, states, att, _ = O.decoder_forward_embedded(sd, REF_UNIT_CFG, torch.from_numpy(g["dec.trg_embed"]), torch.from_numpy(g["dec.memory"]),
+                                                        src_mask, trg_mask, return_attention=True)
+    for got, key in ((logits, "logits"), (att, "att"), (states, "states")):
+        torch.testing.assert_close(got, torch.from_numpy(g["dec." + key]), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got[0, 0], torch.from_numpy(g[f"dec.test_const_{key}_row0"]), rtol=1e-4, atol=1e-4)
+    # the product's model builder computes the same residual scales (initialization.py of the reference, :176-210)
+    import copy
+    from golden_cfg import FIXTURES
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.vocabulary import Vocabulary
+    cfg = copy.deepcopy(FIXTURES["model_deepnet"]["cfg"])
+    cfg["encoder"]["num_layers"] = cfg["decoder"]["num_layers"] = 6
+    model = build_model(cfg, None, Vocabulary.synthetic(20))
+    assert {layer.alpha for layer in model.encoder.layers} == {float(g["deepnet_alpha_6_6"][0])}
+    assert {layer.alpha for layer in model.decoder.layers} == {float(g["deepnet_alpha_6_6"][1])}
