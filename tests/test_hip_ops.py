@@ -646,6 +646,45 @@ def test_gemm_bf16_p192_persistent_tile(device, M, N, K):
         lib().js2t_gemm_p192_mode(-1)
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_gemm_p192_variants_agree_on_random_shapes(device, seed):
+    """The three forms of the persistent 192x128 kernel - one block per CU with a three-slot ring, two blocks per CU with two-slot
+    rings, eight multiplying + four requesting waves - on random shapes (ragged last row tile, partial last column tile, partial
+    last K stage, fewer tiles than CUs and several per block) with random epilogues: bit-identical results, and the plain
+    product close to fp32 math."""
+    from joeys2t_amd._lib import lib
+    rs = np.random.RandomState(100 + seed)
+    M = int(rs.choice([1, 47, 192, 193, 500, 2592, 3001, 12000, 25000]))
+    N = int(rs.choice([128, 136, 264, 512, 1000, 1536, 2048]))
+    K = int(rs.choice([192, 200, 256, 520, 1024, 2048]))
+    A = rnd(M, K, seed=seed).bfloat16().to(device)
+    B = rnd(N, K, seed=seed + 50).bfloat16().to(device)
+    bias = rnd(N, seed=3).to(device)
+    res = rnd(M, N, seed=4).bfloat16().to(device)
+    rng = ops.dropout_rng(device)
+    epilogues = [{}, dict(bias=bias), dict(bias=bias, act="relu", dropout_p=0.1, rng=rng, rng_stream=7),
+                 dict(bias=bias, dropout_p=0.2, rng=rng, rng_stream=9, residual=res, ldr=N, res_scale=1.0), dict(gate=res, ldg=N, gate_scale=1.1),
+                 dict(bias=bias, act="relu", alpha=0.5), dict(residual=res, ldr=N, res_scale=0.5)]
+    kw = epilogues[int(rs.randint(len(epilogues)))]
+    outs = {}
+    lib().js2t_gemm_p192_mode(1)
+    try:
+        for ring in (3, 2, 4):
+            lib().js2t_gemm_p192_ring(ring)
+            C = torch.full((M, N), float("nan"), device=device, dtype=torch.bfloat16)
+            ops.gemm(A, B, C, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+            torch.cuda.synchronize()
+            outs[ring] = C
+    finally:
+        lib().js2t_gemm_p192_ring(-1)
+        lib().js2t_gemm_p192_mode(-1)
+    assert torch.equal(outs[2], outs[3]) and torch.equal(outs[4], outs[3]), (M, N, K, sorted(kw))
+    assert torch.isfinite(outs[3].float()).all()
+    if not kw:
+        ref = A.float().cpu() @ B.float().cpu().t()
+        torch.testing.assert_close(outs[3].float().cpu(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
+
+
 def test_transposed_weight_shadow(device):
     """ParamStore.view_t: the transposed bf16 shadow of fused / single 2-D weights follows the parameters (also after an update)."""
     from joeys2t_amd.runtime import ParamStore
