@@ -16,7 +16,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(int iters, float* out, int random_data) {
+__global__ __launch_bounds__(256) void k(int iters, float* out, int random_data, unsigned long long* ticks) {
+  const unsigned long long t0_ = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   for (int i = t; i < 40960 / 4; i += blockDim.x) {
@@ -77,10 +78,13 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, int random_data)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
   if (s == 12345.f) out[0] = s;
+  if (threadIdx.x == 0) ticks[blockIdx.x] = __builtin_readcyclecounter() - t0_;
 }
 
 template <int MODE>
 static void run(const char* name, int blocks_per_cu, float* out, int random_data) {
+  static unsigned long long* ticks = nullptr;
+  if (!ticks) CK(hipMalloc(&ticks, 1024 * sizeof(unsigned long long)));
   const int iters = 2000, grid = 256 * blocks_per_cu;
   CK(hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 + 256));
   hipEvent_t e0, e1;
@@ -89,17 +93,22 @@ static void run(const char* name, int blocks_per_cu, float* out, int random_data
   float best = 1e30f;
   for (int r = 0; r < 4; ++r) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 40960 + 256, 0, iters, out, random_data);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 40960 + 256, 0, iters, out, random_data, ticks);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     if (r && ms < best) best = ms;
   }
+  unsigned long long h[1024];
+  CK(hipMemcpy(h, ticks, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double tk = 0;
+  for (int i = 0; i < grid; ++i) tk += (double)h[i];
+  tk /= grid;
   const double flop = (double)grid * 4 * iters * 48 * 16384.0;
-  printf("%s %-44s %d block(s)/CU  %7.1f ns per 48 MFMAs per wave  %7.1f TFLOP/s  -> %.2f GHz if MFMA-bound at 16 cycles\n", random_data ? "random  " : "constant", name,
+  printf("%s %-44s %d block(s)/CU  %7.1f ns per 48 MFMAs per wave  %7.1f TFLOP/s  -> %.2f GHz if MFMA-bound at 16 cycles; s_memtime %.2f ticks/ns\n", random_data ? "random  " : "constant", name,
          blocks_per_cu, best * 1e6 / iters / blocks_per_cu * blocks_per_cu, flop / (best * 1e-3) / 1e12,
-         (double)blocks_per_cu * iters * 48 * 16 / (best * 1e-3) / 1e9);
+         (double)blocks_per_cu * iters * 48 * 16 / (best * 1e-3) / 1e9, tk / (best * 1e6));  // every block is resident for (nearly) the whole launch
 }
 
 int main() {
