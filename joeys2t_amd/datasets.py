@@ -19,86 +19,108 @@ from torch.utils.data import BatchSampler, Sampler
 logger = logging.getLogger(__name__)
 
 
-class SentenceBatchSampler(BatchSampler):
-    """Mini-batches of `batch_size` instances (reference datasets.py:1164-1246)."""
+class _InstanceBatcher(BatchSampler):
+    """What the two batch samplers share: walk the index sampler, look every instance up in its dataset, skip the ones the
+    length filter emptied, and cut a batch whenever `_closed(n_instances, widest)` says so.  `widest` is the largest
+    `_weigh(src, trg)` seen in the open batch; what is left over at the end of an epoch is handed out unless `drop_last`."""
 
     def __init__(self, sampler: Sampler, batch_size: int, drop_last: bool, seed: int):
         super().__init__(sampler, batch_size, drop_last)
         self.seed = seed
 
+    # -- the batching rule (overridden per sampler) ------------------------------------------------------------------------
+    def _weigh(self, src, trg) -> int:
+        return 1
+
+    def _closed(self, n_instances: int, widest: int) -> bool:
+        raise NotImplementedError
+
+    def _usable_instances(self):
+        dataset = self.sampler.data_source
+        for index in self.sampler:
+            _, src, trg = dataset[index]
+            if src is not None:
+                yield index, self._weigh(src, trg)
+
+    def __iter__(self) -> Iterator[List[int]]:
+        open_batch: List[int] = []
+        widest = 0
+        for index, weight in self._usable_instances():
+            open_batch.append(index)
+            widest = max(widest, weight)
+            if self._closed(len(open_batch), widest):
+                yield open_batch
+                open_batch, widest = [], 0
+        if open_batch and self.drop_last:
+            logger.warning("Drop indices %s.", open_batch)
+        elif open_batch:
+            yield open_batch
+
+    # -- sampler plumbing ----------------------------------------------------------------------------------------------------
     @property
     def num_samples(self) -> int:
-        assert self.sampler.data_source.indices is not None
+        """Instances one epoch draws: the index sampler's own length where it defines one, else the dataset's index list."""
+        pool = self.sampler.data_source.indices
+        if pool is None:
+            raise AssertionError("the dataset has no active index list")
         try:
-            return len(self.sampler)
+            n = len(self.sampler)
         except NotImplementedError:
-            return len(self.sampler.data_source.indices)
-
-    def __iter__(self) -> Iterator[List[int]]:
-        batch = []
-        d = self.sampler.data_source
-        for idx in self.sampler:
-            _, src, _ = d[idx]
-            if src is not None:  # otherwise drop the instance
-                batch.append(idx)
-                if len(batch) >= self.batch_size:
-                    yield batch
-                    batch = []
-        if len(batch) > 0:
-            if not self.drop_last:
-                yield batch
-            else:
-                logger.warning("Drop indices %s.", batch)
-
-    def __len__(self) -> int:
-        if self.drop_last:
-            return self.num_samples // self.batch_size
-        return (self.num_samples + self.batch_size - 1) // self.batch_size
+            n = len(pool)
+        return n
 
     def set_seed(self, seed: int) -> None:
+        """Re-seed dataset and index sampler (a sampler with its own `set_seed` also re-draws its random subset)."""
         assert seed is not None, seed
-        self.sampler.data_source.seed = seed
-        if hasattr(self.sampler, "set_seed"):
-            self.sampler.set_seed(seed)  # set seed and resample
-        elif hasattr(self.sampler, "generator"):
-            self.sampler.generator.manual_seed(seed)
+        inner = self.sampler
+        inner.data_source.seed = seed
+        reseed = getattr(inner, "set_seed", None)
+        if reseed is not None:
+            reseed(seed)
+        elif getattr(inner, "generator", None) is not None:
+            inner.generator.manual_seed(seed)
 
     def reset(self) -> None:
-        if hasattr(self.sampler, "reset"):
-            self.sampler.reset()
+        undo = getattr(self.sampler, "reset", None)
+        if undo is not None:
+            undo()
+
+    def _generator(self):
+        return getattr(self.sampler, "generator", None)
 
     def get_state(self):
-        return self.sampler.generator.get_state() if hasattr(self.sampler, "generator") else None
+        gen = self._generator()
+        return None if gen is None else gen.get_state()
 
     def set_state(self, state) -> None:
-        if hasattr(self.sampler, "generator"):
-            self.sampler.generator.set_state(state)
+        gen = self._generator()
+        if gen is not None:
+            gen.set_state(state)
 
 
-class TokenBatchSampler(SentenceBatchSampler):
-    """Mini-batches by token count incl. padding (reference datasets.py:1249-1295): the batch closes when
-    max_tokens_so_far * len(batch) >= batch_size; `len()` is undefined, as in the reference."""
+class SentenceBatchSampler(_InstanceBatcher):
+    """Mini-batches of `batch_size` instances (contract of the reference's datasets.py:1164-1246)."""
 
-    def __iter__(self) -> Iterator[List[int]]:
-        batch, max_tokens = [], 0
-        d = self.sampler.data_source
-        for idx in self.sampler:
-            _, src, trg = d[idx]
-            if src is not None:
-                src_len = len(src)
-                trg_len = 0 if trg is None else len(trg)
-                n_tokens = 0 if src_len == 0 else max(src_len + 1, trg_len + 1)
-                batch.append(idx)
-                if n_tokens > max_tokens:
-                    max_tokens = n_tokens
-                if max_tokens * len(batch) >= self.batch_size:
-                    yield batch
-                    batch, max_tokens = [], 0
-        if len(batch) > 0:
-            if not self.drop_last:
-                yield batch
-            else:
-                logger.warning("Drop indices %s.", batch)
+    def _closed(self, n_instances: int, widest: int) -> bool:
+        return n_instances >= self.batch_size
+
+    def __len__(self) -> int:
+        whole, rest = divmod(self.num_samples, self.batch_size)
+        return whole if (self.drop_last or rest == 0) else whole + 1
+
+
+class TokenBatchSampler(_InstanceBatcher):
+    """Mini-batches by padded token count (contract of the reference's datasets.py:1249-1295): an instance weighs
+    max(len(src), len(trg)) + 1 (0 for an empty source), and the batch closes once widest * n_instances reaches batch_size -
+    no bucketing.  The number of batches is not known ahead of an epoch: `len()` raises, as in the reference."""
+
+    def _weigh(self, src, trg) -> int:
+        if len(src) == 0:
+            return 0
+        return 1 + max(len(src), 0 if trg is None else len(trg))
+
+    def _closed(self, n_instances: int, widest: int) -> bool:
+        return widest * n_instances >= self.batch_size
 
     def __len__(self):
         raise NotImplementedError

@@ -9,7 +9,7 @@ produced all of its gradients, overlapping the exchange with the rest of backwar
 One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" serves the CPU tests."""
 import math
 import os
-from typing import Optional, Union
+from typing import List, Optional, Union
 
 import torch
 import torch.distributed as dist
@@ -258,91 +258,81 @@ class FlatGradReducer:
         self.exchange_mode = False
 
 
-class DistributedSubsetSampler(Sampler):
-    """Shared-seed permutation, truncated to a multiple of the world size, strided by rank (reference :244-342).
-    `dataset` needs `.indices` (list) like the reference's BaseDataset; `random_subset` is honoured via `_subsample`."""
-
-    def __init__(self, dataset: Dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True,
-                 drop_last: bool = True, generator: torch.Generator = None):
-        if num_replicas is None:
-            if not use_ddp():
-                raise RuntimeError("Requires distributed package to be available")
-            num_replicas = dist.get_world_size()
-        if rank is None:
-            if not use_ddp():
-                raise RuntimeError("Requires distributed package to be available")
-            rank = dist.get_rank()
-        if rank >= num_replicas or rank < 0:
-            raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}]")
-        self.data_source = dataset
-        self.num_replicas, self.rank, self.shuffle, self.drop_last, self.generator = num_replicas, rank, shuffle, drop_last, generator
-
-    @property
-    def num_samples(self) -> int:
-        return len(self.data_source.indices)
-
-    def __iter__(self):
-        indices = self.data_source.indices
-        if self.shuffle:
-            perm = torch.randperm(len(indices), generator=self.generator).tolist()
-            indices = [indices[i] for i in perm]
-        if len(indices) % self.num_replicas != 0 and not self.drop_last:
-            raise RuntimeError("`len(dataset)` must be divisible by `world_size`.")
-        total = (self.num_samples // self.num_replicas) * self.num_replicas
-        indices = indices[:total]
-        self.data_source.indices = indices
-        per_replica = indices[self.rank:self.num_samples:self.num_replicas]
-        assert len(per_replica) == math.ceil(self.num_samples / self.num_replicas)
-        return iter(per_replica)
-
-    def __len__(self) -> int:
-        # the reference defines no __len__ of its own: torch's DistributedSampler.__len__ returns self.num_samples, which the
-        # class overrides with the TOTAL number of (kept) indices, not the per-rank share (helpers_for_ddp.py:293-296)
-        return self.num_samples
-
-    def _subsample(self):
-        orig_len, subset_len = len(self.data_source), getattr(self.data_source, "random_subset", -1)
-        if 0 < subset_len < orig_len:
-            subset = torch.randperm(n=orig_len, generator=self.generator).tolist()[:subset_len]
-            self.data_source.indices = sorted(subset)
-
-    def reset(self):
-        self.data_source.reset_indices()
-
-    def set_seed(self, seed: int) -> None:
-        self.generator.manual_seed(seed)
-        self._subsample()
+def _epoch_order(pool: List[int], shuffle: bool, generator: Optional[torch.Generator]) -> List[int]:
+    """The dataset's index list in the order one epoch visits it (one randperm draw from `generator` when shuffling)."""
+    if not shuffle:
+        return list(pool)
+    return [pool[j] for j in torch.randperm(len(pool), generator=generator).tolist()]
 
 
-class RandomSubsetSampler(Sampler):
-    """Single-process counterpart (reference :345-391)."""
+def _rank_share(order: List[int], rank: int, world: int, drop_last: bool):
+    """-> (kept, mine): `order` cut to a multiple of `world` (an uneven list is an error unless drop_last), and every
+    world-th entry of it starting at `rank`."""
+    extra = len(order) % world
+    if extra and not drop_last:
+        raise RuntimeError("`len(dataset)` must be divisible by `world_size`.")
+    kept = order[:len(order) - extra]
+    return kept, kept[rank::world]
 
-    def __init__(self, data_source: Dataset, shuffle: bool, generator: torch.Generator):
+
+class _SubsetSampler(Sampler):
+    """Index sampler over `data_source.indices` (the reference's BaseDataset keeps the active subset there) with one shared
+    torch.Generator: `set_seed` re-seeds it and re-draws the dataset's `random_subset`, `reset` restores the full index list."""
+
+    def __init__(self, data_source: Dataset, shuffle: bool, generator: Optional[torch.Generator]):
         self.data_source, self.shuffle, self.generator = data_source, shuffle, generator
 
     @property
     def num_samples(self) -> int:
         return len(self.data_source.indices)
 
-    def __iter__(self):
-        indices = self.data_source.indices
-        if self.shuffle:
-            perm = torch.randperm(n=len(indices), generator=self.generator).tolist()
-            return iter([indices[i] for i in perm])
-        return iter(indices)
-
     def __len__(self) -> int:
         return self.num_samples
 
-    def _subsample(self):
-        orig_len, subset_len = len(self.data_source), getattr(self.data_source, "random_subset", -1)
-        if 0 < subset_len < orig_len:
-            subset = torch.randperm(n=orig_len, generator=self.generator).tolist()[:subset_len]
-            self.data_source.indices = sorted(subset)
-
-    def reset(self):
+    def reset(self) -> None:
         self.data_source.reset_indices()
 
     def set_seed(self, seed: int) -> None:
         self.generator.manual_seed(seed)
         self._subsample()
+
+    def _subsample(self) -> None:
+        """Honour `dataset.random_subset` = k: keep k indices drawn from the generator, in ascending order."""
+        size = len(self.data_source)
+        k = getattr(self.data_source, "random_subset", -1)
+        if k <= 0 or k >= size:
+            return
+        drawn = torch.randperm(n=size, generator=self.generator)[:k]
+        self.data_source.indices = sorted(drawn.tolist())
+
+
+class DistributedSubsetSampler(_SubsetSampler):
+    """One rank's share of an epoch (contract of the reference's helpers_for_ddp.py:244-342, pinned by a 2-rank capture in
+    tests/golden/ddp.npz): every rank shuffles with the same seed, the order is cut to a multiple of the world size and
+    dealt out round-robin.  Two things the capture shows and this class keeps: the dataset's index list is REPLACED by the
+    cut order (so the next epoch permutes that list), and `len()` is the total number of kept indices, not the share."""
+
+    def __init__(self, dataset: Dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None, shuffle: bool = True,
+                 drop_last: bool = True, generator: torch.Generator = None):
+        if (num_replicas is None or rank is None) and not use_ddp():
+            raise RuntimeError("Requires distributed package to be available")
+        world = dist.get_world_size() if num_replicas is None else num_replicas
+        me = dist.get_rank() if rank is None else rank
+        if not 0 <= me < world:
+            raise ValueError(f"Invalid rank {me}, rank should be in the interval [0, {world - 1}]")
+        super().__init__(dataset, shuffle, generator)
+        self.num_replicas, self.rank, self.drop_last = world, me, drop_last
+
+    def __iter__(self):
+        order = _epoch_order(self.data_source.indices, self.shuffle, self.generator)
+        kept, mine = _rank_share(order, self.rank, self.num_replicas, self.drop_last)
+        self.data_source.indices = kept
+        return iter(mine)
+
+
+class RandomSubsetSampler(_SubsetSampler):
+    """Single-process counterpart (contract of the reference's helpers_for_ddp.py:345-391): the whole index list, shuffled
+    per epoch when asked to."""
+
+    def __iter__(self):
+        return iter(_epoch_order(self.data_source.indices, self.shuffle, self.generator))

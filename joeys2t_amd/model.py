@@ -211,31 +211,38 @@ class Model(nn.Module):
 
 
 class DataParallelWrapper(nn.Module):
-    """Attribute pass-through for a (DDP-)wrapped model (reference model.py:323-363): `wrapper.module.module`
-    is the Model; state_dict()/load_state_dict() address the inner model so checkpoints carry no prefixes."""
+    """What TrainManager holds under DDP (contract of the reference's model.py:323-363): a shell around a data-parallel
+    wrapper `module` whose own `.module` is the Model.  Attribute reads fall through shell -> wrapper -> Model, forward()
+    goes through the wrapper (that is where the gradient exchange hooks in), and state_dict() / load_state_dict() talk to
+    the Model directly, so checkpoints written under DDP carry un-prefixed keys."""
 
     def __init__(self, module: nn.Module):
         super().__init__()
-        assert hasattr(module, "module")
+        if not hasattr(module, "module"):
+            raise AssertionError("DataParallelWrapper wraps a data-parallel module (something with a `.module`)")
         self.module = module
 
+    @property
+    def _model(self) -> nn.Module:
+        return self._modules["module"].module
+
     def __getattr__(self, name):
-        try:
-            return super().__getattr__(name)
-        except AttributeError:
+        wrapper = self._modules["module"]
+        for lookup in (lambda: nn.Module.__getattr__(self, name), lambda: getattr(wrapper, name), lambda: getattr(wrapper.module, name)):
             try:
-                return getattr(self.module, name)
+                return lookup()
             except AttributeError:
-                return getattr(self.module.module, name)
-
-    def state_dict(self, *args, **kwargs):
-        return self.module.module.state_dict(*args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        return self.module.module.load_state_dict(*args, **kwargs)
+                continue
+        raise AttributeError(f"neither {type(self).__name__}, {type(wrapper).__name__} nor {type(wrapper.module).__name__} has {name!r}")
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        return self._model.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self._model.load_state_dict(*args, **kwargs)
 
 
 def build_model(cfg: Dict = None, src_vocab=None, trg_vocab=None) -> Model:
