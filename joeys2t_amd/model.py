@@ -249,14 +249,23 @@ def build_model(cfg: Dict = None, src_vocab=None, trg_vocab=None) -> Model:
     """Build and initialise the model from the `model` section of a JoeyNMT config (reference model.py:366-506)."""
     enc_cfg, dec_cfg = dict(cfg["encoder"]), dict(cfg["decoder"])
     task = "MT" if src_vocab is not None else "S2T"
-    if task != "S2T":
-        raise ConfigurationError("joeys2t_amd builds the speech-to-text path only (src_vocab must be None)")
     trg_pad_index = trg_vocab.pad_index
-    src_pad_index = trg_pad_index
-    src_embed = nn.Identity()
+    if task == "MT":
+        # text source (configs/transformer_small.yaml, the plumbing config): an embedding table instead of fbank frames, no
+        # sub-sampler, no CTC head; everything behind the embedding is the same HIP path
+        src_pad_index = src_vocab.pad_index
+        src_embed = Embeddings(**enc_cfg["embeddings"], vocab_size=len(src_vocab), padding_idx=src_pad_index)
+        if enc_cfg["embeddings"]["embedding_dim"] != enc_cfg["hidden_size"]:
+            raise ConfigurationError("for transformer, emb_size must be the same as hidden_size.")
+    else:
+        src_pad_index = trg_pad_index
+        src_embed = nn.Identity()
     if cfg.get("tied_embeddings", False):
-        raise ConfigurationError("Embedding cannot be tied since vocabularies differ.")
-    trg_embed = Embeddings(**dec_cfg["embeddings"], vocab_size=len(trg_vocab), padding_idx=trg_pad_index)
+        if task != "MT" or src_vocab != trg_vocab:
+            raise ConfigurationError("Embedding cannot be tied since vocabularies differ.")
+        trg_embed = src_embed
+    else:
+        trg_embed = Embeddings(**dec_cfg["embeddings"], vocab_size=len(trg_vocab), padding_idx=trg_pad_index)
 
     if enc_cfg.get("type", "transformer") != "transformer" or dec_cfg.get("type", "transformer") != "transformer":
         raise ConfigurationError("RNN model not supported for s2t task. use transformer.")
@@ -266,7 +275,8 @@ def build_model(cfg: Dict = None, src_vocab=None, trg_vocab=None) -> Model:
                                  pad_index=src_pad_index)
     dec_dropout = dec_cfg.get("dropout", 0.0)
     dec_emb_dropout = dec_cfg["embeddings"].get("dropout", dec_dropout)
-    dec_cfg["encoder_output_size_for_ctc"] = encoder.output_size
+    if task == "S2T":
+        dec_cfg["encoder_output_size_for_ctc"] = encoder.output_size
     decoder = TransformerDecoder(**dec_cfg, encoder=None, vocab_size=len(trg_vocab), emb_size=trg_embed.embedding_dim,
                                  emb_dropout=dec_emb_dropout)
     model = Model(encoder=encoder, decoder=decoder, src_embed=src_embed, trg_embed=trg_embed, src_vocab=src_vocab,

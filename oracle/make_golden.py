@@ -171,6 +171,76 @@ def golden_model(name, cfg, V=20, B=3, T=37, seed=7, smoothing=0.1, ctc_weight=0
     print(name, "loss", total.item(), xent.item(), ctc.item(), n_correct.item(), "beam", bids.shape)
 
 
+def small_mt_cfg():
+    """The `model:` section of the reference's configs/transformer_small.yaml (BASELINE.json configs[0]), read from the file."""
+    import yaml
+    cfg = yaml.safe_load((REF / "configs/transformer_small.yaml").read_text())["model"]
+    assert cfg["tied_softmax"] and not cfg["tied_embeddings"] and cfg["encoder"]["hidden_size"] == 64
+    return cfg
+
+
+def golden_model_mt(name="model_mt", V=30, B=5, seed=11, beam=5, alpha=1.0):
+    """configs/transformer_small.yaml as a text-to-text model (task "MT": source Embeddings, no sub-sampler, no CTC layer,
+    tied softmax) on the reverse task its tutorial trains (docs/source/tutorial.rst: the target is the source reversed),
+    with the config's own loss (crossentropy, label_smoothing 0.0) and decoding settings (beam 5, alpha 1.0, max length 31)."""
+    from joeynmt.batch import Batch
+    from joeynmt.model import build_model
+    from joeynmt.search import search
+    torch.manual_seed(42)
+    cfg = small_mt_cfg()
+    vocab = make_vocab(V)
+    model = build_model(copy.deepcopy(cfg), src_vocab=vocab, trg_vocab=make_vocab(V))
+    model.loss_function = ("crossentropy", 0.0, 0.0)  # (type, label_smoothing, ctc_weight): training.loss / label_smoothing of the config
+    assert model.decoder.ctc_output_layer is None and model.decoder.output_layer.weight is model.trg_embed.lut.weight
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(123)
+        for n, p in model.named_parameters():
+            if "bias" in n or "layer_norm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    n_tok = torch.randint(3, 13, (B, ), generator=g)
+    n_tok[0] = 12
+    S = int(n_tok.max()) + 1
+    src = torch.full((B, S), SPECIALS["pad"], dtype=torch.long)
+    trg = torch.full((B, S + 1), SPECIALS["pad"], dtype=torch.long)
+    for b in range(B):
+        n = int(n_tok[b])
+        words = torch.randint(4, V, (n, ), generator=g)
+        src[b, :n], src[b, n] = words, SPECIALS["eos"]
+        trg[b, 0], trg[b, 1:1 + n], trg[b, 1 + n] = SPECIALS["bos"], words.flip(0), SPECIALS["eos"]
+    batch = Batch(src=src, src_length=n_tok + 1, src_prompt_mask=None, trg=trg, trg_length=n_tok + 2, trg_prompt_mask=None,
+                  indices=torch.arange(B), device=torch.device("cpu"), pad_index=1, eos_index=3, is_train=True, task="MT")
+    out = {f"sd.{k}": v for k, v in np_sd(model.state_dict()).items()}
+    out.update(src=src.numpy(), src_length=(n_tok + 1).numpy(), trg_full=trg.numpy(), trg_length_full=(n_tok + 2).numpy(),
+               trg_input=batch.trg_input.numpy(), trg=batch.trg.numpy(), trg_length=batch.trg_length.numpy(),
+               trg_mask=batch.trg_mask.numpy(), src_mask=batch.src_mask.numpy(), ntokens=np.int64(batch.ntokens))
+    kw = dict(vars(batch))
+    with torch.no_grad():
+        enc, _, src_mask, _ = model(return_type="encode", **kw)
+        logits, hidden, att, _ = model(return_type="decode", encoder_output=enc, encoder_hidden=None, src_mask=batch.src_mask,
+                                       trg_input=batch.trg_input, unroll_steps=None, trg_mask=batch.trg_mask, return_attention=True)
+    out.update(enc_out=enc.numpy(), logits=logits.numpy(), dec_hidden=hidden.numpy(), att=att.numpy())
+    model.zero_grad()
+    total, nll, ctc, n_correct = model(return_type="loss", **kw)
+    assert nll is None and ctc is None
+    total.backward()
+    out.update(loss_total=total.item(), n_correct=n_correct.item())
+    for n, p in model.named_parameters():
+        out[f"grad.{n}"] = p.grad.numpy().copy()
+    with torch.no_grad():
+        gids, gscores, _ = search(model, batch, max_output_length=31, beam_size=1, beam_alpha=-1, return_prob="hyp")
+        bids, bscores, _ = search(model, batch, max_output_length=31, beam_size=beam, beam_alpha=alpha, n_best=1, return_prob="hyp")
+        bidsn, bscoresn, _ = search(model, batch, max_output_length=-1, beam_size=beam, beam_alpha=alpha, n_best=beam,
+                                    return_prob="hyp")
+    out.update(greedy_ids=gids, greedy_scores=gscores, beam_ids=bids, beam_scores=bscores, beam_ids_nbest=bidsn,
+               beam_scores_nbest=bscoresn, beam_size=np.int64(beam), beam_alpha=np.float64(alpha))
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    import json
+    (OUT / "model_mt_cfg.json").write_text(json.dumps(cfg, indent=1, sort_keys=True) + "\n")
+    print(name, "loss", total.item(), n_correct.item(), "greedy", gids.shape, "beam", bids.shape, bidsn.shape)
+
+
 def golden_units():
     """Operator-level captures + constants that the reference's own unit tests assert."""
     from joeynmt.data_augmentation import CMVN, SpecAugment
@@ -738,7 +808,7 @@ def main():
         "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
         "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
-        "ref_unit_tests": golden_ref_unit_tests,
+        "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

@@ -177,6 +177,24 @@ def encoder_forward(sd: SD, cfg: dict, src: Tensor, src_length: Tensor, prefix: 
     return x, mask, lengths
 
 
+def encoder_forward_text(sd: SD, cfg: dict, src_ids: Tensor, pad_index: int, prefix: str = "encoder"):
+    """Text source (task "MT", configs/transformer_small.yaml): Model._encode embeds the ids with `src_embed`
+    (model.py:225-238, embeddings.py:55-64), Batch supplies src_mask = (src != pad) (batch.py:99-100), and the encoder runs
+    without its sub-sampler (encoders.py:241-288) -> (x, mask [B,1,S])."""
+    e = cfg["encoder"]
+    w = sd["src_embed.lut.weight"]
+    x = F.embedding(src_ids, w)
+    if e["embeddings"].get("scale", False):
+        x = x * math.sqrt(w.size(1))
+    mask = (src_ids != pad_index).unsqueeze(1)
+    x = x + positional_table(5000, x.size(-1))[: x.size(1)].unsqueeze(0)
+    for i in range(e["num_layers"]):
+        x = encoder_layer(sd, f"{prefix}.layers.{i}", x, mask, e)
+    if e["layer_norm"] == "pre":
+        x = layer_norm(sd, prefix + ".layer_norm", x)
+    return x, mask
+
+
 # ------------------------------------------------------------------------------------------------ Conformer (a30)
 def conv_module(sd: SD, prefix: str, x: Tensor, train: bool, new_stats: Optional[dict] = None) -> Tensor:
     """ConvolutionModule.forward, transformer_layers.py:458-475, on the tensor it is GIVEN: the layer hands it
@@ -313,7 +331,10 @@ def ctc_loss(ctc_log_probs: Tensor, trg: Tensor, input_lengths: Tensor, target_l
 
 def model_loss(sd: SD, cfg: dict, batch: dict, specials: dict, smoothing: float, ctc_weight: Optional[float]):
     """Model.forward(return_type="loss"), model.py:113-148 -> (total, xent, ctc|None, n_correct, logits, ctc_logits)."""
-    enc, src_mask, _ = encoder_forward(sd, cfg, batch["src"], batch["src_length"])
+    if "src_embed.lut.weight" in sd:  # text source (MT): no sub-sampler, mask from the pad positions
+        enc, src_mask = encoder_forward_text(sd, cfg, batch["src"], specials["pad"])
+    else:
+        enc, src_mask, _ = encoder_forward(sd, cfg, batch["src"], batch["src_length"])
     out, _, _, ctc_out = decoder_forward(sd, cfg, batch["trg_input"], enc, src_mask, batch["trg_mask"])
     log_probs = F.log_softmax(out, dim=-1)
     xent = xent_loss(log_probs, batch["trg"], specials["pad"], smoothing)

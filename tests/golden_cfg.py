@@ -33,3 +33,10 @@ def oracle_cfg(cfg):
         a_enc, a_dec = 0.81 * (n**4 * m)**(1 / 16), (3 * m)**(1 / 4)
     c["encoder"]["alpha"], c["decoder"]["alpha"] = a_enc, a_dec
     return c
+
+
+def mt_cfg():
+    """Model section of the reference's configs/transformer_small.yaml, as oracle/make_golden.py read it from the file."""
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).resolve().parent / "golden" / "model_mt_cfg.json").read_text())

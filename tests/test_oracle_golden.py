@@ -269,3 +269,53 @@ def test_reference_unit_test_known_answers():
     model = build_model(cfg, None, Vocabulary.synthetic(20))
     assert {layer.alpha for layer in model.encoder.layers} == {float(g["deepnet_alpha_6_6"][0])}
     assert {layer.alpha for layer in model.decoder.layers} == {float(g["deepnet_alpha_6_6"][1])}
+
+
+def _mt_batch(g):
+    return {"src": torch.from_numpy(g["src"]), "src_length": torch.from_numpy(g["src_length"]),
+            "trg_input": torch.from_numpy(g["trg_input"]), "trg": torch.from_numpy(g["trg"]),
+            "trg_length": torch.from_numpy(g["trg_length"]), "trg_mask": torch.from_numpy(g["trg_mask"])}
+
+
+def test_text_source_model_matches_reference():
+    """BASELINE config 0, configs/transformer_small.yaml (task MT, reverse task): source embedding, encoder without
+    sub-sampler, tied softmax, cross-entropy only - activations, loss, every gradient, greedy and beam-5 hypotheses of the
+    reference (tests/golden/model_mt.npz) against the oracle's text-source path."""
+    from golden_cfg import mt_cfg
+    g = load_golden("model_mt")
+    cfg = oracle_cfg(mt_cfg())
+    sd = {k: v.clone().requires_grad_(True) for k, v in golden_sd(g).items() if not k.endswith("pe.pe")}
+    sd["decoder.output_layer.weight"] = sd["trg_embed.lut.weight"]  # tied softmax: ONE parameter (model.py:470-478)
+    b = _mt_batch(g)
+    enc, mask = O.encoder_forward_text(sd, cfg, b["src"], SPECIALS["pad"])
+    assert np.array_equal(mask.numpy(), g["src_mask"])
+    torch.testing.assert_close(enc.detach(), torch.from_numpy(g["enc_out"]), **TOL)
+    logits, hidden, att, ctc = O.decoder_forward(sd, cfg, b["trg_input"], enc, mask, b["trg_mask"], return_attention=True)
+    assert ctc is None
+    torch.testing.assert_close(logits.detach(), torch.from_numpy(g["logits"]), **TOL)
+    torch.testing.assert_close(att.detach(), torch.from_numpy(g["att"]), **TOL)
+    total, xent, ctcl, ncor, _, _ = O.model_loss(sd, cfg, b, SPECIALS, 0.0, None)
+    assert ctcl is None and abs(total.item() - g["loss_total"]) <= 1e-4 * abs(g["loss_total"]) and int(ncor) == int(g["n_correct"])
+    total.backward()
+    n_checked = 0
+    for k, v in g.items():
+        if k.startswith("grad."):
+            got = sd[k[5:]].grad
+            scale = np.abs(v).max() + 1e-6
+            assert np.abs(got.numpy() - v).max() <= 1e-4 * scale + 1e-5, k
+            n_checked += 1
+    assert n_checked > 50 and "grad.decoder.output_layer.weight" not in g  # the tied weight appears once, under trg_embed
+    with torch.no_grad():
+        sdd = {k: v.detach() for k, v in sd.items()}
+        enc, mask = O.encoder_forward_text(sdd, cfg, b["src"], SPECIALS["pad"])
+        ids, scores = O.greedy(sdd, cfg, SPECIALS, enc, mask, 31, return_prob=True)
+        assert np.array_equal(ids.numpy(), g["greedy_ids"])
+        np.testing.assert_allclose(scores.numpy(), g["greedy_scores"], rtol=1e-4, atol=1e-4)
+        k = int(g["beam_size"])
+        ids, scores = O.beam_search(sdd, cfg, SPECIALS, enc, mask, k, 31, float(g["beam_alpha"]), n_best=1)
+        assert np.array_equal(ids.numpy(), g["beam_ids"])
+        np.testing.assert_allclose(scores.numpy(), g["beam_scores"], rtol=1e-4, atol=1e-4)
+        max_len = int(max(g["src_length"]) * 1.5)
+        ids, scores = O.beam_search(sdd, cfg, SPECIALS, enc, mask, k, max_len, float(g["beam_alpha"]), n_best=k)
+        assert np.array_equal(ids.numpy(), g["beam_ids_nbest"])
+        np.testing.assert_allclose(scores.numpy(), g["beam_scores_nbest"], rtol=1e-4, atol=1e-4)
