@@ -409,12 +409,13 @@ def host_cpu():
     return usable, model, os.cpu_count() or usable
 
 
-def cpu_baseline(n_utts=BATCH, threads=None, timed_steps=2):
+def cpu_baseline(n_utts=BATCH, threads=None, warmup_steps=3, timed_steps=10, gpu_decode=None):
     """The CPU oracle (plain fp32 PyTorch/NumPy restatement of the reference path) timed on the host cores on the SAME
     workload as the GPU line - one batch of 32 utterances of 15 s through fbank -> ... -> loss -> backward -> clip -> AdamW
-     - with every CPU this process may use (count and model string stated): 1 warm-up + 2 timed
-    steps at ~6 s each.  Plus (ii) of BASELINE.md section 3: beam-5 decode RTF of the oracle's search (full-prefix decoder
-    pass, no KV cache, exactly the reference's algorithm) on a bounded sample."""
+     - with every CPU this process may use (count and model string stated): 3 warm-up + 10 timed
+    steps (BASELINE.md's plan; ~6 s each on the 16-thread share of the GPU box), cut to 1 + 2 on a host whose first step
+    takes more than 10 s.  Plus (ii) of BASELINE.md section 3: beam-5 decode RTF of the oracle's search (full-prefix decoder
+    pass, no KV cache, exactly the reference's algorithm) on the GPU leg's workload (cpu_decode_rtf)."""
     import copy
     from joeys2t_amd.model import build_model
     from joeys2t_amd.vocabulary import Vocabulary
@@ -449,21 +450,25 @@ def cpu_baseline(n_utts=BATCH, threads=None, timed_steps=2):
         opt.step()
 
     t0 = time.perf_counter()
-    step()  # warm-up
+    step()  # first warm-up step
     warm = time.perf_counter() - t0
-    print(f"[bench] cpu baseline: {threads} threads on {cpu_model}; warm-up step {warm:.1f} s", file=sys.stderr, flush=True)
-    if warm > 25.0:  # a slow or over-subscribed host: the bounded sample is the warm-up step plus one timed step at most
-        timed_steps = 1
-    t0 = time.perf_counter()
-    for i in range(timed_steps):
+    print(f"[bench] cpu baseline: {threads} threads on {cpu_model}; first step {warm:.1f} s", file=sys.stderr, flush=True)
+    if warm > 10.0:  # a slow or over-subscribed host: keep the sample bounded
+        warmup_steps, timed_steps = 1, 2
+    for _ in range(warmup_steps - 1):
         step()
-        print(f"[bench] cpu baseline: timed step {i + 1}/{timed_steps} done", file=sys.stderr, flush=True)
-    dt = (time.perf_counter() - t0) / timed_steps
+    times = []
+    for i in range(timed_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu baseline: timed step {i + 1}/{timed_steps}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
+    dt = float(np.median(times))  # report the median
     frames = n_utts * (1 + (SAMPLES - 400) // 160)
     out = {"value": round(frames / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
-           "cpus_online": online, "s_per_step": round(dt, 3),
+           "cpus_online": online, "s_per_step": round(dt, 3), "s_per_step_min_max": [round(min(times), 3), round(max(times), 3)],
            "sample": f"{n_utts} utterances x 15 s (the GPU line's batch), LS100 model, full train step (fbank..AdamW), fp32, "
-                     f"1 warm-up + {timed_steps} timed steps"}
+                     f"{warmup_steps} warm-up + {timed_steps} timed steps, median"}
     try:
         out["decode_beam5"] = cpu_decode_rtf()
     except Exception as exc:  # a side figure of a side figure
@@ -471,9 +476,12 @@ def cpu_baseline(n_utts=BATCH, threads=None, timed_steps=2):
     return out
 
 
-def cpu_decode_rtf(n_utts=4, beam=5, alpha=1.0, max_len=30):
+def cpu_decode_rtf(n_utts=BATCH, beam=5, alpha=1.0, max_len=100, budget_s=150.0):
     """beam-5 decode of the CPU oracle (search.py:345-825 restated: full-prefix decoder pass per
-    step, encoder states tiled beam-fold) on mustc_st.yaml shapes.  Bounded sample: 4 utterances x 15 s, 30 steps."""
+    step, encoder states tiled beam-fold) on mustc_st.yaml shapes - the GPU leg's workload: 32 utterances x 15 s, 100 steps.
+    Time-boxed: a 2-utterance, 8-step probe prices an (utterance, step) pair first; if the full workload would take longer than
+    `budget_s`, fewer utterances are decoded (all 100 steps kept) and `n_utts` says how many - bench.py then decodes the same
+    sub-sample on the GPU as well (`decode_beam5.same_sample_as_cpu`), so the two RTFs always describe one workload."""
     import copy
     from joeys2t_amd.model import build_model
     from joeys2t_amd.vocabulary import Vocabulary
@@ -484,18 +492,31 @@ def cpu_decode_rtf(n_utts=4, beam=5, alpha=1.0, max_len=30):
     cfg["encoder"]["alpha"], cfg["decoder"]["alpha"] = 0.81 * (n**4 * m)**(1 / 16), (3 * m)**(1 / 4)
     model = build_model(copy.deepcopy(MUSTC_MODEL), None, Vocabulary.synthetic(VOCAB))
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    wave = synth_waveforms(n_utts, SAMPLES).numpy()
     specials = dict(unk=0, pad=1, bos=2, eos=3)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        feats = [O.cmvn(O.fbank(wave[u])).astype(np.float32) for u in range(n_utts)]
-        padded, lengths, _ = O.pad_features(feats)
-        enc, mask, _ = O.encoder_forward(sd, cfg, torch.from_numpy(padded), torch.tensor(lengths))
-        ids, _ = O.beam_search(sd, cfg, specials, enc, mask, beam, max_len, alpha, n_best=1)
-    dt = time.perf_counter() - t0
+
+    def decode(nu, steps):
+        wave = synth_waveforms(nu, SAMPLES).numpy()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            feats = [O.cmvn(O.fbank(wave[u])).astype(np.float32) for u in range(nu)]
+            padded, lengths, _ = O.pad_features(feats)
+            enc, mask, _ = O.encoder_forward(sd, cfg, torch.from_numpy(padded), torch.tensor(lengths))
+            ids, _ = O.beam_search(sd, cfg, specials, enc, mask, beam, steps, alpha, n_best=1)
+        return time.perf_counter() - t0, int(ids.shape[1])
+
+    probe_s, _ = decode(2, 8)
+    per_pair = probe_s / (2 * 8)
+    # the full-prefix pass grows with the prefix: step t re-runs t + 1 positions, but the re-projected encoder states (375
+    # positions per hypothesis and layer) dominate, so an (utterance, step) pair at step 100 costs ~1.3 x one at step 8
+    est_full = 1.3 * per_pair * n_utts * max_len
+    if est_full > budget_s:
+        n_utts = max(1, min(n_utts, int(budget_s / (1.3 * per_pair * max_len))))
+    print(f"[bench] cpu decode: probe {probe_s:.1f} s, full workload estimated {est_full:.0f} s -> decoding {n_utts} utterances", file=sys.stderr, flush=True)
+    dt, steps = decode(n_utts, max_len)
     audio_s = n_utts * SAMPLES / 16000.0
-    return {"rtf": round(dt / audio_s, 5), "wall_s": round(dt, 2), "audio_s": audio_s, "beam": beam, "steps": int(ids.shape[1]),
-            "sample": f"{n_utts} utterances x 15 s, beam {beam}, at most {max_len} steps (the GPU leg decodes 32 utterances, 100 steps)",
+    return {"rtf": round(dt / audio_s, 5), "wall_s": round(dt, 2), "audio_s": audio_s, "beam": beam, "steps": steps, "n_utts": n_utts,
+            "sample": f"{n_utts} utterances x 15 s, beam {beam}, at most {max_len} steps" + (" (the GPU leg's workload)" if n_utts == BATCH else
+                      f" (time-boxed to ~{budget_s:.0f} s; the GPU leg reports the same sub-sample under same_sample_as_cpu)"),
             "decoding": "reference algorithm: full-prefix decoder pass per step, no KV cache"}
 
 
@@ -511,7 +532,7 @@ MUSTC_MODEL = {
 }
 
 
-def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos_scale=0.0):
+def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos_scale=0.0, n_utts=BATCH):
     """Second half of BASELINE.json's metric: beam-5 decode real-time factor on configs/mustc_st.yaml shapes
     (12+6 layers, H=8, beam 5, alpha 1.0, max_output_length 100), 32 synthetic 15 s utterances resident in HBM.
     RTF = wall time of front-end + encode + beam search / seconds of audio."""
@@ -533,12 +554,12 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos
             w[3] = torch.nn.functional.normalize(torch.randn(w.shape[1]), dim=0) * eos_scale
     model.finalize(device, dtype).eval()
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=5000, cmvn=dict(norm_means=True, norm_vars=True, before=True))
-    wave = synth_waveforms(BATCH, SAMPLES).to(device)
+    wave = synth_waveforms(n_utts, SAMPLES).to(device)
 
     def run():
-        feats, lengths = proc.batch_from_waveforms(wave, [SAMPLES] * BATCH, is_train=False, out_dtype=dtype)
+        feats, lengths = proc.batch_from_waveforms(wave, [SAMPLES] * n_utts, is_train=False, out_dtype=dtype)
         b = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=None, trg_length=None,
-                  trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1, eos_index=3, is_train=False,
+                  trg_prompt_mask=None, indices=torch.arange(n_utts), device=device, pad_index=1, eos_index=3, is_train=False,
                   task="S2T", n_gpu=1)
         b.sort_by_src_length()
         ids, _, _ = search(model, b, max_output_length=max_len, beam_size=beam, beam_alpha=alpha, n_best=1)
@@ -550,21 +571,21 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos
     ids = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    audio_s = BATCH * SAMPLES / 16000.0
+    audio_s = n_utts * SAMPLES / 16000.0
     # decoder FLOP of this decode with and without the key/value cache: per position and layer the projections
     # cost 8 d^2 (self) + 4 d^2 (cross q, o) + 4 d ff (FFN); attention 4 d per key; without a cache every step redoes the
     # whole prefix and re-projects the encoder states (4 d^2 per encoder position, hypothesis and layer)
     e, dcfg = MUSTC_MODEL["encoder"], MUSTC_MODEL["decoder"]
     d, ff, nl = dcfg["hidden_size"], dcfg["ff_size"], dcfg["num_layers"]
     S = ((1 + (SAMPLES - 400) // 160 - 1) // 2) // 2 + 1
-    rows, steps = BATCH * beam, int(ids.shape[1])
+    rows, steps = n_utts * beam, int(ids.shape[1])
     per_pos = nl * (12 * d * d + 4 * d * ff)
-    cached = sum(rows * (per_pos + nl * 4 * d * (t + 1 + S) + 2 * d * VOCAB) for t in range(steps)) + BATCH * S * nl * 4 * d * d
+    cached = sum(rows * (per_pos + nl * 4 * d * (t + 1 + S) + 2 * d * VOCAB) for t in range(steps)) + n_utts * S * nl * 4 * d * d
     uncached = sum(rows * ((t + 1) * per_pos + nl * (4 * d * (t + 1) * (t + 2) // 2 + 4 * d * S * (t + 1)) + nl * S * 4 * d * d + 2 * d * VOCAB)
                    for t in range(steps))
     hyp_len = [int((row != 1).sum()) for row in np.asarray(ids)]  # non-pad tokens per best hypothesis (EOS cut by the search)
     return {"rtf": round(dt / audio_s, 6), "wall_s": round(dt, 3), "audio_s": audio_s, "beam": beam, "alpha": alpha,
-            "steps": steps, "steps_per_s": round(steps / dt, 1),
+            "n_utts": n_utts, "steps": steps, "steps_per_s": round(steps / dt, 1),
             "hyp_len_min_median_max": [int(np.min(hyp_len)), int(np.median(hyp_len)), int(np.max(hyp_len))], "decoder_tflop_kv_cached": round(cached / 1e12, 3),
             "decoder_tflop_full_prefix": round(uncached / 1e12, 3), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16",
             "decoding": "KV-cached, hipGraph-replayed step"}
@@ -741,6 +762,14 @@ def main():
                 cpu = cpu_baseline()
             except Exception as exc:  # the baseline is a reported side figure; never lose the GPU line over it
                 cpu = {"error": repr(exc)}
+            # the two decode RTFs describe one workload: if the CPU leg had to be cut to fewer utterances, decode those on the GPU too
+            cd = cpu.get("decode_beam5") if isinstance(cpu, dict) else None
+            if isinstance(cd, dict) and isinstance(decode, dict) and "rtf" in decode and cd.get("n_utts", BATCH) != BATCH:
+                try:
+                    same = decode_rtf(device, n_utts=cd["n_utts"])
+                    decode["same_sample_as_cpu"] = {k: same[k] for k in ("rtf", "wall_s", "n_utts", "steps")}
+                except Exception as exc:
+                    decode["same_sample_as_cpu"] = {"error": repr(exc)}
         value = world * frames_per_step * args.steps / elapsed
         out = {
             "metric": "audio frames/sec (train step, 80-mel, 15 s utt, bs32 per GPU)", "value": round(value, 1),

@@ -1,4 +1,4 @@
-"""GPU: the train step at BASELINE.json's FULL size (configs/librispeech_100h.yaml: 16 + 6 layers, d 512, 4 heads, ff 2048,
+"""GPU: the train step at BASELINE.json's FULL size (configs/librispeech_100h.yaml: 16 + 8 layers, d 512, 4 heads, ff 2048,
 V 5000, 32 utterances of up to 15 s = 1498 frames, bf16) - too large for the CPU oracle, so checked through properties the
 computation has at any size (reference training.py:541-596, model.py:95-168):
 
@@ -22,7 +22,7 @@ V, B = 5000, 32
 
 @pytest.fixture(scope="module")
 def full_case(device):
-    cfg = width_cfg(4, 16, 6)
+    cfg = width_cfg(4, 16, 8)  # librispeech_100h.yaml:110-137: 16 encoder + 8 decoder layers
     torch.manual_seed(21)
     base = make_model(cfg, V, None, None, None, 0.3)
     sd = {k: v.clone() for k, v in base.state_dict().items()}
