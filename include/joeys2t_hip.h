@@ -259,6 +259,17 @@ int js2t_softmax_bwd(const void* P, const void* dPd, void* dS, int64_t Z, int64_
 int js2t_attn_head_mean(const void* P, float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
                         int64_t ld, int dt, js2t_stream stream);
 
+/* Relative-position bias on the materialised attention path (EXTENSION, BASELINE.json configs[4] "rel-pos attn"; the
+ * reference's MultiHeadedAttention, transformer_layers.py:86-98, has no such term - this is where it would enter, between the
+ * scaled q k^T product and the mask): S[b,h,q,k] += rel_bias[h, clamp(k - q, -R, R) + R], in place on the [B*H, Tq, ld]
+ * score buffer; rel_bias f32 [H, 2R+1].  The fused kernels (js2t_flash_attn_*) take the table through js2t_attn_desc. */
+int js2t_rel_bias_add(void* S, const float* rel_bias, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld, int32_t R,
+                      int dt, js2t_stream stream);
+/* d_rel_bias[h, r] += sum of dS[b,h,q,k] over all (b, q, k) with clamp(k - q, -R, R) + R == r (dS: gradient of the scaled,
+ * biased scores as js2t_softmax_bwd writes it); ADDS into d_rel_bias (f32 [H, 2R+1]). */
+int js2t_rel_bias_grad(const void* dS, float* d_rel_bias, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld, int32_t R,
+                       int dt, js2t_stream stream);
+
 /* --------------------------------------------------------------------------------------------------
  * Vocabulary-sized rows: log-softmax, label-smoothed cross-entropy, CTC.
  */

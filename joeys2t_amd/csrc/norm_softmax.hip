@@ -421,6 +421,45 @@ __global__ void attn_head_mean_kernel(const T* __restrict__ P, float* __restrict
   }
 }
 
+// Relative-position bias on the MATERIALISED attention path (extension, see js2t_rel_bias_add): the fused kernels add the
+// term on chip; this pair serves fp32 compute / odd head sizes, i.e. the parity tests of the composed config-5 model.
+template <typename T>
+__global__ void rel_bias_add_kernel(T* __restrict__ S, const float* __restrict__ bias, int64_t B, int64_t H, int64_t Tq,
+                                    int64_t Tk, int64_t ld, int R) {
+  const int64_t total = B * H * Tq * Tk;
+  const int W = 2 * R + 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / Tk, k = i - row * Tk, q = row % Tq, h = (row / Tq) % H;
+    const int64_t dlt = k - q;
+    const int r = (int)(dlt < -R ? -R : (dlt > R ? R : dlt)) + R;
+    T* at = S + row * ld + k;
+    io<T>::st(at, io<T>::ld(at) + bias[h * W + r]);
+  }
+}
+
+// d_bias[h, r] += sum over (b, q, k with clamp(k - q) == r) of dS: one block per (head, slab of query rows), an LDS
+// histogram of 2R + 1 bins per block, one global atomic per bin and block
+template <typename T>
+__global__ void rel_bias_grad_kernel(const T* __restrict__ dS, float* __restrict__ d_bias, int64_t B, int64_t H, int64_t Tq,
+                                     int64_t Tk, int64_t ld, int R, int64_t rows_per_block) {
+  extern __shared__ float hist[];
+  const int W = 2 * R + 1;
+  const int64_t h = blockIdx.y;
+  for (int i = threadIdx.x; i < W; i += blockDim.x) hist[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, B * Tq);  // rows of this head: (b, q) pairs
+  for (int64_t i = r0 * Tk + threadIdx.x; i < r1 * Tk; i += blockDim.x) {
+    const int64_t bq = i / Tk, k = i - bq * Tk, b = bq / Tq, q = bq - b * Tq;
+    const float g = io<T>::ld(dS + ((b * H + h) * Tq + q) * ld + k);
+    const int64_t dlt = k - q;
+    const int r = (int)(dlt < -R ? -R : (dlt > R ? R : dlt)) + R;
+    if (g != 0.f) atomicAdd(&hist[r], g);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += blockDim.x)
+    if (hist[i] != 0.f) atomicAdd(d_bias + h * W + i, hist[i]);
+}
+
 }  // namespace
 
 template <typename T, int NCH>
@@ -603,6 +642,30 @@ extern "C" int js2t_attn_head_mean(const void* P, float* out, int64_t B, int64_t
   if (g > 4096) g = 4096;
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((attn_head_mean_kernel<T>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                                         (const T*)P, out, B, H, Tq, Tk, ld));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_rel_bias_add(void* S, const float* rel_bias, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld,
+                                 int32_t R, int dt, js2t_stream stream) {
+  if (B * H * Tq * Tk == 0) return JS2T_OK;
+  JS2T_CHECK(S && rel_bias && R >= 0 && ld >= Tk, "rel_bias_add: bad arguments");
+  int64_t g = (B * H * Tq * Tk + 255) / 256;
+  if (g > 4096) g = 4096;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_add_kernel<T>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (T*)S,
+                                        rel_bias, B, H, Tq, Tk, ld, (int)R));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_rel_bias_grad(const void* dS, float* d_rel_bias, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld,
+                                  int32_t R, int dt, js2t_stream stream) {
+  if (B * H * Tq * Tk == 0) return JS2T_OK;
+  JS2T_CHECK(dS && d_rel_bias && R >= 0 && R <= 4096 && ld >= Tk && H <= 65535, "rel_bias_grad: bad arguments");
+  const int64_t rows = B * Tq, rpb = 64;
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_grad_kernel<T>), dim3((unsigned)cdiv(rows, rpb), (unsigned)H), dim3(256),
+                                        (size_t)(2 * R + 1) * sizeof(float), (hipStream_t)stream, (const T*)dS, d_rel_bias, B, H,
+                                        Tq, Tk, ld, (int)R, rpb));
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

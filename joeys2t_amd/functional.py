@@ -187,17 +187,23 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
         # fused kernel: scores / probabilities stay on chip; the forward keeps (out, lse) for backward
         out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
         return out, None, lse
-    if rel_bias is not None:
-        raise NotImplementedError("relative-position bias: fused attention kernels only (bf16 compute, head size 128 or 64)")
     S = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
     ops.gemm(q_t, k_t, S, M=Tq, N=Tk, K=dh, lda=q_t.stride(0), ldb=k_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
              a_strides=(Tq * q_t.stride(0), dh), b_strides=(Tk * k_t.stride(0), dh), c_strides=(H * Tq * ld, Tq * ld),
              a_off=q_off, b_off=k_off, alpha=1.0 / math.sqrt(dh))
+    if rel_bias is not None:  # materialised path (fp32 compute / head sizes the fused kernels do not take)
+        _check_rel_bias(rel_bias, H)
+        ops.rel_bias_add(S, rel_bias, B, H, Tq, Tk, ld)
     P, Pd = ops.softmax_fwd(S, mask, B, H, Tq, Tk, ld, p, rng, site)
     ctx = torch.empty((B * Tq, H * dh), dtype=dt, device=dev)
     ops.gemm(Pd, v_t, ctx, M=Tq, N=dh, K=Tk, lda=ld, ldb=v_t.stride(0), ldc=H * dh, trans_b=True, batch=Z, batch_inner=H,
              a_strides=(H * Tq * ld, Tq * ld), b_strides=(Tk * v_t.stride(0), dh), c_strides=(Tq * H * dh, dh), b_off=v_off)
     return ctx, P, Pd
+
+
+def _check_rel_bias(t, H):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[0] != H or t.shape[1] % 2 != 1 or not t.is_contiguous():
+        raise ops.Js2tError(f"relative-position bias must be contiguous float32 [H, 2R+1], got {tuple(t.shape)} {t.dtype}")
 
 
 def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, shp: AttnShape, P, Pd, p,
@@ -218,6 +224,9 @@ def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_of
     ops.gemm(dctx, v_t, dPd, M=Tq, N=Tk, K=dh, lda=dctx.stride(0), ldb=v_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
              a_strides=(Tq * dctx.stride(0), dh), b_strides=(Tk * v_t.stride(0), dh), c_strides=sP, b_off=v_off)
     dS = ops.softmax_bwd(P, dPd, Z, Tq, Tk, ld, p, rng, site)
+    if d_rel_bias is not None:
+        _check_rel_bias(d_rel_bias, H)
+        ops.rel_bias_grad(dS, d_rel_bias, B, Tq=Tq, Tk=Tk, H=H, ld=ld)
     # dv[k,:] = sum_q Pd[q,k] dctx[q,:]
     ops.gemm(Pd, dctx, dv_t, M=Tk, N=dh, K=Tq, lda=ld, ldb=dctx.stride(0), ldc=dv_t.stride(0), trans_a=True, trans_b=True,
              batch=Z, batch_inner=H, a_strides=sP, b_strides=(Tq * dctx.stride(0), dh),

@@ -551,6 +551,23 @@ def attn_head_mean(P, B, H, Tq, Tk, ld):
     return out
 
 
+def rel_bias_add(S, rel_bias, B, H, Tq, Tk, ld):
+    """S[b,h,q,k] += rel_bias[h, clamp(k - q)] in place (js2t_rel_bias_add; the materialised attention path)."""
+    _dev(S, rel_bias)
+    R = (rel_bias.shape[1] - 1) // 2
+    check(lib().js2t_rel_bias_add(_p(S), _p(rel_bias), C.c_int64(B), C.c_int64(H), C.c_int64(Tq), C.c_int64(Tk), C.c_int64(ld),
+                                  C.c_int32(R), dt_code(S), _stream()), "js2t_rel_bias_add")
+    return S
+
+
+def rel_bias_grad(dS, d_rel_bias, B, H, Tq, Tk, ld):
+    """d_rel_bias += the per-(head, clipped distance) sums of dS (js2t_rel_bias_grad)."""
+    _dev(dS, d_rel_bias)
+    R = (d_rel_bias.shape[1] - 1) // 2
+    check(lib().js2t_rel_bias_grad(_p(dS), _p(d_rel_bias), C.c_int64(B), C.c_int64(H), C.c_int64(Tq), C.c_int64(Tk), C.c_int64(ld),
+                                   C.c_int32(R), dt_code(dS), _stream()), "js2t_rel_bias_grad")
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
