@@ -112,6 +112,8 @@ class FlatAdamW:
         st.dirty = lp is None and st.dirty
         if lp is not None and st.flat_lp_t is not None:
             st.refresh_t()  # transposed shadows follow the updated weights (one kernel; part of the captured step)
+        if lp is not None:
+            st.refresh_folds()  # gamma-scaled weights of the LayerNorm folds, likewise
 
     def state_dict(self) -> Dict:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}

@@ -707,6 +707,41 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
   }
 }
 
+
+// ---- LayerNorm fold (js2t_gemm_desc::ln_stats / row_stats) helpers shared by the register-direct epilogues
+// Row statistics travel as 64-bit FIXED-POINT sums: the producer's column groups add their partial sums with integer atomics,
+// which commute exactly - the statistics, and with them every activation downstream, are bit-for-bit reproducible from run
+// to run (f32 atomics would make the rounding of the sums depend on arrival order, and 24 layers amplify that to 1e-3).
+// S0 = sum x in units of 2^-20, S1 = sum x^2 in units of 2^-16: |x| up to ~5e5 before S1 overflows, far beyond anything a
+// bf16 residual stream holds while training is alive (a NaN / Inf in x still reaches the output through the product itself).
+constexpr float LNF_S0 = 1048576.f, LNF_S1 = 65536.f;
+__device__ __forceinline__ void lnf_moments(const int64_t* stats, int m, float inv_k, float eps, float& mean, float& rstd) {
+  typedef long long ll2_t __attribute__((ext_vector_type(2)));
+  const ll2_t sv = *(const ll2_t*)(stats + 2 * (int64_t)m);
+  mean = (float)sv[0] * (inv_k / LNF_S0);
+  rstd = 1.f / sqrtf(fmaxf(fmaf(-mean, mean, (float)sv[1] * (inv_k / LNF_S1)), 0.f) + eps);
+}
+__device__ __forceinline__ void lnf_add(int64_t* stats, int m, float s1, float s2) {
+  __hip_atomic_fetch_add((long long*)stats + 2 * (int64_t)m, (long long)__float2ll_rn(s1 * LNF_S0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add((long long*)stats + 2 * (int64_t)m + 1, (long long)__float2ll_rn(s2 * LNF_S1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v;
+}
+// sum over the 4 lanes that share lane & 15 (one per DPP row)
+__device__ __forceinline__ float col4_sum(float v) {
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+__device__ __forceinline__ float bf16_round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+
 // Register-direct epilogue for the permuted accumulator layout (k-contiguous B operand): lane (g = lane>>4, r = lane&15)
 // holds, for each of its MI row blocks, the 16 consecutive columns n0 + 64*wn + 16g .. +15 of row 16i + r.  Returns false
 // (nothing done) when the tile needs the general path: partial N tile, unaligned rows, pre-activation output, beta,
@@ -728,6 +763,21 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
   if (!fast) return false;
   const int n = n0 + wn * 64 + 16 * (lane >> 4);
   const int mrow = m0 + wm * (BM / 2) + (lane & 15);
+  const bool lnf = d.ln_stats != nullptr, wstats = d.row_stats != nullptr;  // js2t_gemm has checked their preconditions
+  float ln_mu[MI], ln_rs[MI], ln_c[16];
+  if (lnf) {
+    const float inv_k = 1.f / (float)d.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      lnf_moments(d.ln_stats, min(mrow + 16 * i, M - 1), inv_k, d.ln_eps, ln_mu[i], ln_rs[i]);
+      if (n == 0 && d.ln_mean && mrow + 16 * i < M) d.ln_mean[mrow + 16 * i] = ln_mu[i], d.ln_rstd[mrow + 16 * i] = ln_rs[i];
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float4 c4 = *(const float4*)(d.ln_colsum + n + 4 * h);
+      ln_c[4 * h] = c4.x, ln_c[4 * h + 1] = c4.y, ln_c[4 * h + 2] = c4.z, ln_c[4 * h + 3] = c4.w;
+    }
+  }
   const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
   const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
   const bool has_drop = d.dropout_p > 0.f;
@@ -763,7 +813,9 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * alpha + bias_r[4 * j + r];
+      for (int r = 0; r < 4; ++r)
+        v[4 * j + r] = lnf ? fmaf(ln_rs[i], fmaf(-ln_mu[i], ln_c[4 * j + r], acc[i][j][r]), bias_r[4 * j + r])
+                           : acc[i][j][r] * alpha + bias_r[4 * j + r];
     if (relu) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -793,6 +845,17 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[8 * h + c] = rr[c] > 0.f ? v[8 * h + c] * gate_scale : 0.f;
       }
+    }
+    if (wstats) {  // row sums of what is stored (bf16-rounded), over this lane's 16 columns, then over the row's four lane groups
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float q = bf16_round(v[c]);
+        s1 += q;
+        s2 = fmaf(q, q, s2);
+      }
+      s1 = col4_sum(s1), s2 = col4_sum(s2);
+      if ((lane >> 4) == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
     }
     if (m < M) {
       const int64_t coff = co + (int64_t)m * d.ldc + n;
@@ -1209,6 +1272,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_w256_kernel(js2t_gemm_desc d
 // epilogue behind, and at fewer than two full rounds of 256x256 tiles the quantisation loss eats the gain (measured:
 // 8192^3 1069 vs 960 TFLOP/s for the 128x128 kernel, but FFN1 12000x2048x512 47 vs 39 us)
 inline bool w256_eligible(const js2t_gemm_desc& d) {
+  if (d.ln_stats || d.row_stats) return false;  // the LayerNorm fold lives in the register-direct epilogues only
   if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
   if ((d.N & 7) || d.M < 256 || d.N < 256) return false;
   if (!g_force_w256 && ((int64_t)cdiv(d.M, 256) * cdiv(d.N, 256) < 512 || d.K < 1024)) return false;
@@ -1293,7 +1357,7 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 // EPI < 0: every epilogue term is decided at run time; EPI >= 0: a bit mask of the terms that are present (alpha = 1),
 // so that the variants the train step uses carry no dead branches - with one wave per SIMD nothing overlaps the
 // epilogue, its instruction count is paid in full.
-constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16;
+constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16, PE_LNF = 32, PE_STATS = 64;
 template <int EPI>
 __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, float (&bias_r)[8]) {
   const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < d.N;  // n >= N: a column group of the N tail
@@ -1324,6 +1388,20 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
   const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
   const int64_t rld = has_res ? d.ldr : d.ldg;
+  // the fold exists in the specialised instantiations only (launch_bf16_p192 refuses other combinations): the run-time
+  // decided variant (EPI < 0) would otherwise carry both paths and spill
+  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0;
+  float ln_c[8];
+  float ln_mu[3][4], ln_rs[3][4];  // mean / reciprocal standard deviation of this lane's twelve rows, requested up front
+  if (lnf) {
+    const float inv_k = 1.f / (float)d.K;
+    const float4 c0 = *(const float4*)(d.ln_colsum + n), c1 = *(const float4*)(d.ln_colsum + n + 4);
+    ln_c[0] = c0.x, ln_c[1] = c0.y, ln_c[2] = c0.z, ln_c[3] = c0.w, ln_c[4] = c1.x, ln_c[5] = c1.y, ln_c[6] = c1.z, ln_c[7] = c1.w;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lnf_moments(d.ln_stats, min(mw + 16 * i + 4 * g + e, M - 1), inv_k, d.ln_eps, ln_mu[i][e], ln_rs[i][e]);
+  }
   // residual / gate rows: block i + 1 is requested before block i is used (twelve rows at once cost too many registers)
   uint4 rg[3][4];
   auto load_rg = [&](int i) {
@@ -1347,8 +1425,15 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
     for (int e = 0; e < 4; ++e) {
       const int m = mrow + e;
       float v[8];
+      if (lnf) {
+        const float mu = ln_mu[i][e], rs = ln_rs[i][e];
+        if (n == 0 && d.ln_mean && m < M) d.ln_mean[m] = mu, d.ln_rstd[m] = rs;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(rs, fmaf(-mu, ln_c[j], acc[i][j][e]), bias_r[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
+      }
       if (relu) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -1373,6 +1458,17 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         unpack_bf16x8(rg[i][e], rr);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
+      }
+      if (wstats) {  // sums of the stored (rounded) values over the lane's 8 columns, then over the 16 lanes of the row group
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float q = bf16_round(v[c]);
+          s1 += q;
+          s2 = fmaf(q, q, s2);
+        }
+        s1 = row16_sum(s1), s2 = row16_sum(s2);
+        if (r == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
       }
       if (m < M) {
         uint4 pk;
@@ -1595,7 +1691,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       P192_T(5);
     }
     p192_store_tile<EPI>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key);
-    stores_behind = tm0 + P_BM <= M;
+    // (a tile whose epilogue also issued the row-statistics atomics has more than twelve requests behind it: smaller count)
+    stores_behind = tm0 + P_BM <= M && !(EPI >= 0 && (EPI & PE_STATS) != 0);
     P192_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
@@ -1646,14 +1743,35 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
 #pragma unroll
       for (int e = 0; e < 4; ++e) rg[i][e] = *(const uint2*)(rsrc + (int64_t)min(mw + 16 * i + 4 * g + e, M - 1) * rld);
   }
+  // the fold exists in the specialised instantiations only (launch_bf16_p192 refuses other combinations): the run-time
+  // decided variant (EPI < 0) would otherwise carry both paths and spill
+  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0;
+  float ln_c[4];
+  float ln_mu[3][4], ln_rs[3][4];
+  if (lnf) {
+    const float inv_k = 1.f / (float)d.K;
+    const float4 c0 = *(const float4*)(d.ln_colsum + n);
+    ln_c[0] = c0.x, ln_c[1] = c0.y, ln_c[2] = c0.z, ln_c[3] = c0.w;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lnf_moments(d.ln_stats, min(mw + 16 * i + 4 * g + e, M - 1), inv_k, d.ln_eps, ln_mu[i][e], ln_rs[i][e]);
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = mw + 16 * i + 4 * g + e;
       float v[4];
+      if (lnf) {
+        const float mu = ln_mu[i][e], rs = ln_rs[i][e];
+        if (n == 0 && d.ln_mean && m < M) d.ln_mean[m] = mu, d.ln_rstd[m] = rs;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(rs, fmaf(-mu, ln_c[j], acc[i][j][e]), bias_r[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
+      }
       if (relu) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -1672,6 +1790,17 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
                              __uint_as_float(q.y & 0xffff0000u)};
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = has_res ? v[c] + res_scale * rr[c] : (rr[c] > 0.f ? v[c] * gate_scale : 0.f);
+      }
+      if (wstats) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float q = bf16_round(v[c]);
+          s1 += q;
+          s2 = fmaf(q, q, s2);
+        }
+        s1 = row16_sum(s1), s2 = row16_sum(s2);
+        if (r == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
       }
       if (m < M) {
         uint2 pk;
@@ -2210,8 +2339,13 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
   // the epilogue combinations of the Transformer train step get their own instantiation, anything else the generic one
   if (d.alpha == 1.f && !d.alpha_dev) {
     const int mask = (d.bias ? PE_BIAS : 0) | (d.act == JS2T_ACT_RELU ? PE_RELU : 0) | (d.dropout_p > 0.f ? PE_DROP : 0) |
-                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0);
+                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_stats ? PE_LNF : 0) | (d.row_stats ? PE_STATS : 0);
     switch (mask) {
+      case PE_BIAS | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_LNF>(d, s);      // q/k/v projections on the raw residual stream
+      case PE_BIAS | PE_RELU | PE_DROP | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP | PE_LNF>(d, s);  // FFN layer 1, same
+      case PE_BIAS | PE_DROP | PE_RES | PE_STATS: return launch_bf16_p192_epi<PE_BIAS | PE_DROP | PE_RES | PE_STATS>(d, s);  // + next LN's row sums
+      case PE_BIAS | PE_RELU | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_LNF>(d, s);  // evaluation mode (no dropout)
+      case PE_BIAS | PE_RES | PE_STATS: return launch_bf16_p192_epi<PE_BIAS | PE_RES | PE_STATS>(d, s);
       case 0: return launch_bf16_p192_epi<0>(d, s);                                    // input gradients
       case PE_BIAS: return launch_bf16_p192_epi<PE_BIAS>(d, s);                        // q/k/v projections
       case PE_BIAS | PE_RELU | PE_DROP: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP>(d, s);  // FFN layer 1
@@ -2219,6 +2353,10 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
       case PE_GATE: return launch_bf16_p192_epi<PE_GATE>(d, s);                        // gradient through ReLU + dropout
       default: break;
     }
+  }
+  if (d.ln_stats || d.row_stats) {
+    js2t_set_error("gemm: ln_stats / row_stats on the persistent kernel: bias [+ ReLU [+ dropout]] with ln_stats, bias [+ dropout] + residual with row_stats only");
+    return JS2T_ERR_INVALID;
   }
   return launch_bf16_p192_epi<-1>(d, s);
 }
@@ -2423,6 +2561,22 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&
                    !d.gate && d.beta == 0.f,
                "gemm: split_k needs an f32 C and a plain epilogue (C must be zero-filled by the caller)");
+  }
+  if (d.ln_stats || d.row_stats) {
+    // the fold lives in the register-direct epilogues of the k-contiguous bf16 kernels (persistent 192x128 and 64/128-row tiles)
+    JS2T_CHECK(d.dtype_ab == JS2T_BF16 && d.dtype_c == JS2T_BF16 && !d.trans_a && !d.trans_b && !d.conv && d.split_k == 1 && d.batch == 1 &&
+                   !d.preact && d.beta == 0.f && !d.a_rowsum && !(d.residual && d.gate) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
+                   !g_force_regstage && !g_force_w256,
+               "gemm: ln_stats / row_stats need a plain k-contiguous bf16 product with a bf16 result");
+    JS2T_CHECK((d.N & 127) == 0 && (d.K & 7) == 0 && d.K >= 8 && (d.lda & 7) == 0 && (d.ldb & 7) == 0 && (d.ldc & 7) == 0 && aligned16(d.A) &&
+                   aligned16(d.B) && aligned16(d.C) && (!d.bias || aligned16(d.bias)),
+               "gemm: ln_stats / row_stats need N % 128 == 0 and 16-byte aligned rows");
+    JS2T_CHECK(!d.row_stats || (((uintptr_t)d.row_stats) & 15) == 0, "gemm: row_stats must be 16-byte aligned");
+    JS2T_CHECK(!d.residual || ((d.ldr & 7) == 0 && aligned16(d.residual)), "gemm: ln_stats / row_stats: misaligned residual");
+    JS2T_CHECK(!d.gate || ((d.ldg & 7) == 0 && aligned16(d.gate)), "gemm: ln_stats / row_stats: misaligned gate");
+    JS2T_CHECK(!d.ln_stats || (d.ln_colsum && aligned16(d.ln_colsum) && (((uintptr_t)d.ln_stats) & 15) == 0 && d.alpha == 1.f && !d.alpha_dev &&
+                               d.ln_eps > 0.f && (!d.ln_mean == !d.ln_rstd)),
+               "gemm: ln_stats needs ln_colsum (16-byte aligned), alpha == 1, ln_eps > 0 and ln_mean / ln_rstd both or neither");
   }
   if (d.dtype_ab == JS2T_FP8_E4M3) {
     // e4m3 x e4m3 -> f32 accumulate -> bf16: the persistent 192x128 kernel only (k-contiguous operands, 16-byte rows)

@@ -217,8 +217,12 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
                                                                  float* __restrict__ partial, float* dgamma_acc,
                                                                  float* dbeta_acc, int64_t rows, int D, T* __restrict__ dxd,
                                                                  float drop_p, const uint64_t* __restrict__ rng, uint32_t rng_stream,
-                                                                 int rows_per_block, int acc_copies, int64_t acc_stride) {
+                                                                 int rows_per_block, int acc_copies, int64_t acc_stride,
+                                                                 const float* __restrict__ beta, T* __restrict__ n_out) {
   extern __shared__ float red[];  // [waves][2][D]
+  // optional third output n_out = xhat * gamma + beta, the LayerNorm's FORWARD result: with the normalisation folded into
+  // the consuming product (js2t_gemm ln_stats) nobody wrote it, and the deferred weight gradient dW = dY^T n still wants it -
+  // re-materialised here while x, mean and rstd are in registers
   // optional second output dxd = dropout_bwd(dx) for the mask of call site rng_stream: the block that produced this
   // LayerNorm's input starts its backward with exactly that product (one read of dx and one launch less)
   const uint32_t dkey = dxd ? dropout_key(rng, rng_stream) : 0u;
@@ -227,13 +231,14 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int nch = D >> 3;
   const int rpw = rows_per_block / nw;
-  float gm[NCH][8], ag[NCH][8], ab[NCH][8];
+  float gm[NCH][8], ag[NCH][8], ab[NCH][8], bt[NCH][8];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     const int c = lane + 64 * j;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; gm[j][i] = 0.f; }
+    for (int i = 0; i < 8; ++i) { ag[j][i] = 0.f; ab[j][i] = 0.f; gm[j][i] = 0.f; bt[j][i] = 0.f; }
     if (c < nch) ld8<float>::ld(gamma + 8 * c, gm[j]);
+    if (n_out && c < nch) ld8<float>::ld(beta + 8 * c, bt[j]);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block + w * rpw;
   for (int rr = 0; rr < rpw; ++rr) {
@@ -275,6 +280,12 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
           for (int i = 0; i < 8; ++i) o[i] += add_scale * av[j][i];
         }
         ld8<T>::st(dx + row * D + 8 * c, o);
+        if (n_out) {
+          float nv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) nv[i] = fmaf(xh[j][i], gm[j][i], bt[j][i]);
+          ld8<T>::st(n_out + row * D + 8 * c, nv);
+        }
         if (dxd) {  // the decisions of dropout_keep4_key(dkey, row, 2c) and (.., 2c + 1), straight from the hash halves
           float od[8];
           const uint32_t rowkey = hash32((uint32_t)row ^ dkey) + 4u * (uint32_t)c;
@@ -460,13 +471,50 @@ __global__ void rel_bias_grad_kernel(const T* __restrict__ dS, float* __restrict
     if (hist[i] != 0.f) atomicAdd(d_bias + h * W + i, hist[i]);
 }
 
+// ---------------------------------------------------------------- weights of the LayerNorm fold
+// table row e: {W f32[N,K], gamma f32[K], beta f32[K], bias f32[N] | 0, Wf bf16[N,K], colsum f32[N], bias_f f32[N], N, K};
+// one wave per weight row: Wf = bf16(W * gamma), colsum = sum of the ROUNDED products (what the MFMAs will see, so that
+// acc - mean * colsum cancels exactly for a constant row), bias_f = bias + W . beta
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const int64_t* __restrict__ table) {
+  const int64_t* e = table + 9 * blockIdx.y;
+  const float* W = (const float*)e[0];
+  const float* gamma = (const float*)e[1];
+  const float* beta = (const float*)e[2];
+  const float* bias = (const float*)e[3];
+  uint16_t* Wf = (uint16_t*)e[4];
+  float* colsum = (float*)e[5];
+  float* bias_f = (float*)e[6];
+  const int64_t N = e[7], K = e[8];
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float cs = 0.f, bs = 0.f;
+  for (int64_t k = 4 * lane; k < K; k += 256) {  // K % 4 == 0 (checked by the host)
+    const float4 w = *(const float4*)(W + n * K + k), g = *(const float4*)(gamma + k), b = *(const float4*)(beta + k);
+    const uint16_t q0 = f32_to_bf16_bits(w.x * g.x), q1 = f32_to_bf16_bits(w.y * g.y), q2 = f32_to_bf16_bits(w.z * g.z),
+                   q3 = f32_to_bf16_bits(w.w * g.w);
+    uint2 pk;
+    pk.x = (uint32_t)q0 | ((uint32_t)q1 << 16);
+    pk.y = (uint32_t)q2 | ((uint32_t)q3 << 16);
+    *(uint2*)(Wf + n * K + k) = pk;
+    cs += (bf16_bits_to_f32(q0) + bf16_bits_to_f32(q1)) + (bf16_bits_to_f32(q2) + bf16_bits_to_f32(q3));
+    bs += (w.x * b.x + w.y * b.y) + (w.z * b.z + w.w * b.w);
+  }
+  cs = wave_sum(cs), bs = wave_sum(bs);
+  if (lane == 0) {
+    colsum[n] = cs;
+    bias_f[n] = bs + (bias ? bias[n] : 0.f);
+  }
+}
+
 }  // namespace
 
 template <typename T, int NCH>
 static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                              const void* add, float add_scale, float* part, float* dga, float* dba, int64_t rows, int D,
                              int64_t nblk, int nw, size_t lds, hipStream_t s, void* dxd, float drop_p, const uint64_t* rng,
-                             uint32_t rng_stream, int rows_per_block, int acc_copies, int64_t acc_stride) {
+                             uint32_t rng_stream, int rows_per_block, int acc_copies, int64_t acc_stride, const float* beta,
+                             void* n_out) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_vec_kernel<T, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -477,7 +525,8 @@ static int launch_ln_bwd_vec(const void* dy, const void* x, const float* gamma, 
     attr_set = true;
   }
   hipLaunchKernelGGL((layernorm_bwd_vec_kernel<T, NCH>), dim3((unsigned)nblk), dim3(64 * nw), lds, s, (const T*)dy, (const T*)x, gamma,
-                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D, (T*)dxd, drop_p, rng, rng_stream, rows_per_block, acc_copies, acc_stride);
+                     mean, rstd, (T*)dx, (const T*)add, add_scale, part, dga, dba, rows, D, (T*)dxd, drop_p, rng, rng_stream, rows_per_block, acc_copies, acc_stride,
+                     beta, (T*)n_out);
   return JS2T_OK;
 }
 
@@ -544,6 +593,15 @@ extern "C" int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const f
                                           int accumulate, int64_t rows, int64_t D, int dt, void* dx_dropped, float drop_p,
                                           const uint64_t* rng_state, uint32_t rng_stream, int32_t acc_copies, int64_t acc_copy_stride,
                                           js2t_stream stream) {
+  return js2t_layernorm_bwd_fused(dy, x, gamma, mean, rstd, dx, add, add_scale, dgamma, dbeta, partial, accumulate, rows, D, dt, dx_dropped,
+                                  drop_p, rng_state, rng_stream, acc_copies, acc_copy_stride, nullptr, nullptr, stream);
+}
+
+extern "C" int js2t_layernorm_bwd_fused(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                        void* dx, const void* add, float add_scale, float* dgamma, float* dbeta, float* partial,
+                                        int accumulate, int64_t rows, int64_t D, int dt, void* dx_dropped, float drop_p,
+                                        const uint64_t* rng_state, uint32_t rng_stream, int32_t acc_copies, int64_t acc_copy_stride,
+                                        const float* beta, void* n_out, js2t_stream stream) {
   const int copies = (accumulate && acc_copies > 1) ? acc_copies : 1;
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0, "layernorm_bwd: bad arguments");
@@ -553,6 +611,8 @@ extern "C" int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const f
   const bool vec = (D % 8 == 0) && D <= 64 * 8 * LNV_MAXCH &&
                    (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)add | (uintptr_t)dxd) & 15) == 0;
   JS2T_CHECK(vec || !dxd, "layernorm_bwd_dropout: the fused dropout output needs the vectorised kernel (D % 8 == 0, D <= 2048, 16-byte aligned)");
+  JS2T_CHECK(!n_out || (vec && beta && (((uintptr_t)n_out | (uintptr_t)beta) & 15) == 0),
+             "layernorm_bwd_fused: n_out needs beta and the vectorised kernel (D % 8 == 0, D <= 2048, 16-byte aligned)");
   if (vec) {
     const bool want_p = dgamma && dbeta;
     const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
@@ -574,13 +634,13 @@ extern "C" int js2t_layernorm_bwd_dropout(const void* dy, const void* x, const f
     float* dba = direct ? dbeta : (float*)nullptr;
     int rc;
     if (dt == JS2T_F32) {
-      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride)
-         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride)
-                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride);
+      rc = D <= 512 ? launch_ln_bwd_vec<float, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out)
+         : D <= 1024 ? launch_ln_bwd_vec<float, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out)
+                     : launch_ln_bwd_vec<float, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out);
     } else {
-      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride)
-         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride)
-                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride);
+      rc = D <= 512 ? launch_ln_bwd_vec<uint16_t, 1>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out)
+         : D <= 1024 ? launch_ln_bwd_vec<uint16_t, 2>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out)
+                     : launch_ln_bwd_vec<uint16_t, 4>(dy, x, gamma, mean, rstd, dx, add, add_scale, part, dga, dba, rows, (int)D, nblk, nw, lds, s, dxd, drop_p, rng_state, rng_stream, rows_per_block, copies, acc_copy_stride, beta, n_out);
     }
     if (rc != JS2T_OK) return rc;
     JS2T_LAUNCH_CHECK();
@@ -666,6 +726,14 @@ extern "C" int js2t_rel_bias_grad(const void* dS, float* d_rel_bias, int64_t B, 
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_grad_kernel<T>), dim3((unsigned)cdiv(rows, rpb), (unsigned)H), dim3(256),
                                         (size_t)(2 * R + 1) * sizeof(float), (hipStream_t)stream, (const T*)dS, d_rel_bias, B, H,
                                         Tq, Tk, ld, (int)R, rpb));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_fold_ln_weights(const int64_t* table, int32_t n_entries, int32_t max_rows, js2t_stream stream) {
+  if (n_entries == 0 || max_rows == 0) return JS2T_OK;
+  JS2T_CHECK(table && n_entries > 0 && n_entries <= 65535 && max_rows > 0, "fold_ln_weights: bad arguments");
+  hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((unsigned)cdiv(max_rows, 4), (unsigned)n_entries), dim3(256), 0, (hipStream_t)stream, table);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

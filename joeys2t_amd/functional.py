@@ -62,13 +62,13 @@ def _fp8_eligible(x2d, w, out_dtype, preact, alpha) -> bool:
 
 
 def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
-               out_dtype=None, preact=None, alpha=1.0):
-    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch."""
+               out_dtype=None, preact=None, alpha=1.0, ln=None, row_stats=None):
+    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / row_stats: see ops.gemm (LayerNorm fold)."""
     _row_major_2d(x2d), _row_major_2d(w)
     M, K = x2d.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
-    if _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
+    if ln is None and row_stats is None and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
         w8, ws = _fp8_weight(w)
         if FP8_DELAYED:
             key = (w.data_ptr(), tuple(w.shape))
@@ -85,7 +85,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
         return y
     ops.gemm(x2d, w, y, M=M, N=N, K=K, lda=x2d.stride(0), ldb=w.stride(0), ldc=N, bias=b, act=act, preact=preact,
              dropout_p=dropout_p, rng=rng, rng_stream=site, residual=residual,
-             ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha)
+             ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha, ln=ln, row_stats=row_stats)
     return y
 
 
@@ -285,6 +285,14 @@ def _ln_fwd(x2d, gamma, beta):
 # Entries hold their tensors, so an address cannot be re-used while it is a key; begin_step() clears both tables.
 _DROP_HINT = {}
 _DROP_READY = {}
+# LayerNorm fold (bf16 pre-LN stacks): the block that WRITES a residual-stream tensor y lets its last product's epilogue add
+# y's row sums / sums of squares into a scratch slice (js2t_gemm row_stats) and leaves the slice under y's address; the next
+# block, whose first act would be LayerNorm(y), takes it and runs its first product on y itself with gamma-scaled weights,
+# finishing the normalisation per output element (js2t_gemm ln_stats; runtime.ParamStore.fold keeps the derived weights).
+# No kernel reads a row just to normalise it; the normalised activations, which the deferred weight gradient still wants,
+# are re-materialised by the block's LayerNorm BACKWARD while it has x, mean and rstd in registers anyway.
+_LN_STATS = {}
+LN_FOLD = os.environ.get("JS2T_LN_FOLD", "1") != "0"  # tests flip this to compare with the standalone LayerNorm kernel
 FUSE_LN_DROPOUT_BWD = os.environ.get("JS2T_LN_DROPOUT_HANDOVER", "1") != "0"  # tests flip this to compare with the separate kernel
 
 
@@ -304,6 +312,11 @@ _CHAIN_ACTIVE = False
 def reset_handover():
     _DROP_HINT.clear()
     _DROP_READY.clear()
+    _LN_STATS.clear()
+
+
+def _fold_operand(t: torch.Tensor) -> bool:
+    return t.dtype == torch.bfloat16 and t.is_contiguous() and t.data_ptr() % 16 == 0 and t.shape[1] % 8 == 0
 
 
 def begin_memory_chain():
@@ -353,15 +366,35 @@ class ResidualBlockFn(torch.autograd.Function):
         if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
                 ops.layernorm_bwd_supports_dropout(x2)):
             ctx.prev_drop = hint[:3]  # (p, site, rng) of the block that produced x
-        if cfg.ln_mode == "pre":
+        lnf = None   # (stats, colsum, eps, mean out, rstd out) when this block's LayerNorm is folded into its first product
+        fold = wts.get("fold") if (LN_FOLD and cfg.ln_mode == "pre" and not FP8_FORWARD) else None
+        sink0 = wts.get("sink") or {}
+        if fold is not None and _fold_operand(x2) and (not torch.is_grad_enabled() or ("_wq" in sink0 and "ln_g" in sink0)):
+            hint = _LN_STATS.pop(x.data_ptr(), None)
+            if hint is not None and hint[1].shape == x.shape and hint[1].dtype == x.dtype:
+                mean = torch.empty((B * T, ), dtype=torch.float32, device=x.device)
+                rstd = torch.empty_like(mean)
+                lnf = (hint[0], fold.colsum, LN_EPS, mean, rstd)
+        if lnf is not None:
+            n = x2  # the product reads the raw rows; what it computes is LN(x) W^T + b
+            saved.update(mean=mean, rstd=rstd, folded=True)
+            w_first = {"self": "w_in", "cross": "w_q", "ffn": "w1"}[cfg.kind]
+            b_first = {"self": "b_in", "cross": "b_q", "ffn": "b1"}[cfg.kind]
+            wts = dict(wts)
+            wts["_" + w_first], wts["_" + b_first] = fold.w, fold.bias
+        elif cfg.ln_mode == "pre":
             n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
             saved.update(mean=mean, rstd=rstd)
         else:
             n = x2
+
+        def first(name):  # weight / bias of the block's first product: the gamma-scaled pair when folded
+            return wts.get("_" + name, wts[name]) if lnf is not None else wts[name]
+
         att_w = None
         if cfg.kind == "self":
             H, dh = cfg.H, d // cfg.H
-            qkv = linear_fwd(n, wts["w_in"], wts["b_in"])  # columns: [k | v | q]
+            qkv = linear_fwd(n, first("w_in"), first("b_in"), ln=lnf)  # columns: [k | v | q]
             shp = AttnShape(B, T, T, H, dh)
             c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0], rel_bias=wts.get("rel_bias"))
             saved.update(qkv=qkv, P=P, Pd=Pd, shp=shp)
@@ -369,7 +402,7 @@ class ResidualBlockFn(torch.autograd.Function):
             H, dh = cfg.H, d // cfg.H
             S = memory.shape[1]
             m2 = memory.reshape(B * S, memory.shape[2])
-            q = linear_fwd(n, wts["w_q"], wts["b_q"])
+            q = linear_fwd(n, first("w_q"), first("b_q"), ln=lnf)
             kv = linear_fwd(m2, wts["w_kv"], wts["b_kv"])  # columns: [k | v]
             shp = AttnShape(B, T, S, H, dh)
             c, P, Pd = attn_fwd(q, 0, kv, 0, kv, d, shp, mask, p_in, rng, sites[0], need_probs=cfg.need_weights)
@@ -384,11 +417,18 @@ class ResidualBlockFn(torch.autograd.Function):
             pre = None
             if cfg.act != "relu" and cfg.act is not None:
                 pre = torch.empty((B * T, wts["w1"].shape[0]), dtype=x.dtype, device=x.device)
-            c = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre)
+            if lnf is not None and pre is not None:
+                raise ops.Js2tError("LayerNorm fold: ReLU / no activation only")  # (the caller does not offer a fold otherwise)
+            c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf)
             saved.update(pre=pre)
         w_last, b_last = (wts["w2"], wts["b2"]) if cfg.kind == "ffn" else (wts["w_out"], wts["b_out"])
+        # the row statistics of what this block writes, for a following block that folds its LayerNorm (see _LN_STATS)
+        out_stats = None
+        if (LN_FOLD and cfg.ln_mode == "pre" and cfg.alpha != 0.0 and not FP8_FORWARD and wts.get("stats_arena") is not None and
+                b_last is not None and _fold_operand(c) and _fold_operand(x2) and w_last.shape[0] % 128 == 0 and w_last.dtype == torch.bfloat16):
+            out_stats = wts["stats_arena"].take(B * T)
         u = linear_fwd(c, w_last, b_last, dropout_p=p_out, rng=rng, site=sites[1],
-                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha)
+                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha, row_stats=out_stats)
         if cfg.ln_mode != "post":
             y = u
         else:
@@ -396,12 +436,16 @@ class ResidualBlockFn(torch.autograd.Function):
             saved.update(mean=mean, rstd=rstd, u=u)
         ctx.cfg, ctx.rng, ctx.sites, ctx.wts, ctx.saved = cfg, rng, sites, wts, saved
         ctx.params = params
-        ctx.x2, ctx.n, ctx.c = x2, n, c
+        ctx.x2, ctx.n, ctx.c = x2, (None if lnf is not None else n), c
         ctx.mask = mask
         ctx.shape = (B, T, d)
         ctx.mem_shape = None if memory is None else tuple(memory.shape)
         ctx.nparams = len(params)
         y = y.view(B, T, d)
+        if out_stats is not None:
+            if len(_LN_STATS) > 64:
+                _LN_STATS.clear()
+            _LN_STATS[y.data_ptr()] = (out_stats, y)
         if p_out > 0 and rng is not None and cfg.ln_mode != "post" and FUSE_LN_DROPOUT_BWD and x.requires_grad:
             if len(_DROP_HINT) > 64:  # forward passes without a training step around them: do not pile up activations
                 _DROP_HINT.clear()
@@ -418,6 +462,15 @@ class ResidualBlockFn(torch.autograd.Function):
         B, T, d = ctx.shape
         p, p_out = cfg.p_in, cfg.p_out
         x2, n, c = ctx.x2, ctx.n, ctx.c
+        n_re = None
+        if sv.get("folded"):
+            # the forward never wrote LN(x): the queued weight-gradient product gets a buffer that this block's LayerNorm
+            # backward (below) fills; without the queue the product runs right away and needs it now
+            sink_b = wts.get("sink") or {}
+            if sink_b.get("_wq") is not None and ops.layernorm_bwd_supports_dropout(x2):
+                n = n_re = torch.empty_like(x2)
+            else:
+                n = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])[0]
         dy2 = dy.reshape(B * T, d)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -493,11 +546,13 @@ class ResidualBlockFn(torch.autograd.Function):
             if ctx.prev_drop is not None:
                 pp, psite, prng = ctx.prev_drop
                 dx2, g["ln_g"], g["ln_b"], dxd = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du, add_scale=cfg.alpha,
-                                                                   grad_out=ln_sink, drop=(pp, prng, psite), copies=ln_copies)
+                                                                   grad_out=ln_sink, drop=(pp, prng, psite), copies=ln_copies,
+                                                                   n_out=n_re, beta=wts["ln_b"])
                 _DROP_READY[dx2.data_ptr()] = (dxd, dx2, (pp, psite), prng)
             else:
                 dx2, g["ln_g"], g["ln_b"] = ops.layernorm_bwd(dn, x2, wts["ln_g"], sv["mean"], sv["rstd"], add=du,
-                                                              add_scale=cfg.alpha, grad_out=ln_sink, copies=ln_copies)
+                                                              add_scale=cfg.alpha, grad_out=ln_sink, copies=ln_copies,
+                                                              n_out=n_re, beta=wts["ln_b"])
         elif cfg.alpha != 0.0:
             dx2 = ops.axpby(dn, 1.0, du, cfg.alpha)
         else:

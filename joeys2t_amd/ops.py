@@ -78,6 +78,7 @@ def dropout_rng(device) -> DropoutRng:
 
 
 # ----------------------------------------------------------------------------------------- GEMM
+ROW_STATS_SCALE = (2.0**20, 2.0**16)  # units of the two fixed-point sums in js2t_gemm's ln_stats / row_stats
 GEMM_TIMER = None  # bench.py installs an object with .wrap(key, flops, launch) to HIP-event-time every GEMM launch
 
 
@@ -99,9 +100,11 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1, a_rowsum=None):
-    """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements."""
-    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum)
+         conv=None, split_k=1, a_rowsum=None, ln=None, row_stats=None):
+    """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements.
+    ln = (stats i64[M,2], colsum f32[N], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product;
+    row_stats i64[M,2]: fixed-point row sums / sums of squares of the stored results are ADDED into it (ROW_STATS_SCALE)."""
+    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum, row_stats)
     if A.dtype != B.dtype:
         raise Js2tError(f"gemm: A/B dtype mismatch {A.dtype} vs {B.dtype}")
     d = GemmDesc()
@@ -147,6 +150,18 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.conv_tin, d.conv_tout, d.conv_c, d.conv_stride, d.conv_pad = (int(v) for v in conv)
     d.split_k = int(split_k)
     d.a_rowsum = None if a_rowsum is None else a_rowsum.data_ptr()
+    if ln is not None:
+        stats, colsum, eps, mean_out, rstd_out = ln
+        _dev(stats, colsum, mean_out, rstd_out)
+        if stats.dtype != torch.int64 or stats.shape != (M, 2) or not stats.is_contiguous() or colsum.dtype != torch.float32 or colsum.numel() != N:
+            raise Js2tError("gemm: ln needs stats i64[M, 2] (fixed-point row sums, see the header) and colsum f32[N]")
+        d.ln_stats, d.ln_colsum, d.ln_eps = stats.data_ptr(), colsum.data_ptr(), float(eps)
+        if mean_out is not None:
+            d.ln_mean, d.ln_rstd = mean_out.data_ptr(), rstd_out.data_ptr()
+    if row_stats is not None:
+        if row_stats.dtype != torch.int64 or row_stats.shape != (M, 2) or not row_stats.is_contiguous():
+            raise Js2tError("gemm: row_stats must be contiguous i64[M, 2]")
+        d.row_stats = row_stats.data_ptr()
     if GEMM_TIMER is not None:
         if d.dtype_ab == FP8:
             key = "gemm_fp8_p192_kernel<0,0,0>"
@@ -412,11 +427,14 @@ class GradCopies:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add_scale=1.0, grad_out=None, drop=None,
-                  copies: Optional[GradCopies] = None):
+                  copies: Optional[GradCopies] = None, n_out=None, beta=None):
     """grad_out = (dgamma_buf, dbeta_buf): accumulate the parameter gradients into these buffers in place.
     drop = (p, rng, site): also return dropout_bwd(dx, p, rng, site) as a fourth value (js2t_layernorm_bwd_dropout).
-    copies: with grad_out, accumulate into that workspace's copies of (dgamma_buf, dbeta_buf) instead (folded by its owner)."""
-    _dev(dy, x, gamma, mean, rstd, add)
+    copies: with grad_out, accumulate into that workspace's copies of (dgamma_buf, dbeta_buf) instead (folded by its owner).
+    n_out (with beta): also write the LayerNorm's forward result xhat * gamma + beta there (js2t_layernorm_bwd_fused)."""
+    _dev(dy, x, gamma, mean, rstd, add, n_out, beta)
+    if n_out is not None and (beta is None or n_out.shape != x.shape or n_out.dtype != x.dtype or not n_out.is_contiguous()):
+        raise Js2tError("layernorm_bwd: n_out must look like x and needs beta")
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty_like(x)
@@ -441,14 +459,22 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
         copies = 1
     p_drop, rng, site = drop if drop is not None else (0.0, None, 0)
     dxd = torch.empty_like(x) if drop is not None else None
-    check(lib().js2t_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(acc_g),
-                                           _p(acc_b), _p(partial), int(grad_out is not None and need_param_grads), C.c_int64(rows),
-                                           C.c_int64(D), dt_code(x), _p(dxd), C.c_float(p_drop), None if rng is None else _p(rng.state),
-                                           C.c_uint32(site & 0xFFFFFFFF), C.c_int32(copies), C.c_int64(stride), _stream()),
-          "js2t_layernorm_bwd_dropout")
+    check(lib().js2t_layernorm_bwd_fused(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(add), C.c_float(add_scale), _p(acc_g),
+                                         _p(acc_b), _p(partial), int(grad_out is not None and need_param_grads), C.c_int64(rows),
+                                         C.c_int64(D), dt_code(x), _p(dxd), C.c_float(p_drop), None if rng is None else _p(rng.state),
+                                         C.c_uint32(site & 0xFFFFFFFF), C.c_int32(copies), C.c_int64(stride), _p(beta) if n_out is not None else None,
+                                         _p(n_out), _stream()),
+          "js2t_layernorm_bwd_fused")
     if drop is None:
         return dx, dgamma, dbeta
     return dx, dgamma, dbeta, dxd
+
+
+def fold_ln_weights(table: torch.Tensor, n_entries: int, max_rows: int):
+    """(Re)derive the gamma-scaled bf16 weights, their column sums and the beta-absorbing biases of every LayerNorm fold
+    (js2t_fold_ln_weights; table int64[n, 9] on the device)."""
+    _dev(table)
+    check(lib().js2t_fold_ln_weights(_p(table), C.c_int32(n_entries), C.c_int32(max_rows), _stream()), "js2t_fold_ln_weights")
 
 
 def layernorm_bwd_supports_dropout(x) -> bool:

@@ -111,6 +111,50 @@ class ParamStore:
                 p.data = view
                 p.grad = None
         self._cache: Dict[Tuple, torch.Tensor] = {}
+        # LayerNorm folds (fold()): derived weights per (LayerNorm, Linear group) pair + the table js2t_fold_ln_weights walks
+        self._folds: Dict[Tuple, LnFold] = {}
+        self._fold_rows: List[List[int]] = []
+        self._fold_table: Optional[torch.Tensor] = None
+        self._fold_max_rows = 0
+
+    # ---- LayerNorm folded into the consuming product ----------------------------------------------
+    def fold(self, weights: Sequence[nn.Parameter], biases: Sequence[nn.Parameter], gamma: nn.Parameter, beta: nn.Parameter):
+        """The LnFold of LayerNorm(gamma, beta) followed by the Linear whose (adjacent) weights / biases are given, created on
+        first use; None when the parameters are not laid out for it (not adjacent, N % 128 != 0, K % 8 != 0)."""
+        key = tuple(id(p) for p in (*weights, *biases, gamma, beta))
+        hit = self._folds.get(key)
+        if hit is not None:
+            return hit
+        if key in self._folds:
+            return None
+        w32, b32 = self.view(list(weights), torch.float32), self.view(list(biases), torch.float32)
+        ok = (w32 is not None and b32 is not None and w32.dim() == 2 and id(gamma) in self.offsets and id(beta) in self.offsets and
+              w32.shape[0] % 128 == 0 and w32.shape[1] % 8 == 0 and gamma.numel() == w32.shape[1] and b32.numel() == w32.shape[0])
+        if not ok or torch.cuda.is_current_stream_capturing():
+            if not ok:
+                self._folds[key] = None
+            return None
+        N, K = w32.shape
+        f = LnFold(torch.empty((N, K), dtype=torch.bfloat16, device=self.device), torch.empty((N, ), dtype=torch.float32, device=self.device),
+                   torch.empty((N, ), dtype=torch.float32, device=self.device))
+        self._folds[key] = f
+        self._fold_rows.append([w32.data_ptr(), gamma.data.data_ptr(), beta.data.data_ptr(), b32.data_ptr(), f.w.data_ptr(),
+                                f.colsum.data_ptr(), f.bias.data_ptr(), N, K])
+        self._fold_max_rows = max(self._fold_max_rows, N)
+        self._fold_table = None
+        row = torch.tensor([self._fold_rows[-1]], dtype=torch.int64, device=self.device)
+        ops.fold_ln_weights(row, 1, N)  # this pair now; all pairs together after every update (refresh_folds)
+        return f
+
+    def refresh_folds(self):
+        """Re-derive every fold from the fp32 masters (one launch): after an optimizer update / load_state_dict."""
+        if not self._fold_rows:
+            return
+        if self._fold_table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops.Js2tError("LayerNorm folds were created after the last eager update: run one eager step before capturing")
+            self._fold_table = torch.tensor(self._fold_rows, dtype=torch.int64, device=self.device)
+        ops.fold_ln_weights(self._fold_table, len(self._fold_rows), self._fold_max_rows)
 
     # ---- gradient views -------------------------------------------------------------------------
     def attach_grads(self, zero: bool = True):
@@ -151,6 +195,7 @@ class ParamStore:
             self.dirty = False
             if self.flat_lp_t is not None:
                 self.refresh_t()
+            self.refresh_folds()
 
     def refresh_t(self):
         """(Re)build the transposed bf16 shadows of all 2-D weight groups from the bf16 shadow: one kernel over a table."""
@@ -218,6 +263,43 @@ class ParamStore:
         return out
 
 
+class LnFold:
+    """Derived operands of one LayerNorm -> nn.Linear pair for js2t_gemm's ln_stats mode: w = bf16(W * gamma) [N, K],
+    colsum f32[N] = row sums of w, bias f32[N] = b + W beta.  Owned and kept current by ParamStore.refresh_folds()."""
+    __slots__ = ("w", "colsum", "bias")
+
+    def __init__(self, w, colsum, bias):
+        self.w, self.colsum, self.bias = w, colsum, bias
+
+
+class RowStatsArena:
+    """i64 [rows, 2] scratch the residual epilogues ADD their fixed-point row sums / sums of squares into (js2t_gemm row_stats), handed
+    out in call order.  Invariant: everything at and beyond `cursor` is zero - begin() (once per Model.forward) re-zeroes
+    what earlier passes used with ONE fill launch instead of one per block; callers that never call begin() simply walk on
+    until the arena is used up and then get freshly zeroed tensors."""
+
+    def __init__(self, device, rows: int = 1 << 20):
+        self.buf = torch.zeros((rows, 2), dtype=torch.int64, device=device)
+        self.cursor = 0
+        self.high = 0
+
+    def begin(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.cursor = 0
+
+    def take(self, rows: int) -> torch.Tensor:
+        end = self.cursor + rows
+        if end > self.buf.shape[0]:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops.Js2tError("RowStatsArena exhausted during hipGraph capture (Model.forward() calls begin())")
+            return torch.zeros((rows, 2), dtype=torch.int64, device=self.buf.device)
+        out = self.buf[self.cursor:end]
+        self.cursor = end
+        self.high = max(self.high, end)
+        return out
+
+
 class WgradQueue:
     """Weight-gradient products put off until the backward pass is over (or `flush_every` of them are waiting).
 
@@ -282,6 +364,7 @@ class Runtime:
         self.on_grads_ready = None  # callable(list of params): DDP bucket bookkeeping for directly written gradients
         self.wgrad_queue: Optional[WgradQueue] = None  # set (TrainStep) to defer + group the weight-gradient products
         self.grad_copies = None  # ops.GradCopies (TrainStep): LayerNorm parameter gradients accumulate into folded copies
+        self._row_stats: Optional[RowStatsArena] = None
 
     @property
     def rng(self) -> ops.DropoutRng:
@@ -308,6 +391,18 @@ class Runtime:
         for p in params:
             ws.append(p.data if p.dtype == dt else ops.cast(p.data, dt))
         return ws[0] if len(ws) == 1 else torch.cat(ws, dim=0)
+
+    def ln_fold(self, weights, biases, ln: Optional[nn.LayerNorm]) -> Optional[LnFold]:
+        """Folded operands for `ln` -> Linear(weights, biases) (functional.LN_FOLD), or None: bf16 compute on a flat store only."""
+        if ln is None or self.store is None or self.compute_dtype != torch.bfloat16 or any(b is None for b in biases):
+            return None
+        return self.store.fold(weights, biases, ln.weight, ln.bias)
+
+    @property
+    def row_stats(self) -> RowStatsArena:
+        if self._row_stats is None:
+            self._row_stats = RowStatsArena(self.device)
+        return self._row_stats
 
     def weight_t(self, params: Sequence[nn.Parameter]) -> Optional[torch.Tensor]:
         """Transposed compute-dtype weight [in, out] for the input-gradient product, when the store keeps one (bf16 compute,
