@@ -61,19 +61,21 @@ const char* js2t_last_error(void);
  * kw*conv_c + c, and A = x[b, t*conv_stride - conv_pad + kw, c] (0 outside [0,conv_tin)).
  * dtype_ab = BF16 needs 16-byte aligned operands and leading dimensions that are multiples of 8.
  * split_k > 1 (weight gradients: few output tiles, K = tokens) spreads the reduction over split_k blocks per tile.
- * ln_stats != NULL ("LayerNorm fold", pre-LN blocks of transformer_layers.py:267-289,348-407): the product runs on the RAW
- * residual stream x and a weight whose columns were scaled by the LayerNorm's gamma, B(n,k) = W(n,k) gamma(k), and the
- * normalisation is finished per output element:
- *   mean(m) = S0/K, rstd(m) = 1/sqrt(max(S1/K - mean^2, 0) + ln_eps)            with {S0, S1} = ln_stats[m] * {2^-20, 2^-16}
- *   v = rstd(m) * (acc(m,n) - mean(m) * ln_colsum[n]) + bias[n]                  (= LN(x) W^T + b for bias = b + W beta)
- * then activation / dropout / ... as usual; ln_mean / ln_rstd (optional) receive the row statistics for the backward pass.
- * row_stats != NULL: the epilogue also adds the row sums and sums of squares of its stored results into row_stats (integer
- * atomics onto whatever is there) - the producer side of the fold: the statistics of the NEXT LayerNorm's input come from
- * the residual epilogue that writes that input, so no kernel reads the row just to normalise it.  The sums are 64-bit fixed
- * point (sum x in units of 2^-20, sum x^2 in units of 2^-16): integer additions commute, so the statistics - and every
- * activation behind them - do not depend on the order in which a row's column groups arrive.
- * Both need: bf16 k-contiguous operands (trans_a = trans_b = 0), batch 1, no conv / split-K / preact / beta, alpha = 1,
- * a bf16 C, N % 128 == 0, 16-byte aligned rows, activation none or ReLU.
+ * LayerNorm fold (pre-LN blocks of transformer_layers.py:267-289,348-407; bf16, model width 512): nn.LayerNorm in front of a
+ * block's first nn.Linear is not a kernel of its own.
+ *   producer, rs_partial != NULL: the epilogue that WRITES a residual-stream tensor also writes, per row and 64-column group,
+ *     the sum and the sum of squares of the values it stores (bf16-rounded) - plain stores, no atomics, nothing to zero.
+ *   consumer, ln_partial != NULL (the producer's rs_partial): the product runs on the RAW residual stream x with the weight
+ *     js2t_fold_ln_weights derives,
+ *       B(n,k) = W(n,k) gamma(k) - (1/K) sum_k' W(n,k') gamma(k')   (gamma-scaled, every row centred: sum_k B(n,k) = 0, so
+ *     that sum_k x(m,k) B(n,k) = sum_k (x(m,k) - mean(m)) W(n,k) gamma(k) without the mean ever being subtracted).  At the
+ *     start of a tile one lane per row adds the row's eight partial pairs (fixed order: reproducible bit for bit), forms
+ *     mean and rstd = 1/sqrt(var + ln_eps), and the epilogue computes
+ *       v = rstd(m) * acc(m,n) + bias[n]     with bias = b + W beta     (= LN(x) W^T + b), then activation / dropout as usual;
+ *     ln_mean / ln_rstd (optional) receive the statistics for the backward pass.
+ * Both: plain k-contiguous bf16 products with a bf16 result (the persistent 192x128 kernel or the 64 / 128-row tile kernel),
+ * N % 128 == 0, alpha = 1, a bias; epilogues bias [+ ReLU [+ dropout]] (consumer, K = 512) and bias [+ dropout] + residual
+ * (producer, N = 512).
  * a_rowsum != NULL: additionally a_rowsum[m] += sum_k op(A)[m,k] (f32 atomics onto whatever is there).  For a weight
  * gradient dW = dY^T X this is the bias gradient (autograd of nn.Linear, transformer_layers.py:75-107), taken from the
  * dY tiles the product already holds in LDS.  bf16 LDS-DMA path with trans_a = trans_b = 1 only (batch == 1, no conv).
@@ -105,12 +107,11 @@ typedef struct js2t_gemm_desc {
   int32_t split_k;          /* >1: K is cut into slices reduced with f32 atomics into a zero-filled f32 C */
   float* a_rowsum;          /* optional f32[M]: += row sums of op(A) */
   /* LayerNorm folded into the product (see below); all optional */
-  const int64_t* ln_stats;  /* i64 [M][2]: {sum_k A(m,k) * 2^20, sum_k A(m,k)^2 * 2^16} of A's rows, fixed point (see below) */
-  const float* ln_colsum;   /* f32 [N]: sum_k B(n,k) of the (gamma-scaled) weight as stored */
+  const float* ln_partial;  /* consumer: f32 [M][8][2], per 64-column group {sum, sum of squares} of A's rows (K = 512) */
   float ln_eps;
-  float* ln_mean;           /* f32 [M] out: the row means / reciprocal standard deviations the epilogue used */
+  float* ln_mean;           /* consumer out (both or neither): f32 [M] row means and 1/sqrt(var + eps) the epilogue used */
   float* ln_rstd;
-  int64_t* row_stats;       /* i64 [M][2]: += the same two fixed-point sums over n of the stored (bf16-rounded) C(m,n) */
+  float* rs_partial;        /* producer out: f32 [M][8][2], the same sums over the stored (bf16-rounded) C's rows (N = 512) */
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
@@ -151,10 +152,10 @@ int js2t_axpby(const void* x, float a, const void* y, float b, void* out, int64_
 /* dst[i] = (dst_dt) src[i].  Autocast-style parameter/activation casts (training.py:558 autocast). */
 int js2t_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, js2t_stream stream);
 
-/* Weights of the LayerNorm fold (js2t_gemm ln_stats), re-derived from the fp32 masters after every optimizer update: for each
- * table row e = {W, gamma, beta, bias, Wf, colsum, bias_f, N, K} (device pointers / sizes as int64):
- *   Wf[n,k] = bf16(W[n,k] * gamma[k]);  colsum[n] = sum_k float(Wf[n,k]);  bias_f[n] = bias[n] + sum_k W[n,k] * beta[k]
- * (W f32 [N,K], gamma / beta f32 [K], bias f32 [N] or 0).  One launch for all entries. */
+/* Weights of the LayerNorm fold (js2t_gemm ln_partial), re-derived from the fp32 masters after every optimizer update: for each
+ * table row e = {W, gamma, beta, bias, Wf, bias_f, N, K} (device pointers / sizes as int64):
+ *   c[n] = sum_k W[n,k] gamma[k];  Wf[n,k] = bf16(W[n,k] gamma[k] - c[n] / K);  bias_f[n] = bias[n] + sum_k W[n,k] beta[k]
+ * (W f32 [N,K], gamma / beta f32 [K], bias f32 [N] or 0, K % 4 == 0).  One launch for all entries. */
 int js2t_fold_ln_weights(const int64_t* table, int32_t n_entries, int32_t max_rows, js2t_stream stream);
 
 /* fp8 forward mode (BASELINE.json configs[4]: "fp8 MFMA"; the reference has no fp8 path - joeynmt/config.py:223-225 knows

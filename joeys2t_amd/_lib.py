@@ -44,8 +44,7 @@ class GemmDesc(C.Structure):
         ("conv_stride", C.c_int32), ("conv_pad", C.c_int32),
         ("split_k", C.c_int32),
         ("a_rowsum", C.c_void_p),
-        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
-        ("row_stats", C.c_void_p),
+        ("ln_partial", C.c_void_p), ("ln_eps", C.c_float), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("rs_partial", C.c_void_p),
     ]
 
 

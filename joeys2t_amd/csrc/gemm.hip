@@ -708,23 +708,8 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
 }
 
 
-// ---- LayerNorm fold (js2t_gemm_desc::ln_stats / row_stats) helpers shared by the register-direct epilogues
-// Row statistics travel as 64-bit FIXED-POINT sums: the producer's column groups add their partial sums with integer atomics,
-// which commute exactly - the statistics, and with them every activation downstream, are bit-for-bit reproducible from run
-// to run (f32 atomics would make the rounding of the sums depend on arrival order, and 24 layers amplify that to 1e-3).
-// S0 = sum x in units of 2^-20, S1 = sum x^2 in units of 2^-16: |x| up to ~5e5 before S1 overflows, far beyond anything a
-// bf16 residual stream holds while training is alive (a NaN / Inf in x still reaches the output through the product itself).
-constexpr float LNF_S0 = 1048576.f, LNF_S1 = 65536.f;
-__device__ __forceinline__ void lnf_moments(const int64_t* stats, int m, float inv_k, float eps, float& mean, float& rstd) {
-  typedef long long ll2_t __attribute__((ext_vector_type(2)));
-  const ll2_t sv = *(const ll2_t*)(stats + 2 * (int64_t)m);
-  mean = (float)sv[0] * (inv_k / LNF_S0);
-  rstd = 1.f / sqrtf(fmaxf(fmaf(-mean, mean, (float)sv[1] * (inv_k / LNF_S1)), 0.f) + eps);
-}
-__device__ __forceinline__ void lnf_add(int64_t* stats, int m, float s1, float s2) {
-  __hip_atomic_fetch_add((long long*)stats + 2 * (int64_t)m, (long long)__float2ll_rn(s1 * LNF_S0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add((long long*)stats + 2 * (int64_t)m + 1, (long long)__float2ll_rn(s2 * LNF_S1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// ---- LayerNorm fold (js2t_gemm_desc::ln_partial / rs_partial) helpers of the register-direct epilogues
+constexpr int LNF_GROUPS = 8;  // row length 512 = 8 groups of 64 columns
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -741,6 +726,25 @@ __device__ __forceinline__ float col4_sum(float v) {
   return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 __device__ __forceinline__ float bf16_round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+// Consumer side, at the start of a tile: lane L < 48 of a wave turns the eight partial {sum, sum of squares} pairs of row
+// row0 + L (64 contiguous bytes, written by the producing product's eight 64-column groups) into that row's
+// 1 / sqrt(var + eps) and keeps it in ONE register across the K loop; the epilogue's lane (g, e) of row block i then fetches
+// the value of row 16 i + 4 g + e from lane 16 i + 4 g + e (ds_bpermute).  Requested here, not in the epilogue: a vector load
+// in the epilogue of the ring kernels returns in order behind the next tile's queued LDS-DMA stages - microseconds.
+__device__ __forceinline__ float lnf_row_rstd(const js2t_gemm_desc& d, int row0, int lane, bool first_col_tile) {
+  const int row = row0 + lane;
+  float rs = 0.f;
+  if (lane < 48 && row < d.M) {
+    const float4* pp = (const float4*)(d.ln_partial + (int64_t)row * (2 * LNF_GROUPS));
+    const float4 a = pp[0], b = pp[1], c = pp[2], e = pp[3];
+    const float s1 = ((a.x + a.z) + (b.x + b.z)) + ((c.x + c.z) + (e.x + e.z));
+    const float s2 = ((a.y + a.w) + (b.y + b.w)) + ((c.y + c.w) + (e.y + e.w));
+    const float inv = 1.f / (float)(64 * LNF_GROUPS), mu = s1 * inv;
+    rs = 1.f / sqrtf(fmaxf(fmaf(-mu, mu, s2 * inv), 0.f) + d.ln_eps);
+    if (first_col_tile && d.ln_mean) d.ln_mean[row] = mu, d.ln_rstd[row] = rs;  // for the LayerNorm backward
+  }
+  return rs;
+}
 
 // Register-direct epilogue for the permuted accumulator layout (k-contiguous B operand): lane (g = lane>>4, r = lane&15)
 // holds, for each of its MI row blocks, the 16 consecutive columns n0 + 64*wn + 16g .. +15 of row 16i + r.  Returns false
@@ -763,19 +767,22 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
   if (!fast) return false;
   const int n = n0 + wn * 64 + 16 * (lane >> 4);
   const int mrow = m0 + wm * (BM / 2) + (lane & 15);
-  const bool lnf = d.ln_stats != nullptr, wstats = d.row_stats != nullptr;  // js2t_gemm has checked their preconditions
-  float ln_mu[MI], ln_rs[MI], ln_c[16];
+  // LayerNorm fold (js2t_gemm has checked the preconditions).  A lane owns whole rows here (row mrow + 16 i, sixteen
+  // consecutive columns), so the consumer side reads the eight partial pairs of its OWN rows - no tile follows in this
+  // kernel, the loads queue behind nothing - and the producer side sums a row's 64-column group over four lanes.
+  const bool lnf = d.ln_partial != nullptr, wstats = d.rs_partial != nullptr;
+  float ln_rs[MI];
   if (lnf) {
-    const float inv_k = 1.f / (float)d.K;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      lnf_moments(d.ln_stats, min(mrow + 16 * i, M - 1), inv_k, d.ln_eps, ln_mu[i], ln_rs[i]);
-      if (n == 0 && d.ln_mean && mrow + 16 * i < M) d.ln_mean[mrow + 16 * i] = ln_mu[i], d.ln_rstd[mrow + 16 * i] = ln_rs[i];
-    }
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const float4 c4 = *(const float4*)(d.ln_colsum + n + 4 * h);
-      ln_c[4 * h] = c4.x, ln_c[4 * h + 1] = c4.y, ln_c[4 * h + 2] = c4.z, ln_c[4 * h + 3] = c4.w;
+      const int row = min(mrow + 16 * i, M - 1);
+      const float4* pp = (const float4*)(d.ln_partial + (int64_t)row * (2 * LNF_GROUPS));
+      const float4 a = pp[0], b = pp[1], c = pp[2], e = pp[3];
+      const float s1 = ((a.x + a.z) + (b.x + b.z)) + ((c.x + c.z) + (e.x + e.z));
+      const float s2 = ((a.y + a.w) + (b.y + b.w)) + ((c.y + c.w) + (e.y + e.w));
+      const float inv = 1.f / (float)(64 * LNF_GROUPS), mu = s1 * inv;
+      ln_rs[i] = 1.f / sqrtf(fmaxf(fmaf(-mu, mu, s2 * inv), 0.f) + d.ln_eps);
+      if (n == 0 && d.ln_mean && mrow + 16 * i < M) d.ln_mean[row] = mu, d.ln_rstd[row] = ln_rs[i];
     }
   }
   const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
@@ -814,8 +821,7 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        v[4 * j + r] = lnf ? fmaf(ln_rs[i], fmaf(-ln_mu[i], ln_c[4 * j + r], acc[i][j][r]), bias_r[4 * j + r])
-                           : acc[i][j][r] * alpha + bias_r[4 * j + r];
+        v[4 * j + r] = lnf ? fmaf(ln_rs[i], acc[i][j][r], bias_r[4 * j + r]) : acc[i][j][r] * alpha + bias_r[4 * j + r];
     if (relu) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -846,7 +852,7 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
         for (int c = 0; c < 8; ++c) v[8 * h + c] = rr[c] > 0.f ? v[8 * h + c] * gate_scale : 0.f;
       }
     }
-    if (wstats) {  // row sums of what is stored (bf16-rounded), over this lane's 16 columns, then over the row's four lane groups
+    if (wstats) {  // sums of what is stored (bf16-rounded) over this lane's 16 columns, then over the group's four lanes
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -855,7 +861,8 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
         s2 = fmaf(q, q, s2);
       }
       s1 = col4_sum(s1), s2 = col4_sum(s2);
-      if ((lane >> 4) == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
+      if ((lane >> 4) == 0 && m < M)
+        *(float2*)(d.rs_partial + 2 * ((int64_t)m * LNF_GROUPS + ((n0 >> 6) + wn))) = make_float2(s1, s2);
     }
     if (m < M) {
       const int64_t coff = co + (int64_t)m * d.ldc + n;
@@ -1272,7 +1279,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_w256_kernel(js2t_gemm_desc d
 // epilogue behind, and at fewer than two full rounds of 256x256 tiles the quantisation loss eats the gain (measured:
 // 8192^3 1069 vs 960 TFLOP/s for the 128x128 kernel, but FFN1 12000x2048x512 47 vs 39 us)
 inline bool w256_eligible(const js2t_gemm_desc& d) {
-  if (d.ln_stats || d.row_stats) return false;  // the LayerNorm fold lives in the register-direct epilogues only
+  if (d.ln_partial || d.rs_partial) return false;  // the LayerNorm fold lives in the persistent 192x128 kernels only
   if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
   if ((d.N & 7) || d.M < 256 || d.N < 256) return false;
   if (!g_force_w256 && ((int64_t)cdiv(d.M, 256) * cdiv(d.N, 256) < 512 || d.K < 1024)) return false;
@@ -1374,7 +1381,7 @@ __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, f
 // would otherwise expose a dependent global-load latency per tile)
 template <int EPI>
 __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane,
-                                                const float (&bias_r)[8], uint32_t drop_key) {
+                                                const float (&bias_r)[8], uint32_t drop_key, float my_rs = 0.f) {
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 8 * r;
   if (n >= d.N) return;  // N is a multiple of 8: a lane's column group lies inside or outside as a whole
@@ -1388,20 +1395,9 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
   const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
   const int64_t rld = has_res ? d.ldr : d.ldg;
-  // the fold exists in the specialised instantiations only (launch_bf16_p192 refuses other combinations): the run-time
-  // decided variant (EPI < 0) would otherwise carry both paths and spill
-  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0;
-  float ln_c[8];
-  float ln_mu[3][4], ln_rs[3][4];  // mean / reciprocal standard deviation of this lane's twelve rows, requested up front
-  if (lnf) {
-    const float inv_k = 1.f / (float)d.K;
-    const float4 c0 = *(const float4*)(d.ln_colsum + n), c1 = *(const float4*)(d.ln_colsum + n + 4);
-    ln_c[0] = c0.x, ln_c[1] = c0.y, ln_c[2] = c0.z, ln_c[3] = c0.w, ln_c[4] = c1.x, ln_c[5] = c1.y, ln_c[6] = c1.z, ln_c[7] = c1.w;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) lnf_moments(d.ln_stats, min(mw + 16 * i + 4 * g + e, M - 1), inv_k, d.ln_eps, ln_mu[i][e], ln_rs[i][e]);
-  }
+  // LayerNorm fold, consumer side: v = rstd(m) * acc + bias (the weights are gamma-scaled and row-centred, js2t_fold_ln_weights);
+  // specialised instantiations only (launch_bf16_p192 refuses other combinations)
+  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0;
   // residual / gate rows: block i + 1 is requested before block i is used (twelve rows at once cost too many registers)
   uint4 rg[3][4];
   auto load_rg = [&](int i) {
@@ -1416,6 +1412,11 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int mrow = mw + 16 * i + 4 * g;
+    float ln_rs[4];
+    if (lnf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ln_rs[e] = __shfl(my_rs, 16 * i + 4 * g + e);
+    }
     if ((has_res || has_gate) && i < 2) load_rg(i + 1);
 #ifdef JS2T_P192_PROF
     if (has_res || has_gate) asm volatile("s_nop 0" ::"v"(rg[i][3].w));  // waits for block i's rows
@@ -1426,10 +1427,8 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
       const int m = mrow + e;
       float v[8];
       if (lnf) {
-        const float mu = ln_mu[i][e], rs = ln_rs[i][e];
-        if (n == 0 && d.ln_mean && m < M) d.ln_mean[m] = mu, d.ln_rstd[m] = rs;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(rs, fmaf(-mu, ln_c[j], acc[i][j][e]), bias_r[j]);
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(ln_rs[e], acc[i][j][e], bias_r[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
@@ -1458,17 +1457,6 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         unpack_bf16x8(rg[i][e], rr);
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
-      }
-      if (wstats) {  // sums of the stored (rounded) values over the lane's 8 columns, then over the 16 lanes of the row group
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float q = bf16_round(v[c]);
-          s1 += q;
-          s2 = fmaf(q, q, s2);
-        }
-        s1 = row16_sum(s1), s2 = row16_sum(s2);
-        if (r == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
       }
       if (m < M) {
         uint4 pk;
@@ -1632,6 +1620,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
     const int tm0 = (lid / tiles_n) * P_BM, tn0 = (lid % tiles_n) * 128;
     float bias_r[8];
     p192_load_bias<EPI>(d, tn0 + 8 * (lane & 15), bias_r);
+    float my_rs = 0.f;
+    if (EPI >= 0 && (EPI & PE_LNF)) my_rs = lnf_row_rstd(d, tm0 + w * 48, lane, tn0 == 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1690,9 +1680,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       cslot = nslot;
       P192_T(5);
     }
-    p192_store_tile<EPI>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key);
-    // (a tile whose epilogue also issued the row-statistics atomics has more than twelve requests behind it: smaller count)
-    stores_behind = tm0 + P_BM <= M && !(EPI >= 0 && (EPI & PE_STATS) != 0);
+    p192_store_tile<EPI>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key, my_rs);
+    stores_behind = tm0 + P_BM <= M;
     P192_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
@@ -1722,7 +1711,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 // One block per CU (120 KB of LDS, 168 registers per wave).
 template <int EPI>
 __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][4], int mw, int n0, int lane,
-                                                 const float (&bias_r)[4], uint32_t drop_key) {
+                                                 const float (&bias_r)[4], uint32_t drop_key, float my_rs = 0.f) {
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 4 * r;
   if (n >= d.N) return;  // N is a multiple of 8 (hence of 4): a lane's column group lies inside or outside as a whole
@@ -1746,28 +1735,21 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
   // the fold exists in the specialised instantiations only (launch_bf16_p192 refuses other combinations): the run-time
   // decided variant (EPI < 0) would otherwise carry both paths and spill
   constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0;
-  float ln_c[4];
-  float ln_mu[3][4], ln_rs[3][4];
-  if (lnf) {
-    const float inv_k = 1.f / (float)d.K;
-    const float4 c0 = *(const float4*)(d.ln_colsum + n);
-    ln_c[0] = c0.x, ln_c[1] = c0.y, ln_c[2] = c0.z, ln_c[3] = c0.w;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) lnf_moments(d.ln_stats, min(mw + 16 * i + 4 * g + e, M - 1), inv_k, d.ln_eps, ln_mu[i][e], ln_rs[i][e]);
-  }
+  const int grp = n0 >> 6, ngrp = d.N >> 6;  // this wave's 64-column group of the row, of N / 64
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
+    float ln_rs[4];
+    if (lnf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ln_rs[e] = __shfl(my_rs, 16 * i + 4 * g + e);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = mw + 16 * i + 4 * g + e;
       float v[4];
       if (lnf) {
-        const float mu = ln_mu[i][e], rs = ln_rs[i][e];
-        if (n == 0 && d.ln_mean && m < M) d.ln_mean[m] = mu, d.ln_rstd[m] = rs;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(rs, fmaf(-mu, ln_c[j], acc[i][j][e]), bias_r[j]);
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(ln_rs[e], acc[i][j][e], bias_r[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = EPI < 0 ? acc[i][j][e] * alpha + bias_r[j] : (has_bias ? acc[i][j][e] + bias_r[j] : acc[i][j][e]);
@@ -1800,7 +1782,7 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
           s2 = fmaf(q, q, s2);
         }
         s1 = row16_sum(s1), s2 = row16_sum(s2);
-        if (r == 0 && m < M) lnf_add(d.row_stats, m, s1, s2);
+        if (r == 0 && m < M) *(float2*)(d.rs_partial + 2 * ((int64_t)m * ngrp + grp)) = make_float2(s1, s2);
       }
       if (m < M) {
         uint2 pk;
@@ -1955,6 +1937,8 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
 #pragma unroll
       for (int c = 0; c < 4; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
     }
+    float my_rs = 0.f;
+    if (EPI >= 0 && (EPI & PE_LNF)) my_rs = lnf_row_rstd(d, tm0 + wm * 48, lane, tn0 == 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -2007,7 +1991,7 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
 #ifdef JS2T_P192S_DBG
     const unsigned long long ce0 = __builtin_readcyclecounter();
 #endif
-    p192s_store_tile<EPI>(d, acc, tm0 + wm * 48, tn0, lane, bias_r, drop_key);
+    p192s_store_tile<EPI>(d, acc, tm0 + wm * 48, tn0, lane, bias_r, drop_key, my_rs);
 #ifdef JS2T_P192S_DBG
     cons_epi += __builtin_readcyclecounter() - ce0;
 #endif
@@ -2295,7 +2279,9 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     if (n_cu == 0) n_cu = cu;
   }
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
-  if (g_p192_ring == 4 || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
+  // the row statistics (rs_*) are written by the loader / consumer form only: its multiplying waves issue no LDS-DMA, so the
+  // fences of the hand-over to the finishing wave wait for nothing but the wave's own stores
+  if (g_p192_ring == 4 || (EPI >= 0 && (EPI & PE_STATS)) || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
   } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
@@ -2339,7 +2325,7 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
   // the epilogue combinations of the Transformer train step get their own instantiation, anything else the generic one
   if (d.alpha == 1.f && !d.alpha_dev) {
     const int mask = (d.bias ? PE_BIAS : 0) | (d.act == JS2T_ACT_RELU ? PE_RELU : 0) | (d.dropout_p > 0.f ? PE_DROP : 0) |
-                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_stats ? PE_LNF : 0) | (d.row_stats ? PE_STATS : 0);
+                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_partial ? PE_LNF : 0) | (d.rs_partial ? PE_STATS : 0);
     switch (mask) {
       case PE_BIAS | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_LNF>(d, s);      // q/k/v projections on the raw residual stream
       case PE_BIAS | PE_RELU | PE_DROP | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP | PE_LNF>(d, s);  // FFN layer 1, same
@@ -2354,8 +2340,8 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
       default: break;
     }
   }
-  if (d.ln_stats || d.row_stats) {
-    js2t_set_error("gemm: ln_stats / row_stats on the persistent kernel: bias [+ ReLU [+ dropout]] with ln_stats, bias [+ dropout] + residual with row_stats only");
+  if (d.ln_partial || d.rs_partial) {
+    js2t_set_error("gemm: LayerNorm fold: bias [+ ReLU [+ dropout]] with ln_partial, bias [+ dropout] + residual with rs_partial only");
     return JS2T_ERR_INVALID;
   }
   return launch_bf16_p192_epi<-1>(d, s);
@@ -2562,21 +2548,23 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
                    !d.gate && d.beta == 0.f,
                "gemm: split_k needs an f32 C and a plain epilogue (C must be zero-filled by the caller)");
   }
-  if (d.ln_stats || d.row_stats) {
-    // the fold lives in the register-direct epilogues of the k-contiguous bf16 kernels (persistent 192x128 and 64/128-row tiles)
+  if (d.ln_partial || d.rs_partial) {
+    // the fold lives in the register-direct epilogues of the k-contiguous bf16 kernels: the persistent 192x128 kernel (three
+    // forms) and, for products with too few tiles for it, the 64 / 128-row tile kernel
     JS2T_CHECK(d.dtype_ab == JS2T_BF16 && d.dtype_c == JS2T_BF16 && !d.trans_a && !d.trans_b && !d.conv && d.split_k == 1 && d.batch == 1 &&
                    !d.preact && d.beta == 0.f && !d.a_rowsum && !(d.residual && d.gate) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU) &&
-                   !g_force_regstage && !g_force_w256,
-               "gemm: ln_stats / row_stats need a plain k-contiguous bf16 product with a bf16 result");
-    JS2T_CHECK((d.N & 127) == 0 && (d.K & 7) == 0 && d.K >= 8 && (d.lda & 7) == 0 && (d.ldb & 7) == 0 && (d.ldc & 7) == 0 && aligned16(d.A) &&
-                   aligned16(d.B) && aligned16(d.C) && (!d.bias || aligned16(d.bias)),
-               "gemm: ln_stats / row_stats need N % 128 == 0 and 16-byte aligned rows");
-    JS2T_CHECK(!d.row_stats || (((uintptr_t)d.row_stats) & 15) == 0, "gemm: row_stats must be 16-byte aligned");
-    JS2T_CHECK(!d.residual || ((d.ldr & 7) == 0 && aligned16(d.residual)), "gemm: ln_stats / row_stats: misaligned residual");
-    JS2T_CHECK(!d.gate || ((d.ldg & 7) == 0 && aligned16(d.gate)), "gemm: ln_stats / row_stats: misaligned gate");
-    JS2T_CHECK(!d.ln_stats || (d.ln_colsum && aligned16(d.ln_colsum) && (((uintptr_t)d.ln_stats) & 15) == 0 && d.alpha == 1.f && !d.alpha_dev &&
-                               d.ln_eps > 0.f && (!d.ln_mean == !d.ln_rstd)),
-               "gemm: ln_stats needs ln_colsum (16-byte aligned), alpha == 1, ln_eps > 0 and ln_mean / ln_rstd both or neither");
+                   !g_force_regstage && !g_force_w256 && d.alpha == 1.f && !d.alpha_dev && d.bias,
+               "gemm: ln_partial / rs_partial need a plain k-contiguous bf16 product with a bf16 result, a bias and alpha == 1");
+    JS2T_CHECK((d.N & 127) == 0 && (d.K & 7) == 0 && d.K >= 64 && (d.lda & 7) == 0 && (d.ldb & 7) == 0 && (d.ldc & 7) == 0 && aligned16(d.A) &&
+                   aligned16(d.B) && aligned16(d.C) && aligned16(d.bias) && (!d.residual || ((d.ldr & 7) == 0 && aligned16(d.residual))) &&
+                   (!d.gate || ((d.ldg & 7) == 0 && aligned16(d.gate))),
+               "gemm: ln_partial / rs_partial need N % 128 == 0 and 16-byte aligned rows");
+    const int fmask = (d.act == JS2T_ACT_RELU ? 2 : 0) | (d.dropout_p > 0.f ? 4 : 0) | (d.residual ? 8 : 0) | (d.gate ? 16 : 0);
+    JS2T_CHECK(!d.ln_partial || fmask == 0 || fmask == 2 || fmask == 6, "gemm: ln_partial: epilogue bias [+ ReLU [+ dropout]] only");
+    JS2T_CHECK(!d.rs_partial || fmask == 8 || fmask == 12, "gemm: rs_partial: epilogue bias [+ dropout] + residual only");
+    JS2T_CHECK(!d.ln_partial || (d.K == 64 * LNF_GROUPS && aligned16(d.ln_partial) && d.ln_eps > 0.f && (!d.ln_mean == !d.ln_rstd)),
+               "gemm: ln_partial: K must be 512 (eight 64-column groups), 16-byte aligned partial sums, ln_eps > 0, ln_mean / ln_rstd both or neither");
+    JS2T_CHECK(!d.rs_partial || (d.N == 64 * LNF_GROUPS && aligned16(d.rs_partial)), "gemm: rs_partial: N must be 512, 16-byte aligned partial sums");
   }
   if (d.dtype_ab == JS2T_FP8_E4M3) {
     // e4m3 x e4m3 -> f32 accumulate -> bf16: the persistent 192x128 kernel only (k-contiguous operands, 16-byte rows)

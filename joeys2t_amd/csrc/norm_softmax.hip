@@ -472,39 +472,36 @@ __global__ void rel_bias_grad_kernel(const T* __restrict__ dS, float* __restrict
 }
 
 // ---------------------------------------------------------------- weights of the LayerNorm fold
-// table row e: {W f32[N,K], gamma f32[K], beta f32[K], bias f32[N] | 0, Wf bf16[N,K], colsum f32[N], bias_f f32[N], N, K};
-// one wave per weight row: Wf = bf16(W * gamma), colsum = sum of the ROUNDED products (what the MFMAs will see, so that
-// acc - mean * colsum cancels exactly for a constant row), bias_f = bias + W . beta
+// table row e: {W f32[N,K], gamma f32[K], beta f32[K], bias f32[N] | 0, Wf bf16[N,K], bias_f f32[N], N, K}; one wave per weight
+// row: c = sum_k W gamma, Wf = bf16(W gamma - c / K) (a centred row: the product of a raw activation row with it equals the
+// product of the mean-free row with W gamma), bias_f = bias + W . beta
 __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const int64_t* __restrict__ table) {
-  const int64_t* e = table + 9 * blockIdx.y;
+  const int64_t* e = table + 8 * blockIdx.y;
   const float* W = (const float*)e[0];
   const float* gamma = (const float*)e[1];
   const float* beta = (const float*)e[2];
   const float* bias = (const float*)e[3];
   uint16_t* Wf = (uint16_t*)e[4];
-  float* colsum = (float*)e[5];
-  float* bias_f = (float*)e[6];
-  const int64_t N = e[7], K = e[8];
+  float* bias_f = (float*)e[5];
+  const int64_t N = e[6], K = e[7];
   const int lane = threadIdx.x & 63;
   const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   float cs = 0.f, bs = 0.f;
   for (int64_t k = 4 * lane; k < K; k += 256) {  // K % 4 == 0 (checked by the host)
     const float4 w = *(const float4*)(W + n * K + k), g = *(const float4*)(gamma + k), b = *(const float4*)(beta + k);
-    const uint16_t q0 = f32_to_bf16_bits(w.x * g.x), q1 = f32_to_bf16_bits(w.y * g.y), q2 = f32_to_bf16_bits(w.z * g.z),
-                   q3 = f32_to_bf16_bits(w.w * g.w);
-    uint2 pk;
-    pk.x = (uint32_t)q0 | ((uint32_t)q1 << 16);
-    pk.y = (uint32_t)q2 | ((uint32_t)q3 << 16);
-    *(uint2*)(Wf + n * K + k) = pk;
-    cs += (bf16_bits_to_f32(q0) + bf16_bits_to_f32(q1)) + (bf16_bits_to_f32(q2) + bf16_bits_to_f32(q3));
+    cs += (w.x * g.x + w.y * g.y) + (w.z * g.z + w.w * g.w);
     bs += (w.x * b.x + w.y * b.y) + (w.z * b.z + w.w * b.w);
   }
-  cs = wave_sum(cs), bs = wave_sum(bs);
-  if (lane == 0) {
-    colsum[n] = cs;
-    bias_f[n] = bs + (bias ? bias[n] : 0.f);
+  cs = wave_sum(cs) / (float)K, bs = wave_sum(bs);
+  for (int64_t k = 4 * lane; k < K; k += 256) {
+    const float4 w = *(const float4*)(W + n * K + k), g = *(const float4*)(gamma + k);
+    uint2 pk;
+    pk.x = (uint32_t)f32_to_bf16_bits(fmaf(w.x, g.x, -cs)) | ((uint32_t)f32_to_bf16_bits(fmaf(w.y, g.y, -cs)) << 16);
+    pk.y = (uint32_t)f32_to_bf16_bits(fmaf(w.z, g.z, -cs)) | ((uint32_t)f32_to_bf16_bits(fmaf(w.w, g.w, -cs)) << 16);
+    *(uint2*)(Wf + n * K + k) = pk;
   }
+  if (lane == 0) bias_f[n] = bs + (bias ? bias[n] : 0.f);
 }
 
 }  // namespace

@@ -62,13 +62,13 @@ def _fp8_eligible(x2d, w, out_dtype, preact, alpha) -> bool:
 
 
 def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
-               out_dtype=None, preact=None, alpha=1.0, ln=None, row_stats=None):
-    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / row_stats: see ops.gemm (LayerNorm fold)."""
+               out_dtype=None, preact=None, alpha=1.0, ln=None, rs_partial=None):
+    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / rs_partial: see ops.gemm (LayerNorm fold)."""
     _row_major_2d(x2d), _row_major_2d(w)
     M, K = x2d.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
-    if ln is None and row_stats is None and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
+    if ln is None and rs_partial is None and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
         w8, ws = _fp8_weight(w)
         if FP8_DELAYED:
             key = (w.data_ptr(), tuple(w.shape))
@@ -85,7 +85,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
         return y
     ops.gemm(x2d, w, y, M=M, N=N, K=K, lda=x2d.stride(0), ldb=w.stride(0), ldc=N, bias=b, act=act, preact=preact,
              dropout_p=dropout_p, rng=rng, rng_stream=site, residual=residual,
-             ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha, ln=ln, row_stats=row_stats)
+             ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha=alpha, ln=ln, rs_partial=rs_partial)
     return y
 
 
@@ -285,12 +285,13 @@ def _ln_fwd(x2d, gamma, beta):
 # Entries hold their tensors, so an address cannot be re-used while it is a key; begin_step() clears both tables.
 _DROP_HINT = {}
 _DROP_READY = {}
-# LayerNorm fold (bf16 pre-LN stacks): the block that WRITES a residual-stream tensor y lets its last product's epilogue add
-# y's row sums / sums of squares into a scratch slice (js2t_gemm row_stats) and leaves the slice under y's address; the next
-# block, whose first act would be LayerNorm(y), takes it and runs its first product on y itself with gamma-scaled weights,
-# finishing the normalisation per output element (js2t_gemm ln_stats; runtime.ParamStore.fold keeps the derived weights).
-# No kernel reads a row just to normalise it; the normalised activations, which the deferred weight gradient still wants,
-# are re-materialised by the block's LayerNorm BACKWARD while it has x, mean and rstd in registers anyway.
+# LayerNorm fold (bf16 pre-LN stacks of width 512): the block that WRITES a residual-stream tensor y lets its last product's
+# epilogue also write the partial row sums / sums of squares of y (js2t_gemm rs_partial) and leaves them under y's address;
+# the next block, whose first act would be LayerNorm(y), takes them and runs its first product on y itself with gamma-scaled,
+# row-centred weights, finishing the normalisation with one multiplication per output element (js2t_gemm ln_partial;
+# runtime.ParamStore.fold keeps the derived weights).  No kernel reads a row just to normalise it; the normalised activations,
+# which the deferred weight gradient still wants, are re-materialised by the block's LayerNorm BACKWARD while it has x, mean
+# and rstd in registers anyway.  Only for products the persistent 192x128 kernel takes (encoder-sized row counts).
 _LN_STATS = {}
 LN_FOLD = os.environ.get("JS2T_LN_FOLD", "1") != "0"  # tests flip this to compare with the standalone LayerNorm kernel
 FUSE_LN_DROPOUT_BWD = os.environ.get("JS2T_LN_DROPOUT_HANDOVER", "1") != "0"  # tests flip this to compare with the separate kernel
@@ -317,6 +318,12 @@ def reset_handover():
 
 def _fold_operand(t: torch.Tensor) -> bool:
     return t.dtype == torch.bfloat16 and t.is_contiguous() and t.data_ptr() % 16 == 0 and t.shape[1] % 8 == 0
+
+
+def fold_shapes_ok(M: int, N: int, K: int) -> bool:
+    """Mirror of the library's shape preconditions for ln_partial / rs_partial (any row count: the persistent 192x128 kernel
+    or, below its tile threshold, the 64 / 128-row tile kernel)."""
+    return N % 128 == 0 and K % 8 == 0 and K >= 64 and M >= 1
 
 
 def begin_memory_chain():
@@ -366,15 +373,16 @@ class ResidualBlockFn(torch.autograd.Function):
         if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
                 ops.layernorm_bwd_supports_dropout(x2)):
             ctx.prev_drop = hint[:3]  # (p, site, rng) of the block that produced x
-        lnf = None   # (stats, colsum, eps, mean out, rstd out) when this block's LayerNorm is folded into its first product
+        lnf = None   # (partial sums of x's rows, eps, mean out, rstd out) when this block's LayerNorm is folded into its first product
         fold = wts.get("fold") if (LN_FOLD and cfg.ln_mode == "pre" and not FP8_FORWARD) else None
         sink0 = wts.get("sink") or {}
-        if fold is not None and _fold_operand(x2) and (not torch.is_grad_enabled() or ("_wq" in sink0 and "ln_g" in sink0)):
+        if (fold is not None and d == ops.LN_FOLD_WIDTH and _fold_operand(x2) and fold_shapes_ok(B * T, fold.w.shape[0], d) and
+                (not torch.is_grad_enabled() or ("_wq" in sink0 and "ln_g" in sink0))):
             hint = _LN_STATS.pop(x.data_ptr(), None)
             if hint is not None and hint[1].shape == x.shape and hint[1].dtype == x.dtype:
                 mean = torch.empty((B * T, ), dtype=torch.float32, device=x.device)
                 rstd = torch.empty_like(mean)
-                lnf = (hint[0], fold.colsum, LN_EPS, mean, rstd)
+                lnf = (hint[0], LN_EPS, mean, rstd)
         if lnf is not None:
             n = x2  # the product reads the raw rows; what it computes is LN(x) W^T + b
             saved.update(mean=mean, rstd=rstd, folded=True)
@@ -424,11 +432,12 @@ class ResidualBlockFn(torch.autograd.Function):
         w_last, b_last = (wts["w2"], wts["b2"]) if cfg.kind == "ffn" else (wts["w_out"], wts["b_out"])
         # the row statistics of what this block writes, for a following block that folds its LayerNorm (see _LN_STATS)
         out_stats = None
-        if (LN_FOLD and cfg.ln_mode == "pre" and cfg.alpha != 0.0 and not FP8_FORWARD and wts.get("stats_arena") is not None and
-                b_last is not None and _fold_operand(c) and _fold_operand(x2) and w_last.shape[0] % 128 == 0 and w_last.dtype == torch.bfloat16):
-            out_stats = wts["stats_arena"].take(B * T)
+        if (LN_FOLD and cfg.ln_mode == "pre" and cfg.alpha != 0.0 and not FP8_FORWARD and wts.get("emit_stats") and
+                b_last is not None and _fold_operand(c) and _fold_operand(x2) and w_last.dtype == torch.bfloat16 and
+                d == ops.LN_FOLD_WIDTH and fold_shapes_ok(B * T, d, c.shape[1])):
+            out_stats = ops.row_partials(B * T, x.device)
         u = linear_fwd(c, w_last, b_last, dropout_p=p_out, rng=rng, site=sites[1],
-                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha, row_stats=out_stats)
+                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha, rs_partial=out_stats)
         if cfg.ln_mode != "post":
             y = u
         else:

@@ -97,7 +97,6 @@ class Model(nn.Module):
             # the bf16 shadow follows the fp32 master: re-cast before every training forward unless the optimizer
             # keeps it in sync itself (store.auto_refresh = False), and whenever the master was marked dirty
             rt.store.refresh(force=self.training and rt.store.auto_refresh)
-            rt.row_stats.begin()  # row-statistics scratch of the LayerNorm folds: one fill per pass instead of one per block
 
     # ------------------------------------------------------------------ loss
     @property

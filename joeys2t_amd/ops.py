@@ -78,7 +78,6 @@ def dropout_rng(device) -> DropoutRng:
 
 
 # ----------------------------------------------------------------------------------------- GEMM
-ROW_STATS_SCALE = (2.0**20, 2.0**16)  # units of the two fixed-point sums in js2t_gemm's ln_stats / row_stats
 GEMM_TIMER = None  # bench.py installs an object with .wrap(key, flops, launch) to HIP-event-time every GEMM launch
 
 
@@ -96,15 +95,23 @@ def _takes_p192(d) -> bool:
     return -(-d.M // 192) * -(-d.N // 128) >= 200
 
 
+LN_FOLD_WIDTH = 512  # row length the LayerNorm fold of js2t_gemm is built for: eight 64-column groups
+
+
+def row_partials(M: int, device) -> torch.Tensor:
+    """f32 [M, 8, 2] for js2t_gemm's rs_partial (producer) / ln_partial (consumer): per 64-column group {sum, sum of squares}."""
+    return torch.empty((M, LN_FOLD_WIDTH // 64, 2), dtype=torch.float32, device=device)
+
+
 def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, batch=1, batch_inner=1,
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1, a_rowsum=None, ln=None, row_stats=None):
+         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements.
-    ln = (stats i64[M,2], colsum f32[N], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product;
-    row_stats i64[M,2]: fixed-point row sums / sums of squares of the stored results are ADDED into it (ROW_STATS_SCALE)."""
-    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum, row_stats)
+    ln = (partial f32[M,8,2], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product (B = the
+    centred, gamma-scaled weight of ParamStore.fold); rs_partial f32[M,8,2]: the stored rows' partial sums are written to it."""
+    _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum, rs_partial)
     if A.dtype != B.dtype:
         raise Js2tError(f"gemm: A/B dtype mismatch {A.dtype} vs {B.dtype}")
     d = GemmDesc()
@@ -151,17 +158,19 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     d.split_k = int(split_k)
     d.a_rowsum = None if a_rowsum is None else a_rowsum.data_ptr()
     if ln is not None:
-        stats, colsum, eps, mean_out, rstd_out = ln
-        _dev(stats, colsum, mean_out, rstd_out)
-        if stats.dtype != torch.int64 or stats.shape != (M, 2) or not stats.is_contiguous() or colsum.dtype != torch.float32 or colsum.numel() != N:
-            raise Js2tError("gemm: ln needs stats i64[M, 2] (fixed-point row sums, see the header) and colsum f32[N]")
-        d.ln_stats, d.ln_colsum, d.ln_eps = stats.data_ptr(), colsum.data_ptr(), float(eps)
+        part, eps, mean_out, rstd_out = ln
+        _dev(part, mean_out, rstd_out)
+        if part.dtype != torch.float32 or part.numel() != M * 16 or not part.is_contiguous():
+            raise Js2tError("gemm: ln needs partial sums f32[M, 8, 2]")
+        d.ln_partial, d.ln_eps = part.data_ptr(), float(eps)
         if mean_out is not None:
+            if min(mean_out.numel(), rstd_out.numel()) < M or mean_out.dtype != torch.float32 or rstd_out.dtype != torch.float32:
+                raise Js2tError("gemm: ln mean / rstd outputs must be f32[M]")
             d.ln_mean, d.ln_rstd = mean_out.data_ptr(), rstd_out.data_ptr()
-    if row_stats is not None:
-        if row_stats.dtype != torch.int64 or row_stats.shape != (M, 2) or not row_stats.is_contiguous():
-            raise Js2tError("gemm: row_stats must be contiguous i64[M, 2]")
-        d.row_stats = row_stats.data_ptr()
+    if rs_partial is not None:
+        if rs_partial.dtype != torch.float32 or rs_partial.numel() != M * 16 or not rs_partial.is_contiguous():
+            raise Js2tError("gemm: rs_partial must be contiguous f32[M, 8, 2]")
+        d.rs_partial = rs_partial.data_ptr()
     if GEMM_TIMER is not None:
         if d.dtype_ab == FP8:
             key = "gemm_fp8_p192_kernel<0,0,0>"
@@ -471,8 +480,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, need_param_grads=True, add=None, add
 
 
 def fold_ln_weights(table: torch.Tensor, n_entries: int, max_rows: int):
-    """(Re)derive the gamma-scaled bf16 weights, their column sums and the beta-absorbing biases of every LayerNorm fold
-    (js2t_fold_ln_weights; table int64[n, 9] on the device)."""
+    """(Re)derive the centred, gamma-scaled bf16 weights and the beta-absorbing biases of every LayerNorm fold
+    (js2t_fold_ln_weights; table int64[n, 8] on the device)."""
     _dev(table)
     check(lib().js2t_fold_ln_weights(_p(table), C.c_int32(n_entries), C.c_int32(max_rows), _stream()), "js2t_fold_ln_weights")
 

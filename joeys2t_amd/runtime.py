@@ -135,11 +135,10 @@ class ParamStore:
                 self._folds[key] = None
             return None
         N, K = w32.shape
-        f = LnFold(torch.empty((N, K), dtype=torch.bfloat16, device=self.device), torch.empty((N, ), dtype=torch.float32, device=self.device),
-                   torch.empty((N, ), dtype=torch.float32, device=self.device))
+        f = LnFold(torch.empty((N, K), dtype=torch.bfloat16, device=self.device), torch.empty((N, ), dtype=torch.float32, device=self.device))
         self._folds[key] = f
         self._fold_rows.append([w32.data_ptr(), gamma.data.data_ptr(), beta.data.data_ptr(), b32.data_ptr(), f.w.data_ptr(),
-                                f.colsum.data_ptr(), f.bias.data_ptr(), N, K])
+                                f.bias.data_ptr(), N, K])
         self._fold_max_rows = max(self._fold_max_rows, N)
         self._fold_table = None
         row = torch.tensor([self._fold_rows[-1]], dtype=torch.int64, device=self.device)
@@ -264,40 +263,12 @@ class ParamStore:
 
 
 class LnFold:
-    """Derived operands of one LayerNorm -> nn.Linear pair for js2t_gemm's ln_stats mode: w = bf16(W * gamma) [N, K],
-    colsum f32[N] = row sums of w, bias f32[N] = b + W beta.  Owned and kept current by ParamStore.refresh_folds()."""
-    __slots__ = ("w", "colsum", "bias")
+    """Derived operands of one LayerNorm -> nn.Linear pair for js2t_gemm's ln_partial mode: w = bf16(W gamma - rowmean(W gamma))
+    [N, K] and bias f32[N] = b + W beta.  Owned and kept current by ParamStore.refresh_folds()."""
+    __slots__ = ("w", "bias")
 
-    def __init__(self, w, colsum, bias):
-        self.w, self.colsum, self.bias = w, colsum, bias
-
-
-class RowStatsArena:
-    """i64 [rows, 2] scratch the residual epilogues ADD their fixed-point row sums / sums of squares into (js2t_gemm row_stats), handed
-    out in call order.  Invariant: everything at and beyond `cursor` is zero - begin() (once per Model.forward) re-zeroes
-    what earlier passes used with ONE fill launch instead of one per block; callers that never call begin() simply walk on
-    until the arena is used up and then get freshly zeroed tensors."""
-
-    def __init__(self, device, rows: int = 1 << 20):
-        self.buf = torch.zeros((rows, 2), dtype=torch.int64, device=device)
-        self.cursor = 0
-        self.high = 0
-
-    def begin(self):
-        if self.high:
-            self.buf[:self.high].zero_()
-        self.cursor = 0
-
-    def take(self, rows: int) -> torch.Tensor:
-        end = self.cursor + rows
-        if end > self.buf.shape[0]:
-            if torch.cuda.is_current_stream_capturing():
-                raise ops.Js2tError("RowStatsArena exhausted during hipGraph capture (Model.forward() calls begin())")
-            return torch.zeros((rows, 2), dtype=torch.int64, device=self.buf.device)
-        out = self.buf[self.cursor:end]
-        self.cursor = end
-        self.high = max(self.high, end)
-        return out
+    def __init__(self, w, bias):
+        self.w, self.bias = w, bias
 
 
 class WgradQueue:
@@ -364,7 +335,6 @@ class Runtime:
         self.on_grads_ready = None  # callable(list of params): DDP bucket bookkeeping for directly written gradients
         self.wgrad_queue: Optional[WgradQueue] = None  # set (TrainStep) to defer + group the weight-gradient products
         self.grad_copies = None  # ops.GradCopies (TrainStep): LayerNorm parameter gradients accumulate into folded copies
-        self._row_stats: Optional[RowStatsArena] = None
 
     @property
     def rng(self) -> ops.DropoutRng:
@@ -397,12 +367,6 @@ class Runtime:
         if ln is None or self.store is None or self.compute_dtype != torch.bfloat16 or any(b is None for b in biases):
             return None
         return self.store.fold(weights, biases, ln.weight, ln.bias)
-
-    @property
-    def row_stats(self) -> RowStatsArena:
-        if self._row_stats is None:
-            self._row_stats = RowStatsArena(self.device)
-        return self._row_stats
 
     def weight_t(self, params: Sequence[nn.Parameter]) -> Optional[torch.Tensor]:
         """Transposed compute-dtype weight [in, out] for the input-gradient product, when the store keeps one (bf16 compute,

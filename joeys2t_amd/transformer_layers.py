@@ -96,8 +96,7 @@ class MultiHeadedAttention(nn.Module):
             if ln_mode == "pre" and Fn.LN_FOLD:  # LayerNorm folded into the q/k/v (cross: q) projection, see functional._LN_STATS
                 first_w, first_b = ([k_.weight, v_.weight, q_.weight], [k_.bias, v_.bias, q_.bias]) if kind == "self" else ([q_.weight], [q_.bias])
                 wts["fold"] = rt.ln_fold(first_w, first_b, ln)
-        if ln_mode == "pre" and rt.store is not None and rt.compute_dtype == torch.bfloat16:
-            wts["stats_arena"] = rt.row_stats
+        wts["emit_stats"] = ln_mode == "pre" and rt.store is not None and rt.compute_dtype == torch.bfloat16
         if self.rel_pos_bias is not None:
             if kind != "self":
                 raise NotImplementedError("relative-position bias is defined for self-attention")
@@ -157,8 +156,7 @@ class PositionwiseFeedForward(nn.Module):
                "w1_t": rt.weight_t([l1.weight]), "w2_t": rt.weight_t([l2.weight]),
                "fold": rt.ln_fold([l1.weight], [l1.bias], self.layer_norm)
                if (self._layer_norm_position == "pre" and self._activation == "relu" and Fn.LN_FOLD) else None,
-               "stats_arena": rt.row_stats if (self._layer_norm_position == "pre" and rt.store is not None and
-                                               rt.compute_dtype == torch.bfloat16) else None,
+               "emit_stats": self._layer_norm_position == "pre" and rt.store is not None and rt.compute_dtype == torch.bfloat16,
                "sink": rt.sinks({"w1": [l1.weight], "b1": [l1.bias], "w2": [l2.weight], "b2": [l2.bias],
                                  "ln_g": [self.layer_norm.weight], "ln_b": [self.layer_norm.bias]}),
                "notify": rt.grads_ready}

@@ -71,6 +71,7 @@ def test_full_size_step_is_invariant_to_batch_order_and_repeatable(device, full_
 
 
 def test_full_size_gradient_is_the_sum_over_half_batches(device, full_case):
+    # (full batch and halves take the same kernels: the LayerNorm fold applies at every row count)
     cfg, sd, batch = full_case
     s0, g0, _ = run(cfg, sd, batch, device)
     halves = [run(cfg, sd, subset(batch, list(range(h, B, 2))), device) for h in (0, 1)]  # odd / even utterances: both ragged
