@@ -178,6 +178,13 @@ int js2t_quantize_fp8_delayed(const void* x, int dt, void* y, int64_t n, float* 
 int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream);
 /* dx[rows,2C] from dy[rows,C] and the saved x. */
 int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int dt, js2t_stream stream);
+/* The same for x[batch * T, 2C] with a device-resident crop length: positions t >= *valid_t of every batch entry come out as 0
+ * (forward) / receive no gradient (backward).  A batch padded to a bucket length (hipGraph replay of varying batches) then
+ * presents the following convolution with what the reference's cropped tensor + nn.Conv1d zero padding present
+ * (encoders.py:356-368).  valid_t == NULL: no crop. */
+int js2t_glu_fwd_crop(const void* x, void* y, int64_t rows, int64_t C, int64_t T, const int64_t* valid_t, int dt, js2t_stream stream);
+int js2t_glu_bwd_crop(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int64_t T, const int64_t* valid_t, int dt,
+                      js2t_stream stream);
 
 /* Transposed bf16 shadows of the 2-D weights: for every group g (table[g] = {element offset, rows, cols, first 64x64 tile},
  * int64 on the device) the [rows, cols] block at src + offset is written as [cols, rows] at dst + offset.  With W^T at
@@ -438,6 +445,11 @@ int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int32_t U, int3
 int js2t_feature_finalize(const float* feat, const int64_t* frame_off, const float* mean, const float* istd,
                           const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
                           int32_t F, float pad_value, js2t_stream stream);
+/* Same with Tmax a bucket length >= the longest utterance: positions t >= *crop_t (device scalar = frames of the longest
+ * utterance) are 0 for every utterance, as if the batch had been cropped there (encoders.py:356-359) and zero-padded. */
+int js2t_feature_finalize_crop(const float* feat, const int64_t* frame_off, const float* mean, const float* istd,
+                               const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
+                               int32_t F, float pad_value, const int64_t* crop_t, js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Update tail over the flat parameter store (training.py:436-456).

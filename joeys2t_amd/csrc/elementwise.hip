@@ -62,23 +62,27 @@ __global__ void axpby_kernel(const T* __restrict__ x, float a, const T* __restri
 }
 
 // ---------------------------------------------------------------- GLU
+// valid_t (device scalar, optional) with rows = batch x T_: positions t >= *valid_t of every batch entry are written as 0 /
+// get a zero gradient - the tensor then looks to the next convolution as if it had been cropped to *valid_t positions
+// (js2t_glu_fwd_crop)
 template <typename T>
-__global__ void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t C) {
-  const int64_t total = rows * C;
+__global__ void glu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int64_t C, int64_t T_,
+                               const int64_t* __restrict__ valid_t) {
+  const int64_t total = rows * C, vt = valid_t ? *valid_t : T_;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / C, c = i - r * C;
     const float a = io<T>::ld(x + r * 2 * C + c), b = io<T>::ld(x + r * 2 * C + C + c);
-    io<T>::st(y + i, a / (1.f + __expf(-b)));
+    io<T>::st(y + i, (r % T_) < vt ? a / (1.f + __expf(-b)) : 0.f);
   }
 }
 template <typename T>
 __global__ void glu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t rows,
-                               int64_t C) {
-  const int64_t total = rows * C;
+                               int64_t C, int64_t T_, const int64_t* __restrict__ valid_t) {
+  const int64_t total = rows * C, vt = valid_t ? *valid_t : T_;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / C, c = i - r * C;
     const float a = io<T>::ld(x + r * 2 * C + c), b = io<T>::ld(x + r * 2 * C + C + c);
-    const float g = io<T>::ld(dy + i);
+    const float g = (r % T_) < vt ? io<T>::ld(dy + i) : 0.f;
     const float s = 1.f / (1.f + __expf(-b));
     io<T>::st(dx + r * 2 * C + c, g * s);
     io<T>::st(dx + r * 2 * C + C + c, g * a * s * (1.f - s));
@@ -420,21 +424,29 @@ extern "C" int js2t_axpby(const void* x, float a, const void* y, float b, void* 
   return JS2T_OK;
 }
 
-extern "C" int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream) {
+extern "C" int js2t_glu_fwd_crop(const void* x, void* y, int64_t rows, int64_t C, int64_t T_, const int64_t* valid_t, int dt,
+                                 js2t_stream stream) {
   if (rows * C == 0) return JS2T_OK;
-  JS2T_CHECK(x && y && rows > 0 && C > 0, "glu_fwd: bad arguments");
+  JS2T_CHECK(x && y && rows > 0 && C > 0 && T_ > 0 && rows % T_ == 0, "glu_fwd: bad arguments");
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((glu_fwd_kernel<T>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0,
-                                        (hipStream_t)stream, (const T*)x, (T*)y, rows, C));
+                                        (hipStream_t)stream, (const T*)x, (T*)y, rows, C, T_, valid_t));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+extern "C" int js2t_glu_fwd(const void* x, void* y, int64_t rows, int64_t C, int dt, js2t_stream stream) {
+  return js2t_glu_fwd_crop(x, y, rows, C, rows > 0 ? rows : 1, nullptr, dt, stream);
+}
+extern "C" int js2t_glu_bwd_crop(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int64_t T_, const int64_t* valid_t,
+                                 int dt, js2t_stream stream) {
+  if (rows * C == 0) return JS2T_OK;
+  JS2T_CHECK(x && dy && dx && rows > 0 && C > 0 && T_ > 0 && rows % T_ == 0, "glu_bwd: bad arguments");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((glu_bwd_kernel<T>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0,
+                                        (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, rows, C, T_, valid_t));
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
 extern "C" int js2t_glu_bwd(const void* x, const void* dy, void* dx, int64_t rows, int64_t C, int dt, js2t_stream stream) {
-  if (rows * C == 0) return JS2T_OK;
-  JS2T_CHECK(x && dy && dx && rows > 0 && C > 0, "glu_bwd: bad arguments");
-  DISPATCH_DT(dt, T, hipLaunchKernelGGL((glu_bwd_kernel<T>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0,
-                                        (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, rows, C));
-  JS2T_LAUNCH_CHECK();
-  return JS2T_OK;
+  return js2t_glu_bwd_crop(x, dy, dx, rows, C, rows > 0 ? rows : 1, nullptr, dt, stream);
 }
 
 extern "C" int js2t_add_pe_dropout(const void* x, const float* pe, const void* extra, void* y, int64_t B, int64_t T_,

@@ -382,13 +382,17 @@ template <typename TO>
 __global__ void feature_finalize_kernel(const float* __restrict__ feat, const int64_t* __restrict__ frame_off,
                                         const float* __restrict__ mean, const float* __restrict__ istd,
                                         const float* __restrict__ fill, const int32_t* __restrict__ masks,
-                                        TO* __restrict__ out, int64_t U, int64_t Tmax, int F, float pad_value) {
-  const int64_t total = U * Tmax * F;
+                                        TO* __restrict__ out, int64_t U, int64_t Tmax, int F, float pad_value,
+                                        const int64_t* __restrict__ crop_t) {
+  // crop_t (device scalar, optional): positions t >= *crop_t of EVERY utterance are 0 instead of pad_value - a batch padded to
+  // a bucket length then looks to the sub-sampler's convolutions like the reference's batch, which is cropped to its longest
+  // utterance and zero-padded by nn.Conv1d beyond (encoders.py:356-359)
+  const int64_t total = U * Tmax * F, crop = crop_t ? *crop_t : Tmax;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t u = i / (Tmax * F), rem = i - u * Tmax * F, t = rem / F;
     const int c = (int)(rem - t * F);
     const int64_t t0 = frame_off[u], T = frame_off[u + 1] - t0;
-    float v = pad_value;
+    float v = t < crop ? pad_value : 0.f;
     if (t < T) {
       v = feat[(t0 + t) * F + c];
       if (mean) v = (v - mean[u * F + c]) * istd[u * F + c];
@@ -450,6 +454,12 @@ extern "C" int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int3
 extern "C" int js2t_feature_finalize(const float* feat, const int64_t* frame_off, const float* mean, const float* istd,
                                      const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
                                      int32_t F, float pad_value, js2t_stream stream) {
+  return js2t_feature_finalize_crop(feat, frame_off, mean, istd, fill, masks, out, out_dt, U, Tmax, F, pad_value, nullptr, stream);
+}
+
+extern "C" int js2t_feature_finalize_crop(const float* feat, const int64_t* frame_off, const float* mean, const float* istd,
+                                          const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
+                                          int32_t F, float pad_value, const int64_t* crop_t, js2t_stream stream) {
   if (U * Tmax * F == 0) return JS2T_OK;
   JS2T_CHECK(feat && frame_off && out, "feature_finalize: null pointer");
   JS2T_CHECK((mean == nullptr) == (istd == nullptr), "feature_finalize: mean and istd go together");
@@ -458,10 +468,10 @@ extern "C" int js2t_feature_finalize(const float* feat, const int64_t* frame_off
   if (g > 8192) g = 8192;
   if (out_dt == JS2T_F32)
     hipLaunchKernelGGL((feature_finalize_kernel<float>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, feat, frame_off,
-                       mean, istd, fill, masks, (float*)out, U, Tmax, F, pad_value);
+                       mean, istd, fill, masks, (float*)out, U, Tmax, F, pad_value, crop_t);
   else if (out_dt == JS2T_BF16)
     hipLaunchKernelGGL((feature_finalize_kernel<uint16_t>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, feat,
-                       frame_off, mean, istd, fill, masks, (uint16_t*)out, U, Tmax, F, pad_value);
+                       frame_off, mean, istd, fill, masks, (uint16_t*)out, U, Tmax, F, pad_value, crop_t);
   else {
     js2t_set_error("feature_finalize: bad dtype");
     return JS2T_ERR_INVALID;

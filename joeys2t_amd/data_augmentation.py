@@ -64,16 +64,19 @@ class CMVN:
 
 def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Sequence[int], *, cmvn: Optional[CMVN],
                       specaugment: Optional[SpecAugment], out_dtype=torch.float32, pad_value: float = 1.0,
-                      max_length: Optional[int] = None, masks_dev: Optional[torch.Tensor] = None):
+                      max_length: Optional[int] = None, masks_dev: Optional[torch.Tensor] = None, t_pad: Optional[int] = None,
+                      crop_t: Optional[torch.Tensor] = None):
     """feat f32 [sum T, F] (ragged, frame_off int64[U+1]) -> padded batch [U, Tmax, F] on the device:
     CMVN (before) -> SpecAugment -> pad with 1.0, i.e. SpeechProcessor.__call__ (tokenizers.py:480-492) followed by
     pad_features (helpers_for_audio.py:130-170), in two launches.  `max_length` truncates (evaluation-time rule,
-    tokenizers.py:474-478) BEFORE the CMVN statistics are taken, as the reference does."""
+    tokenizers.py:474-478) BEFORE the CMVN statistics are taken, as the reference does.
+    t_pad / crop_t (graph replay of varying batches): the output is [U, t_pad, F] whatever `frames` says (the real counts are
+    in frame_off on the device) and positions >= *crop_t (device int64 scalar: the longest utterance) are 0, not 1.0."""
     ops._dev(feat, frame_off)
     U, F = len(frames), feat.shape[1]
     dev = feat.device
     eff = [min(int(t), max_length) if max_length else int(t) for t in frames]
-    Tmax = max(eff)
+    Tmax = max(eff) if t_pad is None else int(t_pad)
     mean = istd = fill = masks = None
     if cmvn is not None:
         if not cmvn.before:
@@ -96,7 +99,7 @@ def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Seque
         elif fill is None:
             raise NotImplementedError("SpecAugment without CMVN needs an explicit mask_value on the fused path")
     out = torch.empty((U, Tmax, F), dtype=out_dtype, device=dev)
-    check(lib().js2t_feature_finalize(_p(feat), _p(frame_off), _p(mean), _p(istd), _p(fill), _p(masks), _p(out),
-                                      ops.dt_code(out), C.c_int64(U), C.c_int64(Tmax), C.c_int32(F), C.c_float(pad_value),
-                                      _stream()), "js2t_feature_finalize")
+    check(lib().js2t_feature_finalize_crop(_p(feat), _p(frame_off), _p(mean), _p(istd), _p(fill), _p(masks), _p(out),
+                                           ops.dt_code(out), C.c_int64(U), C.c_int64(Tmax), C.c_int32(F), C.c_float(pad_value),
+                                           _p(crop_t), _stream()), "js2t_feature_finalize")
     return out, eff

@@ -48,10 +48,13 @@ class Conv1dSubsampler(nn.Module):
             t_in = Fn.conv_out_len(t_in, k)
         return t_in
 
-    def forward(self, src_tokens: Tensor, src_lengths: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    def forward(self, src_tokens: Tensor, src_lengths: Tensor, crop: Tensor = None) -> Tuple[Tensor, Tensor, Tensor]:
         """-> (x [B,T',C], out_seq_lens [B], padding mask [B,1,T']).  The input is expected to be cropped to the
         longest utterance already (pad_features guarantees it, helpers_for_audio.py:159-161); the reference's
-        re-crop (:356-359) costs a host sync and is only taken for host-side length tensors."""
+        re-crop (:356-359) costs a host sync and is only taken for host-side length tensors.
+        crop (device int64 [n_layers], optional): the batch is padded to a BUCKET length (graphed.GraphedTrainStep) and
+        crop[i] is the number of output positions layer i has for the longest real utterance - each layer but the last
+        zeroes what lies beyond, so the next convolution sees the zero padding nn.Conv1d gives the reference's cropped tensor."""
         rt = runtime_of(self)
         if not src_lengths.is_cuda:
             max_len = int(src_lengths.max())
@@ -60,9 +63,10 @@ class Conv1dSubsampler(nn.Module):
                 src_tokens = src_tokens[:, :max_len, :]
             src_lengths = src_lengths.to(src_tokens.device)
         x = rt.act_in(src_tokens.contiguous())
-        for conv in self.conv_layers:
+        for i, conv in enumerate(self.conv_layers):
+            valid = crop[i:i + 1] if (crop is not None and i + 1 < self.n_layers) else None
             x = Fn.Conv1dGluFn.apply(x, conv.weight, conv.bias, rt.compute_dtype,
-                                     rt.sinks({"w": [conv.weight], "b": [conv.bias]}), rt.grads_ready)
+                                     rt.sinks({"w": [conv.weight], "b": [conv.bias]}), rt.grads_ready, valid)
         out_lens, mask = ops.subsample_lengths_mask(src_lengths, x.size(1), self.kernel_sizes)
         # the mask's row sums, which the CTC loss asks for (model.py:125): = min(out_lens, T'), and T' is the sub-sampled
         # length of the longest utterance, so out_lens itself; saves a cast + reduction per step
@@ -99,7 +103,7 @@ class TransformerEncoder(Encoder):
     def forward(self, src_embed: Tensor, src_length: Tensor, mask: Tensor = None, **kwargs):
         """-> (hidden states [B,T',d], None, mask [B,1,T'])."""
         if self.subsample:
-            src_embed, src_length, ss_mask = self.subsampler(src_embed, src_length)
+            src_embed, src_length, ss_mask = self.subsampler(src_embed, src_length, kwargs.get("src_crop", None))
             if mask is None:
                 mask = ss_mask
         if mask is None:

@@ -781,8 +781,11 @@ class Conv1dGluFn(torch.autograd.Function):
     (encoders.py:362-368) as an implicit-im2col MFMA GEMM + GLU epilogue kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, compute_dtype, sink=None, notify=None):
+    def forward(ctx, x, weight, bias, compute_dtype, sink=None, notify=None, valid_t=None):
+        """valid_t (device int64 scalar, optional): output positions >= *valid_t are zeroed, as if the tensor ended there (a
+        batch padded to a bucket length in front of the NEXT convolution, see ops.glu_fwd)."""
         ctx.sink, ctx.notify, ctx.leaves = sink, notify, (weight, bias)
+        ctx.valid_t = valid_t
         B, T, Cin = x.shape
         Cout, _, K = weight.shape
         stride, pad = 2, K // 2
@@ -802,7 +805,7 @@ class Conv1dGluFn(torch.autograd.Function):
         else:
             col = None
             ops.gemm(x, wp, pre, M=M, N=Cout, K=K * Cin, lda=stride * Cin, ldb=K * Cin, ldc=Cout, bias=bias, conv=conv)
-        y = ops.glu_fwd(pre)
+        y = ops.glu_fwd(pre, Tout, valid_t)
         ctx.x, ctx.wp, ctx.pre, ctx.conv, ctx.col = (x if col is None else None), wp, pre, conv, col
         ctx.dims = (B, T, Cin, Cout, K, Tout)
         return y.view(B, Tout, Cout // 2)
@@ -815,7 +818,7 @@ class Conv1dGluFn(torch.autograd.Function):
         dy2 = dy.reshape(M, Cout // 2)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dpre = ops.glu_bwd(pre, dy2)
+        dpre = ops.glu_bwd(pre, dy2, Tout, ctx.valid_t)
         sink = ctx.sink or {}
         db = ops.colsum(dpre, out=sink.get("b"), accumulate=True) if sink else ops.colsum(dpre)
         # dWp^T[K*Cin, Cout] = im2col(x)^T[K*Cin, M] . dpre[M, Cout]
@@ -836,4 +839,4 @@ class Conv1dGluFn(torch.autograd.Function):
             dcol = torch.empty((M, K * Cin), dtype=pre.dtype, device=pre.device)
             ops.gemm(dpre, wp, dcol, M=M, N=K * Cin, K=Cout, lda=Cout, ldb=K * Cin, ldc=K * Cin, trans_b=True)
             dx = ops.col2im(dcol, B, T, Tout, Cin, K, conv[3], conv[4])
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None

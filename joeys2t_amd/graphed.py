@@ -1,0 +1,211 @@
+"""Train steps over VARYING batches replayed from hipGraphs: one graph per shape bucket.
+
+The reference's loader cuts a new (B, T, L) every step (TokenBatchSampler, joeynmt/datasets.py:1249-1295; the step itself is
+training.py:541-596).  Launching the ~530 kernels of a step from Python costs ~19 ms against ~12 ms of GPU work, and a
+captured hipGraph only replays ONE shape.  So shapes are bucketed - frames up to the next multiple of `frame_bucket`, target
+length up to the next multiple of `target_bucket`, the utterance count as it comes - and everything that differs between two
+batches of a bucket lives in device memory the graph reads:
+
+  * utterance offsets / frame counts of the fbank front-end (the kernels take them from device tables already),
+  * sub-sampled lengths and masks (computed on the device from the length vector),
+  * targets, target lengths, SpecAugment parameters, the learning rate of the step,
+  * the crop lengths that make a batch padded to the bucket look to the sub-sampler's convolutions like the reference's
+    batch, which ends at its longest utterance (js2t_feature_finalize_crop, js2t_glu_*_crop).
+
+All of it travels in ONE pinned buffer -> ONE host-to-device copy per step.  A bucket seen for the first time runs its batch
+eagerly (that is the training step) and is captured right after; graphs share one memory pool and are kept in an LRU list.
+Results are those of TrainStep.micro_step on the un-padded batch (tests/test_hip_graphed.py; dropout masks differ because the
+row index of a position depends on the padded length - as they differ from the reference's torch RNG anyway)."""
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from joeys2t_amd import ops
+from joeys2t_amd.batch import Batch
+from joeys2t_amd.helpers_for_audio import get_extractor
+from joeys2t_amd.tokenizers import SpeechProcessor
+from joeys2t_amd.training import TrainStep
+
+
+def _round_up(x: int, m: int) -> int:
+    return -(-x // m) * m
+
+
+class _Bucket:
+    """Static device inputs of one (B, T bucket, L bucket) and the graph captured over them."""
+
+    def __init__(self, key, n_conv: int, win: int, shift: int, device, pad_index: int):
+        B, Tb, Lb = key
+        self.key = key
+        self.n_samples_cap = win + (Tb - 1) * shift
+        Lc = Lb - 1  # columns of trg_input / trg (batch.py:82-86: BOS dropped / last column dropped)
+        # one packed buffer of int64 words; every static tensor is a view of its device copy
+        fields = [("soff", B), ("foff", B + 1), ("src_length", B), ("crop", 1 + n_conv), ("trg_length", B), ("trg_input", B * Lc),
+                  ("trg", B * Lc), ("masks", B * 4), ("lr", 1), ("order", B)]
+        self.slices: Dict[str, slice] = {}
+        off = 0
+        for name, n in fields:
+            self.slices[name] = slice(off, off + n)
+            off += n
+        # the host side is a ring: the copy of step i may still be queued when the host fills in step i + 1
+        self.hosts = [torch.zeros((off, ), dtype=torch.int64).pin_memory() for _ in range(3)]
+        self.copied = [None, None, None]
+        self.turn = 0
+        self.host = self.hosts[0]
+        self.dev = torch.zeros((off, ), dtype=torch.int64, device=device)
+        self.wave = torch.zeros((B, self.n_samples_cap), dtype=torch.float32, device=device)
+        d = self.dev
+        self.soff, self.foff, self.crop = d[self.slices["soff"]], d[self.slices["foff"]], d[self.slices["crop"]]
+        self.masks = d[self.slices["masks"]].view(torch.int32).view(B, 8)
+        self.lr = d[self.slices["lr"]].view(torch.float32)[:1]
+        self.order = d[self.slices["order"]]
+        b = Batch.__new__(Batch)  # filled in by hand: Batch.__init__ syncs with the device (EOS search, token count)
+        b.src, b.src_length, b.src_mask, b.src_prompt_mask = None, d[self.slices["src_length"]], None, None
+        b.trg_input, b.trg = d[self.slices["trg_input"]].view(B, Lc), d[self.slices["trg"]].view(B, Lc)
+        b.trg_length, b.trg_mask, b.trg_prompt_mask = d[self.slices["trg_length"]], None, None
+        b.indices = torch.arange(B)
+        b.nseqs, b.ntokens, b.has_trg, b.is_train, b.task = B, 0, True, True, "S2T"
+        b.src_max_len, b.repad = Tb, False
+        b.src_crop = self.crop[1:]  # per sub-sampler layer: output positions of the longest real utterance
+        self.batch = b
+        self.pad_index = pad_index
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.replays = 0
+
+    def next_host(self):
+        """the staging buffer for this step (waits, on the host, only if its copy of three steps ago has not run yet)"""
+        self.turn = (self.turn + 1) % len(self.hosts)
+        if self.copied[self.turn] is not None:
+            self.copied[self.turn].synchronize()
+        self.host = self.hosts[self.turn]
+
+    def upload(self):
+        self.dev.copy_(self.host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.copied[self.turn] = ev
+
+    def host_view(self, name: str) -> torch.Tensor:
+        return self.host[self.slices[name]]
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(TrainStep(model, ...), SpeechProcessor(...)); step.run(wave, n_samples, trg, trg_len) per batch.
+
+    wave f32 [B, N] on the device (raw 16 kHz samples, e.g. from datasets.PrefetchLoader), n_samples: host list, trg int64
+    [B, L] on the host (BOS ... EOS, padded with pad_index), trg_len: host list / tensor (including BOS and EOS)."""
+
+    def __init__(self, step: TrainStep, proc: SpeechProcessor, compute_dtype=torch.bfloat16, frame_bucket: int = 64,
+                 target_bucket: int = 8, max_graphs: int = 24, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True):
+        if step.batch_multiplier != 1:
+            raise NotImplementedError("GraphedTrainStep: one optimizer update per batch (batch_multiplier 1)")
+        if step.reducer is not None:
+            raise NotImplementedError("GraphedTrainStep: single-GPU steps (the data-parallel step is cut around its RCCL calls, bench.py)")
+        if step.normalization == "tokens":
+            raise NotImplementedError("GraphedTrainStep: 'tokens' normalisation changes a captured constant per batch; use 'batch'")
+        self.step, self.proc, self.dtype = step, proc, compute_dtype
+        self.device = step.store.device
+        self.frame_bucket, self.target_bucket, self.max_graphs = int(frame_bucket), int(target_bucket), int(max_graphs)
+        self.pad_index, self.eos_index = pad_index, eos_index
+        self.use_graphs = use_graphs
+        self.ex = get_extractor(self.device, proc.sample_rate, proc.num_freq)
+        self.kernel_sizes = list(step.model.encoder.subsampler.kernel_sizes)
+        self.buckets: "OrderedDict[tuple, _Bucket]" = OrderedDict()
+        self.pool = torch.cuda.graph_pool_handle()
+        step.optimizer.device_schedule = True  # update count and learning rate are read from device memory
+        step.external_lr = True                # ... and the rate arrives with the batch (one copy), not by a fill per step
+        self.ntokens = 0
+        self.counts = {"eager": 0, "replay": 0, "captured": 0, "evicted": 0}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _bucket(self, key) -> _Bucket:
+        bk = self.buckets.get(key)
+        if bk is None:
+            while len(self.buckets) >= self.max_graphs:
+                self.buckets.popitem(last=False)
+                self.counts["evicted"] += 1
+            bk = _Bucket(key, len(self.kernel_sizes), self.ex.win_len, self.ex.shift, self.device, self.pad_index)
+            self.buckets[key] = bk
+        else:
+            self.buckets.move_to_end(key)
+        return bk
+
+    def _body(self, bk: _Bucket):
+        B, Tb, _ = bk.key
+        step = self.step
+        step.optimizer.lr_dev.copy_(bk.lr)  # the step's learning rate, as it arrived in the packed buffer
+        feats = self.proc.batch_from_tables(bk.wave, bk.soff, bk.foff, B, Tb, bk.crop[0:1], is_train=True, out_dtype=self.dtype,
+                                            masks_dev=bk.masks)
+        b = bk.batch
+        b.src = feats
+        b.trg_mask = (b.trg != self.pad_index).unsqueeze(1)
+        return step.micro_step(b, sort=False, update=True, overlap=False)
+
+    def run(self, wave: torch.Tensor, n_samples: Sequence[int], trg: torch.Tensor, trg_len) -> str:
+        """One training step on this batch; returns how it ran ("eager" on a bucket's first sight, else "replay")."""
+        ex, step = self.ex, self.step
+        B = len(n_samples)
+        if not wave.is_cuda or wave.dtype != torch.float32 or wave.dim() != 2 or wave.shape[0] != B:
+            raise ops.Js2tError("GraphedTrainStep.run: wave must be a float32 [B, N] tensor on the GPU")
+        frames = [ex.n_frames(int(n)) for n in n_samples]
+        if min(frames) < 1:
+            raise ops.Js2tError("GraphedTrainStep.run: an utterance shorter than one frame (filter with SpeechProcessor.keep_mask)")
+        order = sorted(range(B), key=lambda i: -frames[i])  # batch.sort_by_src_length() of training.py:555, on the host
+        trg_len = [int(v) for v in (trg_len.tolist() if torch.is_tensor(trg_len) else trg_len)]
+        L = max(trg_len)
+        key = (B, _round_up(frames[order[0]], self.frame_bucket), _round_up(L, self.target_bucket))
+        bk = self._bucket(key)
+        Tb, Lb = key[1], key[2]
+        # ---- everything that varies inside the bucket, into the pinned buffer
+        bk.next_host()
+        fr = np.asarray([frames[i] for i in order], dtype=np.int64)
+        bk.host_view("soff").copy_(torch.arange(B, dtype=torch.int64) * bk.wave.shape[1])
+        bk.host_view("foff").copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(fr)])))
+        bk.host_view("src_length").copy_(torch.from_numpy(fr))
+        crop = [int(fr[0])]
+        for k in self.kernel_sizes:  # Conv1dSubsampler.get_out_seq_lens_tensor (encoders.py:348-352) of the longest utterance
+            crop.append((crop[-1] + 2 * (k // 2) - (k - 1) - 1) // 2 + 1)
+        bk.host_view("crop").copy_(torch.tensor(crop, dtype=torch.int64))
+        t = torch.full((B, Lb), self.pad_index, dtype=torch.int64)
+        t[:, :min(L, trg.shape[1])] = trg[order][:, :L]
+        # Batch.__init__ (batch.py:79-96): input = EOS -> pad, last column dropped; target = BOS dropped; length - 1
+        bk.host_view("trg_input").copy_(torch.where(t == self.eos_index, torch.full_like(t, self.pad_index), t)[:, :-1].reshape(-1))
+        bk.host_view("trg").copy_(t[:, 1:].reshape(-1))
+        bk.host_view("trg_length").copy_(torch.tensor([trg_len[i] - 1 for i in order], dtype=torch.int64))
+        masks = self.proc.draw_masks(fr.tolist()) if self.proc.specaugment is not None else np.zeros((B, 8), dtype=np.int32)
+        bk.host_view("masks").view(torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(masks)).reshape(-1))
+        bk.host_view("lr").view(torch.float32)[0] = float(step.optimizer.param_groups[0]["lr"])
+        bk.host_view("order").copy_(torch.tensor(order, dtype=torch.int64))
+        bk.upload()
+        ncol = min(wave.shape[1], bk.wave.shape[1])
+        if ncol < max(n_samples):
+            raise ops.Js2tError("GraphedTrainStep.run: waveform buffer shorter than its longest utterance")
+        bk.wave[:, :ncol].copy_(wave.index_select(0, bk.order)[:, :ncol])  # rows in sorted order (samples past an utterance are never read)
+        self.ntokens += int((t[:, 1:] != self.pad_index).sum())
+        # ---- run
+        if bk.graph is not None:
+            bk.graph.replay()
+            bk.replays += 1
+            step.after_update()
+            self.counts["replay"] += 1
+            return "replay"
+        self._body(bk)  # first sight of this bucket: the step runs eagerly (micro_step -> update -> after_update) ...
+        self.counts["eager"] += 1
+        if self.use_graphs:  # ... and is captured over the same static inputs for every later batch of the bucket
+            g = torch.cuda.CUDAGraph()
+            micro = step.micro
+            with torch.cuda.graph(g, pool=self.pool):
+                self._body(bk)
+            step.micro = micro
+            bk.graph = g
+            self.counts["captured"] += 1
+        return "eager"
+
+    def read_stats(self, reset: bool = True):
+        out = self.step.read_stats(reset=reset)
+        out["ntokens"] = float(self.ntokens)  # counted on the host: the captured statistics kernel carries a per-bucket constant
+        if reset:
+            self.ntokens = 0
+        return out

@@ -104,13 +104,21 @@ class FbankExtractor:
                 self._plans.clear()
             self._plans[key] = plan
         frames, d_soff, d_foff, total = plan
+        return self.batch_tables(wave, d_soff, d_foff, U, total), d_foff, frames
+
+    def batch_tables(self, wave: torch.Tensor, d_soff: torch.Tensor, d_foff: torch.Tensor, U: int, total_cap: int) -> torch.Tensor:
+        """The same with the offset tables already on the device (int64 sample_off[U], frame_off[U + 1]): nothing on the host
+        depends on the utterances' lengths, so one captured launch serves every batch whose frames fit `total_cap` rows (the
+        kernel reads the real total from frame_off[U]; rows beyond it are left unwritten)."""
+        ops._dev(wave, d_soff, d_foff)
+        total = int(total_cap)
         feat = torch.empty((total, self.n_mel), dtype=torch.float32, device=self.device)
         check(lib().js2t_fbank(_p(wave), _p(d_soff), _p(d_foff), C.c_int32(U), C.c_int64(total), _p(self.window),
                                _p(self.tw_re), _p(self.tw_im), _p(self.mel_start), _p(self.mel_len), _p(self.mel_woff),
                                _p(self.mel_w), _p(feat), C.c_int32(self.win_len), C.c_int32(self.shift), C.c_int32(self.n_fft),
                                C.c_int32(self.n_mel), C.c_float(2.0**15), C.c_float(self.preemph),
                                C.c_float(float(np.finfo(np.float32).eps)), _stream()), "js2t_fbank")
-        return feat, d_foff, frames
+        return feat
 
 
 _extractors: Dict[Tuple, FbankExtractor] = {}

@@ -239,19 +239,21 @@ def transpose_groups(src, dst, table, n_groups: int, total_tiles: int):
     check(lib().js2t_transpose_groups(_p(src), _p(dst), _p(table), int(n_groups), C.c_int64(total_tiles), _stream()), "js2t_transpose_groups")
 
 
-def glu_fwd(x: torch.Tensor) -> torch.Tensor:
-    _dev(x)
+def glu_fwd(x: torch.Tensor, T: Optional[int] = None, valid_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[rows, 2C] -> [rows, C]; with (T, valid_t): rows = batch * T and positions t >= *valid_t (device int64 scalar) come out 0."""
+    _dev(x, valid_t)
     rows, c2 = x.shape[0], x.shape[1]
     y = torch.empty((rows, c2 // 2), dtype=x.dtype, device=x.device)
-    check(lib().js2t_glu_fwd(_p(x), _p(y), C.c_int64(rows), C.c_int64(c2 // 2), dt_code(x), _stream()), "js2t_glu_fwd")
+    check(lib().js2t_glu_fwd_crop(_p(x), _p(y), C.c_int64(rows), C.c_int64(c2 // 2), C.c_int64(T if valid_t is not None else max(rows, 1)),
+                                  _p(valid_t), dt_code(x), _stream()), "js2t_glu_fwd")
     return y
 
 
-def glu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
-    _dev(x, dy)
+def glu_bwd(x: torch.Tensor, dy: torch.Tensor, T: Optional[int] = None, valid_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(x, dy, valid_t)
     dx = torch.empty_like(x)
-    check(lib().js2t_glu_bwd(_p(x), _p(dy), _p(dx), C.c_int64(x.shape[0]), C.c_int64(x.shape[1] // 2), dt_code(x),
-                             _stream()), "js2t_glu_bwd")
+    check(lib().js2t_glu_bwd_crop(_p(x), _p(dy), _p(dx), C.c_int64(x.shape[0]), C.c_int64(x.shape[1] // 2),
+                                  C.c_int64(T if valid_t is not None else max(x.shape[0], 1)), _p(valid_t), dt_code(x), _stream()), "js2t_glu_bwd")
     return dx
 
 

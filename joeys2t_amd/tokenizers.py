@@ -54,6 +54,21 @@ class SpeechProcessor:
         return finalize_features(feat, frame_off, frames, cmvn=self.cmvn, specaugment=sa, out_dtype=out_dtype,
                                  max_length=self.max_length if self.max_length > 0 else None, masks_dev=masks_dev)
 
+    def batch_from_tables(self, wave: torch.Tensor, d_soff: torch.Tensor, d_foff: torch.Tensor, n_utts: int, t_pad: int,
+                          crop_t: torch.Tensor, is_train: bool = True, out_dtype=torch.float32,
+                          masks_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """batch_from_waveforms for hipGraph replay over VARYING batches: utterance offsets / frame counts come from device
+        tables, the output is [n_utts, t_pad, F] (t_pad: a bucket length >= the longest utterance) with 1.0 behind each
+        utterance and 0 from *crop_t (the longest utterance's frames) on; SpecAugment parameters from masks_dev."""
+        ex = get_extractor(wave.device, self.sample_rate, self.num_freq)
+        feat = ex.batch_tables(wave, d_soff, d_foff, n_utts, n_utts * t_pad)
+        sa = self.specaugment if is_train else None
+        if sa is not None and masks_dev is None:
+            raise ValueError("batch_from_tables: SpecAugment parameters must be supplied in masks_dev")
+        out, _ = finalize_features(feat, d_foff, [t_pad] * n_utts, cmvn=self.cmvn, specaugment=sa, out_dtype=out_dtype,
+                                   max_length=None, masks_dev=masks_dev, t_pad=t_pad, crop_t=crop_t)
+        return out
+
     def __repr__(self):
         return (f"{self.__class__.__name__}(level={self.level}, normalize={self.normalize}, "
                 f"filter_by_length=({self.min_length}, {self.max_length}), specaugment={self.specaugment}, cmvn={self.cmvn})")

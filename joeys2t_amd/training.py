@@ -64,6 +64,7 @@ class TrainStep:
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
         self.stats = torch.zeros(6, dtype=torch.float64, device=self.store.device)
         self._grad_seeds: Dict[float, torch.Tensor] = {}  # device constants seeding backward, by normalisation factor
+        self.external_lr = False  # True: the caller delivers the step's learning rate to optimizer.lr_dev itself (graphed.py)
 
     def exchange_and_flush(self, plan=None):
         """Deferred weight-gradient products + gradient exchange of one optimizer step, overlapped: each range of the flat
@@ -153,7 +154,8 @@ class TrainStep:
     def after_update(self):
         if self.scheduler is not None:
             self.scheduler.step(self.steps)
-            self.optimizer.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
+            if not self.external_lr:
+                self.optimizer.lr_dev.fill_(self.optimizer.param_groups[0]["lr"])
         self.steps += 1
 
     # ---- checkpoints in the reference's layout (training.py:149-190,220-285) ---------------------------------------------
