@@ -277,6 +277,98 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     return eager_step, graph_step, capture, step, sum(frames_list), (model, state)
 
 
+def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utts=512, use_graphs=True):
+    """Side figure: the train step over batches that change every step, as the reference's loader cuts them - utterances of
+    10-17 s drawn by TokenBatchSampler (datasets.py:1249-1295 of the reference) from a shuffled synthetic corpus, handed to the
+    GPU one batch ahead by PrefetchLoader (pinned rows -> HBM on a copy stream), run by graphed.GraphedTrainStep (one hipGraph
+    per (B, frames / 64, target length / 8) bucket; first sight of a bucket = eager step + capture).  `warmup` steps fill the
+    buckets; the timed steps include whatever new buckets still turn up.  value = UN-padded frames per second."""
+    import copy
+    from joeys2t_amd.datasets import PrefetchLoader, TokenBatchSampler
+    from joeys2t_amd.graphed import GraphedTrainStep
+    from joeys2t_amd.helpers_for_ddp import RandomSubsetSampler
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.finalize(device, dtype, seed=seed)
+    step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0, learning_rate_warmup=10000,
+                     learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1, n_gpu=1, overlap_ctc=True)
+    proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
+                           specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
+                           cmvn=dict(norm_means=True, norm_vars=True, before=True))
+    gstep = GraphedTrainStep(step, proc, compute_dtype=dtype, use_graphs=use_graphs)
+    # the corpus: pool_utts utterances of 10-17 s in pinned host memory (slices of one noise buffer), targets of 40-80 tokens
+    g = torch.Generator().manual_seed(4321)
+    n_samples = torch.randint(160000, 272001, (pool_utts, ), generator=g).tolist()
+    noise = (0.1 * torch.randn(272000 + 4096 * 8, generator=g)).clamp_(-1.0, 1.0).pin_memory()
+    starts = torch.randint(0, 4096 * 8, (pool_utts, ), generator=g).tolist()
+    tlen = torch.randint(40, 81, (pool_utts, ), generator=g).tolist()
+    targets = [torch.cat([torch.tensor([2]), torch.randint(4, VOCAB, (k, ), generator=g), torch.tensor([3])]) for k in tlen]
+    frames = [1 + (n - 400) // 160 for n in n_samples]
+
+    class Corpus:
+        def __init__(self):
+            self.indices, self.random_subset, self.seed = list(range(pool_utts)), -1, seed
+
+        def __len__(self):
+            return pool_utts
+
+        def reset_indices(self):
+            self.indices = list(range(pool_utts))
+
+        def __getitem__(self, i):  # (index, source, target): the samplers only ask for lengths
+            return i, range(frames[i]), range(tlen[i] + 2)
+
+    sampler = TokenBatchSampler(RandomSubsetSampler(Corpus(), shuffle=True, generator=torch.Generator().manual_seed(seed)),
+                                batch_size=BATCH * 1650, drop_last=True, seed=seed)
+
+    def load(idx):
+        L = max(tlen[i] for i in idx) + 2
+        trg = torch.full((len(idx), L), 1, dtype=torch.long)
+        for r, i in enumerate(idx):
+            trg[r, :tlen[i] + 2] = targets[i]
+        return {"wave": [noise[starts[i]:starts[i] + n_samples[i]] for i in idx], "n_samples": [n_samples[i] for i in idx], "trg": trg.numpy(),
+                "trg_len": [tlen[i] + 2 for i in idx]}
+
+    def batches():
+        while True:  # epoch after epoch (the sampler re-shuffles)
+            for b in sampler:
+                yield b
+
+    it = iter(PrefetchLoader(batches(), load, device))
+    n_frames = 0
+
+    def one():
+        nonlocal n_frames
+        item = next(it)
+        how = gstep.run(item["wave"], item["n_samples"], torch.from_numpy(item["trg"]), item["trg_len"])
+        n_frames += sum(1 + (n - 400) // 160 for n in item["n_samples"])
+        return how
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    gstep.read_stats()
+    n_frames, before = 0, dict(gstep.counts)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = gstep.read_stats()
+    return {"ms_per_step": round(dt / steps * 1e3, 3), "frames_per_s_unpadded": round(n_frames / dt, 1), "steps": steps, "warmup": warmup,
+            "utterances_per_batch": round(stats["nseqs"] / steps, 2), "buckets": len(gstep.buckets),
+            "timed_steps_replayed": gstep.counts["replay"] - before["replay"], "timed_steps_eager_plus_capture": gstep.counts["eager"] - before["eager"],
+            "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8) bucket" if use_graphs else "eager",
+            "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
+                    "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
+
+
 def encoder_forward(model, batch, reps=20):
     """BASELINE.json's stated target is a fraction of the bf16 MFMA peak on the ENCODER FORWARD: time it alone (subsampler +
     16 layers + final LayerNorm, train mode / dropout on, hipGraph replay) and price it with SURVEY 8(d)'s count:
@@ -604,6 +696,7 @@ def main():
                     help="skip the side figures (encoder-forward and Conformer fp8 timings): a kernel trace of the train step alone")
     ap.add_argument("--ragged", action="store_true", help="utterances of 10-17 s instead of 32 x 15 s (value counts un-padded frames)")
     ap.add_argument("--host-inputs", action="store_true", help="copy the waveforms from pinned host memory every step (PCIe-inclusive rate; not the headline value)")
+    ap.add_argument("--varying", action="store_true", help="side figure only: a new ragged batch every step (TokenBatchSampler + PrefetchLoader + one hipGraph per shape bucket)")
     args = ap.parse_args()
 
     # JS2T_BENCH_BACKEND=gloo + several ranks on one card rehearses the N > 1 code path on a single-GPU box
@@ -630,6 +723,14 @@ def main():
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, **kw)
     n_ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
+    if args.varying:
+        if world != 1:
+            sys.exit("bench.py --varying: single GPU")
+        res = varying_bench(device, args.steps if args.steps != 20 else 100, args.warmup if args.warmup != 5 else 60, use_graphs=not args.no_graph)
+        print(json.dumps({"metric": "audio frames/sec (train step, varying batches)", "value": res["frames_per_s_unpadded"], "unit": "frames/s",
+                          "n_gpus": 1, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "configs/librispeech_100h.yaml ASR train step, a new batch every step"}, "varying": res}), flush=True)
+        return
     from joeys2t_amd import ops
     eager_step, graph_step, capture, step, frames_per_step, (model, state) = build_step(
         device, world, ragged=args.ragged, host_inputs=args.host_inputs, ddp=(world > 1 or force_ddp))
@@ -745,6 +846,12 @@ def main():
         except Exception as exc:  # a side figure of an extension: never lose the headline line over it
             roofline["conformer_fp8_forward"] = {"error": repr(exc)}
 
+    varying = None
+    if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:
+        try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
+            varying = varying_bench(device, 60, 40)
+        except Exception as exc:
+            varying = {"error": repr(exc)}
     decode = None
     if rank == 0 and world == 1 and not args.no_decode:
         try:
@@ -786,7 +893,7 @@ def main():
                        "capture_error": capture_error,
                        "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else ("bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32"),
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode,
+            "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode, "varying_batches": varying,
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():

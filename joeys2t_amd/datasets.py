@@ -149,6 +149,16 @@ class PrefetchLoader:
                     pinned = v if v.is_pinned() else v.pin_memory()
                     out[k] = pinned.to(self.device, non_blocking=True)
                     out.setdefault("_pinned", []).append(pinned)  # keep the staging buffer alive until the copy ran
+                elif isinstance(v, (list, tuple)) and len(v) > 0 and all(torch.is_tensor(t) and t.device.type == "cpu" and t.dim() == 1 for t in v):
+                    # rows of differing length (e.g. utterances that already sit in pinned memory): one device tensor
+                    # [len(v), longest], zero behind each row, filled by one asynchronous copy per row - no host-side gather
+                    width = max(int(t.numel()) for t in v)
+                    dst = torch.zeros((len(v), width), dtype=v[0].dtype, device=self.device)
+                    for r, t in enumerate(v):
+                        src = t if t.is_pinned() else t.pin_memory()
+                        dst[r, :t.numel()].copy_(src, non_blocking=True)
+                        out.setdefault("_pinned", []).append(src)
+                    out[k] = dst
                 else:
                     out[k] = v
             ev = torch.cuda.Event()

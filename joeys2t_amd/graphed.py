@@ -180,7 +180,7 @@ class GraphedTrainStep:
         bk.host_view("order").copy_(torch.tensor(order, dtype=torch.int64))
         bk.upload()
         ncol = min(wave.shape[1], bk.wave.shape[1])
-        if ncol < max(n_samples):
+        if ncol < ex.win_len + (int(fr[0]) - 1) * ex.shift:  # (samples behind an utterance's last whole frame are never read)
             raise ops.Js2tError("GraphedTrainStep.run: waveform buffer shorter than its longest utterance")
         bk.wave[:, :ncol].copy_(wave.index_select(0, bk.order)[:, :ncol])  # rows in sorted order (samples past an utterance are never read)
         self.ntokens += int((t[:, 1:] != self.pad_index).sum())
