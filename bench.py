@@ -325,7 +325,7 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
             return i, range(frames[i]), range(tlen[i] + 2)
 
     sampler = TokenBatchSampler(RandomSubsetSampler(Corpus(), shuffle=True, generator=torch.Generator().manual_seed(seed)),
-                                batch_size=BATCH * 1650, drop_last=True, seed=seed)
+                                batch_size=BATCH * 1650, drop_last=False, seed=seed)
 
     def load(idx):
         L = max(tlen[i] for i in idx) + 2
@@ -367,6 +367,71 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
             "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
+
+
+def measure_roofline(eager_step, model):
+    """HIP-event timing of every GEMM launch of two eager train steps on ONE GPU (a spin kernel holds the GPU while the host
+    enqueues the step, so the timed kernels run back to back) -> the `roofline` object of the JSON line."""
+    from joeys2t_amd import ops
+    timer = GemmTimer()
+    # The eager pass is launch-bound on the host (~40 us of Python per kernel): an event pair around a launch
+    # would also time the GPU waiting for the next packet.  A spin kernel in front of each step holds the GPU
+    # while the host enqueues the whole step, so the timed kernels then run back to back from a full queue.
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    torch.cuda._sleep(10_000_000)
+    s1.record()
+    torch.cuda.synchronize()
+    cycles_per_ms = 10_000_000 / max(s0.elapsed_time(s1), 1e-3)
+    ops.GEMM_TIMER = timer
+    overlap_ctc, model.overlap_ctc = model.overlap_ctc, False  # one stream: every launch is timed alone on the GPU
+    for _ in range(2):
+        torch.cuda._sleep(int(80 * cycles_per_ms))
+        eager_step()
+        torch.cuda.synchronize()
+    model.overlap_ctc = overlap_ctc
+    ops.GEMM_TIMER = None
+    # an event pair with nothing between its records still reads a few microseconds (the two timestamp packets):
+    # measured here the same way and taken off every timed launch
+    torch.cuda._sleep(int(20 * cycles_per_ms))
+    empty = GemmTimer()
+    for _ in range(256):
+        empty.wrap("empty", 0.0, lambda: None)
+    pair_overhead = empty.summary()["empty"][2] / 256
+    agg = timer.summary()
+    for v in agg.values():
+        v[2] = max(v[2] - v[0] * pair_overhead, 1e-9)
+    # dominant kernel = the bf16 LDS-DMA MFMA GEMM family: the persistent 192x128 kernel (forward and input-gradient
+    # products of the encoder-sized layers), the 128/64-row tile kernel (everything else) and its grouped launch
+    # form (the deferred weight gradients); per-kernel figures are listed beside it
+    fam = {k: v for k, v in agg.items() if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_"))}
+    n = sum(v[0] for v in fam.values())
+    flops = sum(v[1] for v in fam.values())
+    secs = sum(v[2] for v in fam.values())
+    achieved = flops / secs / 1e12
+    algo_bytes = sum(v[3] for v in fam.values()) / n
+    # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE): a committed
+    # measurement, stamped with the kernel source it was taken on - null as soon as csrc/gemm.hip has changed since
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / "gemm_traffic.json"
+    if tfile.exists():
+        tj = json.loads(tfile.read_text())
+        import hashlib
+        sha = hashlib.sha256((ROOT / "joeys2t_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()[:16]
+        traffic_src = {"file": "profiles/gemm_traffic.json", "measured_at_commit": tj.get("measured_at_commit"),
+                       "measured_on": tj.get("measured_on"), "gemm_hip_sha16": tj.get("gemm_hip_sha16"),
+                       "current_gemm_hip_sha16": sha, "stale": tj.get("gemm_hip_sha16") != sha}
+        if not traffic_src["stale"]:
+            traffic = tj.get("hbm_bytes_per_launch")
+    key = "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
+    roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(algo_bytes),
+                "flop_per_launch": round(flops / n), "launches_per_step": n // 2,
+                "avg_launch_us": round(secs / n * 1e6, 2), "event_pair_overhead_us": round(pair_overhead * 1e6, 2),
+                "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
+                                         "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
+    return roofline
 
 
 def encoder_forward(model, batch, reps=20):
@@ -716,6 +781,19 @@ def main():
     force_ddp = world == 1 and os.environ.get("JS2T_BENCH_FORCE_DDP", "0") == "1"
     if force_ddp:
         os.environ["JS2T_DDP_SINGLE"] = "1"  # the one-rank communicator really issues its all-reduces
+    roofline_pre = None
+    if world > 1 and rank == 0 and not args.no_roofline:
+        # Data-parallel lines describe themselves too: the dominant kernel family does not change with N (every rank runs the
+        # N = 1 step's kernels on its own 32 utterances), so rank 0 times it on its GPU alone BEFORE the process group forms -
+        # the eager timing passes would otherwise issue collectives on one rank only.  The other ranks wait at the rendezvous.
+        try:
+            es, _, _, st1, _, (m1, _) = build_step(device, 1, ddp=False)
+            roofline_pre = measure_roofline(es, m1)
+            roofline_pre["measured"] = "rank 0, single-GPU step, before the process group formed"
+            del es, st1, m1
+            torch.cuda.empty_cache()
+        except Exception as exc:  # never lose the N > 1 line over its side figure
+            roofline_pre = {"error": repr(exc)[:300]}
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -779,66 +857,10 @@ def main():
     stats = step.read_stats()
 
     roofline = None
-    if rank == 0 and world == 1 and not args.no_roofline:  # N = 1 only: the eager passes would issue collectives on one rank alone
-        timer = GemmTimer()
-        # The eager pass is launch-bound on the host (~40 us of Python per kernel): an event pair around a launch
-        # would also time the GPU waiting for the next packet.  A spin kernel in front of each step holds the GPU
-        # while the host enqueues the whole step, so the timed kernels then run back to back from a full queue.
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        torch.cuda._sleep(10_000_000)
-        s1.record()
-        torch.cuda.synchronize()
-        cycles_per_ms = 10_000_000 / max(s0.elapsed_time(s1), 1e-3)
-        ops.GEMM_TIMER = timer
-        overlap_ctc, model.overlap_ctc = model.overlap_ctc, False  # one stream: every launch is timed alone on the GPU
-        for _ in range(2):
-            torch.cuda._sleep(int(80 * cycles_per_ms))
-            eager_step()
-            torch.cuda.synchronize()
-        model.overlap_ctc = overlap_ctc
-        ops.GEMM_TIMER = None
-        # an event pair with nothing between its records still reads a few microseconds (the two timestamp packets):
-        # measured here the same way and taken off every timed launch
-        torch.cuda._sleep(int(20 * cycles_per_ms))
-        empty = GemmTimer()
-        for _ in range(256):
-            empty.wrap("empty", 0.0, lambda: None)
-        pair_overhead = empty.summary()["empty"][2] / 256
-        agg = timer.summary()
-        for v in agg.values():
-            v[2] = max(v[2] - v[0] * pair_overhead, 1e-9)
-        # dominant kernel = the bf16 LDS-DMA MFMA GEMM family: the persistent 192x128 kernel (forward and input-gradient
-        # products of the encoder-sized layers), the 128/64-row tile kernel (everything else) and its grouped launch
-        # form (the deferred weight gradients); per-kernel figures are listed beside it
-        fam = {k: v for k, v in agg.items() if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_"))}
-        n = sum(v[0] for v in fam.values())
-        flops = sum(v[1] for v in fam.values())
-        secs = sum(v[2] for v in fam.values())
-        achieved = flops / secs / 1e12
-        algo_bytes = sum(v[3] for v in fam.values()) / n
-        # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE): a committed
-        # measurement, stamped with the kernel source it was taken on - null as soon as csrc/gemm.hip has changed since
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "gemm_traffic.json"
-        if tfile.exists():
-            tj = json.loads(tfile.read_text())
-            import hashlib
-            sha = hashlib.sha256((ROOT / "joeys2t_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()[:16]
-            traffic_src = {"file": "profiles/gemm_traffic.json", "measured_at_commit": tj.get("measured_at_commit"),
-                           "measured_on": tj.get("measured_on"), "gemm_hip_sha16": tj.get("gemm_hip_sha16"),
-                           "current_gemm_hip_sha16": sha, "stale": tj.get("gemm_hip_sha16") != sha}
-            if not traffic_src["stale"]:
-                traffic = tj.get("hbm_bytes_per_launch")
-        key = "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
-        roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": round(algo_bytes),
-                    "flop_per_launch": round(flops / n), "launches_per_step": n // 2,
-                    "avg_launch_us": round(secs / n * 1e6, 2), "event_pair_overhead_us": round(pair_overhead * 1e6, 2),
-                    "all_gemm_kernels": {k: {"launches_per_step": v[0] // 2, "tflops": round(v[1] / v[2] / 1e12, 2),
-                                             "ms_per_step": round(v[2] / 2 * 1e3, 3)} for k, v in agg.items()}}
-
+    if rank == 0 and world == 1 and not args.no_roofline:  # N = 1: on the step that was just timed
+        roofline = measure_roofline(eager_step, model)
+    elif rank == 0 and roofline_pre is not None:  # N > 1: measured on rank 0's GPU before the process group formed (see above)
+        roofline = roofline_pre
     if roofline is not None and not args.no_extras:
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
         try:
