@@ -469,7 +469,7 @@ def encoder_forward(model, batch, reps=20):
 PEAK_FP8_TFLOPS = 5000.0  # dense fp8 MFMA peak (MI355X_MICROARCH.md); the kernel uses the non-scaled K = 32 form, which issues at the bf16 rate
 
 
-def conformer_fp8_forward(device, reps=10):
+def conformer_fp8_forward(device, reps=10, modes=("fp8", "bf16")):
     """BASELINE.json configs[4]: Conformer-style encoder (relative-position attention + depthwise convolution module) on
     librispeech_960h shapes with fp8 MFMA - encoder forward on 32 x 15 s of synthetic features, train mode (dropout on),
     hipGraph replay; timed with e4m3 forward products (functional.FP8_FORWARD) and, beside it, in plain bf16.
@@ -502,7 +502,7 @@ def conformer_fp8_forward(device, reps=10):
     tokens = BATCH * tp
     flop = layers * tokens * (2 * 4 * d * ff + 8 * d * d + 4 * tp * d + 4 * d * d + 2 * d * d + 2 * k * d) + 2 * tokens * d * d + 41e9 * (BATCH / 32)
     out = {}
-    for mode in ("fp8", "bf16"):
+    for mode in modes:
         Fn.FP8_FORWARD = mode == "fp8"
         try:
             with torch.no_grad():

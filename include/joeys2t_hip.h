@@ -112,6 +112,8 @@ typedef struct js2t_gemm_desc {
   float* ln_mean;           /* consumer out (both or neither): f32 [M] row means and 1/sqrt(var + eps) the epilogue used */
   float* ln_rstd;
   float* rs_partial;        /* producer out: f32 [M][8][2], the same sums over the stored (bf16-rounded) C's rows (N = 512) */
+  float* fp8_state;         /* e4m3 products: delayed-scale state of the kernel that quantised A (js2t_layernorm_fwd_fp8): block 0 hands
+                             * the collected maximum over, state[0] = state[1] / 448, state[1] *= 15/16 (decayed, not cleared), when the product is done */
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
@@ -251,6 +253,13 @@ int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_lengths, ui
  */
 int js2t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int64_t rows, int64_t D, float eps, int dt, js2t_stream stream);
+/* The same with the result also (y == NULL: only) as e4m3 bytes for the fp8 forward mode (extension, see js2t_quantize_fp8):
+ * y8 = e4m3(clamp(LN(x) / S)), S = q_state[0]; the call's max |LN(x)| is collected in q_state[1] (f32[4], 16-byte aligned) and
+ * becomes the next call's scale when the consuming product hands it over (js2t_gemm_desc.fp8_state);
+ * *q_scale_out = S * (*q_mul or 1).  The quantisation of a LayerNorm-fed nn.Linear input then has no pass of its own. */
+int js2t_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* q_state,
+                           const float* q_mul, float* q_scale_out, float* mean, float* rstd, int64_t rows, int64_t D, float eps,
+                           int dt, js2t_stream stream);
 /* dx (dt) = LN'(dy) [+ add_scale * add]  (add: optional residual-branch gradient, same shape as dx);
  * dgamma/dbeta f32[D] (may both be NULL); partial = f32[2 * ceil(rows/16) * D] workspace. */
 int js2t_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,

@@ -1685,6 +1685,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
     P192_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
+  if (FP8 && d.fp8_state && blockIdx.x == 0 && t == 0) {
+    // delayed activation scale of the producer that quantised A (js2t_layernorm_fwd_fp8): this product sits between two of its
+    // calls on the stream, so it does the hand-over - the maximum the last call collected becomes the next call's scale.
+    // (This launch's own scale arrived in alpha_dev, a separate word.)
+    // The collected maximum is not cleared but DECAYED (x 15/16): the next call's blocks then post their maximum only if it
+    // comes within 6 % of the last one - a handful of atomics instead of one per block that finishes while the word still
+    // reads 0 (measured: 12 us per LayerNorm launch); a shrinking activation range is followed at 6 % per call.
+    const float am = d.fp8_state[1];
+    if (am > 0.f) d.fp8_state[0] = am * (1.f / 448.f);
+    d.fp8_state[1] = am * 0.9375f;
+  }
 #ifdef JS2T_P192_PROF
   if (blockIdx.x == 0 && t == 0)
     for (int i = 0; i < 8; ++i) g_p192_prof[i] = prof_[i];

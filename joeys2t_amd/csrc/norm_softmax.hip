@@ -161,14 +161,25 @@ constexpr int LNV_MAXCH = 4;        // chunks of 8 columns per lane -> D <= 2048
 constexpr int LNV_ROWS = 64;        // most rows per block in the backward kernel (shared by its 4..16 waves)
 constexpr int LNV_MIN_ROWS = 16;    // fewest (sizes the caller's partial-sum workspace: 2 * ceil(rows / 16) * D floats)
 
+// y8 / q_state (optional, js2t_layernorm_fwd_fp8): the result ALSO (y may then be NULL: only) as e4m3 bytes with a delayed
+// per-tensor scale - q_state[0] = scale in use, [1] = running max |y| of this call.  The quantisation of a LayerNorm-fed
+// nn.Linear input then costs no pass of its own: the normalised row is in registers here anyway.
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, T* __restrict__ y,
                                                                 float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                                int D, float eps) {
+                                                                int D, float eps, uint8_t* __restrict__ y8 = nullptr,
+                                                                float* __restrict__ q_state = nullptr, const float* __restrict__ q_mul = nullptr,
+                                                                float* __restrict__ q_scale_out = nullptr) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  __shared__ float q_red[ROWS_PER_BLOCK];
+  float q_inv = 0.f, q_max = 0.f;
+  if (y8) {
+    const float S = q_state[0];
+    q_inv = S > 0.f ? 1.f / S : 0.f;
+    if (q_scale_out && blockIdx.x == 0 && threadIdx.x == 0) *q_scale_out = (S > 0.f ? S : 1.f) * (q_mul ? *q_mul : 1.f);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
   const int nch = D >> 3;
   float v[LNV_MAXCH][8];
   float s = 0.f;
@@ -199,10 +210,37 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const T* __restr
       ld8<float>::ld(beta + 8 * c, bt);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mu) * rs * gm[i] + bt[i];
-      ld8<T>::st(y + row * D + 8 * c, o);
+      if (y) ld8<T>::st(y + row * D + 8 * c, o);
+      if (y8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          q_max = fmaxf(q_max, fabsf(o[i]));
+          o[i] = fminf(fmaxf(o[i] * q_inv, -448.f), 448.f);
+        }
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
+        *(uint2*)(y8 + row * D + 8 * c) = make_uint2((uint32_t)lo, (uint32_t)hi);
+      }
     }
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }  // rows of this wave
+  if (y8) {
+    // delayed scaling: post this block's max |y| - only if it beats what is there, so a handful of blocks do.  The hand-over
+    // (q_state[0] = q_state[1] / 448, q_state[1] = 0) is left to the consuming product (js2t_gemm fp8_state): it runs between
+    // this call and the next one on the stream, so no arrival ticket - 3000 same-address atomics, ~0.1 ms - is needed here.
+    q_max = wave_max(q_max);
+    if (lane == 0) q_red[threadIdx.x >> 6] = q_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = 0.f;
+      for (int i = 0; i < ROWS_PER_BLOCK; ++i) m = fmaxf(m, q_red[i]);
+      unsigned int* st = (unsigned int*)q_state;
+      if (__float_as_uint(m) > *(volatile unsigned int*)(st + 1)) atomicMax(st + 1, __float_as_uint(m));
+    }
+  }
 }
 
 // dx (+ add) and per-block partial sums of dgamma / dbeta: partial[(2*blk + 0)*D + c], partial[(2*blk + 1)*D + c].
@@ -550,6 +588,21 @@ extern "C" int js2t_layernorm_fwd(const void* x, const float* gamma, const float
   }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, D, eps));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_layernorm_fwd_fp8(const void* x, const float* gamma, const float* beta, void* y, void* y8, float* q_state,
+                                      const float* q_mul, float* q_scale_out, float* mean, float* rstd, int64_t rows, int64_t D, float eps,
+                                      int dt, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(x && gamma && beta && y8 && q_state && mean && rstd && rows > 0 && D > 0, "layernorm_fwd_fp8: bad arguments");
+  JS2T_CHECK((D % 8 == 0) && D <= 64 * 8 * LNV_MAXCH && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)q_state) & 15) == 0 &&
+                 (((uintptr_t)y8) & 7) == 0,
+             "layernorm_fwd_fp8: D % 8 == 0, D <= 2048, 16-byte aligned rows / state");
+  DISPATCH_DT(dt, T, hipLaunchKernelGGL((layernorm_fwd_vec_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, (int)D, eps, (uint8_t*)y8,
+                                        q_state, q_mul, q_scale_out));
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

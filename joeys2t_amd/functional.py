@@ -35,10 +35,15 @@ def _row_major_2d(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-# fp8 forward mode (BASELINE config 5, "fp8 MFMA"; an extension - the reference computes in fp32 / fp16 only): the forward
-# product of every eligible nn.Linear runs on e4m3 operands with per-tensor dynamic scales (activations re-quantised per
-# call on the device, weights once per optimizer step); backward keeps the bf16 activations and weights it has anyway.
+# fp8 forward mode (BASELINE config 5, "fp8 MFMA"; an extension - the reference computes in fp32 / fp16 only): forward products
+# of nn.Linear layers on e4m3 operands with per-tensor scales (weights quantised once per optimizer step, activations with a
+# delayed scale that adapts on the device); backward keeps the bf16 activations and weights it has anyway.
+# Which products: those whose INPUT is quantised by the kernel that produces it - a LayerNorm in front of the Linear writes
+# e4m3 next to (no_grad: instead of) bf16 while the normalised row is in registers (js2t_layernorm_fwd_fp8): q/k/v projections,
+# first feed-forward layers.  A separate quantisation pass per input (round 2: every eligible Linear, FP8_SEPARATE_PASS) costs
+# more than the e4m3 product saves: 8.8 ms against 6.6 ms in bf16 on the Conformer encoder of bench.py.
 FP8_FORWARD = os.environ.get("JS2T_FP8_FORWARD", "0") == "1"
+FP8_SEPARATE_PASS = os.environ.get("JS2T_FP8_SEPARATE_PASS", "0") == "1"  # also Linears whose input needs a pass of its own
 _FP8_WEIGHTS = {}  # (data_ptr, shape) -> (ops.WEIGHT_VERSION, e4m3 weight, scale f32[1])
 _FP8_STATES = {}   # (weight data_ptr, shape) -> delayed-scaling state of the activations that meet this weight
 FP8_DELAYED = os.environ.get("JS2T_FP8_DELAYED", "1") != "0"  # one quantisation pass with the previous call's scale
@@ -61,26 +66,52 @@ def _fp8_eligible(x2d, w, out_dtype, preact, alpha) -> bool:
             N % 8 == 0 and N >= 128 and M >= 1)
 
 
+def _fp8_state(w, calibrate_on):
+    """delayed-scaling state of the activations that meet weight `w`; created (calibrated on `calibrate_on`) at first use"""
+    key = (w.data_ptr(), tuple(w.shape))
+    st = _FP8_STATES.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise ops.Js2tError("fp8 forward: run one eager step before capturing (activation scales are calibrated on first use)")
+        st = _FP8_STATES[key] = ops.new_fp8_state(calibrate_on)
+    return st
+
+
+def ln_fwd_fp8(x2d, gamma, beta, w, want_y: bool):
+    """LayerNorm in front of the Linear with weight `w`, emitting the e4m3 operand of that product: -> (n | None, mean, rstd, x8)
+    with x8 = (e4m3 tensor, scale f32[1] = s_x * s_w) for linear_fwd(x8=...)."""
+    w8, ws = _fp8_weight(w)
+    key = (w.data_ptr(), tuple(w.shape))
+    if key not in _FP8_STATES:  # calibrate on this call's own LayerNorm output (eager, once)
+        _fp8_state(w, ops.layernorm_fwd(x2d, gamma, beta, LN_EPS)[0])
+    n, mean, rstd, y8, sc = ops.layernorm_fwd_fp8(x2d, gamma, beta, LN_EPS, _FP8_STATES[key], mul=ws, want_y=want_y)
+    return n, mean, rstd, (y8, sc, _FP8_STATES[key])
+
+
 def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
-               out_dtype=None, preact=None, alpha=1.0, ln=None, rs_partial=None):
-    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / rs_partial: see ops.gemm (LayerNorm fold)."""
-    _row_major_2d(x2d), _row_major_2d(w)
-    M, K = x2d.shape
+               out_dtype=None, preact=None, alpha=1.0, ln=None, rs_partial=None, x8=None):
+    """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / rs_partial: see ops.gemm (LayerNorm fold).
+    x8 = (e4m3 x, scale): the input already quantised by its producer (ln_fwd_fp8): e4m3 product, x2d only supplies the shape."""
+    M, K = (x8[0].shape if x8 is not None else x2d.shape)
+    _row_major_2d(w)
     N = w.shape[0]
+    if x8 is not None:
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=w.device)
+        w8, _ = _fp8_weight(w)
+        ops.gemm(x8[0], w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
+                 residual=residual, ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha_dev=x8[1],
+                 fp8_state=x8[2])
+        return y
+    _row_major_2d(x2d)
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
-    if ln is None and rs_partial is None and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and act in (None, "relu"):
+    if (ln is None and rs_partial is None and FP8_SEPARATE_PASS and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and
+            act in (None, "relu")):
         w8, ws = _fp8_weight(w)
         if FP8_DELAYED:
-            key = (w.data_ptr(), tuple(w.shape))
-            st = _FP8_STATES.get(key)
-            if st is None:
-                if torch.cuda.is_current_stream_capturing():
-                    raise ops.Js2tError("fp8 forward: run one eager step before capturing (activation scales are calibrated on first use)")
-                st = _FP8_STATES[key] = ops.new_fp8_state(x2d)
-            x8, sc = ops.quantize_fp8_delayed(x2d, st, mul=ws)
+            x8q, sc = ops.quantize_fp8_delayed(x2d, _fp8_state(w, x2d), mul=ws)
         else:
-            x8, sc = ops.quantize_fp8(x2d, mul=ws)  # sc = s_x * s_w on the device: the GEMM's alpha_dev
-        ops.gemm(x8, w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
+            x8q, sc = ops.quantize_fp8(x2d, mul=ws)  # sc = s_x * s_w on the device: the GEMM's alpha_dev
+        ops.gemm(x8q, w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
                  residual=residual, ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha_dev=sc)
         return y
     ops.gemm(x2d, w, y, M=M, N=N, K=K, lda=x2d.stride(0), ldb=w.stride(0), ldc=N, bias=b, act=act, preact=preact,
@@ -373,6 +404,7 @@ class ResidualBlockFn(torch.autograd.Function):
         if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
                 ops.layernorm_bwd_supports_dropout(x2)):
             ctx.prev_drop = hint[:3]  # (p, site, rng) of the block that produced x
+        x8_first = None  # fp8 forward mode: the first product's input as e4m3, written by the LayerNorm kernel
         lnf = None   # (partial sums of x's rows, eps, mean out, rstd out) when this block's LayerNorm is folded into its first product
         fold = wts.get("fold") if (LN_FOLD and cfg.ln_mode == "pre" and not FP8_FORWARD) else None
         sink0 = wts.get("sink") or {}
@@ -391,7 +423,13 @@ class ResidualBlockFn(torch.autograd.Function):
             wts = dict(wts)
             wts["_" + w_first], wts["_" + b_first] = fold.w, fold.bias
         elif cfg.ln_mode == "pre":
-            n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
+            w0 = wts[{"self": "w_in", "cross": "w_q", "ffn": "w1"}[cfg.kind]]
+            if (FP8_FORWARD and (cfg.kind != "ffn" or cfg.act in (None, "relu")) and _fp8_eligible(x2, w0, None, None, 1.0) and
+                    ops.layernorm_bwd_supports_dropout(x2)):
+                # the LayerNorm writes the e4m3 operand of the block's first product itself (and bf16 only if backward wants it)
+                n, mean, rstd, x8_first = ln_fwd_fp8(x2, wts["ln_g"], wts["ln_b"], w0, want_y=torch.is_grad_enabled())
+            else:
+                n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
             saved.update(mean=mean, rstd=rstd)
         else:
             n = x2
@@ -402,7 +440,7 @@ class ResidualBlockFn(torch.autograd.Function):
         att_w = None
         if cfg.kind == "self":
             H, dh = cfg.H, d // cfg.H
-            qkv = linear_fwd(n, first("w_in"), first("b_in"), ln=lnf)  # columns: [k | v | q]
+            qkv = linear_fwd(n, first("w_in"), first("b_in"), ln=lnf, x8=x8_first)  # columns: [k | v | q]
             shp = AttnShape(B, T, T, H, dh)
             c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0], rel_bias=wts.get("rel_bias"))
             saved.update(qkv=qkv, P=P, Pd=Pd, shp=shp)
@@ -410,7 +448,7 @@ class ResidualBlockFn(torch.autograd.Function):
             H, dh = cfg.H, d // cfg.H
             S = memory.shape[1]
             m2 = memory.reshape(B * S, memory.shape[2])
-            q = linear_fwd(n, first("w_q"), first("b_q"), ln=lnf)
+            q = linear_fwd(n, first("w_q"), first("b_q"), ln=lnf, x8=x8_first)
             kv = linear_fwd(m2, wts["w_kv"], wts["b_kv"])  # columns: [k | v]
             shp = AttnShape(B, T, S, H, dh)
             c, P, Pd = attn_fwd(q, 0, kv, 0, kv, d, shp, mask, p_in, rng, sites[0], need_probs=cfg.need_weights)
@@ -427,7 +465,7 @@ class ResidualBlockFn(torch.autograd.Function):
                 pre = torch.empty((B * T, wts["w1"].shape[0]), dtype=x.dtype, device=x.device)
             if lnf is not None and pre is not None:
                 raise ops.Js2tError("LayerNorm fold: ReLU / no activation only")  # (the caller does not offer a fold otherwise)
-            c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf)
+            c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf, x8=x8_first)
             saved.update(pre=pre)
         w_last, b_last = (wts["w2"], wts["b2"]) if cfg.kind == "ffn" else (wts["w_out"], wts["b_out"])
         # the row statistics of what this block writes, for a following block that folds its LayerNorm (see _LN_STATS)

@@ -107,7 +107,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None):
+         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None, fp8_state=None):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements.
     ln = (partial f32[M,8,2], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product (B = the
     centred, gamma-scaled weight of ParamStore.fold); rs_partial f32[M,8,2]: the stored rows' partial sums are written to it."""
@@ -167,6 +167,9 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
             if min(mean_out.numel(), rstd_out.numel()) < M or mean_out.dtype != torch.float32 or rstd_out.dtype != torch.float32:
                 raise Js2tError("gemm: ln mean / rstd outputs must be f32[M]")
             d.ln_mean, d.ln_rstd = mean_out.data_ptr(), rstd_out.data_ptr()
+    if fp8_state is not None:
+        _dev(fp8_state)
+        d.fp8_state = fp8_state.data_ptr()
     if rs_partial is not None:
         if rs_partial.dtype != torch.float32 or rs_partial.numel() != M * 16 or not rs_partial.is_contiguous():
             raise Js2tError("gemm: rs_partial must be contiguous f32[M, 8, 2]")
@@ -381,6 +384,22 @@ def layernorm_fwd(x, gamma, beta, eps: float):
     check(lib().js2t_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), C.c_int64(rows), C.c_int64(D),
                                    C.c_float(eps), dt_code(x), _stream()), "js2t_layernorm_fwd")
     return y, mean, rstd
+
+
+def layernorm_fwd_fp8(x, gamma, beta, eps: float, state: torch.Tensor, mul: Optional[torch.Tensor] = None, want_y: bool = True):
+    """LayerNorm whose result also (want_y=False: only) comes out as e4m3 with the delayed scale of `state` (new_fp8_state):
+    -> (y | None, mean, rstd, y8 float8_e4m3fn, scale f32[1] = S [* mul]) - js2t_layernorm_fwd_fp8."""
+    _dev(x, gamma, beta, state, mul)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x) if want_y else None
+    y8 = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    scale = torch.empty((1, ), dtype=torch.float32, device=x.device)
+    check(lib().js2t_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y), _p(y8), _p(state), _p(mul), _p(scale), _p(mean), _p(rstd),
+                                       C.c_int64(rows), C.c_int64(D), C.c_float(eps), dt_code(x), _stream()), "js2t_layernorm_fwd_fp8")
+    return y, mean, rstd, y8, scale
 
 
 class GradCopies:

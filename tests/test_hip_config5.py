@@ -127,8 +127,11 @@ def test_conformer_relpos_bf16_fused_close_to_fp32(device):
         assert cos > 0.98 and abs(gb.norm().item() / ga.norm().item() - 1) < 0.1, (n, cos)
 
 
-def test_fp8_forward_close_to_bf16(device):
-    """functional.FP8_FORWARD on the composed model: every eligible nn.Linear forward on e4m3 operands (per-tensor scales).
+@pytest.mark.parametrize("separate_pass", [False, True])
+def test_fp8_forward_close_to_bf16(device, separate_pass):
+    """functional.FP8_FORWARD on the composed model: nn.Linear forwards on e4m3 operands (per-tensor scales) - by default those
+    whose input the LayerNorm kernel quantises as it writes it (q/k/v projection and the first layer of both feed-forward
+    modules: 3 per Conformer layer), with FP8_SEPARATE_PASS every eligible one (8 per layer + the input Linear).
     Bound: e4m3 keeps 3 mantissa bits, so an element is off by at most 2^-4 relative (uniform: 2^-4 / sqrt(3) = 3.6 % rms); a
     product of two rounded operands by 5.1 % rms, and a dot product of terms with independent errors keeps that RELATIVE rms
     only if all terms had one sign - with mixed signs the sum's error relative to the sum is larger by |terms|_2 sqrt(K) /
@@ -138,29 +141,64 @@ def test_fp8_forward_close_to_bf16(device):
     from joeys2t_amd import functional as Fn
     src, lengths = _inputs(device)
     enc = _wide(device, torch.bfloat16).eval()
-    seen = []
-    real = Fn.ops.gemm
+    seen, quant = [], []
+    real, real_q = Fn.ops.gemm, Fn.ops.quantize_fp8_delayed
 
     def spy(A, Bm, Cc, **k):
         seen.append(A.dtype)
         return real(A, Bm, Cc, **k)
 
+    def spy_q(*a, **k):
+        quant.append(1)
+        return real_q(*a, **k)
+
     with torch.no_grad():
         ref, _, _ = enc(src, lengths, None)
-        old = Fn.FP8_FORWARD
-        Fn.FP8_FORWARD = True
-        Fn.ops.gemm = spy
+        old = (Fn.FP8_FORWARD, Fn.FP8_SEPARATE_PASS)
+        Fn.FP8_FORWARD, Fn.FP8_SEPARATE_PASS = True, separate_pass
+        Fn.ops.gemm, Fn.ops.quantize_fp8_delayed = spy, spy_q
         try:
             out, _, _ = enc(src, lengths, None)
             out2, _, _ = enc(src, lengths, None)  # second call: delayed scaling uses the first call's maxima
         finally:
-            Fn.FP8_FORWARD = old
-            Fn.ops.gemm = real
+            Fn.FP8_FORWARD, Fn.FP8_SEPARATE_PASS = old
+            Fn.ops.gemm, Fn.ops.quantize_fp8_delayed = real, real_q
     n8 = sum(d == torch.float8_e4m3fn for d in seen)
-    assert n8 >= 2 * 3 * 7, (n8, len(seen))  # per layer: 2 x (FFN1, FFN2), QKV, out-proj, pointwise conv 1 / 2 (+ input Linear)
+    if separate_pass:
+        assert n8 >= 2 * 3 * 7 and len(quant) >= 2 * 3 * 4, (n8, len(quant))
+    else:
+        assert n8 == 2 * 3 * 3 and not quant, (n8, len(quant))  # LayerNorm-fed products only, and no quantisation pass at all
     a = ref.float()
     for o in (out, out2):
         rel = ((o.float() - a).norm() / a.norm()).item()
         cos = torch.nn.functional.cosine_similarity(o.float().flatten(), a.flatten(), dim=0).item()
         assert rel < 0.08 and cos > 0.996, (rel, cos)
     assert not torch.equal(out, ref)
+
+
+def test_layernorm_fp8_output_matches_quantised_layernorm(device):
+    """js2t_layernorm_fwd_fp8: the e4m3 bytes equal js2t_quantize_fp8_delayed of the bf16 LayerNorm output up to the bf16
+    rounding the separate path puts in between; mean / rstd / bf16 output identical to the plain kernel; the state adapts."""
+    from joeys2t_amd import ops
+    g = torch.Generator().manual_seed(8)
+    rows, D = 1000, 512
+    x = (2 * torch.randn(rows, D, generator=g)).bfloat16().to(device)
+    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to(device), (0.1 * torch.randn(D, generator=g)).to(device)
+    y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    state = ops.new_fp8_state(y_ref)
+    s0 = float(state[0])
+    mul = torch.tensor([0.5], device=device)
+    y, mean, rstd, y8, sc = ops.layernorm_fwd_fp8(x, gamma, beta, 1e-6, state, mul=mul)
+    assert torch.equal(y, y_ref) and torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+    assert float(sc) == pytest.approx(s0 * 0.5, rel=1e-6)
+    deq = y8.float() * s0
+    assert ((deq - y_ref.float()).abs() <= 0.0626 * y_ref.float().abs() + 2 * s0 * 2**-9 + 1e-3).all()  # 2^-4 relative + subnormal step
+    # the call's maximum waits in state[1]; the consuming e4m3 product hands it over (js2t_gemm fp8_state)
+    assert float(state[0]) == s0 and float(state[1]) == pytest.approx(float(y_ref.float().abs().max()), rel=1e-2)
+    w8 = torch.randn(256, D, generator=g).to(device).to(torch.float8_e4m3fn)
+    out = torch.empty((rows, 256), dtype=torch.bfloat16, device=device)
+    ops.gemm(y8, w8, out, M=rows, N=256, K=D, lda=D, ldb=D, ldc=256, alpha_dev=sc, fp8_state=state)
+    amax = float(y_ref.float().abs().max())
+    assert float(state[0]) == pytest.approx(amax / 448.0, rel=1e-2) and float(state[1]) == pytest.approx(amax * 0.9375, rel=1e-2)
+    n, _, _, y8b, _ = ops.layernorm_fwd_fp8(x, gamma, beta, 1e-6, state, want_y=False)
+    assert n is None and y8b.shape == y8.shape
