@@ -633,7 +633,7 @@ def cpu_baseline(n_utts=BATCH, threads=None, warmup_steps=3, timed_steps=10, gpu
     return out
 
 
-def cpu_decode_rtf(n_utts=BATCH, beam=5, alpha=1.0, max_len=100, budget_s=150.0):
+def cpu_decode_rtf(n_utts=BATCH, beam=5, alpha=1.0, max_len=100, budget_s=60.0):
     """beam-5 decode of the CPU oracle (search.py:345-825 restated: full-prefix decoder pass per
     step, encoder states tiled beam-fold) on mustc_st.yaml shapes - the GPU leg's workload: 32 utterances x 15 s, 100 steps.
     Time-boxed: a 2-utterance, 8-step probe prices an (utterance, step) pair first; if the full workload would take longer than

@@ -63,15 +63,70 @@ def activation(name: str):
 
 
 # --------------------------------------------------------------------------------------------------
+# bf16 emulation (a YARDSTICK for the tests' bf16 bounds, not part of the reference's arithmetic)
+# --------------------------------------------------------------------------------------------------
+# With `bf16_emulation(True)` the same fp32 functions round where a bf16 compute path must round whatever its kernels look
+# like: every activation that is stored between two operators (and its gradient on the way back) and both operands of every
+# matrix product take a bf16 round trip; sums stay in fp32.  How far THIS run's gradients move from the plain fp32 run is what
+# bf16 storage costs at a given model width and depth - an estimate that owes nothing to the HIP kernels, against which their
+# bf16 gradients are then judged (tests/test_hip_config_width.py).
+_EMULATE_BF16 = False
+
+
+class bf16_emulation:
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global _EMULATE_BF16
+        self.prev, _EMULATE_BF16 = _EMULATE_BF16, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self.prev
+
+
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _RoundValue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _stored(x: Tensor) -> Tensor:
+    """an activation kept in bf16 between two operators: value and gradient both rounded"""
+    return _RoundBoth.apply(x) if _EMULATE_BF16 and x.is_floating_point() else x
+
+
+def _operand(w: Tensor) -> Tensor:
+    """a parameter entering a product as bf16 (its gradient is accumulated in fp32)"""
+    return _RoundValue.apply(w) if _EMULATE_BF16 and w.is_floating_point() else w
+
+
+# --------------------------------------------------------------------------------------------------
 # layers (reference transformer_layers.py / encoders.py / decoders.py)
 # --------------------------------------------------------------------------------------------------
 def linear(sd: SD, prefix: str, x: Tensor) -> Tensor:
-    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+    return _stored(F.linear(_stored(x), _operand(sd[prefix + ".weight"]), sd.get(prefix + ".bias")))
 
 
 def layer_norm(sd: SD, prefix: str, x: Tensor) -> Tensor:
     """nn.LayerNorm(eps=1e-6): transformer_layers.py:146,248,339-340"""
-    return F.layer_norm(x, (x.size(-1), ), sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-6)
+    return _stored(F.layer_norm(_stored(x), (x.size(-1), ), sd[prefix + ".weight"], sd[prefix + ".bias"], eps=1e-6))
 
 
 def rel_pos_scores(rel_bias: Tensor, Tq: int, Tk: int) -> Tensor:
@@ -98,7 +153,7 @@ def mha(sd: SD, prefix: str, k: Tensor, v: Tensor, q: Tensor, mask: Optional[Ten
     if mask is not None:
         scores = scores.masked_fill(~mask.unsqueeze(1), float("-inf"))
     weights = torch.softmax(scores, dim=-1)
-    ctx = torch.matmul(weights, v).transpose(1, 2).contiguous().view(B, -1, d)
+    ctx = torch.matmul(_stored(weights), v).transpose(1, 2).contiguous().view(B, -1, d)
     out = linear(sd, prefix + ".output_layer", ctx)
     if return_weights:
         return out, weights.sum(dim=1) / num_heads
@@ -157,8 +212,9 @@ def conv_subsample(sd: SD, prefix: str, x: Tensor, lengths: Tensor, kernel_sizes
         x = x[:, :max_len, :]
     x = x.transpose(1, 2).contiguous()
     for i, k in enumerate(kernel_sizes):
-        x = F.conv1d(x, sd[f"{prefix}.conv_layers.{i}.weight"], sd[f"{prefix}.conv_layers.{i}.bias"], stride=2, padding=k // 2)
-        x = F.glu(x, dim=1)
+        x = _stored(F.conv1d(_stored(x), _operand(sd[f"{prefix}.conv_layers.{i}.weight"]), sd[f"{prefix}.conv_layers.{i}.bias"], stride=2,
+                             padding=k // 2))
+        x = _stored(F.glu(x, dim=1))
     return x.transpose(1, 2).contiguous(), subsample_lengths(lengths, kernel_sizes)
 
 
@@ -294,10 +350,10 @@ def decoder_forward_embedded(sd: SD, cfg: dict, trg_embed: Tensor, memory: Tenso
                                return_attention=(return_attention and i == n - 1))
     if dcfg["layer_norm"] == "pre":
         x = layer_norm(sd, prefix + ".layer_norm", x)
-    out = F.linear(x, sd[prefix + ".output_layer.weight"])
+    out = F.linear(_stored(x), _operand(sd[prefix + ".output_layer.weight"]))  # the vocabulary logits stay fp32
     ctc = None
     if prefix + ".ctc_output_layer.weight" in sd:
-        ctc = F.linear(memory, sd[prefix + ".ctc_output_layer.weight"])
+        ctc = _stored(F.linear(_stored(memory), _operand(sd[prefix + ".ctc_output_layer.weight"])))
     return out, x, att, ctc
 
 

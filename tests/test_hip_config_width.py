@@ -234,6 +234,50 @@ def test_ls100_width_bf16_gradients_through_trainstep(device, overlap_ctc):
     assert abs(got_norm - ref_norm) <= 1e-2 * ref_norm, (got_norm, ref_norm)
 
 
+def test_ls100_width_bf16_against_an_independent_yardstick(device):
+    """What SHOULD bf16 cost at this width?  The oracle run once more with a bf16 round trip wherever any bf16 compute path must
+    round - every stored activation and its gradient, both operands of every product; sums in fp32 (oracle.bf16_emulation) - moves
+    each gradient tensor by some relative L2 distance from the plain fp32 run.  That distance owes nothing to the HIP kernels.
+    The HIP path's own distance from the fp32 run may be at most 2 x it (the kernels round at a few more places: attention
+    probabilities inside the fused kernel, the bf16 delta of the flash backward, bf16 bias / LayerNorm gradient inputs) plus
+    0.3 % absolute; the same bound for the cosine defect.  Measured on MI355X: median tensor 0.65 % (HIP) against 0.60 % (emulated
+    oracle), worst tensor 5.0 % against 5.5 % - the HIP path's bf16 error IS what bf16 storage costs at this width."""
+    from joeys2t_amd.training import TrainStep
+    from oracle import s2t_oracle as O
+    cfg, V = width_cfg(4, 2, 1), 5000
+    torch.manual_seed(3)
+    base = make_model(cfg, V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    names = {n for n, _ in base.named_parameters()}
+    batch = synth_batch(V, [1498, 1200, 901], [60, 45, 70], seed=5)
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"] = ocfg["decoder"]["alpha"] = 1.0
+    _, g32 = oracle_loss_and_grads(sd, ocfg, names, *batch, 0.3, scale=1.0 / 3)
+    with O.bf16_emulation():
+        _, gem = oracle_loss_and_grads(sd, ocfg, names, *batch, 0.3, scale=1.0 / 3)
+    model = make_model(cfg, V, sd, device, torch.bfloat16, 0.3, train=True)
+    step = TrainStep(model, learning_rate=2e-3, adam_betas=(0.9, 0.98), clip_grad_norm=10.0, normalization="batch", overlap_ctc=True)
+    step.micro_step(hip_batch(*batch, device), update=False)
+    torch.cuda.synchronize()
+    rep = grad_report(model, g32)
+    gmax = max(v[2] for v in rep.values())
+    rows, bad = [], []
+    for n, (l2, cos, rn) in rep.items():
+        if rn < 1e-3 * gmax:
+            continue
+        r, e = g32[n].flatten().double(), gem[n].flatten().double()
+        l2e = (e - r).norm().item() / r.norm().item()
+        cose = F.cosine_similarity(e, r, dim=0).item()
+        rows.append((n, l2, l2e, 1 - cos, 1 - cose))
+        if l2 > 2.0 * l2e + 3e-3 or (1 - cos) > 2.0 * (1 - cose) + 1e-4:
+            bad.append((n, round(l2, 4), round(l2e, 4), round(1 - cos, 5), round(1 - cose, 5)))
+    worst = max(rows, key=lambda t: t[1])
+    med_h, med_e = float(np.median([t[1] for t in rows])), float(np.median([t[2] for t in rows]))
+    print(f"bf16 yardstick: median rel L2 HIP {med_h:.4f} / emulated oracle {med_e:.4f}; worst HIP tensor {worst[0]} {worst[1]:.4f} "
+          f"(emulated {worst[2]:.4f})")
+    assert not bad, bad
+
+
 # ------------------------------------------------------------------------------------------------ LS960: V = 10000
 def test_ls960_vocab_xent_ctc_lse(device):
     from joeys2t_amd import ops
