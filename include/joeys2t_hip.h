@@ -112,6 +112,11 @@ typedef struct js2t_gemm_desc {
   float* ln_mean;           /* consumer out (both or neither): f32 [M] row means and 1/sqrt(var + eps) the epilogue used */
   float* ln_rstd;
   float* rs_partial;        /* producer out: f32 [M][8][2], the same sums over the stored (bf16-rounded) C's rows (N = 512) */
+  uint8_t* c8;              /* e4m3 products: optional second output, the result as e4m3 bytes [M][ldc8] (C may then be NULL) ... */
+  int64_t ldc8;
+  float* c8_state;          /* ... written with the delayed scale c8_state[0]; the launch's max |v| is collected in c8_state[1] */
+  const float* c8_mul;      /* ... and *c8_scale_out = c8_state[0] * (*c8_mul or 1): the alpha_dev of the product that consumes c8 */
+  float* c8_scale_out;
   float* fp8_state;         /* e4m3 products: delayed-scale state of the kernel that quantised A (js2t_layernorm_fwd_fp8): block 0 hands
                              * the collected maximum over, state[0] = state[1] / 448, state[1] *= 15/16 (decayed, not cleared), when the product is done */
 } js2t_gemm_desc;

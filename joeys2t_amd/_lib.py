@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32),
         ("a_rowsum", C.c_void_p),
         ("ln_partial", C.c_void_p), ("ln_eps", C.c_float), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("rs_partial", C.c_void_p),
+        ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_state", C.c_void_p), ("c8_mul", C.c_void_p), ("c8_scale_out", C.c_void_p),
         ("fp8_state", C.c_void_p),
     ]
 

@@ -1379,7 +1379,9 @@ __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, f
 }
 // bias_r: the lane's 8 bias values, fetched when the tile started; drop_key: fetched when the kernel started (both
 // would otherwise expose a dependent global-load latency per tile)
-template <int EPI>
+// OUT8 (the e4m3 kernels only): d.c8 != NULL adds a second output, the result as e4m3 bytes with the delayed scale of d.c8_state
+// (the operand of a FOLLOWING e4m3 product, quantised here instead of by a pass of its own); d.C may then be NULL.
+template <int EPI, bool OUT8 = false>
 __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane,
                                                 const float (&bias_r)[8], uint32_t drop_key, float my_rs = 0.f) {
   const int g = lane >> 4, r = lane & 15;
@@ -1398,6 +1400,13 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
   // LayerNorm fold, consumer side: v = rstd(m) * acc + bias (the weights are gamma-scaled and row-centred, js2t_fold_ln_weights);
   // specialised instantiations only (launch_bf16_p192 refuses other combinations)
   constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0;
+  float q8_inv = 0.f, q8_max = 0.f;
+  if constexpr (OUT8) {
+    if (d.c8) {
+      const float S = d.c8_state[0];
+      q8_inv = S > 0.f ? 1.f / S : 0.f;
+    }
+  }
   // residual / gate rows: block i + 1 is requested before block i is used (twelve rows at once cost too many registers)
   uint4 rg[3][4];
   auto load_rg = [&](int i) {
@@ -1458,7 +1467,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = rr[c] > 0.f ? v[c] * gate_scale : 0.f;
       }
-      if (m < M) {
+      if (m < M && (!OUT8 || d.C)) {
         uint4 pk;
         pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
         pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
@@ -1466,8 +1475,29 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
         *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
       }
+      if constexpr (OUT8) {
+        if (d.c8 && m < M) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            q8_max = fmaxf(q8_max, fabsf(v[c]));
+            v[c] = fminf(fmaxf(v[c] * q8_inv, -448.f), 448.f);
+          }
+          int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+          int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+          *(uint2*)(d.c8 + (int64_t)m * d.ldc8 + n) = make_uint2((uint32_t)lo, (uint32_t)hi);
+        }
+      }
     }
     P192_E(2 + 2 * i);
+  }
+  if constexpr (OUT8) {
+    if (d.c8) {  // this tile's max |v| for the NEXT call's scale: posted only if it beats what is there (decayed by the consumer)
+      q8_max = wave_max(q8_max);
+      unsigned int* st = (unsigned int*)d.c8_state;
+      if (lane == 0 && __float_as_uint(q8_max) > *(volatile unsigned int*)(st + 1)) atomicMax(st + 1, __float_as_uint(q8_max));
+    }
   }
 }
 
@@ -1615,6 +1645,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
   const bool any_drop = EPI < 0 ? d.dropout_p > 0.f : (EPI & PE_DROP) != 0;
   const uint32_t drop_key = any_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
   bool stores_behind = false;
+  if (FP8 && d.c8 && d.c8_scale_out && blockIdx.x == 0 && t == 0) {  // the scale the e4m3 output of THIS launch is written with
+    const float S = d.c8_state[0];
+    *d.c8_scale_out = (S > 0.f ? S : 1.f) * (d.c8_mul ? *d.c8_mul : 1.f);
+  }
   for (int v = blockIdx.x; v < ntiles; v += G) {
     const int lid = xcd_remap(v, ntiles);
     const int tm0 = (lid / tiles_n) * P_BM, tn0 = (lid % tiles_n) * 128;
@@ -1680,7 +1714,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
       cslot = nslot;
       P192_T(5);
     }
-    p192_store_tile<EPI>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key, my_rs);
+    p192_store_tile<EPI, FP8>(d, acc, tm0 + w * 48, tn0, lane, bias_r, drop_key, my_rs);
     stores_behind = tm0 + P_BM <= M;
     P192_T(6);
   }
@@ -2007,6 +2041,11 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
     cons_epi += __builtin_readcyclecounter() - ce0;
 #endif
   }
+  if (FP8 && d.fp8_state && blockIdx.x == 0 && t == 0) {  // delayed activation scale of A's producer: see gemm_bf16_p192_kernel
+    const float am = d.fp8_state[1];
+    if (am > 0.f) d.fp8_state[0] = am * (1.f / 448.f);
+    d.fp8_state[1] = am * 0.9375f;
+  }
 #ifdef JS2T_P192S_DBG
   if (blockIdx.x == 0 && t == 0)
     g_p192s_prof[0] = __builtin_readcyclecounter() - cons_t0, g_p192s_prof[1] = cons_bar, g_p192s_prof[6] = cons_epi;
@@ -2312,6 +2351,8 @@ int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<-1, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<-1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2322,7 +2363,11 @@ int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
     n_cu = (cu & ~7) ? (cu & ~7) : cu;
   }
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
-  if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
+  if (!d.c8 && (g_p192_ring == 4 || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu))) {
+    // about one tile per CU: eight multiplying + four requesting waves, as for bf16 (the e4m3 second output lives in the ring forms)
+    const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<-1, true>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
+  } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
     const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192_kernel<-1, 2, true>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
   } else {
@@ -2538,7 +2583,10 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   JS2T_CHECK(d.M >= 0 && d.N >= 0 && d.K >= 0 && d.batch >= 0, "gemm: negative size");
   if (d.M == 0 || d.N == 0 || d.batch == 0) return JS2T_OK;
-  JS2T_CHECK(d.A && d.B && d.C, "gemm: null operand");
+  JS2T_CHECK(d.A && d.B && (d.C || (d.c8 && d.dtype_ab == JS2T_FP8_E4M3)), "gemm: null operand");
+  JS2T_CHECK(!d.c8 || (d.dtype_ab == JS2T_FP8_E4M3 && d.c8_state && d.ldc8 >= d.N && (d.ldc8 & 7) == 0 && (((uintptr_t)d.c8) & 7) == 0 &&
+                       (((uintptr_t)d.c8_state) & 15) == 0),
+             "gemm: c8 (e4m3 second output) needs e4m3 operands, c8_state (16-byte aligned) and 8-byte aligned rows");
   JS2T_CHECK(d.batch_inner >= 1, "gemm: batch_inner must be >= 1");
   JS2T_CHECK(d.dtype_ab == JS2T_F32 || d.dtype_ab == JS2T_BF16 || d.dtype_ab == JS2T_FP8_E4M3, "gemm: bad dtype_ab");
   JS2T_CHECK(d.dtype_c == JS2T_F32 || d.dtype_c == JS2T_BF16, "gemm: bad dtype_c");
@@ -2583,7 +2631,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
                    d.beta == 0.f && !d.a_rowsum && !(d.residual && d.gate) && (d.act == JS2T_ACT_NONE || d.act == JS2T_ACT_RELU),
                "gemm fp8: plain k-contiguous products with a bf16 result only");
     JS2T_CHECK((d.N & 7) == 0 && d.N >= 128 && (d.K & 15) == 0 && d.K >= 128 && (d.lda & 15) == 0 && (d.ldb & 15) == 0 && aligned16(d.A) &&
-                   aligned16(d.B) && aligned16(d.C) && (d.ldc & 7) == 0,
+                   aligned16(d.B) && (!d.C || aligned16(d.C)) && (d.ldc & 7) == 0,
                "gemm fp8: N % 8 == 0, N >= 128, K % 16 == 0, K >= 128, 16-byte aligned rows");
     JS2T_CHECK(!d.residual || ((d.ldr & 7) == 0 && aligned16(d.residual)), "gemm fp8: misaligned residual");
     JS2T_CHECK(!d.gate || ((d.ldg & 7) == 0 && aligned16(d.gate)), "gemm fp8: misaligned gate");

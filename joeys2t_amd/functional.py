@@ -89,19 +89,28 @@ def ln_fwd_fp8(x2d, gamma, beta, w, want_y: bool):
 
 
 def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual=None, res_scale=1.0,
-               out_dtype=None, preact=None, alpha=1.0, ln=None, rs_partial=None, x8=None):
+               out_dtype=None, preact=None, alpha=1.0, ln=None, rs_partial=None, x8=None, y8_for=None, want_y=True):
     """y[M,N] = epilogue(x2d[M,K] @ w[N,K]^T + b) — one js2t_gemm launch.  ln / rs_partial: see ops.gemm (LayerNorm fold).
-    x8 = (e4m3 x, scale): the input already quantised by its producer (ln_fwd_fp8): e4m3 product, x2d only supplies the shape."""
+    x8 = (e4m3 x, scale, state): the input already quantised by its producer (ln_fwd_fp8 or an e4m3 product's second output):
+    e4m3 product, x2d only supplies the shape.  y8_for = weight of the FOLLOWING Linear (with x8 only): the result is also
+    written as e4m3 for that product -> returns (y | None when not want_y, x8 triple for the next linear_fwd)."""
     M, K = (x8[0].shape if x8 is not None else x2d.shape)
     _row_major_2d(w)
     N = w.shape[0]
     if x8 is not None:
-        y = torch.empty((M, N), dtype=torch.bfloat16, device=w.device)
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=w.device) if (want_y or y8_for is None) else None
         w8, _ = _fp8_weight(w)
+        c8 = nxt = None
+        if y8_for is not None:
+            _, ws_next = _fp8_weight(y8_for)
+            st_next = _FP8_STATES[(y8_for.data_ptr(), tuple(y8_for.shape))]  # calibrated by the caller on a first bf16 pass
+            out8 = torch.empty((M, N), dtype=torch.float8_e4m3fn, device=w.device)
+            sc_next = torch.empty((1, ), dtype=torch.float32, device=w.device)
+            c8, nxt = (out8, st_next, ws_next, sc_next), (out8, sc_next, st_next)
         ops.gemm(x8[0], w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=b, act=act, dropout_p=dropout_p, rng=rng, rng_stream=site,
                  residual=residual, ldr=0 if residual is None else residual.stride(0), res_scale=res_scale, alpha_dev=x8[1],
-                 fp8_state=x8[2])
-        return y
+                 fp8_state=x8[2], c8=c8)
+        return y if y8_for is None else (y, nxt)
     _row_major_2d(x2d)
     y = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
     if (ln is None and rs_partial is None and FP8_SEPARATE_PASS and _fp8_eligible(x2d, w, out_dtype, preact, alpha) and
@@ -404,7 +413,7 @@ class ResidualBlockFn(torch.autograd.Function):
         if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
                 ops.layernorm_bwd_supports_dropout(x2)):
             ctx.prev_drop = hint[:3]  # (p, site, rng) of the block that produced x
-        x8_first = None  # fp8 forward mode: the first product's input as e4m3, written by the LayerNorm kernel
+        x8_first = x8_second = None  # fp8 forward mode: the products' inputs as e4m3, written by the kernels that produce them
         lnf = None   # (partial sums of x's rows, eps, mean out, rstd out) when this block's LayerNorm is folded into its first product
         fold = wts.get("fold") if (LN_FOLD and cfg.ln_mode == "pre" and not FP8_FORWARD) else None
         sink0 = wts.get("sink") or {}
@@ -465,7 +474,19 @@ class ResidualBlockFn(torch.autograd.Function):
                 pre = torch.empty((B * T, wts["w1"].shape[0]), dtype=x.dtype, device=x.device)
             if lnf is not None and pre is not None:
                 raise ops.Js2tError("LayerNorm fold: ReLU / no activation only")  # (the caller does not offer a fold otherwise)
-            c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf, x8=x8_first)
+            x8_second = None
+            w2 = wts["w2"]
+            if (x8_first is not None and cfg.act in (None, "relu") and w2.dtype == torch.bfloat16 and w2.is_contiguous() and
+                    w2.shape[1] % 16 == 0 and w2.shape[1] >= 128 and w2.shape[0] % 8 == 0 and w2.shape[0] >= 128):
+                # e4m3 chain: this product also writes the e4m3 operand of the second feed-forward product (K = ff: where the
+                # halved operand bytes matter most); the bf16 copy only if backward will want it
+                if (w2.data_ptr(), tuple(w2.shape)) not in _FP8_STATES:  # first use: calibrate the hidden layer's scale on a bf16 pass
+                    c = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], x8=x8_first)
+                    _fp8_state(w2, c)
+                c, x8_second = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], x8=x8_first,
+                                          y8_for=w2, want_y=torch.is_grad_enabled())
+            else:
+                c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf, x8=x8_first)
             saved.update(pre=pre)
         w_last, b_last = (wts["w2"], wts["b2"]) if cfg.kind == "ffn" else (wts["w_out"], wts["b_out"])
         # the row statistics of what this block writes, for a following block that folds its LayerNorm (see _LN_STATS)
@@ -475,7 +496,8 @@ class ResidualBlockFn(torch.autograd.Function):
                 d == ops.LN_FOLD_WIDTH and fold_shapes_ok(B * T, d, c.shape[1])):
             out_stats = ops.row_partials(B * T, x.device)
         u = linear_fwd(c, w_last, b_last, dropout_p=p_out, rng=rng, site=sites[1],
-                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha, rs_partial=out_stats)
+                       residual=x2 if cfg.alpha != 0.0 else None, res_scale=cfg.alpha, rs_partial=out_stats,
+                       x8=x8_second if cfg.kind == "ffn" else None)
         if cfg.ln_mode != "post":
             y = u
         else:

@@ -107,24 +107,27 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None, fp8_state=None):
+         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None, fp8_state=None, c8=None):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements.
     ln = (partial f32[M,8,2], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product (B = the
     centred, gamma-scaled weight of ParamStore.fold); rs_partial f32[M,8,2]: the stored rows' partial sums are written to it."""
     _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum, rs_partial)
+    if C_out is None and c8 is None:
+        raise Js2tError("gemm: no output")
     if A.dtype != B.dtype:
         raise Js2tError(f"gemm: A/B dtype mismatch {A.dtype} vs {B.dtype}")
+    c_dtype = torch.bfloat16 if C_out is None else C_out.dtype  # e4m3 products may write ONLY their e4m3 second output (c8)
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.batch, d.batch_inner = int(batch), int(batch_inner)
-    d.dtype_ab, d.dtype_c = dt_code(A), dt_code(C_out)
+    d.dtype_ab, d.dtype_c = dt_code(A), dt_code(c_dtype)
     d.trans_a, d.trans_b = int(bool(trans_a)), int(bool(trans_b))
-    esa, esc = A.element_size(), C_out.element_size()
+    esa, esc = A.element_size(), (2 if C_out is None else C_out.element_size())
     d.A = A.data_ptr() + a_off * esa
     d.lda, d.a_stride_o, d.a_stride_i = int(lda), int(a_strides[0]), int(a_strides[1])
     d.B = B.data_ptr() + b_off * esa
     d.ldb, d.b_stride_o, d.b_stride_i = int(ldb), int(b_strides[0]), int(b_strides[1])
-    d.C = C_out.data_ptr() + c_off * esc
+    d.C = None if C_out is None else C_out.data_ptr() + c_off * esc
     d.ldc, d.c_stride_o, d.c_stride_i = int(ldc), int(c_strides[0]), int(c_strides[1])
     d.alpha = float(alpha)
     d.alpha_dev = None if alpha_dev is None else alpha_dev.data_ptr()
@@ -134,7 +137,7 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.bias = bias.data_ptr()
     d.act = ACT_CODES[act]
     if preact is not None:
-        if preact.dtype != C_out.dtype:
+        if preact.dtype != c_dtype:
             raise Js2tError("gemm: preact dtype must match C")
         d.preact = preact.data_ptr() + c_off * esc
     d.dropout_p = float(dropout_p)
@@ -144,11 +147,11 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.rng_state = rng.state.data_ptr()
         d.rng_stream = int(rng_stream)
     if residual is not None:
-        if residual.dtype != C_out.dtype:
+        if residual.dtype != c_dtype:
             raise Js2tError("gemm: residual dtype must match C")
         d.residual, d.ldr, d.res_scale = residual.data_ptr(), int(ldr), float(res_scale)
     if gate is not None:
-        if gate.dtype != C_out.dtype:
+        if gate.dtype != c_dtype:
             raise Js2tError("gemm: gate dtype must match C")
         d.gate, d.ldg, d.gate_scale = gate.data_ptr(), int(ldg), float(gate_scale)
     d.beta = float(beta)
@@ -170,6 +173,14 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     if fp8_state is not None:
         _dev(fp8_state)
         d.fp8_state = fp8_state.data_ptr()
+    if c8 is not None:  # (e4m3 out [M, N], delayed-scale state f32[4], mul f32[1] | None, scale_out f32[1] | None)
+        out8, st8, mul8, sc8 = c8
+        _dev(out8, st8, mul8, sc8)
+        if out8.dtype != torch.float8_e4m3fn or out8.shape != (M, N) or not out8.is_contiguous():
+            raise Js2tError("gemm: c8 output must be a contiguous float8_e4m3fn [M, N]")
+        d.c8, d.ldc8, d.c8_state = out8.data_ptr(), N, st8.data_ptr()
+        d.c8_mul = None if mul8 is None else mul8.data_ptr()
+        d.c8_scale_out = None if sc8 is None else sc8.data_ptr()
     if rs_partial is not None:
         if rs_partial.dtype != torch.float32 or rs_partial.numel() != M * 16 or not rs_partial.is_contiguous():
             raise Js2tError("gemm: rs_partial must be contiguous f32[M, 8, 2]")

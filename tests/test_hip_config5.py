@@ -131,7 +131,7 @@ def test_conformer_relpos_bf16_fused_close_to_fp32(device):
 def test_fp8_forward_close_to_bf16(device, separate_pass):
     """functional.FP8_FORWARD on the composed model: nn.Linear forwards on e4m3 operands (per-tensor scales) - by default those
     whose input the LayerNorm kernel quantises as it writes it (q/k/v projection and the first layer of both feed-forward
-    modules: 3 per Conformer layer), with FP8_SEPARATE_PASS every eligible one (8 per layer + the input Linear).
+    modules) or the preceding e4m3 product writes as e4m3 next to bf16 (the second feed-forward layer): 5 per Conformer layer, with FP8_SEPARATE_PASS every eligible one (8 per layer + the input Linear).
     Bound: e4m3 keeps 3 mantissa bits, so an element is off by at most 2^-4 relative (uniform: 2^-4 / sqrt(3) = 3.6 % rms); a
     product of two rounded operands by 5.1 % rms, and a dot product of terms with independent errors keeps that RELATIVE rms
     only if all terms had one sign - with mixed signs the sum's error relative to the sum is larger by |terms|_2 sqrt(K) /
@@ -165,9 +165,11 @@ def test_fp8_forward_close_to_bf16(device, separate_pass):
             Fn.ops.gemm, Fn.ops.quantize_fp8_delayed = real, real_q
     n8 = sum(d == torch.float8_e4m3fn for d in seen)
     if separate_pass:
-        assert n8 >= 2 * 3 * 7 and len(quant) >= 2 * 3 * 4, (n8, len(quant))
+        assert n8 >= 2 * 3 * 7 and len(quant) >= 2 * 3 * 3, (n8, len(quant))  # own passes: output projection, two pointwise convolutions
     else:
-        assert n8 == 2 * 3 * 3 and not quant, (n8, len(quant))  # LayerNorm-fed products only, and no quantisation pass at all
+        # LayerNorm-fed products + the second feed-forward product (fed by the first one's e4m3 output): 5 per layer and forward,
+        # plus the two bf16-output calibration passes of each feed-forward module's first use; no quantisation pass at all
+        assert n8 == 2 * 3 * 5 + 3 * 2 and not quant, (n8, len(quant))
     a = ref.float()
     for o in (out, out2):
         rel = ((o.float() - a).norm() / a.norm()).item()
@@ -202,3 +204,29 @@ def test_layernorm_fp8_output_matches_quantised_layernorm(device):
     assert float(state[0]) == pytest.approx(amax / 448.0, rel=1e-2) and float(state[1]) == pytest.approx(amax * 0.9375, rel=1e-2)
     n, _, _, y8b, _ = ops.layernorm_fwd_fp8(x, gamma, beta, 1e-6, state, want_y=False)
     assert n is None and y8b.shape == y8.shape
+
+
+@pytest.mark.parametrize("M,N,K,with_c", [(12000, 2048, 512, True), (700, 256, 256, False)])
+def test_e4m3_product_writes_the_e4m3_operand_of_the_next_one(device, M, N, K, with_c):
+    """js2t_gemm c8: an e4m3 product (bias + ReLU + dropout epilogue) also writes its result as e4m3 with the delayed scale of
+    c8_state - what js2t_quantize_fp8_delayed would make of the bf16 result, minus the bf16 rounding in between; the launch's
+    max |v| is collected for the next scale; C may be left out."""
+    from joeys2t_amd import ops
+    g = torch.Generator().manual_seed(12)
+    a8, sa = ops.quantize_fp8(torch.randn(M, K, generator=g).bfloat16().to(device))
+    w8, sw = ops.quantize_fp8((torch.randn(N, K, generator=g) * 0.05).bfloat16().to(device), mul=sa)
+    bias = torch.randn(N, generator=g).to(device)
+    ref = ((a8.float() @ w8.float().t()) * float(sw) + bias).relu()
+    state = torch.zeros(4, device=device)
+    state[0] = float(ref.max()) / 448.0
+    mul, sc = torch.tensor([0.25], device=device), torch.zeros(1, device=device)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=device) if with_c else None
+    y8 = torch.empty((M, N), dtype=torch.float8_e4m3fn, device=device)
+    ops.gemm(a8, w8, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha_dev=sw, bias=bias, act="relu", c8=(y8, state, mul, sc))
+    s0 = float(ref.max()) / 448.0
+    assert float(sc) == pytest.approx(s0 * 0.25, rel=1e-6)
+    deq = y8.float() * s0
+    assert ((deq - ref).abs() <= 0.0626 * ref.abs() + 2 * s0 * 2**-9 + 2e-2).all()
+    assert float(state[1]) == pytest.approx(float(ref.max()), rel=2e-2) and float(state[0]) == pytest.approx(s0)
+    if with_c:
+        torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
