@@ -26,6 +26,8 @@ from torch import Tensor
 from joeys2t_amd import ops
 from joeys2t_amd.helpers import adjust_mask_size, tile
 from joeys2t_amd.incremental import IncrementalDecoder
+
+SYNC_EVERY = 8  # plain greedy / beam decoding looks at the device (has every hypothesis ended?) once per this many steps
 from joeys2t_amd.helpers_for_ddp import ddp_merge
 
 
@@ -137,6 +139,7 @@ def transformer_greedy(src_mask: Tensor, max_output_length: int, model, encoder_
     inc = None
     if kwargs.get("incremental", True) and not opt.full_prefix:
         inc = IncrementalDecoder(model, encoder_output, src_mask, 1, max_output_length)
+    done_flags, n_steps = [], None
     for step in range(max_output_length):
         has_col = prompt is not None and prompt.size(1) > step + 1
         forced_word = prompt[:, step + 1:step + 2] if has_col else None
@@ -175,8 +178,19 @@ def transformer_greedy(src_mask: Tensor, max_output_length: int, model, encoder_
         if opt.return_attention:
             yt = torch.cat([yt, att.unsqueeze(1)], dim=1)
         finished |= ids.eq(model.eos_index)
-        if bool(finished.all()):
-            break
+        # the reference stops at the first step at which every hypothesis has emitted EOS (:332-334) - a device -> host round
+        # trip per step.  Here the flag of every step is kept on the device and looked at every SYNC_EVERY steps; the steps
+        # that ran past the stopping point are cut off below, so the result is the reference's, column for column.
+        done_flags.append(finished.all().view(1))
+        if (step + 1) % SYNC_EVERY == 0 or step + 1 == max_output_length:
+            flags = torch.cat(done_flags).cpu()
+            if bool(flags.any()):
+                n_steps = int(torch.nonzero(flags)[0]) + 1
+                break
+    if n_steps is not None:  # drop what was generated after the stopping point
+        ys = ys[:, :n_steps + 1]
+        yv = yv[:, :n_steps + 1] if return_prob else None
+        yt = yt[:, :n_steps + 1] if opt.return_attention else None
     ys = ddp_merge(ys, model.pad_index)
     yv = ddp_merge(yv, 0.0) if return_prob else None
     yt = ddp_merge(yt, 0.0) if opt.return_attention else None
@@ -222,6 +236,15 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
     hypotheses = [[] for _ in range(B)]
     results = {"predictions": [[] for _ in range(B)], "scores": [[] for _ in range(B)]}
     is_finished = torch.zeros((B, beam_size), dtype=torch.bool, device=dev)
+    # plain decoding (no option that edits the scores on the host) with the key/value cache: the search runs without a
+    # device -> host round trip per step, see `if fast:` below
+    fast = inc is not None and not opt.edits and kwargs.get("sync_free", True)
+    if fast:
+        seq_all = torch.full((max_output_length, B * beam_size, max_output_length + 1), pad, dtype=torch.long, device=dev)
+        fin_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.bool, device=dev)
+        score_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.float32, device=dev)
+        ended = torch.zeros((B, ), dtype=torch.bool, device=dev)
+        n_run = 0
 
     for step in range(max_output_length):
         nb = alive_seq.size(0) // beam_size
@@ -268,7 +291,19 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             is_finished.fill_(True)
         end_condition = is_finished.all(-1)
 
-        if bool(is_finished.any()):
+        if fast:
+            # No look at the device in this step.  The reference removes an utterance from the batch once all its beams have
+            # finished (:757-781) and files finished hypotheses as they appear (:683-717); both only READ the step's tensors, and
+            # utterances do not interact - so every utterance stays in the batch (one captured step graph for the whole search),
+            # the step's tensors are kept, and the filing happens once, after the loop, exactly as it would have step by step.
+            # Whether everything has ended is asked every SYNC_EVERY steps.
+            seq_all[step, :, :step + 2] = alive_seq
+            fin_all[step], score_all[step] = is_finished, topk_scores
+            ended |= end_condition
+            n_run = step + 1
+            if (step + 1) % SYNC_EVERY == 0 and bool(ended.all()):
+                break
+        elif bool(is_finished.any()):
             # one device->host transfer per step for the bookkeeping below (the reference syncs per hypothesis, :683-717)
             # and the tests of :683-717 for all (utterance, beam) pairs at once: with a trained model some hypothesis ends at
             # most steps, and a Python loop of small tensor operations per pair (~1 ms per step at 32 x 5) costs more than the
@@ -313,6 +348,30 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             encoder_output = encoder_output.index_select(0, select_indices)
             src_mask = src_mask.index_select(0, select_indices)
 
+    if fast:
+        # the filing the reference does inside the loop (:683-717,757-781), step by step over what the steps left behind
+        seq_h, fin_h_all, score_h_all = seq_all[:n_run].cpu(), fin_all[:n_run].cpu().numpy(), score_all[:n_run].cpu()
+        live = np.ones((B, ), dtype=bool)
+        for step in range(n_run):
+            fin_np = fin_h_all[step]
+            if not (fin_np & live[:, None]).any():
+                continue
+            end_np = fin_np.all(-1)
+            pred_h = seq_h[step].view(B, beam_size, -1)[:, :, :step + 2]
+            pred_np = pred_h.numpy()
+            n_eos = (pred_np[:, :, 1:] == eos).sum(-1)  # 0: still open, 1: ends here or ended earlier, > 1: collected earlier
+            take = fin_np & live[:, None] & (((n_eos == 0) & (step + 1 == max_output_length)) | ((n_eos == 1) & (pred_np[:, :, -1] == eos)))
+            for i, j in zip(*np.nonzero(take)):  # row-major: utterances ascending, beams ascending, as the reference's loops
+                hypotheses[i].append((score_h_all[step, i, j], pred_h[i, j, 1:]))
+            for i in np.nonzero(end_np & live)[0]:
+                for n, (score, pred) in enumerate(sorted(hypotheses[i], key=lambda x: x[0], reverse=True)):
+                    if n >= n_best:
+                        break
+                    results["scores"][i].append(score)
+                    results["predictions"][i].append(pred)
+            live &= ~end_np
+            if not live.any():
+                break
     for b in range(B):
         for _ in range(n_best - len(results["predictions"][b])):
             results["predictions"][b].append(torch.tensor([unk]).long())

@@ -179,3 +179,19 @@ def test_ctc_greedy_matches_oracle(device, name):
     ref_ids, ref_len = O.ctc_best_path(logits.numpy(), mask.squeeze(1).sum(1).numpy(), model.bos_index, model.pad_index)
     assert np.array_equal(n, ref_len)
     assert np.array_equal(ids, ref_ids)
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_sync_free_beam_search_files_the_same_hypotheses(device, name):
+    """The default beam search never looks at the device inside a step (every utterance stays in the batch, the steps' tensors
+    are kept, finished hypotheses are filed after the loop); with sync_free=False it files them step by step and drops ended
+    utterances as the reference does (search.py:683-717,757-781).  Same ids, same scores, for n_best up to the beam size."""
+    from joeys2t_amd.search import search
+    model, g = build(name, device)
+    model.eval()
+    b = batch_kwargs(g, device)
+    for k, nb, alpha, L in ((3, 3, 1.0, 12), (5, 2, 0.6, 9), (2, 1, 0.0, 30)):
+        a = search(model, b, max_output_length=L, beam_size=k, beam_alpha=alpha, n_best=nb, return_prob="hyp")
+        c = search(model, b, max_output_length=L, beam_size=k, beam_alpha=alpha, n_best=nb, return_prob="hyp", sync_free=False)
+        assert np.array_equal(a[0], c[0]), (k, nb)
+        np.testing.assert_array_equal(a[1], c[1])
