@@ -282,6 +282,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[tt][r] = ((bits >> (4 * tt + r)) & 1u) ? s[tt][r] : -INFINITY;
       }
+#ifdef JS2T_ATTN_NOMAX
+      // measurement build (profiles/README.md, "what a one-pass softmax could save"): no running maximum, no rescale --
+      // the cost floor of any scheme that knows the row maximum before the key loop starts. Right only for bounded scores.
+      const float mnew = 0.f, msafe = 0.f, corr = 1.f;
+#else
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
@@ -291,6 +296,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
       const float mnew = fmaxf(mi, mx);
       const float msafe = mnew == -INFINITY ? 0.f : mnew;
       const float corr = __builtin_amdgcn_exp2f(mi - msafe);  // exp2(-inf) = 0 on the first live tile
+#endif
       float rs = 0.f;
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
