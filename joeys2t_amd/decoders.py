@@ -1,7 +1,9 @@
 """Transformer decoder with the reference's module / parameter names (joeynmt/decoders.py:498-635),
 computed by HIP kernels; includes the CTC projection of the encoder output (:560-565,622-623)."""
-from torch import Tensor, nn
+from typing import Optional
+
 import torch
+from torch import Tensor, nn
 
 from joeys2t_amd import functional as Fn
 from joeys2t_amd.helpers import freeze_params, subsequent_mask
@@ -39,6 +41,39 @@ class TransformerDecoder(Decoder):
         if encoder_output_size is not None:
             self.ctc_output_layer = nn.Linear(encoder_output_size, vocab_size, bias=False)
 
+    def _cross_kv_params(self):
+        atts = [layer.src_trg_att for layer in self.layers]
+        return ([p for a in atts for p in (a.k_layer.weight, a.v_layer.weight)],
+                [p for a in atts for p in (a.k_layer.bias, a.v_layer.bias)])
+
+    def fuse_groups(self):
+        """The cross-attention k / v weights of ALL layers adjacent in the flat store ([k_0; v_0; k_1; ...], biases likewise):
+        their projections of the encoder states are one product (memory_kv).  The decoder comes before its layers in
+        module order, so these groups win over MultiHeadedAttention's [k; v; q] (whose q then stands alone, as the cross
+        block wants it)."""
+        return list(self._cross_kv_params())
+
+    def memory_kv(self, memory: Tensor) -> Optional[Tensor]:
+        """k_layer / v_layer of every layer's src_trg_att applied to the encoder states in ONE product (the reference:
+        per layer, transformer_layers.py:66-68 under :383) -> [B*S, L*2d], layer i's [k | v] from column i*2d; None when
+        that cannot be had - parameters not adjacent in a flat store, or gradients wanted outside TrainStep.micro_step (see
+        functional.MemoryKVFn) - and the layers project for themselves."""
+        rt = runtime_of(self)
+        if not Fn.GROUP_MEMORY_KV or len(self.layers) < 2 or rt.store is None or memory.dim() != 3:
+            return None
+        ws, bs = self._cross_kv_params()
+        if any(b is None for b in bs):
+            return None
+        w, b = rt.store.view(ws, rt.compute_dtype), rt.store.view(bs, torch.float32)
+        if w is None or b is None:
+            return None
+        memory = rt.act_in(memory)
+        need_grad = torch.is_grad_enabled() and (memory.requires_grad or any(p.requires_grad for p in ws + bs))
+        if need_grad and not Fn.chain_active():
+            return None
+        wts = {"w_kv": w, "b_kv": b, "w_kv_t": rt.weight_t(ws), "sink": rt.sinks({"w_kv": ws, "b_kv": bs}), "notify": rt.grads_ready}
+        return Fn.MemoryKVFn.apply(memory, wts, *ws, *bs)
+
     def project(self, layer: nn.Linear, x: Tensor, out_dtype) -> Tensor:
         rt = runtime_of(self)
         x = rt.act_in(x)
@@ -64,9 +99,12 @@ class TransformerDecoder(Decoder):
         last_layer = len(self.layers) - 1
         return_attention = kwargs.get("return_attention", False)
         att = None
+        kv_all = self.memory_kv(encoder_output)
+        d2 = 2 * self._hidden_size
         for i, layer in enumerate(self.layers):
             x, att = layer(x=x, memory=encoder_output, src_mask=src_mask, trg_mask=trg_mask,
-                           return_attention=(return_attention and i == last_layer))
+                           return_attention=(return_attention and i == last_layer),
+                           memory_kv=None if kv_all is None else (kv_all, i * d2))
         if self.layer_norm is not None:
             sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
             x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")),

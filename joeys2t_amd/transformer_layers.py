@@ -7,7 +7,7 @@ Mirrors joeynmt/transformer_layers.py (reference): MultiHeadedAttention (:17-115
 ...); their torch forward is never called.  All math runs in joeys2t_amd.functional (libjoeys2t_hip.so).
 """
 import math
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -72,12 +72,17 @@ class MultiHeadedAttention(nn.Module):
         return w
 
     def run_block(self, x: Tensor, memory: Optional[Tensor], mask: Optional[Tensor], *, ln: Optional[nn.LayerNorm],
-                  ln_mode: str, alpha: float, out_dropout: float, need_weights: bool = False):
-        """[LN] -> attention -> output projection (+dropout) + alpha*x [-> LN] as one fused autograd node."""
+                  ln_mode: str, alpha: float, out_dropout: float, need_weights: bool = False,
+                  memory_kv: Optional[Tuple[Tensor, int]] = None):
+        """[LN] -> attention -> output projection (+dropout) + alpha*x [-> LN] as one fused autograd node.
+        `memory_kv` = (projections [B*S, L*2d] of the encoder states for all decoder layers, this layer's first column): the
+        block reads its keys and values from there instead of projecting `memory` itself (functional.MemoryKVFn)."""
         rt = runtime_of(self)
         kind = "self" if memory is None else "cross"
         x = rt.act_in(x)
-        if memory is not None:
+        if memory_kv is not None:
+            memory = memory_kv[0]
+        elif memory is not None:
             memory = rt.act_in(memory)
         cfg = Fn.BlockCfg(kind=kind, num_heads=self.num_heads, alpha=alpha, ln_mode=ln_mode, training=self.training,
                           attn_dropout=self.dropout.p, out_dropout=out_dropout, need_weights=need_weights)
@@ -104,6 +109,9 @@ class MultiHeadedAttention(nn.Module):
             params = params + [self.rel_pos_bias]
             smap.update(rel_bias=[self.rel_pos_bias])
         wts["sink"], wts["notify"] = rt.sinks(smap), rt.grads_ready
+        if memory_kv is not None:  # k_layer / v_layer ran in MemoryKVFn, which also owns their gradients
+            wts["kv_off"] = int(memory_kv[1])
+            wts["notify_skip"] = {id(k_.weight), id(v_.weight), id(k_.bias), id(v_.bias)}
         rng = _rng(rt, x) if cfg.any_dropout else None
         if mask is not None and not mask.is_contiguous():
             mask = mask.contiguous()
@@ -234,12 +242,12 @@ class TransformerDecoderLayer(nn.Module):
         assert self._layer_norm_position in {"pre", "post"}
 
     def forward(self, x: Tensor, memory: Tensor, src_mask: Tensor, trg_mask: Tensor, return_attention: bool = False,
-                **kwargs):
+                memory_kv: Optional[Tuple[Tensor, int]] = None, **kwargs):
         h1, _ = self.trg_trg_att.run_block(x, None, trg_mask, ln=self.x_layer_norm, ln_mode=self._layer_norm_position,
                                            alpha=self.alpha, out_dropout=self.dropout.p)
         h2, att = self.src_trg_att.run_block(h1, memory, src_mask, ln=self.dec_layer_norm,
                                              ln_mode=self._layer_norm_position, alpha=self.alpha,
-                                             out_dropout=self.dropout.p, need_weights=return_attention)
+                                             out_dropout=self.dropout.p, need_weights=return_attention, memory_kv=memory_kv)
         out = self.feed_forward(h2)
         return out, (att if return_attention else None)
 
