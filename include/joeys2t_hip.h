@@ -545,6 +545,28 @@ typedef struct js2t_attn_desc {
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * Gradient exchange (data parallel, one process per GPU): what DistributedDataParallel's bucketed all-reduce does for the
+ * reference (prediction.py:508-515 wraps the model; helpers_for_ddp.py:17-38 sets the process group up, :157-174 reduces
+ * scalars) - an RCCL communicator over xGMI.  Bootstrap: rank 0 calls js2t_comm_unique_id, the host side broadcasts the
+ * js2t_comm_unique_id_bytes() bytes by whatever channel it has (torch.distributed / gloo store), every rank calls
+ * js2t_comm_init with them (collective: returns when all `world` ranks have).  librccl is resolved at first use.
+ *
+ * js2t_comm_allreduce_async: in-place sum (average != 0: mean) of buf[count] (JS2T_F32 or JS2T_BF16) over all ranks, enqueued
+ * on the communicator's own stream behind everything `producer` has been given so far; returns at once.  Calls on one
+ * communicator run in call order; every rank must issue the same sequence.
+ * js2t_comm_wait: `consumer` (a stream) waits on the device for everything enqueued so far (host == 0), or the calling
+ * thread does (host != 0; consumer ignored).  js2t_comm_stream: the communicator's stream, for work that belongs between
+ * two collectives (casts into / out of a bf16 staging buffer).  js2t_comm_destroy drains it first.
+ */
+int64_t js2t_comm_unique_id_bytes(void);
+int js2t_comm_unique_id(void* out, int64_t nbytes);
+int js2t_comm_init(void** comm_out, const void* unique_id, int64_t id_bytes, int32_t world, int32_t rank, int32_t device);
+int js2t_comm_allreduce_async(void* comm, void* buf, int64_t count, int32_t dtype, int32_t average, js2t_stream producer);
+int js2t_comm_wait(void* comm, js2t_stream consumer, int32_t host);
+js2t_stream js2t_comm_stream(void* comm);
+int js2t_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,9 +103,14 @@ class FlatGradReducer:
     no_sync() after the forward, which does not disarm the reducer) — the summed gradient is identical."""
 
     def __init__(self, store, n_buckets: int = 4, average: bool = True, comm_stream: Optional["torch.cuda.Stream"] = None,
-                 ranges=None, comm_dtype: Optional[torch.dtype] = None):
+                 ranges=None, comm_dtype: Optional[torch.dtype] = None, comm=None):
         self.store = store
         self.average = average
+        # comm (joeys2t_amd.comm.Communicator): the collectives go through the C boundary (js2t_comm_allreduce_async on the
+        # communicator's own stream) instead of torch.distributed.all_reduce; same buckets, same order, same staging
+        self.comm = comm
+        if comm is not None:
+            comm_stream = comm.stream
         # comm_dtype=torch.bfloat16 (GPU + RCCL only): a range goes over the links as bf16 - cast into a staging buffer, averaged
         # there, cast back into the fp32 flat gradient, all on the communication stream.  Half the bytes on xGMI (point-to-point
         # links: a ring all-reduce is bound by one of them) for a rounding of 2^-9 relative on gradients that come out of bf16
@@ -177,6 +182,23 @@ class FlatGradReducer:
         self.launched[bi] = True
         lo, hi = self.ranges[bi]
         buf = self.store.flat_grad[lo:hi]
+        if self.comm is not None:
+            if self.comm_dtype is not None and self.comm_dtype != torch.float32:
+                from joeys2t_amd import ops
+                if self._stage is None:
+                    self._stage = torch.empty(self.store.total, dtype=self.comm_dtype, device=self.store.device)
+                st = self._stage[lo:hi]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):  # cast, collective, cast back: one after the other on the communicator's stream
+                    self.comm_stream.wait_event(ev)
+                    ops.cast(buf, self.comm_dtype, out=st)
+                    self.comm.all_reduce_async(st, average=self.average, producer=self.comm_stream)
+                    ops.cast(st, torch.float32, out=buf)
+            else:
+                self.comm.all_reduce_async(buf, average=self.average)
+            self.works.append((None, buf, None))
+            return
         op = dist.ReduceOp.AVG if (self.average and dist.get_backend() == "nccl") else dist.ReduceOp.SUM
         if self.on_gpu and self.comm_dtype is not None and self.comm_dtype != torch.float32 and dist.get_backend() == "nccl":
             from joeys2t_amd import ops
@@ -249,6 +271,8 @@ class FlatGradReducer:
         for bi in range(len(self.ranges)):
             self._launch(bi)
         for w, buf, op in self.works:
+            if w is None:  # through the C boundary: ordered by the stream join below
+                continue
             w.wait()
             if self.average and op == dist.ReduceOp.SUM:
                 buf.div_(self.world)

@@ -13,6 +13,7 @@ Python never travels to the GPU box, so this module reproduces exactly the numer
 MI355X-first differences (results unchanged): statistics stay on the device (no .item() per micro-batch; the reference
 syncs 6 times, :422-423,591-594); clip coefficient, AdamW, bf16 re-cast and gradient clearing are one fused pass over
 the flat store; under DDP the gradient exchange is bucketed RCCL on a side stream (helpers_for_ddp.FlatGradReducer)."""
+import os
 from typing import Dict, Optional
 
 import torch
@@ -30,7 +31,7 @@ class TrainStep:
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
                  learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
                  batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False,
-                 defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None):
+                 defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None, comm=None):
         self.model = model
         model.overlap_ctc = bool(overlap_ctc)
         self.rt = model.runtime
@@ -57,8 +58,15 @@ class TrainStep:
         self.rt.grad_copies = ops.GradCopies(self.store.device) if defer_wgrads else None
         self.reducer = None
         if use_ddp():
+            # comm: a joeys2t_amd.comm.Communicator, or "cabi" (JS2T_COMM=cabi) to bootstrap one over the process group that is
+            # up - the collectives then go through js2t_comm_* of the C boundary instead of torch.distributed.all_reduce
+            if comm is None and os.environ.get("JS2T_COMM", "") == "cabi":
+                comm = "cabi"
+            if comm == "cabi":
+                from joeys2t_amd.comm import Communicator
+                comm = Communicator.from_process_group(self.store.device)
             self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None,
-                                           comm_dtype=comm_dtype)
+                                           comm_dtype=comm_dtype, comm=comm)
         # bucket bookkeeping by per-parameter notifications only without the queue (with it: exchange_and_flush)
         self.rt.on_grads_ready = self.reducer.params_ready if (self.reducer is not None and self.rt.wgrad_queue is None) else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]

@@ -111,3 +111,69 @@ def test_bf16_gradient_exchange_over_rccl_single_rank(device):
     assert torch.equal(before, after)
     before, after = res["bf16"]
     assert torch.equal(after, before.bfloat16().float()) and not torch.equal(after, before)
+
+
+def _cabi_worker(rank, port, ret):
+    """One rank: the exchange through the C boundary (js2t_comm_*), id broadcast over a gloo group - no torch RCCL backend at all."""
+    import torch.distributed as dist
+    from joeys2t_amd.comm import Communicator
+    from joeys2t_amd.helpers_for_ddp import FlatGradReducer
+    from joeys2t_amd.runtime import ParamStore
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["JS2T_DDP_SINGLE"] = "1"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = Communicator.from_process_group(dev)
+        out = {}
+        # (a) the communicator on its own: ordered behind the producer stream, in front of the consumer stream
+        for dt in (torch.float32, torch.bfloat16):
+            x = torch.zeros(1 << 20, dtype=dt, device=dev)
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(4):
+                big = big @ big.t() * 1e-4  # keeps the producer stream busy: the collective must not start before fill_ below
+            x.fill_(3.0)
+            comm.all_reduce_async(x, average=True)
+            comm.wait()
+            y = x * 2
+            comm.all_reduce_async(y, average=False)
+            comm.wait(host=True)
+            out[str(dt)] = (float(x.float().min()), float(x.float().max()), float(y.float().min()), float(y.float().max()))
+        # (b) under the reducer: same buckets, fp32 and bf16 staging
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 32)).to(dev)
+        store = ParamStore(net, dev)
+        store.attach_grads()
+        for name, dt in (("fp32", None), ("bf16", torch.bfloat16)):
+            red = FlatGradReducer(store, n_buckets=3, comm_dtype=dt, comm=comm)
+            store.flat_grad.copy_(torch.randn(store.total, generator=torch.Generator().manual_seed(5)).to(dev))
+            before = store.flat_grad.clone()
+            red.begin(armed=True)
+            red.finish()
+            after = store.flat_grad * 1.0  # on the compute stream: finish() has made it wait for the communicator's
+            torch.cuda.synchronize()
+            out[name] = (before.cpu(), after.cpu(), len(red.works) == len(red.ranges) >= 2)
+            for h in red._hooks:
+                h.remove()
+        comm.close()
+        with pytest.raises(Exception):
+            comm.all_reduce_async(torch.zeros(4, device=dev))
+        ret["res"] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_exchange_through_the_c_boundary_single_rank(device):
+    """SURVEY 8(b)'s js2t_comm_{init, allreduce_async, wait, destroy}: a real (one-rank) RCCL communicator bootstrapped from
+    an id that travelled through the host side, in-place mean / sum, stream-ordered; and FlatGradReducer driving it."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cabi_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    res = ret["res"]
+    for dt in ("torch.float32", "torch.bfloat16"):
+        assert res[dt] == (3.0, 3.0, 6.0, 6.0), res[dt]
+    before, after, n = res["fp32"]
+    assert n and torch.equal(before, after)  # one collective per bucket
+    before, after, n = res["bf16"]
+    assert n and torch.equal(after, before.bfloat16().float()) and not torch.equal(after, before)
