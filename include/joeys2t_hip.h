@@ -465,6 +465,13 @@ int js2t_feature_finalize_crop(const float* feat, const int64_t* frame_off, cons
                                const float* fill, const int32_t* masks, void* out, int out_dt, int64_t U, int64_t Tmax,
                                int32_t F, float pad_value, const int64_t* crop_t, js2t_stream stream);
 
+/* CMVN and / or SpecAugment applied to the ragged features IN PLACE - the orders and mask counts the fused pair above does not
+ * cover (tokenizers.py:480-492 with CMVN(before=False); data_augmentation.py:54-68 with freq_mask_n / time_mask_n > 2):
+ * x = (x - mean[u,c]) * istd[u,c] when mean is given, then fill[u] inside any mask of utterance u.
+ * masks: int32[U, n_freq + n_time, 2] = (start, width), the n_freq frequency masks first; NULL = none. */
+int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int32_t F, const float* mean, const float* istd,
+                           const float* fill, const int32_t* masks, int32_t n_freq, int32_t n_time, js2t_stream stream);
+
 /* --------------------------------------------------------------------------------------------------
  * Update tail over the flat parameter store (training.py:436-456).
  */

@@ -407,7 +407,47 @@ __global__ void feature_finalize_kernel(const float* __restrict__ feat, const in
   }
 }
 
+// ---------------------------------------------------------------- CMVN / SpecAugment on the ragged features, in place
+// The general form of what feature_finalize fuses for the configured case (CMVN before SpecAugment, two masks of each kind):
+// x[t, c] of utterance u becomes (x - mean[u, c]) * istd[u, c] (mean given), then fill[u] where (t, c) lies in one of the
+// n_freq frequency masks or n_time time masks of the utterance.  masks: int32[U, n_freq + n_time, 2] = (start, width),
+// frequency masks first.  With it the other orders are compositions: CMVN(before=False) = transform(masks) -> cmvn_stats ->
+// feature_finalize(mean, istd); any number of masks = cmvn_stats -> transform(mean, istd, masks) -> feature_finalize.
+__global__ void feature_transform_kernel(float* __restrict__ feat, const int64_t* __restrict__ frame_off, int F,
+                                         const float* __restrict__ mean, const float* __restrict__ istd,
+                                         const float* __restrict__ fill, const int32_t* __restrict__ masks, int n_freq, int n_time) {
+  const int u = blockIdx.y;
+  const int64_t t0 = frame_off[u], n = (frame_off[u + 1] - t0) * F;
+  const int32_t* m = masks ? masks + (int64_t)u * 2 * (n_freq + n_time) : nullptr;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / F;
+    const int c = (int)(i - t * F);
+    float v = feat[t0 * F + i];
+    if (mean) v = (v - mean[(int64_t)u * F + c]) * istd[(int64_t)u * F + c];
+    if (m) {
+      bool hit = false;
+      for (int k = 0; k < n_freq; ++k) hit = hit || (m[2 * k + 1] > 0 && c >= m[2 * k] && c < m[2 * k] + m[2 * k + 1]);
+      for (int k = n_freq; k < n_freq + n_time; ++k) hit = hit || (m[2 * k + 1] > 0 && t >= m[2 * k] && t < m[2 * k] + m[2 * k + 1]);
+      if (hit) v = fill[u];
+    }
+    feat[t0 * F + i] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int32_t F, const float* mean, const float* istd,
+                                      const float* fill, const int32_t* masks, int32_t n_freq, int32_t n_time, js2t_stream stream) {
+  if (U == 0) return JS2T_OK;
+  JS2T_CHECK(feat && frame_off && F > 0, "feature_transform: null pointer");
+  JS2T_CHECK((mean == nullptr) == (istd == nullptr), "feature_transform: mean and istd go together");
+  JS2T_CHECK(!masks || (fill && n_freq >= 0 && n_time >= 0 && n_freq + n_time > 0), "feature_transform: masks need fill values and counts");
+  JS2T_CHECK(U <= 65535, "feature_transform: at most 65535 utterances per call");
+  hipLaunchKernelGGL(feature_transform_kernel, dim3(16, (unsigned)U), dim3(256), 0, (hipStream_t)stream, feat, frame_off, F, mean, istd, fill,
+                     masks, masks ? n_freq : 0, masks ? n_time : 0);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
 
 extern "C" int js2t_fbank(const float* wave, const int64_t* sample_off, const int64_t* frame_off, int32_t U,
                           int64_t total_frames, const float* window, const float* tw_re, const float* tw_im,

@@ -6,6 +6,7 @@ this image and carry no arithmetic of the hot path (tensorboard, sacrebleu, subw
 sacremoses, torchaudio) are replaced by empty stub modules before `import joeynmt`; nothing from the reference
 is copied into the repository — only inputs and outputs of its functions.
 """
+import json
 import sys
 import types
 from pathlib import Path
@@ -798,6 +799,42 @@ def golden_ref_unit_tests(name="ref_unit_tests"):
     print("wrote", name, len(out), "arrays")
 
 
+def golden_frontend_general():
+    """SpeechProcessor.__call__'s cmvn / specaugment block (tokenizers.py:480-492) on the reference's own classes, for the
+    settings beside the configured one: CMVN after SpecAugment, more than two masks of a kind, SpecAugment without CMVN
+    (local-mean fill), evaluation-time truncation in front of it all.  Three utterances, np.random seeded once per case."""
+    from joeynmt.data_augmentation import CMVN, SpecAugment
+    rs = np.random.RandomState(8)
+    # (long enough that two 30-frame time masks leave most frames alone: with nearly every frame at the fill value the reference's
+    # float32 `square_sums / n - mean**2` is cancellation noise, and no implementation that sums differently can reproduce it)
+    utts = [(rs.randn(n, 80) * 2.5 + 0.7).astype(np.float32) for n in (161, 123, 140)]
+    cases = {
+        "after": (dict(norm_means=True, norm_vars=True, before=False), dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=30, time_mask_p=1.0), None),
+        "many": (dict(norm_means=True, norm_vars=True, before=True), dict(freq_mask_n=3, freq_mask_f=15, time_mask_n=4, time_mask_t=12, time_mask_p=1.0), None),
+        "many_after": (dict(norm_means=True, norm_vars=False, before=False), dict(freq_mask_n=4, freq_mask_f=10, time_mask_n=3, time_mask_t=9, time_mask_p=0.5), None),
+        "nocmvn": (None, dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=30, time_mask_p=1.0), None),
+        "after_trunc": (dict(norm_means=True, norm_vars=True, before=False), dict(freq_mask_n=3, freq_mask_f=20, time_mask_n=1, time_mask_t=10, time_mask_p=1.0), 135),
+    }
+    out = {f"in{i}": u for i, u in enumerate(utts)}
+    for name, (ck, sk, max_len) in cases.items():
+        cmvn = CMVN(**ck) if ck is not None else None
+        sa = SpecAugment(**sk)
+        np.random.seed(77)
+        for i, item in enumerate(utts):
+            item = item.copy()
+            if max_len is not None and item.shape[0] > max_len:
+                item = item[:max_len, :]
+            if cmvn and cmvn.before:
+                item = cmvn(item)
+            item = sa(item)
+            if cmvn and not cmvn.before:
+                item = cmvn(item)
+            out[f"{name}_{i}"] = item.astype(np.float32)
+    np.savez_compressed(OUT / "frontend_general.npz", **out)
+    (OUT / "frontend_general.json").write_text(json.dumps({k: dict(cmvn=v[0], specaugment=v[1], max_length=v[2]) for k, v in cases.items()}, indent=1))
+    print("frontend_general:", sorted(cases))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -808,7 +845,7 @@ def main():
         "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
         "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
-        "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt,
+        "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt, "frontend_general": golden_frontend_general,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

@@ -73,6 +73,45 @@ def test_cmvn_specaugment_pad(device, out_dtype):
     assert torch.all(out2[1, 20:] == 1.0)
 
 
+@pytest.mark.parametrize("case", ["after", "many", "many_after", "nocmvn", "after_trunc"])
+def test_frontend_orders_and_mask_counts_beside_the_configured_one(device, case):
+    """CMVN(before=False), more than two masks of a kind, SpecAugment without CMVN, truncation first - finalize_features' general
+    path (js2t_cmvn_stats / js2t_feature_transform / js2t_feature_finalize composed in the reference's order) against the
+    reference's own classes (frontend_general.npz, tokenizers.py:474-492)."""
+    import json
+    from pathlib import Path
+    from conftest import load_golden
+    from joeys2t_amd.data_augmentation import CMVN, SpecAugment, finalize_features
+    g = load_golden("frontend_general")
+    spec = json.loads((Path(__file__).resolve().parent / "golden" / "frontend_general.json").read_text())[case]
+    feats = [g[f"in{i}"] for i in range(3)]
+    frames = [f.shape[0] for f in feats]
+    flat = torch.from_numpy(np.concatenate(feats)).to(device)
+    keep = flat.clone()
+    foff = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int64, device=device)
+    cmvn = CMVN(**spec["cmvn"]) if spec["cmvn"] else None
+    np.random.seed(77)
+    out, lens = finalize_features(flat, foff, frames, cmvn=cmvn, specaugment=SpecAugment(**spec["specaugment"]), out_dtype=torch.float32,
+                                  max_length=spec["max_length"])
+    want = [g[f"{case}_{i}"] for i in range(3)]
+    assert lens == [w.shape[0] for w in want] and out.shape[1] == max(lens)
+    rng = np.random.RandomState(77)
+    for i, w in enumerate(want):
+        got = out[i, :w.shape[0]].cpu().numpy()
+        ok = np.ones(80, dtype=bool)
+        sa_kw = spec["specaugment"]
+        params = O.specaugment_params(w.shape[0], 80, rng, **sa_kw)
+        if cmvn is not None and not cmvn.before and cmvn.norm_vars and params is not None:
+            # a frequency-masked bin is constant when CMVN sees it: variance 0, divided by sqrt(1e-10) - the reference's value there
+            # is its float32 column mean's last-place error times 1e5 (up to ~0.1), the kernel's (mean taken in double) is 0
+            for f0, f in params[0]:
+                ok[f0:f0 + f] = False
+            assert np.abs(got[:, ~ok]).max(initial=0.0) < 1e-3 and np.abs(w[:, ~ok]).max(initial=0.0) < 1.0
+        np.testing.assert_allclose(got[:, ok], w[:, ok], rtol=1e-5, atol=3e-5, err_msg=f"{case} {i}")
+        assert torch.all(out[i, w.shape[0]:] == 1.0)
+    assert torch.equal(flat, keep)  # the caller's features are left alone (the general path works on a copy)
+
+
 def test_flat_adamw_and_clip_match_torch(device):
     from joeys2t_amd.builders import FlatAdamW, WarmupInverseSquareRootScheduler
     from joeys2t_amd.runtime import ParamStore

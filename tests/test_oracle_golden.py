@@ -319,3 +319,32 @@ def test_text_source_model_matches_reference():
         ids, scores = O.beam_search(sdd, cfg, SPECIALS, enc, mask, k, max_len, float(g["beam_alpha"]), n_best=k)
         assert np.array_equal(ids.numpy(), g["beam_ids_nbest"])
         np.testing.assert_allclose(scores.numpy(), g["beam_scores_nbest"], rtol=1e-4, atol=1e-4)
+
+
+def _frontend_general_cases():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).resolve().parent / "golden" / "frontend_general.json").read_text())
+
+
+def oracle_frontend(item, cmvn, sa, max_length, rng):
+    """SpeechProcessor.__call__'s cmvn / specaugment block (tokenizers.py:474-492) on the oracle's restatements."""
+    if max_length is not None and item.shape[0] > max_length:
+        item = item[:max_length]
+    if cmvn and cmvn["before"]:
+        item = O.cmvn(item, cmvn["norm_means"], cmvn["norm_vars"])
+    item = O.specaugment_apply(item, O.specaugment_params(item.shape[0], item.shape[1], rng, **sa))
+    if cmvn and not cmvn["before"]:
+        item = O.cmvn(item, cmvn["norm_means"], cmvn["norm_vars"])
+    return item
+
+
+def test_frontend_orders_and_mask_counts_beside_the_configured_one():
+    """CMVN after SpecAugment, three / four masks of a kind, SpecAugment without CMVN, truncation first: the oracle against the
+    reference's own classes composed as SpeechProcessor.__call__ composes them (frontend_general.npz)."""
+    g = load_golden("frontend_general")
+    for name, case in _frontend_general_cases().items():
+        rng = np.random.RandomState(77)
+        for i in range(3):
+            got = oracle_frontend(g[f"in{i}"].copy(), case["cmvn"], case["specaugment"], case["max_length"], rng)
+            np.testing.assert_allclose(got, g[f"{name}_{i}"], rtol=1e-5, atol=1e-5, err_msg=f"{name} {i}")
