@@ -39,3 +39,21 @@ def test_no_cpu_fallback():
         ops.glu_fwd(x)
     with pytest.raises(ops.Js2tError):
         ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-6)
+
+
+def test_comm_entry_points_reject_bad_arguments():
+    """js2t_comm_* (the RCCL communicator behind the boundary): argument checks only - no GPU, no RCCL call."""
+    from joeys2t_amd import comm
+    L = comm._bind(_lib.lib())
+    assert L.js2t_comm_unique_id_bytes() == 128
+    assert L.js2t_comm_unique_id(None, 128) != 0 and b"128" in L.js2t_last_error()
+    h = ctypes.c_void_p()
+    assert L.js2t_comm_init(ctypes.byref(h), b"\0" * 128, 64, 1, 0, 0) != 0       # an id of the wrong size
+    assert L.js2t_comm_init(ctypes.byref(h), b"\0" * 128, 128, 2, 2, 0) != 0      # rank outside the world
+    assert h.value is None
+    assert L.js2t_comm_allreduce_async(None, None, 0, 0, 0, None) != 0
+    assert L.js2t_comm_wait(None, None, 0) != 0
+    assert L.js2t_comm_stream(None) is None
+    assert L.js2t_comm_destroy(None) == 0
+    with pytest.raises(_lib.Js2tError):
+        comm.Communicator(0, 1, torch.device("cpu"), exchange_id=lambda b: b)
