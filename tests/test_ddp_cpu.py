@@ -164,3 +164,18 @@ def test_ddp_helpers_match_reference_capture():
                 np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0, err_msg=f"rank{r}.{k}")
             else:
                 assert np.array_equal(got, ref), (r, k, got, ref)
+
+
+def _comm_bootstrap(rank, world):
+    """The host side's part of js2t_comm_init: rank 0 draws the ncclUniqueId, the 128 bytes travel over the group that is up."""
+    from joeys2t_amd import comm
+    mine = comm.unique_id() if rank == 0 else None
+    got = comm._broadcast_id(mine)
+    return (got, mine)
+
+
+def test_communicator_id_reaches_every_rank():
+    res = run2(_comm_bootstrap)
+    (id0, mine0), (id1, mine1) = res[0], res[1]
+    assert isinstance(id0, bytes) and len(id0) == 128 and id0 == id1 == mine0 and mine1 is None
+    assert any(id0)  # not the zero buffer
