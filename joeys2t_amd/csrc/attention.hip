@@ -101,9 +101,7 @@ __device__ __forceinline__ void own_frags(const uint16_t* base, int64_t ld, int 
   for (int ks = 0; ks < NKS; ++ks) f[ks] = *(const bf16x8_t*)(base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
-  const s16x8_t v = {(short)f32_to_bf16_bits(a[0]), (short)f32_to_bf16_bits(a[1]), (short)f32_to_bf16_bits(a[2]),
-                     (short)f32_to_bf16_bits(a[3]), (short)f32_to_bf16_bits(b[0]), (short)f32_to_bf16_bits(b[1]),
-                     (short)f32_to_bf16_bits(b[2]), (short)f32_to_bf16_bits(b[3])};
+  const uint4 v = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
   return __builtin_bit_cast(bf16x8_t, v);
 }
 // Reductions over the 4 lanes that share (lane & 15), i.e. over the wave's four 16-lane rows.  gfx950's row swaps do the
@@ -135,8 +133,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 __device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) {
   uint2 pk;
-  pk.x = (uint32_t)f32_to_bf16_bits(v[0] * sc) | ((uint32_t)f32_to_bf16_bits(v[1] * sc) << 16);
-  pk.y = (uint32_t)f32_to_bf16_bits(v[2] * sc) | ((uint32_t)f32_to_bf16_bits(v[3] * sc) << 16);
+  pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
+  pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
   *(uint2*)p = pk;
 }
 

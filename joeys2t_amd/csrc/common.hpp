@@ -38,6 +38,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(uint16_t, h);
 }
 
+// two values -> one dword of bf16 bits (lo in the low half): ONE v_cvt_pk_bf16_f32.  Written as two scalar conversions joined by
+// shift / or, the compiler converts with a wasted half each and spends two or three more VALU instructions putting the halves together.
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t_;
+  const f32x2_t_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t_));
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void dwconv_outer_lds_kernel(const uint16_t* _
     for (int j = 0; j < 8; ++j)
       if (lb + j < L)
         *(uint32_t*)(y + ((int64_t)(lb + j) * N + n) * C + c0 + 2 * cp) =
-            (uint32_t)f32_to_bf16_bits(a0[j]) | ((uint32_t)f32_to_bf16_bits(a1[j]) << 16);
+            pack_bf16x2(a0[j], a1[j]);
   }
 }
 template <bool FLIP>

@@ -32,8 +32,8 @@ template <> struct vec4<uint16_t> {
   }
   static __device__ __forceinline__ void st(uint16_t* p, const float (&v)[4]) {
     uint2 x;
-    x.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-    x.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+    x.x = pack_bf16x2(v[0], v[1]);
+    x.y = pack_bf16x2(v[2], v[3]);
     *(uint2*)p = x;
   }
 };
@@ -314,10 +314,10 @@ __global__ void col2im_vec_kernel(const uint16_t* __restrict__ dcol, uint16_t* _
       }
     }
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16_bits(s[0]) | ((uint32_t)f32_to_bf16_bits(s[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16_bits(s[2]) | ((uint32_t)f32_to_bf16_bits(s[3]) << 16);
-    o.z = (uint32_t)f32_to_bf16_bits(s[4]) | ((uint32_t)f32_to_bf16_bits(s[5]) << 16);
-    o.w = (uint32_t)f32_to_bf16_bits(s[6]) | ((uint32_t)f32_to_bf16_bits(s[7]) << 16);
+    o.x = pack_bf16x2(s[0], s[1]);
+    o.y = pack_bf16x2(s[2], s[3]);
+    o.z = pack_bf16x2(s[4], s[5]);
+    o.w = pack_bf16x2(s[6], s[7]);
     *(uint4*)(dx + (b * tin + tau) * C + c) = o;
   }
 }

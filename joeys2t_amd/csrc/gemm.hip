@@ -91,8 +91,8 @@ __device__ __forceinline__ void gemm_epilogue4(const js2t_gemm_desc& d, int z, i
       *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
       uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+      pk.x = pack_bf16x2(v[0], v[1]);
+      pk.y = pack_bf16x2(v[2], v[3]);
       *(uint2*)((uint16_t*)d.C + coff) = pk;
     }
   } else {
@@ -535,10 +535,10 @@ __device__ __forceinline__ void gemm_epilogue8(const js2t_gemm_desc& d, int z, i
   }
   if (full && d.dtype_c == JS2T_BF16 && ((coff & 7) == 0)) {
     uint4 pk;
-    pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-    pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-    pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-    pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+    pk.x = pack_bf16x2(v[0], v[1]);
+    pk.y = pack_bf16x2(v[2], v[3]);
+    pk.z = pack_bf16x2(v[4], v[5]);
+    pk.w = pack_bf16x2(v[6], v[7]);
     *(uint4*)((uint16_t*)d.C + coff) = pk;
   } else if (full && d.dtype_c == JS2T_F32 && ((coff & 3) == 0)) {
     *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
@@ -674,10 +674,10 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
           const int64_t coff = co + (int64_t)m * d.ldc + n;
           if (bf16_out) {
             uint4 pk;
-            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-            pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-            pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            pk.z = pack_bf16x2(v[4], v[5]);
+            pk.w = pack_bf16x2(v[6], v[7]);
             *(uint4*)((uint16_t*)d.C + coff) = pk;
           } else {
             if (d.beta != 0.f) {  // in-place accumulation of an f32 gradient
@@ -870,10 +870,10 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           uint4 pk;
-          pk.x = (uint32_t)f32_to_bf16_bits(v[8 * h + 0]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16_bits(v[8 * h + 2]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 3]) << 16);
-          pk.z = (uint32_t)f32_to_bf16_bits(v[8 * h + 4]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 5]) << 16);
-          pk.w = (uint32_t)f32_to_bf16_bits(v[8 * h + 6]) | ((uint32_t)f32_to_bf16_bits(v[8 * h + 7]) << 16);
+          pk.x = pack_bf16x2(v[8 * h + 0], v[8 * h + 1]);
+          pk.y = pack_bf16x2(v[8 * h + 2], v[8 * h + 3]);
+          pk.z = pack_bf16x2(v[8 * h + 4], v[8 * h + 5]);
+          pk.w = pack_bf16x2(v[8 * h + 6], v[8 * h + 7]);
           *(uint4*)((uint16_t*)d.C + coff + 8 * h) = pk;
         }
       } else {
@@ -1263,10 +1263,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_w256_kernel(js2t_gemm_desc d
         }
         if (m < M) {
           uint4 pk;
-          pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-          pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-          pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          pk.z = pack_bf16x2(v[4], v[5]);
+          pk.w = pack_bf16x2(v[6], v[7]);
           *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
         }
       }
@@ -1469,10 +1469,10 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
       }
       if (m < M && (!OUT8 || d.C)) {
         uint4 pk;
-        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-        pk.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-        pk.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        pk.z = pack_bf16x2(v[4], v[5]);
+        pk.w = pack_bf16x2(v[6], v[7]);
         *(uint4*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
       }
       if constexpr (OUT8) {
@@ -1831,8 +1831,8 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
       }
       if (m < M) {
         uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
         *(uint2*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
       }
     }

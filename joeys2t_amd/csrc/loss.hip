@@ -503,10 +503,10 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
   if (vec) {
     for (int c = threadIdx.x; c < (int)(V >> 3); c += LB) {
       uint4 q;
-      q.x = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 0]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 1]) << 16);
-      q.y = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 2]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 3]) << 16);
-      q.z = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 4]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 5]) << 16);
-      q.w = (uint32_t)f32_to_bf16_bits(gs * row[8 * c + 6]) | ((uint32_t)f32_to_bf16_bits(gs * row[8 * c + 7]) << 16);
+      q.x = pack_bf16x2(gs * row[8 * c + 0], gs * row[8 * c + 1]);
+      q.y = pack_bf16x2(gs * row[8 * c + 2], gs * row[8 * c + 3]);
+      q.z = pack_bf16x2(gs * row[8 * c + 4], gs * row[8 * c + 5]);
+      q.w = pack_bf16x2(gs * row[8 * c + 6], gs * row[8 * c + 7]);
       ((uint4*)dr)[c] = q;
     }
   } else {

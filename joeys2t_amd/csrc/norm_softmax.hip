@@ -140,10 +140,10 @@ template <> struct ld8<uint16_t> {
   }
   static __device__ __forceinline__ void st(uint16_t* p, const float (&v)[8]) {
     uint4 r;
-    r.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-    r.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-    r.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-    r.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
+    r.x = pack_bf16x2(v[0], v[1]);
+    r.y = pack_bf16x2(v[2], v[3]);
+    r.z = pack_bf16x2(v[4], v[5]);
+    r.w = pack_bf16x2(v[6], v[7]);
     *(uint4*)p = r;
   }
 };
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const int64_t* __r
   for (int64_t k = 4 * lane; k < K; k += 256) {
     const float4 w = *(const float4*)(W + n * K + k), g = *(const float4*)(gamma + k);
     uint2 pk;
-    pk.x = (uint32_t)f32_to_bf16_bits(fmaf(w.x, g.x, -cs)) | ((uint32_t)f32_to_bf16_bits(fmaf(w.y, g.y, -cs)) << 16);
-    pk.y = (uint32_t)f32_to_bf16_bits(fmaf(w.z, g.z, -cs)) | ((uint32_t)f32_to_bf16_bits(fmaf(w.w, g.w, -cs)) << 16);
+    pk.x = pack_bf16x2(fmaf(w.x, g.x, -cs), fmaf(w.y, g.y, -cs));
+    pk.y = pack_bf16x2(fmaf(w.z, g.z, -cs), fmaf(w.w, g.w, -cs));
     *(uint2*)(Wf + n * K + k) = pk;
   }
   if (lane == 0) bias_f[n] = bs + (bias ? bias[n] : 0.f);

@@ -73,8 +73,8 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
     if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lp) {
       uint2 pk;
-      pk.x = (uint32_t)f32_to_bf16_bits(pa[0]) | ((uint32_t)f32_to_bf16_bits(pa[1]) << 16);
-      pk.y = (uint32_t)f32_to_bf16_bits(pa[2]) | ((uint32_t)f32_to_bf16_bits(pa[3]) << 16);
+      pk.x = pack_bf16x2(pa[0], pa[1]);
+      pk.y = pack_bf16x2(pa[2], pa[3]);
       *(uint2*)(lp + i) = pk;
     }
   }
