@@ -15,16 +15,15 @@ class _Tanh(nn.Module):
         raise RuntimeError("placeholder activation module: the HIP GEMM epilogue applies tanh")
 
 
+_ACTIVATIONS = {"relu": nn.ReLU, "gelu": nn.GELU, "tanh": _Tanh, "swish": nn.SiLU}
+
+
 def build_activation(activation: str = "relu") -> Callable:
-    if activation == "relu":
-        return nn.ReLU
-    if activation == "gelu":
-        return nn.GELU
-    if activation == "tanh":
-        return _Tanh
-    if activation == "swish":
-        return nn.SiLU
-    raise ConfigurationError("Invalid activation function. Valid options: 'relu', 'gelu', 'tanh', 'swish'.")
+    """The module class behind a config's `activation` key (the HIP blocks only read its name: functional.BlockCfg.act)."""
+    try:
+        return _ACTIVATIONS[activation]
+    except KeyError:
+        raise ConfigurationError("Invalid activation function. Valid options: " + ", ".join(repr(k) for k in _ACTIVATIONS) + ".") from None
 
 
 # ------------------------------------------------------------------------------------------------ update tail

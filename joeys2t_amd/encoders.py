@@ -38,9 +38,9 @@ class Conv1dSubsampler(nn.Module):
     def get_out_seq_lens_tensor(self, in_seq_lens_tensor: Tensor) -> Tensor:
         """floor((len + 2*(k//2) - (k-1) - 1)/2 + 1) per layer (reference :348-352), for host tensors / tests.
         The device path computes the same integers in js2t_subsample_lengths_mask."""
-        out = in_seq_lens_tensor.clone()
-        for k in self.kernel_sizes:
-            out = ((out.float() + 2 * (k // 2) - (k - 1) - 1) / 2 + 1).floor().long()
+        out = in_seq_lens_tensor.long()
+        for k in self.kernel_sizes:  # stride 2, padding k // 2: in whole numbers
+            out = torch.div(out + 2 * (k // 2) - k, 2, rounding_mode="floor") + 1
         return out
 
     def out_len(self, t_in: int) -> int:

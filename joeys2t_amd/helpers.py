@@ -27,10 +27,10 @@ def subsequent_mask(size: int, device=None) -> Tensor:
 
 
 def set_seed(seed: int) -> None:
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    random.seed(seed)
-    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+    """One seed for every generator a run draws from: torch (CPU and all GPUs), numpy (SpecAugment), random."""
+    for seeder in (torch.manual_seed, np.random.seed, random.seed):
+        seeder(seed)
+    if torch.cuda.device_count() > 0 and torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
 
 

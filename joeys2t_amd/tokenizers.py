@@ -75,15 +75,14 @@ class SpeechProcessor:
 
 
 # ------------------------------------------------------------------------------------------------ text side: evaluation tail
+_SPACE_RUNS = re.compile("[ \u3000]+")
+
+
 def remove_extra_spaces(s: str) -> str:
-    """helpers.py:409-431 of the reference"""
-    s = re.sub("\u200b", "", s)
-    s = re.sub("[ \u3000]+", " ", s)
-    s = s.replace(" ?", "?")
-    s = s.replace(" !", "!")
-    s = s.replace(" ,", ",")
-    s = s.replace(" .", ".")
-    s = s.replace(" :", ":")
+    """Zero-width spaces out, runs of (ideographic) spaces to one, no space in front of ? ! , . : (helpers.py:409-431 of the reference)."""
+    s = _SPACE_RUNS.sub(" ", s.replace("\u200b", ""))
+    for mark in "?!,.:":
+        s = s.replace(" " + mark, mark)
     return s.strip()
 
 
