@@ -210,6 +210,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  // the first K (V) image is requested before anything else is fetched: the key mask below waits for its own loads before it can
+  // write them to LDS, and a request issued behind that wait starts a second memory round trip where one would do
+  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
+  if (!SB) img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   bf16x8_t qf[NKS];
   own_frags<NKS>(Qb, a.ldq, q0, a.Tq, lane, qf);
   f32x4_t o[NCT];
@@ -226,8 +230,6 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kmask(kmask, a, b, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
-  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
-  if (!SB) img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = t_start_;
@@ -408,6 +410,8 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
   const bool drop = a.p > 0.f;
   const float keep_p = 1.f - a.p;
+  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);  // first, as in flash_fwd_kernel
+  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   bf16x8_t qf[NKS], gf[NKS];
   float lse2, dl2;
   {
@@ -442,8 +446,6 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
     stage_rel(rel_s, a, h, t);
     for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
   }
-  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
-  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -575,6 +577,8 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  img_dma<DH>(Qb, a.ldq, 0, a.Tq, smem, t);  // first, as in flash_fwd_kernel: the key-validity test below waits for its mask byte
+  img_dma<DH>(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
   bf16x8_t kf[NKS], vf[NKS];
   own_frags<NKS>(Kb, a.ldk, k0, a.Tk, lane, kf);
   own_frags<NKS>(Vb, a.ldv, k0, a.Tk, lane, vf);
@@ -596,8 +600,6 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   const bool all_keys = __all(key_valid) != 0;  // wave-uniform: no per-element key test needed
   const int nqt = (a.Tq + KT - 1) / KT;
   if (REL) stage_rel(rel_s, a, h, t);  // visible after the first barrier of the sweep
-  img_dma<DH>(Qb, a.ldq, 0, a.Tq, smem, t);
-  img_dma<DH>(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
   // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in registers: fetching
   // them at the top of the iteration they are used in put a global-load round trip in front of every tile
   float lse_r = 0.f, dl_r = 0.f;
