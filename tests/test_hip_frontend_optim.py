@@ -232,3 +232,41 @@ def test_prefetch_loader_copies_one_batch_ahead(device):
     assert [i for i, _, _ in got] == list(range(5))
     for i, _, w in got:
         assert torch.equal(w.cpu(), data[i])
+
+
+def test_feature_transform_edges(device):
+    """js2t_feature_transform: no masks (normalisation only), masks of width 0, an utterance of one frame, and the argument checks."""
+    import ctypes as C
+    from joeys2t_amd import ops
+    from joeys2t_amd._lib import Js2tError, check, lib
+    L = lib()
+    frames = [1, 37, 5]
+    rs = np.random.RandomState(1)
+    x = torch.from_numpy(rs.randn(sum(frames), 80).astype(np.float32)).to(device)
+    foff = torch.tensor(np.concatenate([[0], np.cumsum(frames)]), dtype=torch.int64, device=device)
+    mean, istd = torch.randn(3, 80, device=device), torch.rand(3, 80, device=device) + 0.5
+    fill = torch.tensor([9.0, -3.0, 0.5], device=device)
+
+    def run(t, mean, istd, fill, masks, nf, nt):
+        check(L.js2t_feature_transform(ops._p(t), ops._p(foff), C.c_int32(3), C.c_int32(80), ops._p(mean), ops._p(istd), ops._p(fill), ops._p(masks),
+                                       C.c_int32(nf), C.c_int32(nt), ops._stream()), "js2t_feature_transform")
+
+    a = x.clone()
+    run(a, mean, istd, None, None, 0, 0)
+    want = torch.cat([(x[foff[u]:foff[u + 1]] - mean[u]) * istd[u] for u in range(3)])
+    assert torch.allclose(a, want, rtol=1e-6, atol=1e-6)
+    # three frequency + one time mask; utterance 0: all widths 0; utterance 1: a band and a stretch; utterance 2: the whole of it
+    masks = torch.tensor([[0, 0, 5, 0, 9, 0, 0, 0], [10, 4, 0, 0, 70, 10, 30, 7], [0, 80, 0, 0, 0, 0, 0, 5]], dtype=torch.int32, device=device)
+    b = x.clone()
+    run(b, None, None, fill, masks, 3, 1)
+    ref = x.clone()
+    u1 = ref[1:38]
+    u1[:, 10:14] = -3.0
+    u1[:, 70:80] = -3.0
+    u1[30:37, :] = -3.0
+    ref[38:43] = 0.5
+    assert torch.equal(b, ref) and torch.equal(b[0], x[0])
+    with pytest.raises(Js2tError):
+        run(x.clone(), mean, None, None, None, 0, 0)      # mean without istd
+    with pytest.raises(Js2tError):
+        run(x.clone(), None, None, None, masks, 3, 1)     # masks without fill values

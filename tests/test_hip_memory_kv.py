@@ -147,3 +147,36 @@ def test_a_cross_block_that_never_runs_backward_is_reported(device):
             Fn.end_memory_chain()
     finally:
         Fn.end_memory_chain(check=False)
+
+
+def test_one_utterance_and_two_layers(device):
+    """Edge sizes: a single utterance, the smallest decoder the grouping applies to (two layers), ragged target lengths."""
+    from joeys2t_amd import functional as Fn
+    from joeys2t_amd.training import TrainStep
+    from test_hip_config_width import hip_batch, make_model, synth_batch, width_cfg
+    cfg = width_cfg(4, 1, 2)
+    torch.manual_seed(9)
+    base = make_model(cfg, V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    out = {}
+    for grouped in (False, True):
+        Fn.GROUP_MEMORY_KV = grouped
+        try:
+            model = make_model(cfg, V, sd, device, torch.float32, 0.3, train=True)
+            step = TrainStep(model, learning_rate=1e-3, clip_grad_norm=1.0, normalization="batch")
+            loss = step.micro_step(hip_batch(*synth_batch(V, [211], [6], seed=1), device), update=False)
+            torch.cuda.synchronize()
+            out[grouped] = (loss.item(), step.store.flat_grad.clone())
+        finally:
+            Fn.GROUP_MEMORY_KV = True
+    assert abs(out[False][0] - out[True][0]) <= 1e-5 * abs(out[False][0])
+    rel = ((out[False][1] - out[True][1]).norm() / out[False][1].norm()).item()
+    assert rel < 2e-5, rel
+
+
+def test_single_layer_decoder_projects_for_itself(device):
+    from test_hip_config_width import make_model, width_cfg
+    model = make_model(width_cfg(4, 1, 1), V, None, device, torch.float32, 0.3, train=False)
+    enc = torch.randn(2, 50, 512, device=device)
+    with torch.no_grad():
+        assert model.decoder.memory_kv(enc) is None
