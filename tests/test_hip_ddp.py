@@ -177,3 +177,58 @@ def test_gradient_exchange_through_the_c_boundary_single_rank(device):
     assert n and torch.equal(before, after)  # one collective per bucket
     before, after, n = res["bf16"]
     assert n and torch.equal(after, before.bfloat16().float()) and not torch.equal(after, before)
+
+
+def _cabi_step_worker(rank, port, ret):
+    """One rank: TrainStep(comm="cabi") - forward, backward, deferred weight gradients, the exchange through js2t_comm_* on the
+    communicator's stream, update - against the same two steps with no process group at all (a mean over one rank changes nothing)."""
+    import torch.distributed as dist
+    from golden_cfg import FIXTURES
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    B, T = 3, 37
+    src = torch.randn(B, T, 8, generator=torch.Generator().manual_seed(7))
+    trg = torch.tensor([[2, 5, 6, 7, 3, 1], [2, 8, 9, 3, 1, 1], [2, 10, 11, 12, 13, 3]])
+    mk = lambda: Batch(src=src, src_length=torch.tensor([37, 30, 25]), src_prompt_mask=None, trg=trg, trg_length=torch.tensor([5, 4, 6]),
+                       trg_prompt_mask=None, indices=torch.arange(B), device=dev, pad_index=1, eos_index=3, is_train=True, task="S2T", n_gpu=1)
+
+    def run(comm):
+        torch.manual_seed(0)
+        model = build_model(copy.deepcopy(FIXTURES["model_pre"]["cfg"]), None, Vocabulary.synthetic(20))
+        model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+        model.finalize(dev, torch.float32)
+        step = TrainStep(model, n_gpu=1, learning_rate=1e-2, learning_rate_warmup=1, comm=comm)
+        for _ in range(2):
+            step.micro_step(mk())
+        torch.cuda.synchronize()
+        return step, step.store.flat.detach().clone().cpu()
+
+    _, plain = run(None)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["JS2T_DDP_SINGLE"] = "1"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        step, got = run("cabi")
+        used = step.reducer is not None and step.reducer.comm is not None and len(step.reducer.works) == len(step.reducer.ranges)
+        step.reducer.comm.close()
+        ret["res"] = (plain, got, used)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_step_with_the_exchange_through_the_c_boundary(device):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cabi_step_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    plain, got, used = ret["res"]
+    assert used  # every range of the flat gradient went through js2t_comm_allreduce_async
+    # two runs of the same two steps differ where an f32 atomic in backward flips the sign of a near-zero gradient (Adam's first steps move
+    # every coordinate by ~lr whatever its gradient's size): a handful of coordinates, each by less than the learning rate.  A range that
+    # went out before its products had run would be off by the learning rate everywhere in it.
+    diff = (plain - got).abs()
+    assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 1e-3
+    assert (diff.norm() / plain.norm()).item() < 1e-4
