@@ -115,6 +115,7 @@ class GraphedTrainStep:
         self.buckets: "OrderedDict[tuple, _Bucket]" = OrderedDict()
         self.pool = torch.cuda.graph_pool_handle()
         step.optimizer.device_schedule = True  # update count and learning rate are read from device memory
+        step.optimizer.step_dev.fill_(step.optimizer.t)  # ... starting from the updates this optimizer has already made
         step.external_lr = True                # ... and the rate arrives with the batch (one copy), not by a fill per step
         self.ntokens = 0
         self.counts = {"eager": 0, "replay": 0, "captured": 0, "evicted": 0}
@@ -188,6 +189,9 @@ class GraphedTrainStep:
         if bk.graph is not None:
             bk.graph.replay()
             bk.replays += 1
+            # the host's count of updates (checkpoints write it, builders.py torch_state_dict) moves once per REAL update:
+            # the replayed kernel counts on the device (step_dev) and never passes FlatAdamW.clip_and_step's `t += 1`
+            step.optimizer.t += 1
             step.after_update()
             self.counts["replay"] += 1
             return "replay"
@@ -195,10 +199,10 @@ class GraphedTrainStep:
         self.counts["eager"] += 1
         if self.use_graphs:  # ... and is captured over the same static inputs for every later batch of the bucket
             g = torch.cuda.CUDAGraph()
-            micro = step.micro
+            micro, t = step.micro, step.optimizer.t  # the capture pass is not a step: host-side counters stay
             with torch.cuda.graph(g, pool=self.pool):
                 self._body(bk)
-            step.micro = micro
+            step.micro, step.optimizer.t = micro, t
             bk.graph = g
             self.counts["captured"] += 1
         return "eager"

@@ -240,7 +240,10 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
     # device -> host round trip per step, see `if fast:` below
     fast = inc is not None and not opt.edits and kwargs.get("sync_free", True)
     if fast:
-        seq_all = torch.full((max_output_length, B * beam_size, max_output_length + 1), pad, dtype=torch.long, device=dev)
+        # what a step leaves behind is its picks (token + the beam it extends), its flags and its scores: O(L * B * k); the
+        # hypotheses themselves are rebuilt on the host from the back-pointers, only for those that get filed
+        tok_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.long, device=dev)
+        parent_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.long, device=dev)
         fin_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.bool, device=dev)
         score_all = torch.zeros((max_output_length, B, beam_size), dtype=torch.float32, device=dev)
         ended = torch.zeros((B, ), dtype=torch.bool, device=dev)
@@ -285,7 +288,10 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             topk_scores = topk_scores.view(-1).index_put((forced_rows, ), torch.zeros_like(forced_rows, dtype=topk_scores.dtype)).view(-1, beam_size)
         batch_index = topk_beam_index + beam_offset[:nb].unsqueeze(1)
         select_indices = batch_index.view(-1)
-        alive_seq = torch.cat([alive_seq.index_select(0, select_indices), topk_ids.view(-1, 1)], -1)
+        if fast:  # only the newest token is read on the device (the decoder keeps its own key / value history)
+            alive_seq = topk_ids.view(-1, 1)
+        else:
+            alive_seq = torch.cat([alive_seq.index_select(0, select_indices), topk_ids.view(-1, 1)], -1)
         is_finished = topk_ids.eq(eos) | is_finished | topk_scores.eq(float("-inf"))
         if step + 1 == max_output_length:
             is_finished.fill_(True)
@@ -297,7 +303,7 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             # utterances do not interact - so every utterance stays in the batch (one captured step graph for the whole search),
             # the step's tensors are kept, and the filing happens once, after the loop, exactly as it would have step by step.
             # Whether everything has ended is asked every SYNC_EVERY steps.
-            seq_all[step, :, :step + 2] = alive_seq
+            tok_all[step], parent_all[step] = topk_ids, topk_beam_index
             fin_all[step], score_all[step] = is_finished, topk_scores
             ended |= end_condition
             n_run = step + 1
@@ -350,19 +356,29 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
 
     if fast:
         # the filing the reference does inside the loop (:683-717,757-781), step by step over what the steps left behind
-        seq_h, fin_h_all, score_h_all = seq_all[:n_run].cpu(), fin_all[:n_run].cpu().numpy(), score_all[:n_run].cpu()
+        tok_h, parent_h = tok_all[:n_run].cpu().numpy(), parent_all[:n_run].cpu().numpy()
+        fin_h_all, score_h_all = fin_all[:n_run].cpu().numpy(), score_all[:n_run].cpu()
+
+        def backtrace(step, i, j):  # hypothesis (i, j) of `step` without BOS, through the beams it extended
+            out = np.empty((step + 1, ), dtype=np.int64)
+            for s in range(step, -1, -1):
+                out[s] = tok_h[s, i, j]
+                j = parent_h[s, i, j]
+            return torch.from_numpy(out)
+
         live = np.ones((B, ), dtype=bool)
+        n_eos = np.zeros((B, beam_size), dtype=np.int64)  # EOS tokens in each live hypothesis so far
         for step in range(n_run):
+            tok = tok_h[step]
+            n_eos = np.take_along_axis(n_eos, parent_h[step], 1) + (tok == eos)
             fin_np = fin_h_all[step]
             if not (fin_np & live[:, None]).any():
                 continue
             end_np = fin_np.all(-1)
-            pred_h = seq_h[step].view(B, beam_size, -1)[:, :, :step + 2]
-            pred_np = pred_h.numpy()
-            n_eos = (pred_np[:, :, 1:] == eos).sum(-1)  # 0: still open, 1: ends here or ended earlier, > 1: collected earlier
-            take = fin_np & live[:, None] & (((n_eos == 0) & (step + 1 == max_output_length)) | ((n_eos == 1) & (pred_np[:, :, -1] == eos)))
+            # n_eos 0: still open, 1: ends here or ended earlier, > 1: collected earlier
+            take = fin_np & live[:, None] & (((n_eos == 0) & (step + 1 == max_output_length)) | ((n_eos == 1) & (tok == eos)))
             for i, j in zip(*np.nonzero(take)):  # row-major: utterances ascending, beams ascending, as the reference's loops
-                hypotheses[i].append((score_h_all[step, i, j], pred_h[i, j, 1:]))
+                hypotheses[i].append((score_h_all[step, i, j], backtrace(step, i, j)))
             for i in np.nonzero(end_np & live)[0]:
                 for n, (score, pred) in enumerate(sorted(hypotheses[i], key=lambda x: x[0], reverse=True)):
                     if n >= n_best:
@@ -395,6 +411,17 @@ def search(model, batch, max_output_length: int, beam_size: int, beam_alpha: flo
     if max_output_length < 0:
         # un-subsampled frame count * 1.5, as the reference computes it (:863-864)
         max_output_length = int(max(batch.src_length.cpu().numpy()) * 1.5)
+    # options the reference derives from the batch (:866-873): source tokens for the source-side penalty / n-gram block,
+    # the forced prefix of a prompted batch
+    if kwargs.get("no_repeat_ngram_size", -1) > 1 or kwargs.get("repetition_penalty", -1) > 1:
+        if batch.src.is_floating_point():
+            # the reference hands the float features to a gather as indices and fails inside torch; say why instead
+            raise ValueError("repetition_penalty / no_repeat_ngram_size read source TOKENS (search.py:866-870); "
+                             "this batch carries speech features")
+        kwargs["encoder_input"] = batch.src
+    if batch.has_trg and batch.trg_prompt_mask is not None:
+        kwargs["decoder_prompt"] = batch.trg_input
+        kwargs["trg_prompt_mask"] = batch.trg_prompt_mask
     if beam_size < 2:
         out, scores, att = transformer_greedy(src_mask=src_mask, max_output_length=max_output_length, model=model,
                                               encoder_output=encoder_output, encoder_hidden=encoder_hidden, **kwargs)

@@ -242,6 +242,97 @@ def golden_model_mt(name="model_mt", V=30, B=5, seed=11, beam=5, alpha=1.0):
     print(name, "loss", total.item(), n_correct.item(), "greedy", gids.shape, "beam", bids.shape, bidsn.shape)
 
 
+def make_vocab_sep(size):
+    """Vocabulary with a prompt marker (sep) - the models that accept forced prefixes need one (model.py:271-282)."""
+    from types import SimpleNamespace
+
+    from joeynmt.vocabulary import Vocabulary
+    cfg = SimpleNamespace(unk_token="<unk>", pad_token="<pad>", bos_token="<s>", eos_token="</s>", sep_token="<sep>", unk_id=0,
+                          pad_id=1, bos_id=2, eos_id=3, sep_id=4, lang_tags=[])
+    return Vocabulary([f"tok{i}" for i in range(size - 5)], cfg)
+
+
+def golden_search_wrapper(name="search_wrapper", V=30, B=5, seed=13, beam=5, alpha=1.0):
+    """The options `search()` DERIVES FROM THE BATCH (search.py:866-873): `encoder_input = batch.src` when a repetition
+    penalty / n-gram block is on, `decoder_prompt` / `trg_prompt_mask` from a prompted batch - through the reference's own
+    `search()` on the transformer_small.yaml model (text source, so that batch.src holds token ids) with a vocabulary that has
+    a prompt marker."""
+    from joeynmt.batch import Batch
+    from joeynmt.model import build_model
+    from joeynmt.search import search
+    torch.manual_seed(43)
+    cfg = small_mt_cfg()
+    model = build_model(copy.deepcopy(cfg), src_vocab=make_vocab_sep(V), trg_vocab=make_vocab_sep(V))
+    assert model.sep_index == 4
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(321)
+        for n, p in model.named_parameters():
+            if "bias" in n or "layer_norm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif "lut" in n:  # a flatter output distribution: the penalty has to be able to change the arg-max
+                p.mul_(0.35)
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    n_tok = torch.randint(4, 11, (B, ), generator=g)
+    n_tok[0] = 10
+    S = int(n_tok.max()) + 1
+    src = torch.full((B, S), SPECIALS["pad"], dtype=torch.long)
+    for b in range(B):
+        n = int(n_tok[b])
+        src[b, :n], src[b, n] = torch.randint(5, 12, (n, ), generator=g), SPECIALS["eos"]  # few distinct words: repeats
+    out = {f"sd.{k}": v for k, v in np_sd(model.state_dict()).items()}
+    out.update(src=src.numpy(), src_length=(n_tok + 1).numpy())
+
+    def plain_batch():
+        return Batch(src=src.clone(), src_length=n_tok + 1, src_prompt_mask=None, trg=None, trg_length=None, trg_prompt_mask=None,
+                     indices=torch.arange(B), device=torch.device("cpu"), pad_index=1, eos_index=3, is_train=False, task="MT")
+
+    # forced prefixes: <s> w w <sep> for some rows, shorter for others (mask 0 behind the prefix), as datasets.py builds them
+    P = 4
+    prm = torch.full((B, P), SPECIALS["pad"], dtype=torch.long)
+    prm_mask = torch.zeros((B, P), dtype=torch.long)
+    prm_len = torch.tensor([4, 3, 4, 2, 3])[:B]
+    for b in range(B):
+        n = int(prm_len[b])
+        prm[b, 0] = SPECIALS["bos"]
+        prm[b, 1:n - 1] = torch.randint(5, V, (n - 2, ), generator=g)
+        prm[b, n - 1] = 4  # <sep>
+        prm_mask[b, :n] = 1
+    out.update(prompt=prm.numpy(), prompt_mask=prm_mask.numpy(), prompt_length=prm_len.numpy())
+
+    def prompted_batch():
+        return Batch(src=src.clone(), src_length=n_tok + 1, src_prompt_mask=None, trg=prm.clone(), trg_length=prm_len.clone(),
+                     trg_prompt_mask=prm_mask.clone(), indices=torch.arange(B), device=torch.device("cpu"), pad_index=1,
+                     eos_index=3, is_train=False, task="MT")
+
+    cases = {
+        "plain_greedy": (plain_batch, dict(beam_size=1, beam_alpha=-1)),
+        "plain_beam": (plain_batch, dict(beam_size=beam, beam_alpha=alpha, n_best=1)),
+        "rep_greedy": (plain_batch, dict(beam_size=1, beam_alpha=-1, repetition_penalty=1.5)),
+        "rep_beam": (plain_batch, dict(beam_size=beam, beam_alpha=alpha, n_best=2, repetition_penalty=1.5)),
+        "ngram_greedy": (plain_batch, dict(beam_size=1, beam_alpha=-1, no_repeat_ngram_size=2)),
+        "ngram_beam": (plain_batch, dict(beam_size=beam, beam_alpha=alpha, n_best=1, no_repeat_ngram_size=2)),
+        "both_beam": (plain_batch, dict(beam_size=3, beam_alpha=alpha, n_best=1, no_repeat_ngram_size=3, repetition_penalty=1.2)),
+        "prompt_greedy": (prompted_batch, dict(beam_size=1, beam_alpha=-1)),
+        "prompt_beam": (prompted_batch, dict(beam_size=beam, beam_alpha=alpha, n_best=1)),
+        "prompt_rep_beam": (prompted_batch, dict(beam_size=beam, beam_alpha=alpha, n_best=1, repetition_penalty=1.5)),
+    }
+    meta = {}
+    with torch.no_grad():
+        for cname, (mk, kw) in cases.items():
+            ids, scores, _ = search(model, mk(), max_output_length=14, return_prob="hyp", generate_unk=False, **kw)
+            out[f"{cname}.ids"], out[f"{cname}.scores"] = ids, scores
+            meta[cname] = {"prompted": mk is prompted_batch, **kw}
+    # the options must have changed something, otherwise the fixture pins nothing
+    assert not np.array_equal(out["plain_greedy.ids"], out["rep_greedy.ids"])
+    assert not np.array_equal(out["plain_greedy.ids"], out["ngram_greedy.ids"])
+    assert not np.array_equal(out["plain_beam.ids"], out["ngram_beam.ids"])
+    assert not np.array_equal(out["plain_beam.ids"], out["prompt_beam.ids"])
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    (OUT / "search_wrapper_cases.json").write_text(json.dumps(meta, indent=1, sort_keys=True) + "\n")
+    print(name, {k: out[f"{k}.ids"].shape for k in cases})
+
+
 def golden_units():
     """Operator-level captures + constants that the reference's own unit tests assert."""
     from joeynmt.data_augmentation import CMVN, SpecAugment
@@ -845,7 +936,7 @@ def main():
         "model_post": lambda: golden_model("model_post", tiny_cfg("post", act="gelu")),
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
         "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
-        "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt, "frontend_general": golden_frontend_general,
+        "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt, "frontend_general": golden_frontend_general, "search_wrapper": golden_search_wrapper,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

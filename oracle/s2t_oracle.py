@@ -635,6 +635,23 @@ def beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor
     return out, scores
 
 
+
+def search_text(sd: SD, cfg: dict, specials: dict, batch: dict, max_output_length: int, beam_size: int, beam_alpha: float,
+                n_best: int = 1, **kwargs):
+    """search, search.py:828-912, for a text-source batch {src, src_length[, trg_input, trg_prompt_mask]}: encode once; the
+    options it derives from the batch (:866-873) - source tokens for the source-side penalty / n-gram block, the forced prefix
+    of a prompted batch - then greedy (beam_size < 2) or beam search -> (ids, scores)."""
+    enc, src_mask = encoder_forward_text(sd, cfg, batch["src"], specials["pad"])
+    if max_output_length < 0:
+        max_output_length = int(max(batch["src_length"].numpy()) * 1.5)
+    if kwargs.get("no_repeat_ngram_size", -1) > 1 or kwargs.get("repetition_penalty", -1) > 1:
+        kwargs["encoder_input"] = batch["src"]
+    if batch.get("trg_prompt_mask") is not None:
+        kwargs["decoder_prompt"], kwargs["trg_prompt_mask"] = batch["trg_input"], batch["trg_prompt_mask"]
+    if beam_size < 2:
+        return greedy(sd, cfg, specials, enc, src_mask, max_output_length, return_prob=True, **kwargs)[:2]
+    return beam_search(sd, cfg, specials, enc, src_mask, beam_size, max_output_length, beam_alpha, n_best=n_best, **kwargs)
+
 # --------------------------------------------------------------------------------------------------
 # audio front-end (reference helpers_for_audio.py, data_augmentation.py; Kaldi fbank from the published spec)
 # --------------------------------------------------------------------------------------------------

@@ -159,3 +159,46 @@ def test_bucket_padding_matches_unpadded_features(device):
     T = x_ref.shape[1]
     assert torch.equal(lens, len_ref) and torch.equal(mask[:, :, :T], mask_ref) and not bool(mask[:, :, T:].any())
     torch.testing.assert_close(x[:, :T], x_ref, rtol=1e-6, atol=1e-6)
+
+
+def test_update_count_and_checkpoint_after_graphed_steps(device, tmp_path):
+    """The host's update count follows the REAL updates (first sights run eagerly + a capture pass, replays never reach
+    FlatAdamW.clip_and_step): optimizer.t == step.steps == step_dev; a checkpoint written after graphed steps resumes onto the
+    parameters of the run that went on (Adam's bias correction reads the count)."""
+    from joeys2t_amd.graphed import GraphedTrainStep
+    from test_hip_config_width import make_model
+    torch.manual_seed(3)
+    base = make_model(_cfg(), V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    proc = _proc()
+    proc.specaugment = None
+    batches = _batches(5, 3) + _batches(10, 2, lo=52000, hi=56000) + _batches(6, 2)  # two buckets: 2 first sights, 5 replays
+    step = _make(sd, device, torch.float32)
+    # two plain updates first: the graphed driver must start counting from them
+    np.random.seed(11)
+    _plain_run(step, proc, _batches(4, 2), device, torch.float32)
+    assert step.optimizer.t == 2
+    gs = GraphedTrainStep(step, proc, compute_dtype=torch.float32, frame_bucket=128, target_bucket=16)
+    assert int(step.optimizer.step_dev) == 2
+    how = [gs.run(w.to(device), ns, trg, tl) for w, ns, trg, tl in batches[:5]]
+    assert how.count("eager") == 2 and how.count("replay") == 3, how
+    assert step.optimizer.t == step.steps == int(step.optimizer.step_dev) == 7
+    path = tmp_path / "after_graphed.ckpt"
+    step.save_checkpoint(path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert {float(s["step"]) for s in ckpt["optimizer_state"]["state"].values()} == {7.0}
+    for w, ns, trg, tl in batches[5:]:
+        gs.run(w.to(device), ns, trg, tl)
+    torch.cuda.synchronize()
+    flat_on = step.store.flat.detach().clone()
+    # resume a fresh driver from the checkpoint and make the same two updates
+    step2 = _make(sd, device, torch.float32)
+    step2.init_from_checkpoint(path)
+    assert step2.optimizer.t == 7 and step2.steps == 7
+    gs2 = GraphedTrainStep(step2, proc, compute_dtype=torch.float32, frame_bucket=128, target_bucket=16)
+    for w, ns, trg, tl in batches[5:]:
+        gs2.run(w.to(device), ns, trg, tl)
+    torch.cuda.synchronize()
+    rel = ((step2.store.flat - flat_on).norm() / flat_on.norm()).item()
+    assert rel < 1e-6, rel
+    assert step2.optimizer.t == step2.steps == int(step2.optimizer.step_dev) == 9

@@ -321,6 +321,32 @@ def test_text_source_model_matches_reference():
         np.testing.assert_allclose(scores.numpy(), g["beam_scores_nbest"], rtol=1e-4, atol=1e-4)
 
 
+def test_search_wrapper_options_match_reference():
+    """The options search() derives from the batch (search.py:866-873) - tests/golden/search_wrapper.npz, captured from the
+    reference's own search() - against the oracle's restatement: ids bit-exact, scores 1e-4."""
+    import json
+    from pathlib import Path
+    from golden_cfg import mt_cfg
+    g = load_golden("search_wrapper")
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "search_wrapper_cases.json").read_text())
+    cfg = oracle_cfg(mt_cfg())
+    sd = {k: v for k, v in golden_sd(g).items() if not k.endswith("pe.pe")}
+    sd["decoder.output_layer.weight"] = sd["trg_embed.lut.weight"]
+    specials = dict(SPECIALS, sep=4, all=[0, 1, 2, 3, 4])
+    prm, pmask = torch.from_numpy(g["prompt"]), torch.from_numpy(g["prompt_mask"])
+    for name, kw in sorted(cases.items()):
+        kw = dict(kw)
+        batch = {"src": torch.from_numpy(g["src"]), "src_length": torch.from_numpy(g["src_length"])}
+        if kw.pop("prompted"):
+            # Batch.__init__ (batch.py:82-96): EOS -> PAD in the teacher-forcing input, no column dropped without an EOS
+            batch["trg_input"], batch["trg_prompt_mask"] = prm, pmask
+        with torch.no_grad():
+            ids, scores = O.search_text(sd, cfg, specials, batch, 14, kw.pop("beam_size"), kw.pop("beam_alpha"),
+                                        n_best=kw.pop("n_best", 1), generate_unk=False, **kw)
+        assert np.array_equal(ids.numpy(), g[f"{name}.ids"]), name
+        np.testing.assert_allclose(scores.numpy(), g[f"{name}.scores"], rtol=1e-4, atol=1e-4, err_msg=name)
+
+
 def _frontend_general_cases():
     import json
     from pathlib import Path
