@@ -490,6 +490,23 @@ int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_b
                float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev,
                float gscale, int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream);
 
+/* The same update over a table of pieces of the flat store, fused with what is derived from the new weights (the two launches
+ * that used to follow every update: js2t_transpose_groups, js2t_fold_ln_weights):
+ *   items int64[n_items, 8] = {kind, off, rows, cols, first unit, fold row | -1, 0, 0}, units numbered consecutively;
+ *   kind 0: elements [off, off + rows) (off, rows multiples of 4), ceil(rows / flat_unit) units;
+ *   kind 1: a row-major fp32 [rows, cols] matrix at element `off` (off % 4 == 0, cols % 4 == 0),
+ *           ceil(rows / unit_rows) * ceil(cols / unit_cols) units; with lp_t_bf16 its transposed bf16 image is written at
+ *           lp_t_bf16 + off as [cols, rows]; fold (cols <= unit_cols only) names a row of `folds`, the table of
+ *           js2t_fold_ln_weights, whose W is this matrix: Wf and bias_f of that row are written from the NEW weights and the
+ *           CURRENT gamma / beta / bias (update those in an earlier launch).
+ * Replaces, per optimizer update, torch.optim.AdamW.step (builders.py:112-114) + the re-derivation of every compute-dtype
+ * copy of the weights.  js2t_adamw_items_geometry reports {flat_unit, unit_rows, unit_cols}. */
+int js2t_adamw_items(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_bf16, void* lp_t_bf16,
+                     const int64_t* items, int32_t n_items, int64_t n_units, const int64_t* folds, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev, float gscale,
+                     int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream);
+void js2t_adamw_items_geometry(int32_t* flat_unit, int32_t* rows, int32_t* cols);
+
 /* --------------------------------------------------------------------------------------------------
  * Beam-search step (search.py:562-646): per live batch element, over its `beam` hypotheses:
  *   log_softmax(logits[row,:]) ; forbidden ids := -inf (search.py:590-601; forbid_ids is a HOST array) ;

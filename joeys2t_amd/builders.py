@@ -60,6 +60,9 @@ def _off(t, lo: int):
     return None if t is None else _C.c_void_p(t.data_ptr() + lo * t.element_size())
 
 
+FUSED_UPDATE = True  # js2t_adamw_items: update + transposed shadows + LayerNorm-fold weights in one pass (False: separate passes)
+
+
 class FlatAdamW:
     """AdamW over a runtime.ParamStore: one fused kernel (js2t_adamw) updates the fp32 master, both moments, the
     bf16 shadow and clears the gradient buffer.  Numerically the torch.optim.AdamW update the reference builds at
@@ -81,6 +84,7 @@ class FlatAdamW:
         self.step_dev = torch.zeros((1, ), dtype=torch.int64, device=store.device)
         self.device_schedule = False
         self.update_ranges = trainable_ranges(store)
+        self._plan_key, self._plan = None, None
 
 
     def clip_and_step(self, max_norm: Optional[float], grad_scale: float = 1.0, zero_grad: bool = True):
@@ -99,6 +103,22 @@ class FlatAdamW:
         if self.device_schedule:  # graph-replayable form: count and learning rate live on the device
             self.step_dev.add_(1)
             lr_dev, step_dev = self.lr_dev, self.step_dev
+        plan = self._fused_plan()
+        if plan is not None:
+            # one table-driven kernel, launched twice: the 1-D parameters first (a LayerNorm fold reads the NEW gamma / beta /
+            # bias), then the matrices - each block also writes the transposed bf16 image and the fold weights of its rows
+            args = (_C.c_float(g["lr"]), _C.c_float(g["betas"][0]), _C.c_float(g["betas"][1]), _C.c_float(g["eps"]),
+                    _C.c_float(g["weight_decay"]), _C.c_int64(self.t), ops._p(coef), _C.c_float(grad_scale), int(zero_grad),
+                    ops._p(lr_dev), ops._p(step_dev), ops._stream())
+            for table, n_items, n_units in plan["launches"]:
+                check(lib().js2t_adamw_items(ops._p(st.flat), ops._p(st.flat_grad), ops._p(self.exp_avg), ops._p(self.exp_avg_sq),
+                                             ops._p(lp), ops._p(st.flat_lp_t if lp is not None else None), ops._p(table),
+                                             _C.c_int32(n_items), _C.c_int64(n_units), ops._p(plan["folds"]), *args), "js2t_adamw_items")
+            ops.WEIGHT_VERSION += 1
+            st.dirty = lp is None and st.dirty
+            if plan["left_folds"] is not None:  # folds whose matrix the kernel does not cover (wider than a unit, part of a group)
+                ops.fold_ln_weights(plan["left_folds"], plan["left_folds"].shape[0], plan["left_max_rows"])
+            return
         # torch.optim.AdamW skips parameters without a gradient: frozen sub-networks (`freeze: True`) get no weight decay
         # and no moment update - one launch per contiguous trainable range (the whole store when nothing is frozen)
         for lo, hi in self.update_ranges:
@@ -113,6 +133,58 @@ class FlatAdamW:
             st.refresh_t()  # transposed shadows follow the updated weights (one kernel; part of the captured step)
         if lp is not None:
             st.refresh_folds()  # gamma-scaled weights of the LayerNorm folds, likewise
+
+    def _fused_plan(self):
+        """Tables of js2t_adamw_items for the store as it is now (which matrices have a transposed shadow, which LayerNorm folds
+        exist - both appear with the first forward pass), or None: frozen parameters / a matrix the kernel's 16-byte accesses
+        do not fit -> the plain kernel + separate passes.  Rebuilt when the store's derived state has changed."""
+        st = self.store
+        if not FUSED_UPDATE or self.update_ranges != [(0, st.total)]:
+            return None
+        key = (len(st._fold_rows), st.flat_lp is not None, st.flat_lp_t is not None)
+        if self._plan_key == key:
+            return self._plan
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdamW: the store changed (new LayerNorm folds / shadows) after the last eager update: "
+                               "run one eager step before capturing")
+        self._plan_key, self._plan = key, None
+        from joeys2t_amd._lib import lib
+        geo = [_C.c_int32() for _ in range(3)]
+        lib().js2t_adamw_items_geometry(*[_C.byref(v) for v in geo])
+        flat_unit, unit_rows, unit_cols = (int(v.value) for v in geo)
+        mats = sorted((off, R, Cc) for off, R, Cc, _ in st._tgroups)
+        if any(Cc % 4 or off % 4 for off, R, Cc in mats):
+            return None
+        base = st.flat.data_ptr()
+        fold_of, left = {}, []
+        for i, row in enumerate(st._fold_rows):  # {W, gamma, beta, bias, Wf, bias_f, N, K}
+            hit = [(off, R, Cc) for off, R, Cc in mats if base + 4 * off == row[0] and R == row[6] and Cc == row[7]]
+            if hit and row[7] <= unit_cols and hit[0][0] not in fold_of:
+                fold_of[hit[0][0]] = i
+            else:
+                left.append(row)
+        small, big, pos = [], [], 0
+        for off, R, Cc in mats:
+            if off > pos:
+                small.append([0, pos, off - pos, 1, 0, -1, 0, 0])
+            big.append([1, off, R, Cc, 0, fold_of.get(off, -1), 0, 0])
+            pos = off + R * Cc
+        if st.total > pos:
+            small.append([0, pos, st.total - pos, 1, 0, -1, 0, 0])
+        launches = []
+        for items in (small, big):
+            if not items:
+                continue
+            units = 0
+            for it in items:
+                it[4] = units
+                units += -(-it[2] // flat_unit) if it[0] == 0 else -(-it[2] // unit_rows) * -(-it[3] // unit_cols)
+            launches.append((torch.tensor(items, dtype=torch.int64, device=st.device), len(items), units))
+        folds = torch.tensor(st._fold_rows, dtype=torch.int64, device=st.device) if st._fold_rows else None
+        self._plan = {"launches": launches, "folds": folds,
+                      "left_folds": torch.tensor(left, dtype=torch.int64, device=st.device) if left else None,
+                      "left_max_rows": max((r[6] for r in left), default=0)}
+        return self._plan
 
     def state_dict(self) -> Dict:
         return {"t": self.t, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": self.param_groups}

@@ -80,6 +80,156 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
   }
 }
 
+// ---------------------------------------------------------------- one pass for AdamW AND everything derived from the new weights
+// The update used to be followed by three passes over the weights it had just written: the bf16 shadow -> transposed bf16
+// shadow (js2t_transpose_groups: 186 MB in, 186 MB out), the fp32 masters -> gamma-scaled, row-centred LayerNorm-fold weights
+// (js2t_fold_ln_weights: 184 MB in, 92 MB out).  Here the block that updates a piece of a weight matrix also writes its
+// transposed bf16 image (through LDS) and, for a matrix a LayerNorm is folded into, the fold's weights and bias, while the new
+// values are in registers.
+// items: int64[n, 8] = {kind, off, rows, cols, first unit, fold row | -1, 0, 0}
+//   kind 0: elements [off, off + rows) of the flat buffers, units of ADAM_FLAT elements;
+//   kind 1: a row-major [rows, cols] matrix at off (cols % 4 == 0, off % 4 == 0), units of ADAM_ROWS rows x ADAM_COLS columns; its
+//           transposed image goes to lp_t + off as [cols, rows] when lp_t is given; fold (only for cols <= ADAM_COLS) names a
+//           row of `folds` = js2t_fold_ln_weights's table {W, gamma, beta, bias | 0, Wf, bias_f, N, K} whose W is this matrix.
+// A fold reads the NEW gamma / beta / bias: the caller updates the 1-D parameters in a launch of their own first.
+constexpr int ADAM_FLAT = 8192, ADAM_ROWS = 32, ADAM_COLS = 512, ADAM_PITCH = ADAM_COLS + 4;
+
+struct AdamConsts {
+  float lr, b1, b2, eps, wd, bc2_sqrt, step_size, gs;
+};
+
+__device__ __forceinline__ void adam4(float (&pa)[4], const float4 gv, float (&ma)[4], float (&va)[4], const AdamConsts& k) {
+  const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float gk = ga[i] * k.gs;
+    pa[i] *= 1.f - k.lr * k.wd;
+    ma[i] = k.b1 * ma[i] + (1.f - k.b1) * gk;
+    va[i] = k.b2 * va[i] + (1.f - k.b2) * gk * gk;
+    const float denom = sqrtf(va[i]) / k.bc2_sqrt + k.eps;
+    pa[i] -= k.step_size * (ma[i] / denom);
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_items_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, uint16_t* __restrict__ lp, uint16_t* __restrict__ lp_t,
+                                                          const int64_t* __restrict__ items, int n_items,
+                                                          const int64_t* __restrict__ folds, float lr, float b1, float b2, float eps,
+                                                          float wd, float bc1, float bc2_sqrt, const float* __restrict__ gscale_dev,
+                                                          float gscale, int zero_grad, const float* __restrict__ lr_dev,
+                                                          const int64_t* __restrict__ step_dev) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[ADAM_ROWS * ADAM_PITCH];
+  AdamConsts k;
+  k.gs = gscale * (gscale_dev ? *gscale_dev : 1.f);
+  if (lr_dev) lr = *lr_dev;
+  if (step_dev) {
+    const double t = (double)(*step_dev);
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  k.lr = lr, k.b1 = b1, k.b2 = b2, k.eps = eps, k.wd = wd, k.bc2_sqrt = bc2_sqrt, k.step_size = lr / bc1;
+  const int64_t bid = blockIdx.x;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {  // last item whose first unit <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid * 8 + 4] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* it = items + 8 * lo;
+  const int64_t kind = it[0], off = it[1], R = it[2], Cc = it[3], u = bid - it[4], fold = it[5];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kind == 0) {
+    const int64_t base = off + u * ADAM_FLAT, end = min(off + R, base + (int64_t)ADAM_FLAT);
+    for (int64_t i = base + threadIdx.x * 4; i < end; i += 1024) {  // ranges are multiples of 4 elements (checked by the host)
+      const float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+      float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+      adam4(pa, gv, ma, va, k);
+      *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+      *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+      *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+      if (zero_grad) *(float4*)(g + i) = zero4;
+      if (lp) *(uint2*)(lp + i) = make_uint2(pack_bf16x2(pa[0], pa[1]), pack_bf16x2(pa[2], pa[3]));
+    }
+    return;
+  }
+  const int64_t chunks = (Cc + ADAM_COLS - 1) / ADAM_COLS;
+  const int64_t strip = u / chunks, r0 = strip * ADAM_ROWS, c0 = (u - strip * chunks) * ADAM_COLS;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t* fe = (fold >= 0 && chunks == 1) ? folds + 8 * fold : nullptr;
+  float4 gam[2] = {zero4, zero4}, bet[2] = {zero4, zero4};
+  if (fe) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t c = 4 * lane + 256 * j;
+      if (c < Cc) gam[j] = *(const float4*)((const float*)fe[1] + c), bet[j] = *(const float4*)((const float*)fe[2] + c);
+    }
+  }
+#pragma unroll 2
+  for (int rr = 0; rr < ADAM_ROWS / 4; ++rr) {
+    const int lr_ = wave * (ADAM_ROWS / 4) + rr;  // row inside the strip
+    const int64_t r = r0 + lr_;
+    if (r >= R) break;  // (uniform over the wave)
+    float pn[2][4];
+    float cs = 0.f, bs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t cl = 4 * lane + 256 * j, c = c0 + cl;
+      if (c < Cc) {
+        const int64_t i = off + r * Cc + c;
+        const float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+        float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+        adam4(pa, gv, ma, va, k);
+        *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+        if (zero_grad) *(float4*)(g + i) = zero4;
+        const uint2 pk = make_uint2(pack_bf16x2(pa[0], pa[1]), pack_bf16x2(pa[2], pa[3]));
+        if (lp) *(uint2*)(lp + i) = pk;
+        *(uint2*)(tile + lr_ * ADAM_PITCH + cl) = pk;
+        if (fe) {  // same order of additions as fold_ln_weights_kernel
+          cs += (pa[0] * gam[j].x + pa[1] * gam[j].y) + (pa[2] * gam[j].z + pa[3] * gam[j].w);
+          bs += (pa[0] * bet[j].x + pa[1] * bet[j].y) + (pa[2] * bet[j].z + pa[3] * bet[j].w);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pn[j][e] = pa[e];
+        }
+      }
+    }
+    if (fe) {
+      cs = wave_sum(cs) / (float)Cc, bs = wave_sum(bs);
+      uint16_t* Wf = (uint16_t*)fe[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t c = 4 * lane + 256 * j;
+        if (c < Cc)
+          *(uint2*)(Wf + r * Cc + c) = make_uint2(pack_bf16x2(fmaf(pn[j][0], gam[j].x, -cs), fmaf(pn[j][1], gam[j].y, -cs)),
+                                                  pack_bf16x2(fmaf(pn[j][2], gam[j].z, -cs), fmaf(pn[j][3], gam[j].w, -cs)));
+      }
+      if (lane == 0) {
+        const float* bias = (const float*)fe[3];
+        ((float*)fe[5])[r] = bs + (bias ? bias[r] : 0.f);
+      }
+    }
+  }
+  if (lp_t == nullptr) return;
+  __syncthreads();
+  // the strip's columns out as rows of the transposed image: 8 rows of one column per thread (16 bytes)
+  const int64_t ncol = min((int64_t)ADAM_COLS, Cc - c0);
+  const bool vec = ((R | off) & 7) == 0;
+  for (int64_t cl = threadIdx.x >> 2; cl < ncol; cl += 64) {
+    const int r8 = (threadIdx.x & 3) * 8;
+    if (r0 + r8 >= R) continue;
+    uint16_t e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = tile[(r8 + q) * ADAM_PITCH + cl];
+    uint16_t* dst = lp_t + off + (c0 + cl) * R + r0 + r8;
+    if (vec) {
+      *(uint4*)dst = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                                e[6] | ((uint32_t)e[7] << 16));
+    } else {
+      for (int q = 0; q < 8 && r0 + r8 + q < R; ++q) dst[q] = e[q];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t js2t_sumsq_partials(int64_t n) { return (n + SQ_PER_BLOCK - 1) / SQ_PER_BLOCK; }
@@ -110,4 +260,25 @@ extern "C" int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq,
                      zero_grad, lr_dev, step_dev);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
+}
+
+extern "C" int js2t_adamw_items(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_bf16, void* lp_t_bf16,
+                                const int64_t* items, int32_t n_items, int64_t n_units, const int64_t* folds, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, const float* gscale_dev, float gscale,
+                                int zero_grad, const float* lr_dev, const int64_t* step_dev, js2t_stream stream) {
+  JS2T_CHECK(p && g && exp_avg && exp_avg_sq && items && n_items > 0 && n_units > 0 && n_units < 0x7fffffff && step >= 1,
+             "adamw_items: bad arguments");
+  JS2T_CHECK(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)lp_bf16) |
+               ((uintptr_t)lp_t_bf16)) & 15) == 0, "adamw_items: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_items_kernel, dim3((unsigned)n_units), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
+                     (uint16_t*)lp_bf16, (uint16_t*)lp_t_bf16, items, (int)n_items, folds, lr, beta1, beta2, eps, weight_decay,
+                     (float)bc1, (float)sqrt(bc2), gscale_dev, gscale, zero_grad, lr_dev, step_dev);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" void js2t_adamw_items_geometry(int32_t* flat_unit, int32_t* rows, int32_t* cols) {
+  *flat_unit = ADAM_FLAT, *rows = ADAM_ROWS, *cols = ADAM_COLS;
 }
