@@ -119,6 +119,9 @@ typedef struct js2t_gemm_desc {
   float* c8_scale_out;
   float* fp8_state;         /* e4m3 products: delayed-scale state of the kernel that quantised A (js2t_layernorm_fwd_fp8): block 0 hands
                              * the collected maximum over, state[0] = state[1] / 448, state[1] *= 15/16 (decayed, not cleared), when the product is done */
+  float* sumsq_partial;     /* js2t_gemm_grouped only (f32 C, no split-K, N % 128 == 0): block b of the launch stores the sum of squares
+                             * of the C values it wrote to sumsq_partial[b], b < js2t_gemm_grouped_blocks(M, N, count) - the weight
+                             * gradients' share of clip_grad_norm_'s norm (builders.py:68-71) without a pass over them */
 } js2t_gemm_desc;
 
 int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
@@ -131,6 +134,8 @@ int js2t_gemm(const js2t_gemm_desc* d, js2t_stream stream);
 #define JS2T_GEMM_GROUP_MAX 32
 int js2t_gemm_grouped(const js2t_gemm_desc* d, int32_t count, const void* const* A, const void* const* B, void* const* C,
                       float* const* a_rowsum, js2t_stream stream);
+/* number of blocks (= entries of sumsq_partial written) of an un-split js2t_gemm_grouped launch */
+int64_t js2t_gemm_grouped_blocks(int32_t M, int32_t N, int32_t count);
 /* Test hook: when on, bf16 GEMMs use the register-staged kernel (the one implicit-conv operands always use)
  * instead of the LDS-DMA kernel, so both can be checked against each other. */
 void js2t_gemm_force_regstage(int on);
@@ -481,6 +486,12 @@ int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int
  * partial: f32[js2t_sumsq_partials(n)] workspace. */
 int64_t js2t_sumsq_partials(int64_t n);
 int js2t_grad_norm_clip(const float* g, int64_t n, float max_norm, float* partial, float* out2, js2t_stream stream);
+/* The same in two steps, for a gradient whose norm is collected piecewise: js2t_sumsq_ranges adds the partial sums of squares
+ * of n_ranges pieces of g (table int64[n_ranges, 3] on the device: {first element, elements, first partial}; a piece of n
+ * elements takes js2t_sumsq_partials(n) partials) to what other kernels left in `partial` (js2t_gemm_desc.sumsq_partial);
+ * js2t_norm_clip turns partial[0 .. n_partial) into out2 = {norm, clip coefficient}. */
+int js2t_sumsq_ranges(const float* g, const int64_t* table, int32_t n_ranges, int64_t n_blocks, float* partial, js2t_stream stream);
+int js2t_norm_clip(const float* partial, int64_t n_partial, float max_norm, float* out2, js2t_stream stream);
 
 /* torch.optim.AdamW step (builders.py:112-114) over flat fp32 buffers, gradient pre-scaled by
  * gscale * (*gscale_dev) (clip coefficient / loss-scale), optional bf16 shadow write and gradient clear.
@@ -492,7 +503,8 @@ int js2t_adamw(float* p, float* g, float* exp_avg, float* exp_avg_sq, void* lp_b
 
 /* The same update over a table of pieces of the flat store, fused with what is derived from the new weights (the two launches
  * that used to follow every update: js2t_transpose_groups, js2t_fold_ln_weights):
- *   items int64[n_items, 8] = {kind, off, rows, cols, first unit, fold row | -1, 0, 0}, units numbered consecutively;
+ *   items int64[n_items, 8] = {kind, off, rows, cols, first unit, fold row | -1, keep gradient, 0}, units numbered
+ *   consecutively; "keep gradient" != 0: this piece's gradient is NOT cleared even with zero_grad (its producer overwrites it);
  *   kind 0: elements [off, off + rows) (off, rows multiples of 4), ceil(rows / flat_unit) units;
  *   kind 1: a row-major fp32 [rows, cols] matrix at element `off` (off % 4 == 0, cols % 4 == 0),
  *           ceil(rows / unit_rows) * ceil(cols / unit_cols) units; with lp_t_bf16 its transposed bf16 image is written at

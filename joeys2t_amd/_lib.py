@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
         ("ln_partial", C.c_void_p), ("ln_eps", C.c_float), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("rs_partial", C.c_void_p),
         ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_state", C.c_void_p), ("c8_mul", C.c_void_p), ("c8_scale_out", C.c_void_p),
         ("fp8_state", C.c_void_p),
+        ("sumsq_partial", C.c_void_p),
     ]
 
 
@@ -89,6 +90,8 @@ def lib():
         _lib.js2t_colsum_partial_rows.argtypes = [C.c_int64]
         _lib.js2t_sumsq_partials.restype = C.c_int64
         _lib.js2t_sumsq_partials.argtypes = [C.c_int64]
+        _lib.js2t_gemm_grouped_blocks.restype = C.c_int64
+        _lib.js2t_gemm_grouped_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)
             _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
         if "JS2T_P192_RING" in os.environ:  # 2 = two blocks per CU with a two-slot ring (js2t_gemm_p192_ring)

@@ -60,7 +60,62 @@ def _off(t, lo: int):
     return None if t is None else _C.c_void_p(t.data_ptr() + lo * t.element_size())
 
 
-FUSED_UPDATE = True  # js2t_adamw_items: update + transposed shadows + LayerNorm-fold weights in one pass (False: separate passes)
+import os as _os  # noqa: E402
+
+FUSED_UPDATE = _os.environ.get("JS2T_FUSED_UPDATE", "1") != "0"  # js2t_adamw_items: update + transposed shadows + LayerNorm-fold weights in one pass (False: separate passes)
+
+
+class SumsqCollector:
+    """Where clip_grad_norm_'s sum of squares (builders.py:68-71) comes from when parts of it are left behind by the kernels
+    that write the gradient: the un-split weight-gradient products store per-block sums of the values they write
+    (js2t_gemm_desc.sumsq_partial) into segments of `partial`; finish() adds the pieces of the flat gradient nobody covered
+    (js2t_sumsq_ranges) and turns everything into {norm, clip coefficient} (js2t_norm_clip)."""
+
+    def __init__(self, grad: torch.Tensor, total: int):
+        from joeys2t_amd._lib import lib
+        self.grad, self.total = grad, total
+        self.per_block = int(total // max(1, lib().js2t_sumsq_partials(_C.c_int64(total)))) or 1
+        cap = 2 * int(lib().js2t_sumsq_partials(_C.c_int64(total))) + 8192
+        self.partial = torch.zeros((cap, ), dtype=torch.float32, device=grad.device)
+        self.pos, self.covered = 0, []
+        self._tables: Dict[tuple, tuple] = {}
+
+    def reset(self):
+        self.pos, self.covered = 0, []
+
+    def segment(self, n_blocks: int, spans):
+        if self.pos + n_blocks > self.partial.numel():
+            raise RuntimeError("SumsqCollector: partial buffer exhausted")
+        seg = self.partial[self.pos:self.pos + n_blocks]
+        self.pos += n_blocks
+        self.covered.extend(spans)
+        return seg
+
+    def finish(self, max_norm: float, out2: torch.Tensor):
+        from joeys2t_amd import ops
+        from joeys2t_amd._lib import check, lib
+        from joeys2t_amd.runtime import RangeSet
+        key = (self.pos, tuple(sorted(self.covered)))
+        hit = self._tables.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("SumsqCollector: a new coverage pattern during capture - run one eager step first")
+            rest = RangeSet([(0, self.total)]).minus(self.covered)
+            rows, pb = [], self.pos
+            for lo, hi in rest:
+                rows.append([lo, hi - lo, pb])
+                pb += int(lib().js2t_sumsq_partials(_C.c_int64(hi - lo)))
+            if pb > self.partial.numel():
+                raise RuntimeError("SumsqCollector: partial buffer exhausted")
+            table = torch.tensor(rows, dtype=torch.int64, device=self.grad.device) if rows else None
+            hit = self._tables[key] = (table, len(rows), pb - self.pos, pb)
+        table, n_ranges, n_blocks, n_partial = hit
+        if n_ranges:
+            check(lib().js2t_sumsq_ranges(ops._p(self.grad), ops._p(table), _C.c_int32(n_ranges), _C.c_int64(n_blocks), ops._p(self.partial),
+                                          ops._stream()), "js2t_sumsq_ranges")
+        check(lib().js2t_norm_clip(ops._p(self.partial), _C.c_int64(n_partial), _C.c_float(max_norm), ops._p(out2), ops._stream()),
+              "js2t_norm_clip")
+        self.reset()
 
 
 class FlatAdamW:
@@ -85,6 +140,10 @@ class FlatAdamW:
         self.device_schedule = False
         self.update_ranges = trainable_ranges(store)
         self._plan_key, self._plan = None, None
+        # set by TrainStep: runtime.RangeSet of gradient elements the update leaves un-cleared (their producers overwrite them,
+        # runtime.WgradQueue) and the collector the weight-gradient epilogues leave their sums of squares with
+        self.keep = None
+        self.collector: Optional[SumsqCollector] = None
 
 
     def clip_and_step(self, max_norm: Optional[float], grad_scale: float = 1.0, zero_grad: bool = True):
@@ -94,9 +153,14 @@ class FlatAdamW:
         st, g = self.store, self.param_groups[0]
         coef = None
         if max_norm is not None and max_norm > 0:
-            check(lib().js2t_grad_norm_clip(ops._p(st.flat_grad), _C.c_int64(st.total), _C.c_float(max_norm),
-                                            ops._p(self._partial), ops._p(self.norm_clip), ops._stream()), "js2t_grad_norm_clip")
+            if self.collector is not None and self.collector.covered:
+                self.collector.finish(max_norm, self.norm_clip)  # the products' epilogues hold most of the sum already
+            else:
+                check(lib().js2t_grad_norm_clip(ops._p(st.flat_grad), _C.c_int64(st.total), _C.c_float(max_norm),
+                                                ops._p(self._partial), ops._p(self.norm_clip), ops._stream()), "js2t_grad_norm_clip")
             coef = self.norm_clip[1:2]
+        if self.collector is not None:
+            self.collector.reset()
         self.t += 1
         lp = st.flat_lp
         lr_dev = step_dev = None
@@ -141,7 +205,7 @@ class FlatAdamW:
         st = self.store
         if not FUSED_UPDATE or self.update_ranges != [(0, st.total)]:
             return None
-        key = (len(st._fold_rows), st.flat_lp is not None, st.flat_lp_t is not None)
+        key = (len(st._fold_rows), st.flat_lp is not None, st.flat_lp_t is not None, None if self.keep is None else self.keep.version)
         if self._plan_key == key:
             return self._plan
         if torch.cuda.is_current_stream_capturing():
@@ -167,7 +231,8 @@ class FlatAdamW:
         for off, R, Cc in mats:
             if off > pos:
                 small.append([0, pos, off - pos, 1, 0, -1, 0, 0])
-            big.append([1, off, R, Cc, 0, fold_of.get(off, -1), 0, 0])
+            kept = int(self.keep is not None and self.keep.contains(off, off + R * Cc))  # overwritten by its producer: not cleared
+            big.append([1, off, R, Cc, 0, fold_of.get(off, -1), kept, 0])
             pos = off + R * Cc
         if st.total > pos:
             small.append([0, pos, st.total - pos, 1, 0, -1, 0, 0])

@@ -623,6 +623,8 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
     if (fast) {
       const bool relu = d.act == JS2T_ACT_RELU, has_res = d.residual != nullptr, has_gate = d.gate != nullptr;
       const bool has_drop = d.dropout_p > 0.f;
+      const bool want_ss = d.sumsq_partial != nullptr && !bf16_out;
+      float ss = 0.f;
       const float keep_scale = 1.f / (1.f - d.dropout_p), res_scale = d.res_scale, gate_scale = d.gate_scale;
       const uint16_t* resp = (const uint16_t*)d.residual + n;
       const uint16_t* gatep = (const uint16_t*)d.gate + n;
@@ -687,8 +689,16 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
             }
             *(float4*)((float*)d.C + coff) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)((float*)d.C + coff + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            if (want_ss) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) ss = fmaf(v[i], v[i], ss);
+            }
           }
         }
+      }
+      if (want_ss) {  // (js2t_gemm_grouped has checked that every tile of the launch takes this path)
+        ss = block_sum(ss, (float*)smem);  // over the staged tile: block_sum starts with a barrier, every thread has read its rows
+        if (t == 0) d.sumsq_partial[blockIdx.x] = ss;
       }
     } else {
       const uint4 none = make_uint4(0u, 0u, 0u, 0u);
@@ -2556,6 +2566,12 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
              "gemm_grouped: plain epilogue only (alpha, beta)");
   if (d.split_k < 1) d.split_k = 1;
   JS2T_CHECK(d.split_k == 1 || (d.dtype_c == JS2T_F32 && d.beta == 0.f), "gemm_grouped: split_k needs f32 C and beta = 0");
+  if (d.sumsq_partial) {
+    // every tile must take the epilogue's row-segment path: whole 128-column tiles, 16-byte aligned f32 rows
+    JS2T_CHECK(d.split_k == 1 && d.dtype_c == JS2T_F32 && (d.N & 127) == 0 && (d.ldc & 3) == 0,
+               "gemm_grouped: sumsq_partial needs f32 C, no split-K, N % 128 == 0, ldc % 4 == 0");
+    for (int i = 0; i < count; ++i) JS2T_CHECK(aligned16(C[i]), "gemm_grouped: sumsq_partial needs 16-byte aligned C");
+  }
   for (int base = 0; base < count; base += JS2T_GEMM_GROUP_MAX) {
     const int n = count - base < JS2T_GEMM_GROUP_MAX ? count - base : JS2T_GEMM_GROUP_MAX;
     GemmGroup grp;
@@ -2567,19 +2583,25 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
     }
     d.A = grp.A[0], d.B = grp.B[0], d.C = grp.C[0];
     int rc;
-    if (p192t_eligible(d, n)) {
+    if (!d.sumsq_partial && p192t_eligible(d, n)) {
       rc = a_rowsum ? launch_grouped_p192t<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_p192t<false>(d, grp, n, (hipStream_t)stream);
     } else {
       rc = d.split_k > 1 ? launch_grouped_tt<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_tt<false>(d, grp, n, (hipStream_t)stream);
     }
     if (rc != JS2T_OK) return rc;
+    if (d.sumsq_partial) d.sumsq_partial += (int64_t)cdiv(d.M, 128) * cdiv(d.N, F_BN) * n;
   }
   return JS2T_OK;
+}
+
+extern "C" int64_t js2t_gemm_grouped_blocks(int32_t M, int32_t N, int32_t count) {
+  return (int64_t)cdiv(M, 128) * cdiv(N, F_BN) * count;
 }
 
 extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
   JS2T_CHECK(dp != nullptr, "gemm: null descriptor");
   js2t_gemm_desc d = *dp;
+  JS2T_CHECK(!d.sumsq_partial, "gemm: sumsq_partial is taken by js2t_gemm_grouped only");
   hipStream_t s = (hipStream_t)stream;
   JS2T_CHECK(d.M >= 0 && d.N >= 0 && d.K >= 0 && d.batch >= 0, "gemm: negative size");
   if (d.M == 0 || d.N == 0 || d.batch == 0) return JS2T_OK;

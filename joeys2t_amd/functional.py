@@ -424,6 +424,8 @@ class ResidualBlockFn(torch.autograd.Function):
         p_in, p_out = cfg.p_in, cfg.p_out
         sites = [rng.next_site() if rng is not None else 0 for _ in range(2)]
         saved = {}
+        # will backward run?  (grad mode is always off inside Function.forward: torch.is_grad_enabled() cannot tell)
+        need_bwd = any(ctx.needs_input_grad)
         hint = _DROP_HINT.pop(x.data_ptr(), None)
         ctx.prev_drop = None
         if (hint is not None and FUSE_LN_DROPOUT_BWD and cfg.ln_mode == "pre" and hint[3].shape == x.shape and
@@ -452,7 +454,7 @@ class ResidualBlockFn(torch.autograd.Function):
             if (FP8_FORWARD and (cfg.kind != "ffn" or cfg.act in (None, "relu")) and _fp8_eligible(x2, w0, None, None, 1.0) and
                     ops.layernorm_bwd_supports_dropout(x2)):
                 # the LayerNorm writes the e4m3 operand of the block's first product itself (and bf16 only if backward wants it)
-                n, mean, rstd, x8_first = ln_fwd_fp8(x2, wts["ln_g"], wts["ln_b"], w0, want_y=torch.is_grad_enabled())
+                n, mean, rstd, x8_first = ln_fwd_fp8(x2, wts["ln_g"], wts["ln_b"], w0, want_y=need_bwd)
             else:
                 n, mean, rstd = _ln_fwd(x2, wts["ln_g"], wts["ln_b"])
             saved.update(mean=mean, rstd=rstd)
@@ -514,7 +516,7 @@ class ResidualBlockFn(torch.autograd.Function):
                     c = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], x8=x8_first)
                     _fp8_state(w2, c)
                 c, x8_second = linear_fwd(n, wts["w1"], wts["b1"], act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], x8=x8_first,
-                                          y8_for=w2, want_y=torch.is_grad_enabled())
+                                          y8_for=w2, want_y=need_bwd)
             else:
                 c = linear_fwd(n, first("w1"), first("b1"), act=cfg.act, dropout_p=p_in, rng=rng, site=sites[0], preact=pre, ln=lnf, x8=x8_first)
             saved.update(pre=pre)

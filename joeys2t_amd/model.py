@@ -16,7 +16,7 @@ from joeys2t_amd import ops
 from joeys2t_amd.builders import ConfigurationError
 from joeys2t_amd.decoders import Decoder, TransformerDecoder
 from joeys2t_amd.embeddings import Embeddings
-from joeys2t_amd.encoders import Encoder, TransformerEncoder
+from joeys2t_amd.encoders import ConformerEncoder, Encoder, TransformerEncoder
 from joeys2t_amd.initialization import initialize_model
 from joeys2t_amd.loss import XentCTCLoss, XentLoss
 from joeys2t_amd.runtime import ParamStore, Runtime, install_runtime
@@ -267,12 +267,23 @@ def build_model(cfg: Dict = None, src_vocab=None, trg_vocab=None) -> Model:
     else:
         trg_embed = Embeddings(**dec_cfg["embeddings"], vocab_size=len(trg_vocab), padding_idx=trg_pad_index)
 
-    if enc_cfg.get("type", "transformer") != "transformer" or dec_cfg.get("type", "transformer") != "transformer":
+    enc_type = enc_cfg.get("type", "transformer")
+    if enc_type not in ("transformer", "conformer") or dec_cfg.get("type", "transformer") != "transformer":
         raise ConfigurationError("RNN model not supported for s2t task. use transformer.")
     enc_dropout = enc_cfg.get("dropout", 0.0)
     enc_emb_dropout = enc_cfg["embeddings"].get("dropout", enc_dropout)
-    encoder = TransformerEncoder(**enc_cfg, emb_size=enc_cfg["embeddings"]["embedding_dim"], emb_dropout=enc_emb_dropout,
-                                 pad_index=src_pad_index)
+    if enc_type == "conformer":
+        # EXTENSION (BASELINE.json configs[4]): the reference's build_model accepts `recurrent` / `transformer` only
+        # (model.py:417-421) although it ships the class (encoders.py:376-445).  Keys beside the transformer's:
+        # `depthwise_conv_kernel_size` (default 31, transformer_layers.py:489) and `rel_pos_clip` (relative-position
+        # attention bias, no counterpart in the reference); the sub-sampler is always on (encoders.py:431).
+        if task != "S2T":
+            raise ConfigurationError("conformer encoder: speech input only (it always sub-samples, encoders.py:431).")
+        encoder = ConformerEncoder(**enc_cfg, emb_size=enc_cfg["embeddings"]["embedding_dim"], emb_dropout=enc_emb_dropout,
+                                   pad_index=src_pad_index)
+    else:
+        encoder = TransformerEncoder(**enc_cfg, emb_size=enc_cfg["embeddings"]["embedding_dim"], emb_dropout=enc_emb_dropout,
+                                     pad_index=src_pad_index)
     dec_dropout = dec_cfg.get("dropout", 0.0)
     dec_emb_dropout = dec_cfg["embeddings"].get("dropout", dec_dropout)
     if task == "S2T":

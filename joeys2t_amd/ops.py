@@ -200,9 +200,10 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
     return C_out
 
 
-def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alpha=1.0, a_rowsums=None):
+def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alpha=1.0, a_rowsums=None, sumsq_partial=None):
     """len(As) independent products C_i = alpha * A_i^T B_i (+ beta C_i) of one shape in one launch (js2t_gemm_grouped):
-    bf16 [K, M] / [K, N] operands (trans_a = trans_b = 1), f32 or bf16 C_i, optional f32[M] row-sum targets."""
+    bf16 [K, M] / [K, N] operands (trans_a = trans_b = 1), f32 or bf16 C_i, optional f32[M] row-sum targets.
+    sumsq_partial: f32[grouped_blocks(M, N, n)] - every block leaves the sum of squares of the values it stored there."""
     n = len(As)
     if not (n == len(Bs) == len(Cs)) or (a_rowsums is not None and len(a_rowsums) != n):
         raise Js2tError("gemm_grouped: list lengths differ")
@@ -219,6 +220,11 @@ def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alp
     d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
     d.alpha, d.beta, d.split_k = float(alpha), float(beta), int(split_k)
     d.res_scale = d.gate_scale = 1.0
+    if sumsq_partial is not None:
+        _dev(sumsq_partial)
+        if sumsq_partial.dtype != torch.float32 or sumsq_partial.numel() < grouped_blocks(d.M, d.N, n):
+            raise Js2tError("gemm_grouped: sumsq_partial must be f32[grouped_blocks(M, N, count)]")
+        d.sumsq_partial = sumsq_partial.data_ptr()
     arr = C.c_void_p * n
     pa, pb, pc = arr(*[t.data_ptr() for t in As]), arr(*[t.data_ptr() for t in Bs]), arr(*[t.data_ptr() for t in Cs])
     pr = None if a_rowsums is None else arr(*[t.data_ptr() for t in a_rowsums])
@@ -228,6 +234,11 @@ def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alp
                         nbytes=n * (2 * (d.M * d.K + d.N * d.K) + Cs[0].element_size() * d.M * d.N * (2 if d.beta else 1)))
     else:
         check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped")
+
+
+def grouped_blocks(M: int, N: int, count: int) -> int:
+    """blocks (= sumsq_partial entries) of an un-split gemm_grouped launch"""
+    return int(lib().js2t_gemm_grouped_blocks(int(M), int(N), int(count)))
 
 
 # ----------------------------------------------------------------------------------------- element-wise

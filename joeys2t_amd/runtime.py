@@ -285,6 +285,19 @@ class WgradQueue:
         self.pending = 0
         self.flush_every = flush_every
         self.after_flush = []  # callables run once the queued gradients are complete (DDP bucket bookkeeping)
+        # set by TrainStep (all optional):
+        #   cand: RangeSet of flat-gradient elements ONE product per micro-batch may overwrite (weights of nn.Linear modules that
+        #         are not shared); an un-split product of the FIRST micro-batch of an update then runs with beta = 0 - no read of
+        #         the old gradient - and its span joins `kept`, the pieces the update (FlatAdamW) no longer clears.  A kept piece
+        #         that a first flush does not overwrite is cleared here, before the queued products run, and leaves the set.
+        #         (Assumption: a weight gradient the queue has overwritten once is produced by the queue or not at all.)
+        #   first: this flush belongs to the first micro-batch of an update; collector: builders.SumsqCollector that takes the
+        #         sums of squares of the final gradients from the products' epilogues (last micro-batch, single GPU).
+        self.cand = None
+        self.kept = None
+        self.first = False
+        self.collector = None
+        self.grad_base = None  # (flat gradient tensor) element offsets of the dW views are taken against it
 
     def add(self, dz2d: torch.Tensor, x2d: torch.Tensor, dw_out: torch.Tensor, db_out: Optional[torch.Tensor]):
         N, K, M = dz2d.shape[1], x2d.shape[1], dz2d.shape[0]
@@ -302,25 +315,109 @@ class WgradQueue:
         for cb in cbs:
             cb()
 
+    def _span(self, t: torch.Tensor):
+        lo = (t.data_ptr() - self.grad_base.data_ptr()) // 4
+        return (lo, lo + t.numel())
+
     def take(self):
-        """The queued products as a plan [(key, items)], emptying the queue.  A plan built while a hipGraph was captured stays
-        valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches."""
+        """The queued products as a plan [(key + (mode, collector), items)], emptying the queue.  A plan built while a hipGraph was
+        captured stays valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches.
+        mode: 1 = the products overwrite their dW (beta 0), 2 = their epilogues leave the sums of squares with the collector."""
+        from joeys2t_amd.functional import wgrad_split
         plan = sorted(self.groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * len(kv[1]))
         self.groups = {}
         self.pending = 0
-        return plan
+        cand, out, written = self.cand, [], []
+        active = cand is not None and self.grad_base is not None and self.flush_every is None
+        seen: Dict[int, int] = {}
+        if active:
+            for _, items in plan:  # a dW that two products add into (a layer applied twice) cannot be overwritten by either
+                for it in items:
+                    seen[it[2].data_ptr()] = seen.get(it[2].data_ptr(), 0) + 1
+        for key, items in plan:
+            mode = 0
+            if active:
+                N, K, M = key[:3]
+                spans = [self._span(it[2]) for it in items]
+                solo = all(seen[it[2].data_ptr()] == 1 and it[2].is_contiguous() and it[2].dtype == torch.float32 for it in items)
+                # un-split whatever the number of tokens (enough output tiles for the chip), not just for this batch
+                unsplit = wgrad_split(N, K, M, count=len(items)) == 1 and wgrad_split(N, K, 1 << 30, count=len(items)) == 1
+                if solo and unsplit and all(cand.contains(*s) for s in spans):
+                    if self.first:
+                        mode |= 1
+                        written.extend(spans)
+                    if self.collector is not None and K % 128 == 0:
+                        mode |= 2
+            out.append((key + (mode, self.collector if mode & 2 else None), items))
+        if active and self.first:
+            for lo, hi in self.kept.minus(written):  # un-cleared, and nothing overwrites it this time
+                self.grad_base[lo:hi].zero_()
+                self.kept.remove(lo, hi)
+            for lo, hi in written:
+                if not self.kept.contains(lo, hi):
+                    self.kept.add(lo, hi)
+        return out
 
     @staticmethod
     def run(plan, on_group_done=None):
         from joeys2t_amd.functional import wgrad_split
-        for (N, K, M, lda, ldb, has_db), items in plan:
+        for key, items in plan:
+            N, K, M, lda, ldb, has_db = key[:6]
+            mode, collector = (key[6], key[7]) if len(key) > 6 else (0, None)
             n = len(items)
             sk = wgrad_split(N, K, M, count=n)
+            part = None
+            if mode & 2:
+                lo = [(it[2].data_ptr() - collector.grad.data_ptr()) // 4 for it in items]
+                part = collector.segment(ops.grouped_blocks(N, K, n), [(a, a + it[2].numel()) for a, it in zip(lo, items)])
             ops.gemm_grouped([it[0] for it in items], [it[1] for it in items], [it[2] for it in items], M=N, N=K, K=M, lda=lda,
-                             ldb=ldb, ldc=K, split_k=sk, beta=0.0 if sk > 1 else 1.0,
-                             a_rowsums=[it[3] for it in items] if has_db else None)
+                             ldb=ldb, ldc=K, split_k=sk, beta=0.0 if (sk > 1 or mode & 1) else 1.0,
+                             a_rowsums=[it[3] for it in items] if has_db else None, sumsq_partial=part)
             if on_group_done is not None:
                 on_group_done(items)
+
+
+class RangeSet:
+    """Disjoint, sorted [lo, hi) element ranges (adjacent ones merged)."""
+
+    def __init__(self, ranges=()):
+        self.r: List[Tuple[int, int]] = []
+        for lo, hi in sorted(ranges):
+            if self.r and lo <= self.r[-1][1]:
+                self.r[-1] = (self.r[-1][0], max(hi, self.r[-1][1]))
+            elif hi > lo:
+                self.r.append((lo, hi))
+        self.version = 0
+
+    def contains(self, lo: int, hi: int) -> bool:
+        return any(a <= lo and hi <= b for a, b in self.r)
+
+    def minus(self, spans) -> List[Tuple[int, int]]:
+        """the parts of this set that no span covers"""
+        out = []
+        cut = RangeSet(spans).r
+        for a, b in self.r:
+            pos = a
+            for lo, hi in cut:
+                if hi <= pos or lo >= b:
+                    continue
+                if lo > pos:
+                    out.append((pos, lo))
+                pos = max(pos, hi)
+            if pos < b:
+                out.append((pos, b))
+        return out
+
+    def remove(self, lo: int, hi: int):
+        self.r = RangeSet(self.minus([(lo, hi)])).r
+        self.version += 1
+
+    def add(self, lo: int, hi: int):
+        self.r = RangeSet(self.r + [(lo, hi)]).r
+        self.version += 1
+
+    def __bool__(self):
+        return bool(self.r)
 
 
 class Runtime:

@@ -56,6 +56,26 @@ class TrainStep:
         # LayerNorm gamma / beta gradients go through per-XCD copies that are folded right after backward (ops.GradCopies);
         # only with the deferred products: the hook-driven exchange (no queue) may send a bucket while backward still runs
         self.rt.grad_copies = ops.GradCopies(self.store.device) if defer_wgrads else None
+        # Weight gradients that ONE un-split product per micro-batch writes: the first micro-batch of an update overwrites them
+        # (no read of the old gradient in its epilogue, no clearing pass in the update: 8 of 38 bytes per parameter), and on a
+        # single GPU the last one leaves the sums of squares clip_grad_norm_ needs behind (no pass over them for the norm).
+        # Candidates: nn.Linear weights that belong to one module only (a tied matrix collects two contributions).
+        q = self.rt.wgrad_queue
+        if q is not None and os.environ.get("JS2T_WGRAD_OVERWRITE", "1") != "0" and self.optimizer.update_ranges == [(0, self.store.total)]:
+            from joeys2t_amd.runtime import RangeSet
+            uses: Dict[int, int] = {}
+            for m in model.modules():
+                for p in m._parameters.values():
+                    if p is not None:
+                        uses[id(p)] = uses.get(id(p), 0) + 1
+            spans = []
+            for m in model.modules():
+                if isinstance(m, torch.nn.Linear) and uses.get(id(m.weight), 0) == 1 and m.weight.requires_grad and id(m.weight) in self.store.offsets:
+                    lo = self.store.offsets[id(m.weight)]
+                    spans.append((lo, lo + m.weight.numel()))
+            q.cand = RangeSet(spans)
+            q.kept = self.optimizer.keep = RangeSet()  # grows with what first flushes are seen to overwrite
+            q.grad_base = self.store.flat_grad
         self.reducer = None
         if use_ddp():
             # comm: a joeys2t_amd.comm.Communicator, or "cabi" (JS2T_COMM=cabi) to bootstrap one over the process group that is
@@ -101,6 +121,15 @@ class TrainStep:
         if sort:
             batch.sort_by_src_length()
         last = (self.micro + 1) % self.batch_multiplier == 0
+        q = self.rt.wgrad_queue
+        if q is not None and q.cand is not None:
+            q.first = self.micro % self.batch_multiplier == 0
+            # the epilogues' sums are those of the LOCAL gradient: under data parallelism the norm is taken after the exchange
+            collect = last and self.reducer is None and self.clip_grad_norm is not None and self.clip_grad_norm > 0
+            if collect and self.optimizer.collector is None:
+                from joeys2t_amd.builders import SumsqCollector
+                self.optimizer.collector = SumsqCollector(self.store.flat_grad, self.store.total)
+            q.collector = self.optimizer.collector if collect else None
         exchange = self.reducer is not None and overlap and (last or self.sync_every_backward)
         use_hooks = exchange and self.rt.wgrad_queue is None  # without the queue: bucket hooks fire during backward
         if use_hooks:

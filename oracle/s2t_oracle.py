@@ -385,10 +385,16 @@ def ctc_loss(ctc_log_probs: Tensor, trg: Tensor, input_lengths: Tensor, target_l
                       reduction="sum", zero_infinity=True)
 
 
-def model_loss(sd: SD, cfg: dict, batch: dict, specials: dict, smoothing: float, ctc_weight: Optional[float]):
-    """Model.forward(return_type="loss"), model.py:113-148 -> (total, xent, ctc|None, n_correct, logits, ctc_logits)."""
+def model_loss(sd: SD, cfg: dict, batch: dict, specials: dict, smoothing: float, ctc_weight: Optional[float], train: bool = False,
+               new_stats: Optional[dict] = None):
+    """Model.forward(return_type="loss"), model.py:113-148 -> (total, xent, ctc|None, n_correct, logits, ctc_logits).
+    `train` / `new_stats` only matter for a Conformer encoder (BatchNorm takes batch statistics in training mode)."""
     if "src_embed.lut.weight" in sd:  # text source (MT): no sub-sampler, mask from the pad positions
         enc, src_mask = encoder_forward_text(sd, cfg, batch["src"], specials["pad"])
+    elif cfg["encoder"].get("type", "transformer") == "conformer":
+        # EXTENSION (BASELINE.json configs[4]): the reference's Model is never built over its ConformerEncoder (model.py:417-421);
+        # the composition is Model._encode_decode's (model.py:170-239) with that encoder class in the encoder's place
+        enc, src_mask, _ = conformer_encoder_forward(sd, cfg, batch["src"], batch["src_length"], train=train, new_stats=new_stats)
     else:
         enc, src_mask, _ = encoder_forward(sd, cfg, batch["src"], batch["src_length"])
     out, _, _, ctc_out = decoder_forward(sd, cfg, batch["trg_input"], enc, src_mask, batch["trg_mask"])

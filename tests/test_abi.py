@@ -57,3 +57,20 @@ def test_comm_entry_points_reject_bad_arguments():
     assert L.js2t_comm_destroy(None) == 0
     with pytest.raises(_lib.Js2tError):
         comm.Communicator(0, 1, torch.device("cpu"), exchange_id=lambda b: b)
+
+
+def test_range_set():
+    """runtime.RangeSet: the bookkeeping of gradient pieces the update leaves un-cleared (host logic)."""
+    from joeys2t_amd.runtime import RangeSet
+    r = RangeSet([(0, 10), (10, 20), (40, 50), (45, 60)])
+    assert r.r == [(0, 20), (40, 60)] and r.contains(5, 15) and not r.contains(15, 45) and r.contains(40, 60)
+    assert r.minus([(5, 8), (18, 45)]) == [(0, 5), (8, 18), (45, 60)]
+    assert r.minus([]) == [(0, 20), (40, 60)] and r.minus([(0, 100)]) == []
+    v = r.version
+    r.remove(0, 20)
+    assert r.r == [(40, 60)] and r.version == v + 1 and bool(r)
+    r.remove(30, 70)
+    assert not r
+    r.add(8, 16)
+    r.add(16, 24)
+    assert r.r == [(8, 24)] and r.contains(10, 20)
