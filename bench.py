@@ -536,6 +536,192 @@ def conformer_fp8_forward(device, reps=10, modes=("fp8", "bf16")):
             "parity": "extension: no reference target (joeynmt has neither rel-pos attention nor fp8)"}
 
 
+PEAK_HBM_TBS = 8.0  # HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def measure_hbm_kernels(eager_step, step):
+    """The HBM-bound kernels of the step against the 8 TB/s roofline (north_star: "achieved HBM GB/s ... against peak"): HIP events
+    around every call of their Python entry points in two back-logged eager steps (the GEMM family's method: a spin kernel holds
+    the GPU while the host enqueues), ALGORITHMIC bytes = each distinct tensor a call reads or writes, once (SURVEY 8(d):
+    LayerNorm 2 passes over the operand per output, losses one read of the logits, CTC one read + one write, the front-end
+    1.44 MB per 15 s utterance, the update 38 bytes per parameter minus what the kept gradients save)."""
+    from joeys2t_amd import builders, ops
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    records = []  # (name, bytes, start, end)
+
+    def tensors_of(x, acc):
+        if torch.is_tensor(x):
+            if x.is_cuda and x.numel() > 0:
+                acc[x.data_ptr()] = max(acc.get(x.data_ptr(), 0), x.numel() * x.element_size())
+        elif isinstance(x, (list, tuple)):
+            for y in x:
+                tensors_of(y, acc)
+        elif isinstance(x, dict):
+            for y in x.values():
+                tensors_of(y, acc)
+
+    def timed(name, fn, fixed_bytes=None):
+        def wrapper(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            s.record(st)
+            out = fn(*a, **k)
+            e.record(st)
+            if fixed_bytes is None:
+                acc = {}
+                tensors_of(a, acc), tensors_of(k, acc), tensors_of(out, acc)
+                nbytes = sum(acc.values())
+            else:
+                nbytes = fixed_bytes(*a, **k)
+            records.append((name, nbytes, s, e))
+            return out
+        return wrapper
+
+    opt, st = step.optimizer, step.store
+
+    def update_bytes(*a, **k):
+        kept = sum(hi - lo for lo, hi in (opt.keep.r if opt.keep is not None else []))
+        n = st.total
+        # read p, g, m, v; write p, m, v; bf16 shadow + transposed shadow; clear the gradients that are not overwritten;
+        # the norm's pass over the gradients whose sums the weight-gradient epilogues did not leave behind
+        lp = 2 * n if st.flat_lp is not None else 0
+        lpt = 2 * sum(R * Cc for _, R, Cc, _ in st._tgroups) if st.flat_lp_t is not None else 0
+        covered = sum(hi - lo for lo, hi in (opt.collector.covered if opt.collector is not None else []))
+        return 28 * n + lp + lpt + 4 * (n - kept) + 4 * (n - covered)
+
+    def frontend_bytes(self, wave, n_samples, *a, **k):  # SURVEY 8(d): one read of the waveform, one write of the f32 features
+        return sum(4 * int(n) + 4 * 80 * (1 + (int(n) - 400) // 160) for n in n_samples)
+
+    patches = [(ops, "layernorm_bwd", None), (ops, "layernorm_fwd", None), (ops, "xent_fwd", None), (ops, "xent_bwd", None),
+               (ops, "row_lse", None), (ops, "ctc_alpha", None), (ops, "ctc_bwd", None), (ops, "embed_fwd", None),
+               (SpeechProcessor, "batch_from_waveforms", frontend_bytes), (builders.FlatAdamW, "clip_and_step", update_bytes)]
+    names = {"batch_from_waveforms": "front_end (fbank + cmvn_stats + feature_finalize)", "clip_and_step": "update (grad norm + AdamW + shadows + LayerNorm folds)",
+             "ctc_alpha": "ctc_alpha_beta", "ctc_bwd": "ctc_grad"}
+    saved = [(o, n, getattr(o, n)) for o, n, _ in patches]
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    torch.cuda._sleep(10_000_000)
+    s1.record()
+    torch.cuda.synchronize()
+    cycles_per_ms = 10_000_000 / max(s0.elapsed_time(s1), 1e-3)
+    model = step.model
+    overlap_ctc, model.overlap_ctc = model.overlap_ctc, False  # one stream: every launch is timed alone on the GPU
+    try:
+        for (o, n, fb), (_, _, fn) in zip(patches, saved):
+            setattr(o, n, timed(names.get(n, n), fn, fb))
+        for _ in range(2):
+            torch.cuda._sleep(int(80 * cycles_per_ms))
+            eager_step()
+            torch.cuda.synchronize()
+    finally:
+        for o, n, fn in saved:
+            setattr(o, n, fn)
+        model.overlap_ctc = overlap_ctc
+    torch.cuda._sleep(int(20 * cycles_per_ms))
+    empty = GemmTimer()
+    for _ in range(256):
+        empty.wrap("empty", 0.0, lambda: None)
+    pair = empty.summary()["empty"][2] / 256
+    torch.cuda.synchronize()
+    agg = {}
+    for name, nbytes, s, e in records:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += nbytes
+        a[2] += max(s.elapsed_time(e) * 1e-3 - pair, 1e-9)
+    out = {}
+    for name, (n, nbytes, secs) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        tbs = nbytes / secs / 1e12
+        out[name] = {"launches_per_step": n // 2, "algorithmic_MB_per_step": round(nbytes / 2 / 1e6, 1), "us_per_step": round(secs / 2 * 1e6, 1),
+                     "achieved_TBps": round(tbs, 2), "frac": round(tbs / PEAK_HBM_TBS, 3)}
+    return {"bound": "hbm", "peak": PEAK_HBM_TBS, "unit": "TB/s", "event_pair_overhead_us": round(pair * 1e6, 2), "kernels": out}
+
+
+def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
+    """BASELINE.json configs[4] as a TRAIN step: build_model(encoder.type: conformer, rel_pos_clip 64, depthwise kernel 31; 16 + 6
+    layers, d 512, V 10000 as librispeech_960h) -> TrainStep (forward, CTC + label-smoothed CE, backward, clip + AdamW), 32 x 15 s
+    of synthetic features, dropout on, hipGraph replay; in bf16 and with e4m3 forward products (functional.FP8_FORWARD; backward
+    stays bf16).  EXTENSION: no reference parity target for the composition (model.py:417-421 refuses the encoder type); parity of
+    the pieces and of the composed loss / gradients against the oracle: tests/test_hip_config5_train.py."""
+    import copy
+    from joeys2t_amd import functional as Fn
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    cfg = copy.deepcopy(LS100_MODEL)
+    cfg["encoder"].update(type="conformer", depthwise_conv_kernel_size=31, rel_pos_clip=64)
+    V = 10000
+    frames = 1 + (SAMPLES - 400) // 160
+    tp = ((frames - 1) // 2) // 2 + 1
+    tokens = BATCH * tp
+    d, ff, k, layers = 512, 2048, 31, cfg["encoder"]["num_layers"]
+    trg, trg_len = synth_targets(BATCH, V, seed=99)
+    L = trg.shape[1] - 1
+    enc_fwd = layers * tokens * (2 * 4 * d * ff + 8 * d * d + 4 * tp * d + 4 * d * d + 2 * d * d + 2 * k * d) + 2 * tokens * d * d + 41e9 * (BATCH / 32)
+    dec_fwd = cfg["decoder"]["num_layers"] * (BATCH * L * (8 * d * d + 4 * L * d + 4 * d * d + 4 * tp * d + 4 * d * ff) + 4 * d * d * tokens) + 2 * BATCH * L * d * V
+    flop = 3 * (enc_fwd + dec_fwd + 2 * tokens * d * V)
+    out = {}
+    for mode in modes:
+        Fn.FP8_FORWARD = mode == "fp8"
+        try:
+            torch.manual_seed(42)
+            model = build_model(copy.deepcopy(cfg), None, Vocabulary.synthetic(V))
+            model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+            with torch.no_grad():
+                for layer in model.encoder.layers:
+                    layer.src_src_att.rel_pos_bias.normal_(0.0, 0.1)
+            model.finalize(device, torch.bfloat16, seed=42)
+            # (the reference's schedule runs the FIRST update at the un-warmed peak rate, training.py:438-456: 2e-3 blows a randomly
+            # initialised Conformer up; a timing figure on synthetic data, so a rate it survives)
+            step = TrainStep(model, learning_rate=3.0e-4, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=10000,
+                             normalization="batch", overlap_ctc=True)
+            step.optimizer.device_schedule = True
+            src = torch.randn(BATCH, frames, 80, device=device).bfloat16()
+            batch = Batch(src=src, src_length=torch.full((BATCH, ), frames, device=device), src_prompt_mask=None, trg=trg, trg_length=trg_len,
+                          trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1, eos_index=3, is_train=True,
+                          task="S2T", n_gpu=1)
+
+            def body():
+                return step.micro_step(batch, sort=False, update=True, overlap=False)
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            for _ in range(3):
+                g.replay()
+            step.read_stats(reset=True)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(reps):
+                g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / reps
+            loss = step.read_stats()["loss"] / reps
+            out[mode] = {"ms_per_step": round(ms, 3), "frames_per_s": round(BATCH * frames / (ms * 1e-3), 1),
+                         "achieved": round(flop / (ms * 1e-3) / 1e12, 1), "loss": round(loss, 3)}
+            del g, step, model
+            torch.cuda.empty_cache()
+        finally:
+            Fn.FP8_FORWARD = False
+    return {"what": "Conformer S2T train step (16 Conformer + 6 Transformer decoder layers, d 512, ff 2048, depthwise k 31, rel-pos clip 64, "
+                    "V 10000, CTC 0.3 + label-smoothed CE), 32 x 15 s, dropout 0.1, clip + AdamW, hipGraph replay",
+            "flop_per_step": flop, "unit": "TFLOP/s", "bf16": out.get("bf16"), "fp8": out.get("fp8"), "peak_bf16": PEAK_BF16_TFLOPS,
+            "frac_bf16": round(out["bf16"]["achieved"] / PEAK_BF16_TFLOPS, 4) if "bf16" in out else None,
+            "fp8_note": "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 in five of a layer's eight forward products; backward in bf16: priced "
+                        "against the bf16 peak, not the 5 PF fp8 figure",
+            "parity": "extension: no reference target for the composition (joeynmt's build_model refuses the encoder type)"}
+
+
 def host_cpu():
     """(threads this process may use, CPU model string, CPUs online) of the host the baseline is timed on"""
     try:
@@ -859,6 +1045,10 @@ def main():
     roofline = None
     if rank == 0 and world == 1 and not args.no_roofline:  # N = 1: on the step that was just timed
         roofline = measure_roofline(eager_step, model)
+        try:
+            roofline["hbm_kernels"] = measure_hbm_kernels(eager_step, step)
+        except Exception as exc:  # a side table: never lose the headline line over it
+            roofline["hbm_kernels"] = {"error": repr(exc)}
     elif rank == 0 and roofline_pre is not None:  # N > 1: measured on rank 0's GPU before the process group formed (see above)
         roofline = roofline_pre
     if roofline is not None and not args.no_extras:
@@ -867,6 +1057,10 @@ def main():
             roofline["conformer_fp8_forward"] = conformer_fp8_forward(device)
         except Exception as exc:  # a side figure of an extension: never lose the headline line over it
             roofline["conformer_fp8_forward"] = {"error": repr(exc)}
+        try:
+            roofline["conformer_train_step"] = conformer_train_step(device)
+        except Exception as exc:
+            roofline["conformer_train_step"] = {"error": repr(exc)}
 
     varying = None
     if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:

@@ -230,5 +230,5 @@ def test_train_step_with_the_exchange_through_the_c_boundary(device):
     # every coordinate by ~lr whatever its gradient's size): a handful of coordinates, each by less than the learning rate.  A range that
     # went out before its products had run would be off by the learning rate everywhere in it.
     diff = (plain - got).abs()
-    assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 1e-3
+    assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 2e-2  # (0.1 - 0.5 % of the coordinates, run to run)
     assert (diff.norm() / plain.norm()).item() < 1e-4
