@@ -1764,12 +1764,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 // B image: granule (j, r, c) as in p192_b_granule, but fragment j of lane r is column 64 (j >> 2) + 4 r + (j & 3): after
 // its four MFMAs along N a lane holds 4 CONSECUTIVE columns and the 16 lanes of a row group store one 128-byte run.
 // One block per CU (120 KB of LDS, 168 registers per wave).
-template <int EPI>
+// OUT8 (the e4m3 kernel only): d.c8 != NULL adds the second output of p192_store_tile - the result as e4m3 bytes with the delayed
+// scale of d.c8_state, four bytes per row and lane; d.C may then be NULL.
+template <int EPI, bool OUT8 = false>
 __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][4], int mw, int n0, int lane,
                                                  const float (&bias_r)[4], uint32_t drop_key, float my_rs = 0.f) {
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 4 * r;
   if (n >= d.N) return;  // N is a multiple of 8 (hence of 4): a lane's column group lies inside or outside as a whole
+  float q8_inv = 0.f, q8_max = 0.f;
+  if constexpr (OUT8) {
+    if (d.c8) {
+      const float S = d.c8_state[0];
+      q8_inv = S > 0.f ? 1.f / S : 0.f;
+    }
+  }
   const float alpha = EPI < 0 ? d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f) : 1.f;
   const bool has_bias = EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0;
   const bool relu = EPI < 0 ? d.act == JS2T_ACT_RELU : (EPI & PE_RELU) != 0;
@@ -1839,12 +1848,31 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
         s1 = row16_sum(s1), s2 = row16_sum(s2);
         if (r == 0 && m < M) *(float2*)(d.rs_partial + 2 * ((int64_t)m * ngrp + grp)) = make_float2(s1, s2);
       }
-      if (m < M) {
+      if (m < M && (!OUT8 || d.C)) {
         uint2 pk;
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
         *(uint2*)((uint16_t*)d.C + (int64_t)m * d.ldc + n) = pk;
       }
+      if constexpr (OUT8) {
+        if (d.c8 && m < M) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            q8_max = fmaxf(q8_max, fabsf(v[c]));
+            v[c] = fminf(fmaxf(v[c] * q8_inv, -448.f), 448.f);
+          }
+          int q = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+          q = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], q, true);
+          *(uint32_t*)(d.c8 + (int64_t)m * d.ldc8 + n) = (uint32_t)q;
+        }
+      }
+    }
+  }
+  if constexpr (OUT8) {
+    if (d.c8) {  // this tile's max |v| for the NEXT call's scale: posted only if it beats what is there (decayed by the consumer)
+      q8_max = wave_max(q8_max);
+      unsigned int* st = (unsigned int*)d.c8_state;
+      if (lane == 0 && __float_as_uint(q8_max) > *(volatile unsigned int*)(st + 1)) atomicMax(st + 1, __float_as_uint(q8_max));
     }
   }
 }
@@ -1854,6 +1882,11 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
 // of the barrier, [2] loader wave 8: ticks in vmcnt wait, [3] in barrier, [4] issuing, [5] stages
 __device__ unsigned long long g_p192s_prof[8];
 extern "C" int js2t_debug_p192s_prof(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192s_prof), 64); }
+#endif
+#ifndef JS2T_FP8_NO_SCALED
+constexpr bool P192S_SCALED = true;  // e4m3 consumers on v_mfma_scale_f32_16x16x128_f8f6f4 (-DJS2T_FP8_NO_SCALED: the K = 32 instruction, for A/B)
+#else
+constexpr bool P192S_SCALED = false;
 #endif
 template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
@@ -1974,8 +2007,97 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
   const uint32_t drop_key = any_drop ? dropout_key(d.rng_state, d.rng_stream) : 0u;
   __builtin_amdgcn_s_barrier();  // stage 0 landed
   asm volatile("" ::: "memory");
-  frag_i4 fm0[3], fn0[4], fm1[3], fn1[4];
   f32x4_t acc[3][4];
+  if constexpr (FP8 && P192S_SCALED) {
+    // e4m3 on the block-scaled instruction: a stage (128 k) is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator (unit
+    // scales, E8M0 127) instead of four v_mfma_f32_16x16x32_fp8_fp8 - twice the issue rate (tools/fp8_mfma_probe.hip: 4.87
+    // against 2.35 PFLOP/s chip-wide).  A lane's 32 operand bytes are its two 16-byte k-half fragments of the stage, for A
+    // and B alike, i.e. the same permutation of k on both sides.  All of a stage's fragments have to be in registers before
+    // its MFMAs start, so the slot is free from then on: lgkmcnt(0) -> barrier -> 12 MFMAs with the 14 reads of the NEXT
+    // stage between them (two register sets, alternating).
+    struct Frags { frag_i4 m[2][3], n[2][4]; };
+    Frags fx, fy;
+    auto read_stage = [&](const unsigned char* st, Frags& f) {
+      read_half(st, aoff0, boff0, f.m[0], f.n[0]);
+      read_half(st, aoff1, boff1, f.m[1], f.n[1]);
+    };
+    auto cat = [](const frag_i4& lo, const frag_i4& hi) {
+      typedef int i8_t __attribute__((ext_vector_type(8)));
+      return i8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto run_stage = [&](Frags& cur, Frags& nxt, const unsigned char* nst) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this stage's fragments are all here: its slot is free
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(cur.m[0][i], cur.m[1][i]), cat(cur.n[0][j], cur.n[1][j]), acc[i][j], 0,
+                                                                       0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        // the next stage's fragments behind the MFMA groups: B first (it is live for the whole stage), A last, into the registers
+        // this stage's A fragments leave (two full sets + 48 accumulators do not fit the 168 registers three waves per SIMD have)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) nxt.n[i][j] = *(const frag_i4*)(nst + (i == 0 ? boff0 : boff1) + j * 2048);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            nxt.m[0][q] = *(const frag_i4*)(nst + aoff0 + q * 2048);
+            nxt.m[1][q] = *(const frag_i4*)(nst + aoff1 + q * 2048);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (d.c8 && d.c8_scale_out && blockIdx.x == 0 && t == 0) {  // the scale the e4m3 output of THIS launch is written with
+      const float S = d.c8_state[0];
+      *d.c8_scale_out = (S > 0.f ? S : 1.f) * (d.c8_mul ? *d.c8_mul : 1.f);
+    }
+    read_stage(smem, fx);
+    // the block's stages as ONE stream, two per iteration: which register set is the current one is then known statically
+    // (chosen by a run-time parity both sets stay live across the loop: 112 + 48 registers and spills)
+    int cslot = 0, v = blockIdx.x, k = 0, tm0 = 0, tn0 = 0;
+    float bias_r[4] = {0.f, 0.f, 0.f, 0.f}, my_rs = 0.f;
+    auto begin_tile = [&]() {
+      const int lid = xcd_remap(v, ntiles);
+      tm0 = (lid / tiles_n) * P_BM, tn0 = (lid % tiles_n) * 128 + 64 * wn;
+      const int n = tn0 + 4 * br;
+      const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < N;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
+      if (EPI >= 0 && (EPI & PE_LNF)) my_rs = lnf_row_rstd(d, tm0 + wm * 48, lane, tn0 == 0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    auto one = [&](Frags& cur, Frags& nxt) {
+      const int nslot = cslot == NST - 1 ? 0 : cslot + 1;
+      run_stage(cur, nxt, smem + nslot * P_STAGE);  // after the block's last stage: unused reads of a stale slot
+      cslot = nslot;
+      if (++k == nk) {
+        p192s_store_tile<EPI, true>(d, acc, tm0 + wm * 48, tn0, lane, bias_r, drop_key, my_rs);
+        k = 0, v += G;
+        if (v < ntiles) begin_tile();
+      }
+    };
+    if (v < ntiles) begin_tile();
+    int sidx = 0;
+    for (; sidx + 1 < nstages; sidx += 2) {
+      one(fx, fy);
+      one(fy, fx);
+    }
+    if (sidx < nstages) one(fx, fy);
+    if (d.fp8_state && blockIdx.x == 0 && t == 0) {  // delayed activation scale of A's producer: see gemm_bf16_p192_kernel
+      const float am = d.fp8_state[1];
+      if (am > 0.f) d.fp8_state[0] = am * (1.f / 448.f);
+      d.fp8_state[1] = am * 0.9375f;
+    }
+    return;
+  }
+  frag_i4 fm0[3], fn0[4], fm1[3], fn1[4];
   read_half(smem, aoff0, boff0, fm0, fn0);
   int cslot = 0;
 #ifdef JS2T_P192S_DBG
@@ -2373,8 +2495,11 @@ int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
     n_cu = (cu & ~7) ? (cu & ~7) : cu;
   }
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
-  if (!d.c8 && (g_p192_ring == 4 || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu))) {
-    // about one tile per CU: eight multiplying + four requesting waves, as for bf16 (the e4m3 second output lives in the ring forms)
+  if ((P192S_SCALED && g_p192_ring < 0) || ((P192S_SCALED || !d.c8) && (g_p192_ring == 4 || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)))) {
+    // eight multiplying + four requesting waves.  With the block-scaled instruction (one v_mfma_scale_f32_16x16x128_f8f6f4 per
+    // accumulator and stage) this form wins on every shape, also above 1.5 tiles per CU where the bf16 products prefer two blocks
+    // per CU: FFN1 23.3 against 25.3 us, QKV 19.5 / 20.9, FFN2 15.5 / 23.1 (tools/fp8_gemm_bench.py); without it (-DJS2T_FP8_NO_SCALED)
+    // the bf16 rule applies and the e4m3 second output lives in the ring forms only
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192s_kernel<-1, true>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
   } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
