@@ -174,7 +174,7 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         elif wave_host is not None:
             wave.copy_(wave_host, non_blocking=True)
 
-    def body():
+    def body(cut_hook=None):
         feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype, masks_dev=masks_dev)
         if state["batch"] is None:
             b = Batch(src=feats, src_length=torch.tensor(lengths, device=device), src_prompt_mask=None, trg=trg,
@@ -186,7 +186,7 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         # single GPU: the whole step incl. the update is ONE captured graph.  Data parallel: the same kernels in the same
         # order, cut where the RCCL calls go: forward + backward (the deferred weight-gradient products stay queued:
         # flush=False), then one piece per weight-gradient group, then the update (see capture()).
-        return step.micro_step(state["batch"], sort=False, update=not ddp, overlap=False, flush=not ddp)
+        return step.micro_step(state["batch"], sort=False, update=not ddp, overlap=False, flush=not ddp, cut_hook=cut_hook)
 
     def eager_step():
         pre_step()
@@ -212,40 +212,77 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         pre_step()
-        with torch.cuda.graph(g, capture_error_mode=mode):
-            body()
-        graphs["step"] = g
-        if ddp:
-            # the products queued during capture reference the graph's static buffers: they are the per-step plan.  Each
+        if not ddp:
+            with torch.cuda.graph(g, capture_error_mode=mode):
+                body()
+            graphs["step"] = g
+        else:
+            # Data parallel: forward + backward as TWO graphs, cut at the encoder's output (TrainStep.micro_step, cut_hook): behind
+            # the first one the decoder side's weight-gradient products run and their ranges of the flat gradient go to RCCL,
+            # which then has the whole encoder backward (the second graph) to move them.  JS2T_EARLY_EXCHANGE=0: one graph.
+            import gc
+            g2 = torch.cuda.CUDAGraph()
+            state["plan_dec"] = None
+
+            def at_cut():
+                g.capture_end()
+                state["plan_dec"] = step.rt.wgrad_queue.take(final=False)
+                g2.capture_begin(pool=g.pool(), capture_error_mode=mode)
+
+            torch.cuda.synchronize()
+            gc.collect()
+            torch.cuda.empty_cache()
+            cap = torch.cuda.Stream(device=device)
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                g.capture_begin(capture_error_mode=mode)
+                try:
+                    body(cut_hook=at_cut)
+                finally:
+                    (g2 if state["plan_dec"] is not None else g).capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            graphs["step"], graphs["step2"] = g, (g2 if state["plan_dec"] is not None else None)
+            # the products queued during capture reference the graphs' static buffers: they are the per-step plan.  Each
             # group (one grouped launch per Linear shape = one range of the flat gradient) becomes a graph of its own, so
             # that the range's all-reduce can be handed to RCCL between two replays; the update is the last piece.
             plan = step.rt.wgrad_queue.take()
-            # one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start): groups
-            # that finish no range ride with the next one that does - eleven groups, four or five pieces
             red = step.reducer
-            pend = [0] * len(red.ranges)
-            for _, items in plan:
-                for it in items:
-                    pend[red.bucket_of_tensor(it[2])] += 1
-            pieces, cur = [], []
-            for entry in plan:
-                cur.append(entry)
-                done = False
-                for it in entry[1]:
-                    bi = red.bucket_of_tensor(it[2])
-                    pend[bi] -= 1
-                    done = done or pend[bi] == 0
-                if done:
+
+            def cut_pieces(plan_part):
+                # one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start):
+                # groups that finish no range ride with the next one that does
+                pend = [0] * len(red.ranges)
+                for _, items in plan_part:
+                    for it in items:
+                        pend[red.bucket_of_tensor(it[2])] += 1
+                pieces, cur = [], []
+                for entry in plan_part:
+                    cur.append(entry)
+                    done = False
+                    for it in entry[1]:
+                        bi = red.bucket_of_tensor(it[2])
+                        pend[bi] -= 1
+                        done = done or pend[bi] == 0
+                    if done:
+                        pieces.append(cur)
+                        cur = []
+                if cur:
                     pieces.append(cur)
-                    cur = []
-            if cur:
-                pieces.append(cur)
-            state["plan"], state["pieces"], graphs["wgrad"] = plan, pieces, []
-            for piece in pieces:
-                gw = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
-                    WgradQueue.run(piece)
-                graphs["wgrad"].append(gw)
+                return pieces
+
+            def capture_pieces(pieces):
+                out = []
+                for piece in pieces:
+                    gw = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
+                        WgradQueue.run(piece)
+                    out.append(gw)
+                return out
+
+            state["plan"], state["pieces"] = plan, cut_pieces(plan)
+            graphs["wgrad"] = capture_pieces(state["pieces"])
+            state["pieces_dec"] = cut_pieces(state["plan_dec"]) if state["plan_dec"] is not None else []
+            graphs["wgrad_dec"] = capture_pieces(state["pieces_dec"])
             gu = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
                 step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
@@ -259,7 +296,17 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         graphs["step"].replay()
         if ddp:
             plan, red = state["plan"], step.reducer
-            if os.environ.get("JS2T_BENCH_NO_EXCHANGE") == "1":  # measurement only: the price of the cut without the collectives
+            no_exchange = os.environ.get("JS2T_BENCH_NO_EXCHANGE") == "1"  # measurement only: the price of the cuts without the collectives
+            if graphs.get("step2") is not None:  # the decoder side's products and ranges, then the encoder's backward
+                if not no_exchange:
+                    red.exchange_begin(state["plan_dec"], partial=True)
+                for piece, gw in zip(state["pieces_dec"], graphs["wgrad_dec"]):
+                    gw.replay()
+                    if not no_exchange:
+                        for _, items in piece:
+                            red.entries_done(items)
+                graphs["step2"].replay()
+            if no_exchange:
                 for gw in graphs["wgrad"]:
                     gw.replay()
                 graphs["update"].replay()
@@ -1104,7 +1151,7 @@ def main():
                        "lengths": "ragged 10-17 s, un-padded frames counted" if args.ragged else "fixed 15 s",
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
                        "launch": ("hipGraph replay" if world == 1 and not force_ddp else
-                                  "hipGraph replay in pieces (fwd+bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
+                                  "hipGraph replay in pieces (fwd + decoder-side bwd | decoder-side weight-gradient groups | encoder bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
                        "capture_error": capture_error,
                        "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else ("bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32"),

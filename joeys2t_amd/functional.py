@@ -777,6 +777,21 @@ class LayerNormFn(torch.autograd.Function):
         return dx.view(ctx.shape), dg, db, None, None
 
 
+class CutFn(torch.autograd.Function):
+    """Identity whose output is where TrainStep cuts the backward pass in two (training.py: autograd.backward(..., inputs=[y]) for
+    the half behind it, y.backward(dy) for the half in front).  The engine RUNS the node a captured non-leaf tensor came out of
+    in both halves - harmless for this one; a node with side effects there (a LayerNorm adding its parameter gradients to the flat
+    store) would add them twice."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) — vocabulary / CTC projections (decoders.py:620-623), Conformer input linear."""
 

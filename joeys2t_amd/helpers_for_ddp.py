@@ -149,6 +149,8 @@ class FlatGradReducer:
         self.on_gpu = store.device.type == "cuda"
         self.comm_stream = comm_stream or (torch.cuda.Stream(device=store.device) if self.on_gpu else None)
         self.armed = False
+        self._partial_open = False
+        self.n_early = 0
         self.count = [0] * len(self.ranges)
         self.launched = [False] * len(self.ranges)
         self.works = []
@@ -158,9 +160,14 @@ class FlatGradReducer:
         # a one-rank communicator exchanges nothing - unless JS2T_DDP_SINGLE=1 asks for the calls anyway (rehearsal of the
         # RCCL path, its side stream and its event ordering on a 1-GPU box: bench.py JS2T_BENCH_FORCE_DDP)
         self.armed = armed and (self.world > 1 or (use_ddp() and os.environ.get("JS2T_DDP_SINGLE", "0") == "1"))
+        self.n_early = 0
         self.count = [0] * len(self.ranges)
         self.launched = [False] * len(self.ranges)
         self.works = []
+
+    def armed_for_exchange(self) -> bool:
+        """would begin(armed=True) arm?  (a one-rank group exchanges nothing unless JS2T_DDP_SINGLE=1 asks for the calls)"""
+        return self.world > 1 or (use_ddp() and os.environ.get("JS2T_DDP_SINGLE", "0") == "1")
 
     def params_ready(self, params):
         """Gradients of `params` were accumulated in place by a kernel (no autograd hook fires for them)."""
@@ -180,6 +187,7 @@ class FlatGradReducer:
         if self.launched[bi]:
             return
         self.launched[bi] = True
+        self.n_early += int(self._partial_open)  # left while the encoder's backward had not started yet
         lo, hi = self.ranges[bi]
         buf = self.store.flat_grad[lo:hi]
         if self.comm is not None:
@@ -231,18 +239,27 @@ class FlatGradReducer:
                 return bi
         raise ValueError("tensor is not a view of the flat gradient")
 
-    def exchange_begin(self, plan):
+    def exchange_begin(self, plan, partial: bool = False):
         """Start the exchange of one optimizer step: `plan` = WgradQueue plan about to run.  Buckets no queued product writes
         into (the non-Linear prefix: LayerNorm, convolution, embedding gradients, complete once backward is over) go out
-        at once; the others as soon as the last product writing into them has been launched (entries_done)."""
-        self.begin(armed=True)
-        if not self.armed:
+        at once; the others as soon as the last product writing into them has been launched (entries_done).
+        partial=True: the backward pass is only done behind the encoder's output - `plan` holds the decoder side's products, the
+        buckets they complete (ParamStore.late_ranges) go out as those products are launched, everything else waits for the
+        second call (partial=False) at the end of backward."""
+        if not self._partial_open:
+            self.begin(armed=True)
+            if not self.armed:
+                return
+            self.exchange_mode = True
+            self.pending = [0] * len(self.ranges)
+        elif not self.armed:
             return
-        self.exchange_mode = True
-        self.pending = [0] * len(self.ranges)
         for _, items in plan:
             for it in items:
                 self.pending[self.bucket_of_tensor(it[2])] += 1
+        self._partial_open = partial
+        if partial:
+            return
         for bi, n in enumerate(self.pending):
             if n == 0:
                 self._launch(bi)
@@ -280,6 +297,7 @@ class FlatGradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.armed = False
         self.exchange_mode = False
+        self._partial_open = False
 
 
 def _epoch_order(pool: List[int], shuffle: bool, generator: Optional[torch.Generator]) -> List[int]:

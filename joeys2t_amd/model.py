@@ -51,6 +51,7 @@ class Model(nn.Module):
             assert isinstance(self.encoder, TransformerEncoder)
             assert isinstance(self.decoder, TransformerDecoder)
         self._rt_obj: Optional[Runtime] = None
+        self._cut_tensor = None  # encoder output of the last training forward (the one tensor between the two halves of backward)
         self.overlap_ctc = False  # loss path: CTC branch on a second stream (TrainStep(overlap_ctc=True))
 
     # ------------------------------------------------------------------ HIP runtime binding
@@ -164,6 +165,7 @@ class Model(nn.Module):
     def _encode_decode(self, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
                        **kwargs):
         encoder_output, encoder_hidden, src_mask = self._encode(src=src, src_length=src_length, src_mask=src_mask, **kwargs)
+        encoder_output = self._mark_cut(encoder_output)
         decoder_output, _, _, _, ctc_output = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden,
                                                            src_mask=src_mask, trg_input=trg_input,
                                                            unroll_steps=trg_input.size(1), trg_mask=trg_mask, **kwargs)
@@ -176,6 +178,7 @@ class Model(nn.Module):
         for ~0.25 ms and the decoder's kernels (2592 target rows) leave most of the chip idle as well.  Autograd runs the
         branch's backward on the same second stream.  Same kernels, same values."""
         encoder_output, encoder_hidden, src_mask = self._encode(src=src, src_length=src_length, src_mask=src_mask, **kwargs)
+        encoder_output = self._mark_cut(encoder_output)
         cur, side = torch.cuda.current_stream(), self.runtime.side_stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
@@ -188,6 +191,15 @@ class Model(nn.Module):
                                                   trg_input=trg_input, unroll_steps=trg_input.size(1), trg_mask=trg_mask,
                                                   compute_ctc=False, **kwargs)
         return decoder_output, ctc_out, src_mask, ctc_loss
+
+    def _mark_cut(self, encoder_output: Tensor) -> Tensor:
+        """The encoder output of a training forward, passed through an identity node: the one tensor that connects the two halves
+        of the backward pass, and where TrainStep may cut it (functional.CutFn says why the node is there)."""
+        self._cut_tensor = None
+        if torch.is_grad_enabled() and encoder_output.requires_grad:
+            from joeys2t_amd.functional import CutFn
+            encoder_output = self._cut_tensor = CutFn.apply(encoder_output)
+        return encoder_output
 
     def _encode(self, src: Tensor, src_length: Tensor, src_mask: Tensor, **_kwargs):
         assert _kwargs.get("task", self.task) == self.task, (_kwargs.get("task"), self.task)

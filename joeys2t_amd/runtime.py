@@ -52,29 +52,41 @@ class ParamStore:
         # shape from ALL layers are adjacent, followed by their bias groups.  The deferred weight-gradient products
         # (WgradQueue) run type by type, so each such range of the flat gradient is complete - and can be handed to RCCL -
         # while the next type's products still run.  `type_ranges` lists (lo, hi) of the prefix and of every type.
+        # ... and SIDE-major above that: the nn.Linear parameters behind the encoder's output (everything registered under
+        # `decoder.` / `trg_embed.`, unless the encoder side shares it) come after all the others.  Their gradients are complete
+        # once the decoder's backward is - the backward pass is cut there (TrainStep.micro_step) and their ranges travel while the
+        # encoder's backward still runs.  `late_ranges` names those ranges of `type_ranges`.
+        late_ids = set()
+        if hasattr(module, "named_parameters"):
+            early_ids = {id(p) for n, p in module.named_parameters(remove_duplicate=False) if not n.startswith(("decoder.", "trg_embed."))}
+            late_ids = {id(p) for n, p in module.named_parameters(remove_duplicate=False) if n.startswith(("decoder.", "trg_embed."))} - early_ids
         lin_key: Dict[int, Tuple] = {}
         for m in module.modules():
             if isinstance(m, nn.Linear):
                 wg = group_of.get(id(m.weight), [m.weight])
-                key = (sum(p.shape[0] for p in wg), wg[0].shape[1])
+                bg = [] if m.bias is None else group_of.get(id(m.bias), [m.bias])
+                side = int(all(id(p) in late_ids for p in (*wg, *bg)))
+                key = (side, sum(p.shape[0] for p in wg), wg[0].shape[1])
                 for p in wg:
                     lin_key[id(p)] = key + (0, )
-                if m.bias is not None:
-                    for p in group_of.get(id(m.bias), [m.bias]):
-                        lin_key.setdefault(id(p), key + (1, ))
+                for p in bg:
+                    lin_key.setdefault(id(p), key + (1, ))
         order = sorted(range(len(groups)), key=lambda i: ((1, ) + lin_key[id(groups[i][0])] if id(groups[i][0]) in lin_key else (0, )) + (i, ))
         groups = [groups[i] for i in order]
         offsets: Dict[int, int] = {}
         total = 0
         self.type_ranges: List[Tuple[int, int]] = []
+        self.late_ranges: List[Tuple[int, int]] = []
         cur_key, cur_lo = "prefix", 0
         for grp in groups:
             k = lin_key.get(id(grp[0]))
-            k = "prefix" if k is None else k[:2]
+            k = "prefix" if k is None else k[:3]
             if k != cur_key:
                 boundary = (total + _ALIGN - 1) // _ALIGN * _ALIGN
                 if boundary > cur_lo:
                     self.type_ranges.append((cur_lo, boundary))
+                    if cur_key != "prefix" and cur_key[0] == 1:
+                        self.late_ranges.append((cur_lo, boundary))
                 cur_key, cur_lo = k, boundary
             total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
             for p in grp:
@@ -83,6 +95,8 @@ class ParamStore:
         total = (total + _ALIGN - 1) // _ALIGN * _ALIGN
         if total > cur_lo:
             self.type_ranges.append((cur_lo, total))
+            if cur_key != "prefix" and cur_key[0] == 1:
+                self.late_ranges.append((cur_lo, total))
         self.total = total
         self.offsets = offsets
         self.params: List[nn.Parameter] = [p for grp in groups for p in grp]
@@ -298,6 +312,7 @@ class WgradQueue:
         self.first = False
         self.collector = None
         self.grad_base = None  # (flat gradient tensor) element offsets of the dW views are taken against it
+        self._written = []     # spans overwritten by earlier (non-final) takes of this micro-batch
 
     def add(self, dz2d: torch.Tensor, x2d: torch.Tensor, dw_out: torch.Tensor, db_out: Optional[torch.Tensor]):
         N, K, M = dz2d.shape[1], x2d.shape[1], dz2d.shape[0]
@@ -319,8 +334,10 @@ class WgradQueue:
         lo = (t.data_ptr() - self.grad_base.data_ptr()) // 4
         return (lo, lo + t.numel())
 
-    def take(self):
-        """The queued products as a plan [(key + (mode, collector), items)], emptying the queue.  A plan built while a hipGraph was
+    def take(self, final: bool = True):
+        """The queued products as a plan [(key + (mode, collector), items)], emptying the queue.  final=False: more products of
+        this micro-batch will follow (the backward pass is cut at the encoder's output, TrainStep.micro_step): the pieces nothing
+        overwrote are only settled by the last take.  A plan built while a hipGraph was
         captured stays valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches.
         mode: 1 = the products overwrite their dW (beta 0), 2 = their epilogues leave the sums of squares with the collector."""
         from joeys2t_amd.functional import wgrad_split
@@ -350,9 +367,12 @@ class WgradQueue:
                         mode |= 2
             out.append((key + (mode, self.collector if mode & 2 else None), items))
         if active and self.first:
-            for lo, hi in self.kept.minus(written):  # un-cleared, and nothing overwrites it this time
-                self.grad_base[lo:hi].zero_()
-                self.kept.remove(lo, hi)
+            written = self._written + written
+            self._written = [] if final else written
+            if final:
+                for lo, hi in self.kept.minus(written):  # un-cleared, and nothing overwrites it this time
+                    self.grad_base[lo:hi].zero_()
+                    self.kept.remove(lo, hi)
             for lo, hi in written:
                 if not self.kept.contains(lo, hi):
                     self.kept.add(lo, hi)

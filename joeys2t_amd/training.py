@@ -26,6 +26,10 @@ from joeys2t_amd.model import Model
 from joeys2t_amd.runtime import WgradQueue
 
 
+# the backward pass cut at the encoder's output under data parallelism (JS2T_EARLY_EXCHANGE=0: one piece, exchange after it)
+EARLY_EXCHANGE = os.environ.get("JS2T_EARLY_EXCHANGE", "1") != "0"
+
+
 class TrainStep:
     def __init__(self, model: Model, *, learning_rate: float = 2.0e-3, adam_betas=(0.9, 0.98), weight_decay: float = 0.0,
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
@@ -87,6 +91,8 @@ class TrainStep:
                 comm = Communicator.from_process_group(self.store.device)
             self.reducer = FlatGradReducer(self.store, n_buckets=n_buckets, ranges=self.store.type_ranges if defer_wgrads else None,
                                            comm_dtype=comm_dtype, comm=comm)
+        # leaves behind the encoder's output: what the first half of a cut backward pass accumulates into (see micro_step)
+        self._late_leaves = [p for n, p in model.named_parameters() if n.startswith(("decoder.", "trg_embed.")) and p.requires_grad]
         # bucket bookkeeping by per-parameter notifications only without the queue (with it: exchange_and_flush)
         self.rt.on_grads_ready = self.reducer.params_ready if (self.reducer is not None and self.rt.wgrad_queue is None) else None
         # running statistics on the device: [loss, nll, ctc, n_correct, nseqs, ntokens]
@@ -108,12 +114,14 @@ class TrainStep:
         WgradQueue.run(plan, self.reducer.entries_done)
         self.reducer.finish()
 
-    def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True, flush: bool = True):
+    def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True, flush: bool = True, cut_hook=None):
         """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss.
         `sort=False` skips batch.sort_by_src_length() (a host sync) for callers that sorted already;
         `update=False` leaves the optimizer step to the caller (hipGraph capture of forward+backward only);
         `overlap=False` disables the gradient exchange here (the caller runs exchange_and_flush() / reducer.reduce_all());
-        `flush=False` leaves the deferred weight-gradient products queued (the caller keeps them as a plan)."""
+        `flush=False` leaves the deferred weight-gradient products queued (the caller keeps them as a plan);
+        `cut_hook`: called between the two halves of the backward pass (cut at the encoder's output) INSTEAD of the partial exchange
+        - for a caller that captures the halves as two hipGraphs and runs the exchange itself between their replays (bench.py)."""
         model = self.model
         model.train()
         self.rt.rng.begin_step()
@@ -146,12 +154,35 @@ class TrainStep:
         seed = self._grad_seeds.get(inv_norm)
         if seed is None:
             seed = self._grad_seeds[inv_norm] = torch.full((), inv_norm, dtype=torch.float32, device=total.device)
+        # Data parallel: the backward pass in two halves, cut at the encoder's output.  Behind it (decoder, target embedding, both
+        # output layers, the CTC branch) every gradient is complete after the first half: the decoder side's weight-gradient
+        # products run there and their ranges of the flat gradient (ParamStore.late_ranges) travel while the encoder's backward
+        # - three quarters of the pass - still runs (the reference's DistributedDataParallel reducer sends its buckets during
+        # backward too, prediction.py:511-513).  The encoder output is the only tensor that connects the halves.
+        enc_out = getattr(model, "_cut_tensor", None)
+        model._cut_tensor = None
+        can_cut = (EARLY_EXCHANGE and enc_out is not None and enc_out.grad_fn is not None and bool(self.store.late_ranges) and
+                   self.rt.wgrad_queue is not None)
+        cut = can_cut and (cut_hook is not None or (exchange and not use_hooks and self.reducer.armed_for_exchange()))
         try:
-            total.backward(gradient=seed)
+            if cut:
+                torch.autograd.backward(total, grad_tensors=seed, inputs=[enc_out] + self._late_leaves)
+                functional.end_memory_chain()  # every cross-attention block has run: the encoder-state gradient is whole
+                if cut_hook is not None:
+                    cut_hook()
+                else:
+                    plan = self.rt.wgrad_queue.take(final=False)
+                    self.reducer.exchange_begin(plan, partial=True)
+                    WgradQueue.run(plan, self.reducer.entries_done)
+                g_enc, enc_out.grad = enc_out.grad, None
+                enc_out.backward(g_enc)
+            else:
+                total.backward(gradient=seed)
         except BaseException:
             functional.end_memory_chain(check=False)
             raise
-        functional.end_memory_chain()
+        if not cut:
+            functional.end_memory_chain()
         if self.rt.grad_copies is not None:
             self.rt.grad_copies.fold()
         if use_hooks:

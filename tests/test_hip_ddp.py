@@ -48,13 +48,23 @@ def _worker(rank, world, port, ret):
         assert ddp.reducer is not None and len(ddp.reducer.ranges) == len(ddp.store.type_ranges) > 2
         ddp.micro_step(mk(), update=False)
         got = ddp.store.flat_grad.clone()
+        n_early = ddp.reducer.n_early  # ranges that left at the cut of the backward pass (behind the encoder's output)
         mean = g_local.clone()
         dist.all_reduce(mean)
         mean /= world
         err = (got - mean).abs().max().item()
         ref = mean.abs().max().item()
         differs = (g_local - mean).abs().max().item()  # the ranks really had different gradients
-        ret[rank] = (err, ref, differs)
+        # the same without the cut: one backward pass, everything exchanged behind it
+        from joeys2t_amd import training
+        training.EARLY_EXCHANGE = False
+        ddp.store.flat_grad.zero_()
+        if ddp.optimizer.keep is not None:
+            for lo, hi in list(ddp.optimizer.keep.r):
+                ddp.optimizer.keep.remove(lo, hi)
+        ddp.micro_step(mk(), update=False)
+        err_uncut = (ddp.store.flat_grad - mean).abs().max().item()
+        ret[rank] = (err, ref, differs, n_early, ddp.reducer.n_early, err_uncut, len(ddp.store.late_ranges))
     finally:
         dist.destroy_process_group()
 
@@ -64,9 +74,13 @@ def test_overlapped_exchange_averages_gradients(device):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for r in (0, 1):
-        err, ref, differs = ret[r]
+        err, ref, differs, n_early, n_early_uncut, err_uncut, n_late = ret[r]
         assert differs > 1e-3 * ref
         assert err <= 2e-3 * ref, (err, ref)  # split-K atomics / bf16 products: not bit-reproducible run to run
+        assert err_uncut <= 2e-3 * ref, (err_uncut, ref)
+        # the decoder side's ranges left while the encoder's backward had not started (training.py: the cut)
+        # (a range whose products do not go through the queue - the 20-row output layers of this tiny model - leaves at the end)
+        assert 3 <= n_early <= n_late and n_early_uncut == 0, (n_early, n_late, n_early_uncut)
 
 
 def _rccl_bf16_worker(rank, port, ret):
@@ -231,4 +245,5 @@ def test_train_step_with_the_exchange_through_the_c_boundary(device):
     # went out before its products had run would be off by the learning rate everywhere in it.
     diff = (plain - got).abs()
     assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 2e-2  # (0.1 - 0.5 % of the coordinates, run to run)
-    assert (diff.norm() / plain.norm()).item() < 1e-4
+    # (1e-4 - 4e-4 run to run; a range exchanged too early is off by the learning rate in every coordinate: > 1e-2 of the norm)
+    assert (diff.norm() / plain.norm()).item() < 2e-3
