@@ -478,6 +478,19 @@ int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int
                            const float* fill, const int32_t* masks, int32_t n_freq, int32_t n_time, js2t_stream stream);
 
 /* --------------------------------------------------------------------------------------------------
+ * Deterministic mode (off by default).  The reference's set_seed (helpers.py:93-104) sets torch.backends.cudnn.deterministic:
+ * two runs from one seed agree bit for bit.  With the switch on, every kernel of the Transformer S2T train step that otherwise
+ * sums through floating-point atomics takes an ordered form:
+ *   js2t_gemm / js2t_gemm_grouped: split_k > 1 runs un-split and ADDS onto C (what the atomics do) - fewer blocks, slower;
+ *   js2t_layernorm_bwd*: accumulate mode goes through the partial slab + the fixed-order final kernel instead of atomics;
+ *   js2t_embed_bwd: the first position of a token id owns the table row and adds the later ones in position order;
+ *   js2t_ctc_bwd: the first occurrence of a label in the extended target sums its later occurrences in order.
+ * Not covered (extension kernels off that path): the relative-position bias gradient, the Conformer's depthwise-convolution
+ * and BatchNorm parameter gradients.  A process-wide switch, read at launch time. */
+void js2t_set_deterministic(int on);
+int js2t_get_deterministic(void);
+
+/* --------------------------------------------------------------------------------------------------
  * Update tail over the flat parameter store (training.py:436-456).
  */
 

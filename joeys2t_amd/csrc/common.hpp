@@ -29,6 +29,8 @@ void js2t_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+extern int g_js2t_deterministic;  // js2t_set_deterministic (core.cpp): ordered sums instead of floating-point atomics
+
 // ---------------------------------------------------------------- dtype helpers
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);

@@ -15,3 +15,9 @@ void js2t_set_error(const char* fmt, ...) {
 
 extern "C" const char* js2t_last_error(void) { return g_err; }
 extern "C" int js2t_abi_version(void) { return 1; }
+
+// Deterministic mode (the reference asks cuDNN for one: helpers.py:93-104, set_seed): every kernel on the Transformer S2T train
+// path that sums through floating-point atomics takes an ordered form instead - see js2t_set_deterministic in the header.
+int g_js2t_deterministic = 0;
+extern "C" void js2t_set_deterministic(int on) { g_js2t_deterministic = on != 0; }
+extern "C" int js2t_get_deterministic(void) { return g_js2t_deterministic; }

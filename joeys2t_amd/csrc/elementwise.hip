@@ -171,6 +171,29 @@ __global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __res
   }
 }
 
+// deterministic form: block r owns table row ids[r] iff no earlier position holds the same id, and then adds the rows of
+// all positions with that id in position order (n_ids is a few thousand: the scans are noise)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_ordered_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+                                                                float* __restrict__ dtable, int64_t n_ids, int64_t D, int64_t vocab,
+                                                                float scale, int64_t pad_idx) {
+  __shared__ int earlier;
+  const int64_t r = blockIdx.x, id = ids[r];
+  if (id < 0 || id >= vocab || id == pad_idx) return;
+  if (threadIdx.x == 0) earlier = 0;
+  __syncthreads();
+  for (int64_t q = threadIdx.x; q < r; q += blockDim.x)
+    if (ids[q] == id) earlier = 1;  // (benign race: every writer stores 1)
+  __syncthreads();
+  if (earlier) return;
+  for (int64_t c = threadIdx.x; c < D; c += blockDim.x) {
+    float acc = dtable[id * D + c];
+    for (int64_t q = r; q < n_ids; ++q)
+      if (ids[q] == id) acc += scale * io<T>::ld(dout + q * D + c);
+    dtable[id * D + c] = acc;
+  }
+}
+
 // ---------------------------------------------------------------- column sums (two-stage, deterministic)
 // Stage 1: block = 64 column-chunks x 4 row-lanes over a 64-row slab; a thread owns 8 consecutive columns (16-byte
 // bf16 loads) when the row length allows, else one column.  Stage 2 adds the per-slab partials in a fixed order with
@@ -497,6 +520,12 @@ extern "C" int js2t_embed_bwd(const int64_t* ids, const void* dout, int dout_dt,
                               int64_t vocab, float scale, int64_t pad_idx, js2t_stream stream) {
   if (n_ids * D == 0) return JS2T_OK;
   JS2T_CHECK(ids && dout && dtable, "embed_bwd: null pointer");
+  if (g_js2t_deterministic) {
+    DISPATCH_DT(dout_dt, T, hipLaunchKernelGGL((embed_bwd_ordered_kernel<T>), dim3((unsigned)n_ids), dim3(256), 0, (hipStream_t)stream, ids,
+                                               (const T*)dout, dtable, n_ids, D, vocab, scale, pad_idx));
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dout_dt, T, hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(ew_grid(n_ids * D)), dim3(EW_THREADS), 0,
                                              (hipStream_t)stream, ids, (const T*)dout, dtable, n_ids, D, vocab, scale, pad_idx));
   JS2T_LAUNCH_CHECK();

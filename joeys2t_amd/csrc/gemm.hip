@@ -1333,6 +1333,13 @@ int launch_bf16_w256(const js2t_gemm_desc& d, hipStream_t s) {
 //  * B fragment rows are permuted as in dma_gemm_block, so each lane owns 16 consecutive output columns and the tile is
 //    stored from registers (direct_tile_epilogue).
 constexpr int P_BM = 192, P_ATILE = P_BM * 128, P_STAGE = P_ATILE + 16384, P_NST = 3, P_LDS = P_NST * P_STAGE, P_PER = 10;
+// ring depth of the loader / consumer form: 3 slots (120 KB); -DJS2T_P192S_NST4: 4 slots = the CU's whole 160 KB (measured, see profiles/README.md)
+#ifdef JS2T_P192S_NST4
+constexpr int PS_NST = 4;
+#else
+constexpr int PS_NST = 3;
+#endif
+constexpr int PS_LDS = PS_NST * P_STAGE;
 // NST = 2 (js2t_gemm_p192_ring(2)): a two-slot ring is 80 KB, so TWO blocks fit a CU and the grid is two blocks per CU.  Each
 // block then has one stage in flight instead of two (its ten requests go out in the second k-half of a stage and must have
 // landed by the middle of the next one) - what one block cannot hide any more (request latency, its epilogue, the switch
@@ -1394,6 +1401,13 @@ __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, f
 template <int EPI, bool OUT8 = false>
 __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane,
                                                 const float (&bias_r)[8], uint32_t drop_key, float my_rs = 0.f) {
+#ifdef JS2T_GEMM_NOEPI  // measurement only (tools/k512_ceiling.py): ring + MFMAs, the tile is dropped - what the feed alone allows
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+  return;
+#endif
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 8 * r;
   if (n >= d.N) return;  // N is a multiple of 8: a lane's column group lies inside or outside as a whole
@@ -1769,6 +1783,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192_kernel(js2t_gemm_desc d
 template <int EPI, bool OUT8 = false>
 __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_t (&acc)[3][4], int mw, int n0, int lane,
                                                  const float (&bias_r)[4], uint32_t drop_key, float my_rs = 0.f) {
+#ifdef JS2T_GEMM_NOEPI
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+  return;
+#endif
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 4 * r;
   if (n >= d.N) return;  // N is a multiple of 8 (hence of 4): a lane's column group lies inside or outside as a whole
@@ -1892,7 +1913,7 @@ template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc d, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using elem_t = typename std::conditional<FP8, uint8_t, uint16_t>::type;
-  constexpr int CSH = FP8 ? 4 : 3, KST = FP8 ? 128 : 64, NST = 3;
+  constexpr int CSH = FP8 ? 4 : 3, KST = FP8 ? 128 : 64, NST = PS_NST;
   const int t = threadIdx.x, lane = t & 63, g = lane >> 4;
   const int w12 = __builtin_amdgcn_readfirstlane(t >> 6);
   const int M = d.M, N = d.N, K = d.K, nk = (K + KST - 1) / KST;
@@ -1953,10 +1974,9 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
       islot = islot == NST - 1 ? 0 : islot + 1;
     };
     set_tile_src(min(iv, ntiles - 1));
-    issue_next();
-    issue_next();
-    issue_next();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_PER) : "memory");  // stage 0 landed
+#pragma unroll
+    for (int q = 0; q < NST; ++q) issue_next();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * P_PER) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
 #ifdef JS2T_P192S_DBG
     unsigned long long pw = 0, pb = 0, pi = 0, c0 = __builtin_readcyclecounter(), c1;
@@ -1965,11 +1985,11 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_p192s_kernel(js2t_gemm_desc 
 #define P192S_L(acc)
 #endif
     for (int sidx = 0; sidx < nstages; ++sidx) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_PER) : "memory");  // stage sidx + 1 landed, sidx + 2 in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * P_PER) : "memory");  // stage sidx + 1 landed, the later ones in flight
       P192S_L(pw);
       __builtin_amdgcn_s_barrier();                                  // ... and every consumer holds stage sidx in registers
       P192S_L(pb);
-      issue_next();                                                  // stage sidx + 3 into the slot of stage sidx
+      issue_next();                                                  // stage sidx + NST into the slot of stage sidx
       P192S_L(pi);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail requests still target this block's LDS
@@ -2449,7 +2469,7 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2465,7 +2485,7 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   // fences of the hand-over to the finishing wave wait for nothing but the wave's own stores
   if (g_p192_ring == 4 || (EPI >= 0 && (EPI & PE_STATS)) || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
-    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
+    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), PS_LDS, s, d, tm, tn);
   } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
     const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192_kernel<EPI, 2>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
@@ -2484,7 +2504,7 @@ int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_bf16_p192_kernel<-1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P_STAGE);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+      e = hipFuncSetAttribute((const void*)gemm_bf16_p192s_kernel<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     int dev = 0, cu = 0;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2501,7 +2521,7 @@ int launch_fp8_p192(const js2t_gemm_desc& d, hipStream_t s) {
     // per CU: FFN1 23.3 against 25.3 us, QKV 19.5 / 20.9, FFN2 15.5 / 23.1 (tools/fp8_gemm_bench.py); without it (-DJS2T_FP8_NO_SCALED)
     // the bf16 rule applies and the e4m3 second output lives in the ring forms only
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
-    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<-1, true>), dim3(grid), dim3(768), P_LDS, s, d, tm, tn);
+    hipLaunchKernelGGL((gemm_bf16_p192s_kernel<-1, true>), dim3(grid), dim3(768), PS_LDS, s, d, tm, tn);
   } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
     const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192_kernel<-1, 2, true>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
@@ -2691,6 +2711,7 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
              "gemm_grouped: plain epilogue only (alpha, beta)");
   if (d.split_k < 1) d.split_k = 1;
   JS2T_CHECK(d.split_k == 1 || (d.dtype_c == JS2T_F32 && d.beta == 0.f), "gemm_grouped: split_k needs f32 C and beta = 0");
+  if (g_js2t_deterministic && d.split_k > 1) d.split_k = 1, d.beta = 1.f;  // K slices summed by atomics -> one slice added onto C
   if (d.sumsq_partial) {
     // every tile must take the epilogue's row-segment path: whole 128-column tiles, 16-byte aligned f32 rows
     JS2T_CHECK(d.split_k == 1 && d.dtype_c == JS2T_F32 && (d.N & 127) == 0 && (d.ldc & 3) == 0,
@@ -2753,6 +2774,7 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(d.dtype_c == JS2T_F32 && !d.bias && d.act == JS2T_ACT_NONE && !d.preact && d.dropout_p == 0.f && !d.residual &&
                    !d.gate && d.beta == 0.f,
                "gemm: split_k needs an f32 C and a plain epilogue (C must be zero-filled by the caller)");
+    if (g_js2t_deterministic) d.split_k = 1, d.beta = 1.f;  // one slice, added onto C: what the atomics of the slices do, in one order
   }
   if (d.ln_partial || d.rs_partial) {
     // the fold lives in the register-direct epilogues of the k-contiguous bf16 kernels: the persistent 192x128 kernel (three

@@ -455,8 +455,10 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
                                                       const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len,
                                                       const float* __restrict__ g_dev, float scale, T* __restrict__ dx,
                                                       int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank,
-                                                      int zero_inf) {
+                                                      int zero_inf, int ordered) {
   extern __shared__ float row[];  // V floats
+  __shared__ float occ_s[CTC_MAX_S];  // ordered form: the positions' terms and labels, summed by each label's first occurrence
+  __shared__ int lab_s[CTC_MAX_S];
   const int64_t bt = blockIdx.x, b = bt / Tmax, t = bt - b * Tmax;
   T* dr = dx + bt * V;
   const float nl = nll[b];
@@ -492,12 +494,45 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
   const int L = (int)min(tgt_len[b], Lmax), S = 2 * L + 1;
   const float* ar = alpha + bt * Smax;
   const float* br = beta + bt * Smax;
-  for (int s = threadIdx.x; s < S; s += LB) {
-    const int lab = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
-    if (lab < 0 || lab >= V) continue;
-    const float lp = io<T>::ld(xr + lab) - l;
-    const float occ = ar[s] + br[s] - lp + nl;
-    if (occ > -80.f) atomicAdd(&row[lab], -__expf(occ));
+  if (!ordered) {
+    for (int s = threadIdx.x; s < S; s += LB) {
+      const int lab = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
+      if (lab < 0 || lab >= V) continue;
+      const float lp = io<T>::ld(xr + lab) - l;
+      const float occ = ar[s] + br[s] - lp + nl;
+      if (occ > -80.f) atomicAdd(&row[lab], -__expf(occ));
+    }
+  } else {
+    // deterministic form (js2t_set_deterministic): a label that occurs several times in the extended target (every blank, repeated
+    // tokens) collects its terms in position order, by the thread of its first occurrence - no float atomics
+    for (int s = threadIdx.x; s < S; s += LB) {
+      const int lab = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
+      float term = 0.f;
+      if (lab >= 0 && lab < V) {
+        const float lp = io<T>::ld(xr + lab) - l;
+        const float occ = ar[s] + br[s] - lp + nl;
+        if (occ > -80.f) term = -__expf(occ);
+      }
+      lab_s[s] = (lab >= 0 && lab < V) ? lab : -1;
+      occ_s[s] = term;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += LB) {
+      const int lab = lab_s[s];
+      if (lab < 0) continue;
+      bool first = true;
+      for (int q = (s & 1); q < s; q += 2)  // same parity only: blanks sit on even positions, labels on odd ones ...
+        if (lab_s[q] == lab) { first = false; break; }
+      if (first && (s & 1)) {               // ... unless a label equals the blank id
+        for (int q = 0; q < s; q += 2)
+          if (lab_s[q] == lab) { first = false; break; }
+      }
+      if (!first) continue;
+      float acc = row[lab];
+      for (int q = s; q < S; ++q)
+        if (lab_s[q] == lab) acc += occ_s[q];
+      row[lab] = acc;
+    }
   }
   __syncthreads();
   if (vec) {
@@ -661,7 +696,7 @@ extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const 
   if (B == 0) return JS2T_OK;
   JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && beta && nll && dlogits, "ctc_bwd: null pointer");
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_bwd: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
-  JS2T_CHECK(V * 4 <= 160 * 1024 - 1024, "ctc_bwd: vocabulary %lld too large for the LDS-staged gradient row", (long long)V);
+  JS2T_CHECK(V * 4 <= 160 * 1024 - 10 * 1024, "ctc_bwd: vocabulary %lld too large for the LDS-staged gradient row", (long long)V);
   const int64_t Smax = 2 * Lmax + 1;
   hipStream_t s = (hipStream_t)stream;
   if (!beta_ready) {
@@ -675,12 +710,12 @@ extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const 
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const float*)logits, lse, alpha,
                        beta, nll, targets, in_len, tgt_len, g_dev, scale, (float*)dlogits, T_, V, Lmax, Smax, blank,
-                       zero_infinity);
+                       zero_infinity, g_js2t_deterministic);
   } else {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ctc_grad_kernel<uint16_t>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const uint16_t*)logits, lse,
                        alpha, beta, nll, targets, in_len, tgt_len, g_dev, scale, (uint16_t*)dlogits, T_, V, Lmax, Smax, blank,
-                       zero_infinity);
+                       zero_infinity, g_js2t_deterministic);
   }
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;

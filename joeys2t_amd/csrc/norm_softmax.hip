@@ -665,7 +665,9 @@ extern "C" int js2t_layernorm_bwd_fused(const void* dy, const void* x, const flo
              "layernorm_bwd_fused: n_out needs beta and the vectorised kernel (D % 8 == 0, D <= 2048, 16-byte aligned)");
   if (vec) {
     const bool want_p = dgamma && dbeta;
-    const bool direct = want_p && accumulate;  // += onto the gradient: atomics from the dx kernel itself
+    // += onto the gradient: atomics from the dx kernel itself - unless the deterministic switch is on (partial slab + the
+    // fixed-order final kernel, which then adds onto the gradient)
+    const bool direct = want_p && accumulate && !(g_js2t_deterministic && partial);
     JS2T_CHECK(!want_p || direct || partial, "layernorm_bwd: partial workspace required for dgamma/dbeta");
     // waves per block: as many as a 64 KB cross-wave reduction buffer allows (16 for D <= 512)
     int nw = 16;

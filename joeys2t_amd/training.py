@@ -35,8 +35,15 @@ class TrainStep:
                  clip_grad_norm: Optional[float] = 10.0, scheduling: Optional[str] = "warmupinversesquareroot",
                  learning_rate_warmup: int = 10000, learning_rate_min: float = 1.0e-6, normalization: str = "batch",
                  batch_multiplier: int = 1, n_gpu: int = 1, n_buckets: int = 4, sync_every_backward: bool = False,
-                 defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None, comm=None):
+                 defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None, comm=None,
+                 deterministic: bool = False):
         self.model = model
+        # deterministic=True: the reference's set_seed asks cuDNN for deterministic kernels (helpers.py:93-104); here the library's
+        # process-wide switch (js2t_set_deterministic) puts every floating-point-atomic sum of the train step on an ordered form -
+        # two runs from one state then agree bit for bit (tests/test_hip_deterministic.py), at a price bench.py reports
+        from joeys2t_amd._lib import lib as _lib
+        self.deterministic = bool(deterministic) or os.environ.get("JS2T_DETERMINISTIC", "0") == "1"
+        _lib().js2t_set_deterministic(int(self.deterministic))
         model.overlap_ctc = bool(overlap_ctc)
         self.rt = model.runtime
         self.store = self.rt.store
