@@ -52,8 +52,19 @@ class Communicator:
             raise Js2tError("Communicator: RCCL needs a GPU (the CPU rehearsal uses torch.distributed's gloo)")
         self._L = _bind(lib())
         self.rank, self.world, self.device = int(rank), int(world), device
-        mine = unique_id() if self.rank == 0 else None
+        # rank 0 draws the id; if that fails there (librccl missing) the others must not be left waiting in the broadcast:
+        # the failure travels instead of the id and every rank raises
+        mine, failed = None, None
+        if self.rank == 0:
+            try:
+                mine = unique_id()
+            except Exception as exc:  # noqa: BLE001
+                mine, failed = b"!" + repr(exc).encode()[:200], exc
         uid = (exchange_id or _broadcast_id)(mine)
+        if failed is not None:
+            raise failed
+        if isinstance(uid, (bytes, bytearray)) and bytes(uid[:1]) == b"!" and len(uid) != int(self._L.js2t_comm_unique_id_bytes()):
+            raise Js2tError("Communicator: rank 0 could not draw an id: " + bytes(uid[1:]).decode(errors="replace"))
         if not isinstance(uid, (bytes, bytearray)) or len(uid) != int(self._L.js2t_comm_unique_id_bytes()):
             raise Js2tError("Communicator: the exchanged id is not an ncclUniqueId")
         self._h = C.c_void_p()

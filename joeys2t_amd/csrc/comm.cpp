@@ -83,6 +83,20 @@ struct Comm {
 
 extern "C" int64_t js2t_comm_unique_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
 
+// The communicator's stream and events live on c->device: the per-call entry points run with that device current, whatever the
+// caller's is, and put the caller's device back.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 extern "C" int js2t_comm_unique_id(void* out, int64_t nbytes) {
   if (!out || nbytes < NCCL_UNIQUE_ID_BYTES) {
     js2t_set_error("js2t_comm_unique_id: need a buffer of %d bytes", NCCL_UNIQUE_ID_BYTES);
@@ -101,11 +115,11 @@ extern "C" int js2t_comm_init(void** comm_out, const void* unique_id, int64_t id
     return JS2T_ERR_INVALID;
   }
   if (!rccl_ready()) return JS2T_ERR_UNSUPPORTED;
-  Comm* c = new Comm();
-  c->world = world, c->rank = rank, c->device = device;
   int prev = 0;
   HIP_OK(hipGetDevice(&prev), "hipGetDevice");
   HIP_OK(hipSetDevice(device), "hipSetDevice");
+  Comm* c = new Comm();  // (after the calls that may return early)
+  c->world = world, c->rank = rank, c->device = device;
   ncclUniqueId id;
   memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);  // blocks until every rank has arrived
@@ -134,6 +148,11 @@ extern "C" int js2t_comm_allreduce_async(void* comm, void* buf, int64_t count, i
     js2t_set_error("js2t_comm_allreduce_async: bad arguments (f32 or bf16 buffer, count > 0)");
     return JS2T_ERR_INVALID;
   }
+  DeviceGuard guard(c->device);
+  if (!guard.ok) {
+    js2t_set_error("js2t_comm_allreduce_async: cannot select device %d", c->device);
+    return JS2T_ERR_LAUNCH;
+  }
   // the collective starts when the producer stream has got as far as this call, and not before
   HIP_OK(hipEventRecord(c->ready, (hipStream_t)producer), "hipEventRecord");
   HIP_OK(hipStreamWaitEvent(c->stream, c->ready, 0), "hipStreamWaitEvent");
@@ -150,6 +169,11 @@ extern "C" int js2t_comm_wait(void* comm, js2t_stream consumer, int32_t host) {
     js2t_set_error("js2t_comm_wait: null communicator");
     return JS2T_ERR_INVALID;
   }
+  DeviceGuard guard(c->device);
+  if (!guard.ok) {
+    js2t_set_error("js2t_comm_wait: cannot select device %d", c->device);
+    return JS2T_ERR_LAUNCH;
+  }
   if (host) {
     HIP_OK(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
   } else {
@@ -163,6 +187,7 @@ extern "C" js2t_stream js2t_comm_stream(void* comm) { return comm ? (js2t_stream
 extern "C" int js2t_comm_destroy(void* comm) {
   Comm* c = (Comm*)comm;
   if (!c) return JS2T_OK;
+  DeviceGuard guard(c->device);
   (void)hipStreamSynchronize(c->stream);
   ncclResult_t r = g_rccl.CommDestroy(c->comm);
   (void)hipEventDestroy(c->ready);

@@ -438,7 +438,9 @@ class ResidualBlockFn(torch.autograd.Function):
         if (fold is not None and d == ops.LN_FOLD_WIDTH and _fold_operand(x2) and fold_shapes_ok(B * T, fold.w.shape[0], d) and
                 (not torch.is_grad_enabled() or ("_wq" in sink0 and "ln_g" in sink0))):
             hint = _LN_STATS.pop(x.data_ptr(), None)
-            if hint is not None and hint[1].shape == x.shape and hint[1].dtype == x.dtype:
+            # the statistics belong to the tensor the producing block returned, unmodified since (views of one storage share a
+            # version counter, an in-place edit in between bumps it): anything else goes through the LayerNorm kernel as before
+            if hint is not None and hint[1].shape == x.shape and hint[1].dtype == x.dtype and hint[2] == x._version == hint[1]._version:
                 mean = torch.empty((B * T, ), dtype=torch.float32, device=x.device)
                 rstd = torch.empty_like(mean)
                 lnf = (hint[0], LN_EPS, mean, rstd)
@@ -546,7 +548,7 @@ class ResidualBlockFn(torch.autograd.Function):
         if out_stats is not None:
             if len(_LN_STATS) > 64:
                 _LN_STATS.clear()
-            _LN_STATS[y.data_ptr()] = (out_stats, y)
+            _LN_STATS[y.data_ptr()] = (out_stats, y, y._version)
         if p_out > 0 and rng is not None and cfg.ln_mode != "post" and FUSE_LN_DROPOUT_BWD and x.requires_grad:
             if len(_DROP_HINT) > 64:  # forward passes without a training step around them: do not pile up activations
                 _DROP_HINT.clear()

@@ -122,6 +122,11 @@ class Model(nn.Module):
         if return_type is None:
             raise ValueError("Please specify return_type: {`loss`, `loss_probs`, `encode`, `decode`, `decode_ctc`}.")
         self._prepare_step()
+        if not torch.is_grad_enabled():
+            # hand-over tables between residual blocks (LayerNorm statistics, dropout hints) are reset per training step by
+            # TrainStep; inference forwards reset them here, so that no activation of an earlier call stays pinned in them
+            from joeys2t_amd import functional as _Fn
+            _Fn.reset_handover()
         if return_type.startswith("loss"):
             assert self.loss_function is not None
             assert "trg" in kwargs and "trg_mask" in kwargs

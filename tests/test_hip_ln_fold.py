@@ -240,3 +240,32 @@ def test_inference_forward_uses_the_fold(device, p192_always):
     assert outs[False][1] == 7 and outs[True][1] == 2, (outs[False][1], outs[True][1])
     a, b = outs[False][0], outs[True][0]
     assert ((a - b).norm() / a.norm()).item() < 1.5e-2
+
+
+@pytest.mark.parametrize("offset", [0.0, 5.0, 30.0])
+def test_fold_with_a_large_row_mean(device, offset):
+    """A residual stream whose rows sit far from zero (|mean| = `offset` standard deviations; deep pre-LN stacks drift that way):
+    the fold takes the variance as E[x^2] - mean^2 from fp32 partial sums and cancels the mean through bf16-rounded centred weights,
+    whose rows no longer sum to exactly 0.  Bound: the deviation from fp32 LayerNorm -> Linear math on the same bf16 input stays
+    within the bf16 rounding of the result plus rstd * |mean| * |sum_k rounding(Wf)| - printed, and asserted against that model."""
+    from joeys2t_amd import ops
+    M, N, K = 3000, 512, 512
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(M, K, generator=g) + offset).bfloat16().to(device)
+    W = (torch.randn(N, K, generator=g) / K**0.5).to(device)
+    gamma, beta, b = (1 + 0.2 * torch.randn(K, generator=g)).to(device), (0.1 * torch.randn(K, generator=g)).to(device), (0.1 * torch.randn(N, generator=g)).to(device)
+    wf, bias_f = _fold_weights(W, gamma, beta, b, device)
+    xf = x.float()
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=device)
+    mean_o, rstd_o = torch.empty(M, device=device), torch.empty(M, device=device)
+    ops.gemm(x, wf, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias_f, ln=(_partials(xf), EPS, mean_o, rstd_o))
+    var = xf.double().var(1, unbiased=False)
+    torch.testing.assert_close(rstd_o.double(), 1 / torch.sqrt(var + EPS), rtol=2e-3, atol=1e-6)  # E[x^2] - mean^2 in fp32 holds at 30 sigma
+    ref = torch.nn.functional.layer_norm(xf, (K, ), gamma, beta, EPS) @ W.t() + b
+    err = (y.float() - ref).abs()
+    # what the rounded centred rows leave of the mean: rstd * mean * sum_k (bf16(Wf) - exact centred W gamma)
+    leak = (rstd_o * mean_o).abs().max().item() * wf.float().sum(1).abs().max().item()
+    bound = 8e-2 + 1.5 * leak
+    print(f"offset {offset}: max |err| {err.max().item():.4f}, mean |err| {err.mean().item():.5f}, modelled leak {leak:.4f}")
+    assert err.max().item() < bound, (err.max().item(), bound)
+    assert err.mean().item() < 6e-3 + 0.5 * leak
