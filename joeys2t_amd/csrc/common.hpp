@@ -68,6 +68,25 @@ __device__ __forceinline__ void st_elem(void* p, int64_t i, int dt, float v) {
   else ((uint16_t*)p)[i] = f32_to_bf16_bits(v);
 }
 
+// ---------------------------------------------------------------- LayerNorm-fold weights: rounding with error feedback
+// Four centred, gamma-scaled weights w*g - cs -> bf16, the rounding error of each carried into the next (and, through `carry`,
+// into the lane's next four).  The consuming product cancels the row mean of its activations through these rows summing to 0;
+// rounded independently their sum is the sum of K rounding errors (~2e-3 for K = 512), which leaks rstd * mean * that into every
+// output - 4 % of the output's scale for a row 30 sigma off zero (tests/test_hip_ln_fold.py).  With the feedback a lane's eight
+// values sum to their exact sum within one last carry.  Shared by js2t_fold_ln_weights and js2t_adamw_items (bit-identical).
+__device__ __forceinline__ uint2 ln_fold_round4(const float (&w)[4], const float4 g, float cs, float& carry) {
+#pragma clang fp contract(off)
+  const float gg[4] = {g.x, g.y, g.z, g.w};
+  uint16_t q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float target = __builtin_fmaf(w[i], gg[i], -cs) + carry;
+    q[i] = f32_to_bf16_bits(target);
+    carry = target - bf16_bits_to_f32(q[i]);
+  }
+  return make_uint2((uint32_t)q[0] | ((uint32_t)q[1] << 16), (uint32_t)q[2] | ((uint32_t)q[3] << 16));
+}
+
 // ---------------------------------------------------------------- wave / block reductions (wave = 64)
 // All-lanes butterfly reductions in the VALU: __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0), i.e. six LDS
 // round trips per reduction on the critical path of every row-wise kernel (LayerNorm: two per row).  Inside a row of 16

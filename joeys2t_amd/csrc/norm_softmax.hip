@@ -511,7 +511,7 @@ __global__ void rel_bias_grad_kernel(const T* __restrict__ dS, float* __restrict
 
 // ---------------------------------------------------------------- weights of the LayerNorm fold
 // table row e: {W f32[N,K], gamma f32[K], beta f32[K], bias f32[N] | 0, Wf bf16[N,K], bias_f f32[N], N, K}; one wave per weight
-// row: c = sum_k W gamma, Wf = bf16(W gamma - c / K) (a centred row: the product of a raw activation row with it equals the
+// row: c = sum_k W gamma, Wf = bf16(W gamma - c / K), rounded with error feedback (a centred row: the product of a raw activation row with it equals the
 // product of the mean-free row with W gamma), bias_f = bias + W . beta
 __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const int64_t* __restrict__ table) {
   const int64_t* e = table + 8 * blockIdx.y;
@@ -532,12 +532,11 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const int64_t* __r
     bs += (w.x * b.x + w.y * b.y) + (w.z * b.z + w.w * b.w);
   }
   cs = wave_sum(cs) / (float)K, bs = wave_sum(bs);
+  float carry = 0.f;  // rounding with error feedback along the lane's own elements (ln_fold_round4)
   for (int64_t k = 4 * lane; k < K; k += 256) {
     const float4 w = *(const float4*)(W + n * K + k), g = *(const float4*)(gamma + k);
-    uint2 pk;
-    pk.x = pack_bf16x2(fmaf(w.x, g.x, -cs), fmaf(w.y, g.y, -cs));
-    pk.y = pack_bf16x2(fmaf(w.z, g.z, -cs), fmaf(w.w, g.w, -cs));
-    *(uint2*)(Wf + n * K + k) = pk;
+    const float wa[4] = {w.x, w.y, w.z, w.w};
+    *(uint2*)(Wf + n * K + k) = ln_fold_round4(wa, g, cs, carry);
   }
   if (lane == 0) bias_f[n] = bs + (bias ? bias[n] : 0.f);
 }

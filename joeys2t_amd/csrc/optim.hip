@@ -222,12 +222,11 @@ __global__ __launch_bounds__(256) void adamw_items_kernel(float* __restrict__ p,
     if (fe) {
       cs = wave_sum(cs) / (float)Cc, bs = wave_sum(bs);
       uint16_t* Wf = (uint16_t*)fe[4];
+      float carry = 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int64_t c = 4 * lane + 256 * j;
-        if (c < Cc)
-          *(uint2*)(Wf + r * Cc + c) = make_uint2(pack_bf16x2(fmaf(pn[j][0], gam[j].x, -cs), fmaf(pn[j][1], gam[j].y, -cs)),
-                                                  pack_bf16x2(fmaf(pn[j][2], gam[j].z, -cs), fmaf(pn[j][3], gam[j].w, -cs)));
+        if (c < Cc) *(uint2*)(Wf + r * Cc + c) = ln_fold_round4(pn[j], gam[j], cs, carry);
       }
       if (lane == 0) {
         const float* bias = (const float*)fe[3];

@@ -246,8 +246,10 @@ def test_inference_forward_uses_the_fold(device, p192_always):
 def test_fold_with_a_large_row_mean(device, offset):
     """A residual stream whose rows sit far from zero (|mean| = `offset` standard deviations; deep pre-LN stacks drift that way):
     the fold takes the variance as E[x^2] - mean^2 from fp32 partial sums and cancels the mean through bf16-rounded centred weights,
-    whose rows no longer sum to exactly 0.  Bound: the deviation from fp32 LayerNorm -> Linear math on the same bf16 input stays
-    within the bf16 rounding of the result plus rstd * |mean| * |sum_k rounding(Wf)| - printed, and asserted against that model."""
+    whose rows no longer sum to exactly 0.  The derived weights are therefore rounded with error feedback (common.hpp:
+    ln_fold_round4 - a lane's eight values keep their exact sum): at 30 sigma the mean |error| of the outputs is 0.014 (independent
+    rounding: 0.041), at 5 sigma 0.0032 (0.0071), at 0 the bf16 floor 0.002.  Bound: the deviation from fp32 LayerNorm -> Linear math
+    on the same bf16 input stays within the bf16 rounding of the result plus rstd * |mean| * |sum_k rounding(Wf)| (printed)."""
     from joeys2t_amd import ops
     M, N, K = 3000, 512, 512
     g = torch.Generator().manual_seed(3)
@@ -265,7 +267,8 @@ def test_fold_with_a_large_row_mean(device, offset):
     err = (y.float() - ref).abs()
     # what the rounded centred rows leave of the mean: rstd * mean * sum_k (bf16(Wf) - exact centred W gamma)
     leak = (rstd_o * mean_o).abs().max().item() * wf.float().sum(1).abs().max().item()
-    bound = 8e-2 + 1.5 * leak
+    bound = 3e-2 + 1.5 * leak
+    assert leak < 2.5e-3 * max(offset, 1.0), leak  # the rows' rounded sums: < 2.5e-3 per sigma of offset (were ~6e-3)
     print(f"offset {offset}: max |err| {err.max().item():.4f}, mean |err| {err.mean().item():.5f}, modelled leak {leak:.4f}")
     assert err.max().item() < bound, (err.max().item(), bound)
-    assert err.mean().item() < 6e-3 + 0.5 * leak
+    assert err.mean().item() < 4e-3 + 0.5 * leak
