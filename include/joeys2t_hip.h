@@ -359,6 +359,10 @@ int js2t_xent_fwd(const void* logits, int dt, const int64_t* trg, float* loss_ro
 int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, const float* lse, const float* g_dev,
                   float scale, void* dlogits, int64_t rows, int64_t V, int64_t pad_idx, float smoothing,
                   js2t_stream stream);
+/* The same with the gradient stored as out_dt: JS2T_BF16 for f32 logits whose gradient is the bf16 operand of the output layer's
+ * backward products next (decoders.py:620 backward) - no f32 gradient [rows, V] to write and cast. */
+int js2t_xent_bwd_as(const void* logits, int dt, const int64_t* trg, const float* lse, const float* g_dev, float scale,
+                     void* dlogits, int out_dt, int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream);
 
 /* Running statistics of TrainManager._train_step (training.py:566-586: loss, nll, ctc are normalised by
  * batch.normalize(), batch.py:135-175; n_correct, nseqs, ntokens are counts) in one launch instead of a dozen scalar

@@ -187,18 +187,20 @@ __global__ __launch_bounds__(LB) void xent_fwd_kernel(const T* __restrict__ x, c
 }
 
 // dx[r,v] = gscale * (softmax - t)   (0 for pad rows);  gscale = scale * (*g_dev)
-template <typename T>
+// TO: the gradient's storage type - the logits' own, or bf16 for f32 logits whose gradient feeds a bf16 product next
+// (js2t_xent_bwd_as: no f32 gradient to write and cast afterwards)
+template <typename T, typename TO = T>
 __global__ __launch_bounds__(LB) void xent_bwd_kernel(const T* __restrict__ x, const int64_t* __restrict__ trg,
                                                       const float* __restrict__ lse, const float* __restrict__ g_dev,
-                                                      float scale, T* __restrict__ dx, int64_t rows, int64_t V, int64_t pad,
+                                                      float scale, TO* __restrict__ dx, int64_t rows, int64_t V, int64_t pad,
                                                       float eps) {
   const int64_t r = blockIdx.x;
   const int64_t g = trg[r];
   const float gs = scale * (g_dev ? *g_dev : 1.f);
   const T* xr = x + r * V;
-  T* dr = dx + r * V;
+  TO* dr = dx + r * V;
   if (g == pad || g < 0 || g >= V) {
-    for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dr + v, 0.f);
+    for (int64_t v = threadIdx.x; v < V; v += LB) io<TO>::st(dr + v, 0.f);
     return;
   }
   const float l = lse[r];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(LB) void xent_bwd_kernel(const T* __restrict__ x, c
   for (int64_t v = threadIdx.x; v < V; v += LB) {
     const float sm = __expf(io<T>::ld(xr + v) - l);
     const float t = (v == g) ? tg : ((v == pad) ? 0.f : u);
-    io<T>::st(dr + v, gs * (sm - t));
+    io<TO>::st(dr + v, gs * (sm - t));
   }
 }
 
@@ -632,6 +634,18 @@ extern "C" int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, con
   JS2T_CHECK(logits && trg && lse && dlogits && V > 2, "xent_bwd: bad arguments");
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((xent_bwd_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
                                         (const T*)logits, trg, lse, g_dev, scale, (T*)dlogits, rows, V, pad_idx, smoothing));
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_xent_bwd_as(const void* logits, int dt, const int64_t* trg, const float* lse, const float* g_dev, float scale,
+                                void* dlogits, int out_dt, int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream) {
+  if (out_dt == dt) return js2t_xent_bwd(logits, dt, trg, lse, g_dev, scale, dlogits, rows, V, pad_idx, smoothing, stream);
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(logits && trg && lse && dlogits && V > 2, "xent_bwd_as: bad arguments");
+  JS2T_CHECK(dt == JS2T_F32 && out_dt == JS2T_BF16, "xent_bwd_as: f32 logits -> bf16 gradient, or equal types");
+  hipLaunchKernelGGL((xent_bwd_kernel<float, uint16_t>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream, (const float*)logits, trg,
+                     lse, g_dev, scale, (uint16_t*)dlogits, rows, V, pad_idx, smoothing);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -358,7 +358,13 @@ _KV_USERS = {}   # data_ptr of the grouped projections -> number of cross blocks
 _KV_GRAD = {}    # data_ptr -> the shared gradient buffer
 
 
+LOGIT_GRAD_DTYPE = {}   # data_ptr of f32 logits -> compute dtype of the projection that produced them (LinearFn -> loss)
+LOGIT_GRAD_READY = {}   # data_ptr of the placeholder gradient autograd carries -> (the gradient in that dtype, the placeholder)
+
+
 def reset_handover():
+    LOGIT_GRAD_DTYPE.clear()
+    LOGIT_GRAD_READY.clear()
     _DROP_HINT.clear()
     _DROP_READY.clear()
     _LN_STATS.clear()
@@ -806,11 +812,19 @@ class LinearFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.shape = shape
         ctx.sink, ctx.notify, ctx.leaves = sink, notify, (weight, bias)
+        if y.dtype != x2.dtype and any(ctx.needs_input_grad):
+            # f32 logits out of a bf16 product: tell the loss that consumes them which type this node's backward multiplies in
+            if len(LOGIT_GRAD_DTYPE) > 16:
+                LOGIT_GRAD_DTYPE.clear()
+            LOGIT_GRAD_DTYPE[y.data_ptr()] = x2.dtype
         return y.view(*shape[:-1], w_compute.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.x2, ctx.w
+        ready = LOGIT_GRAD_READY.pop(dy.data_ptr(), None)
+        if ready is not None and ready[1].shape == dy.shape and ready[0].dtype == x2.dtype:
+            dy = ready[0].view(dy.shape)  # the loss wrote its gradient in this node's compute type (loss._XentFn.backward)
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()

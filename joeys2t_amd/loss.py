@@ -13,6 +13,9 @@ from torch import Tensor, nn
 from joeys2t_amd import ops
 
 
+_NAN = {}  # device -> 0-d NaN tensor (the placeholder gradient of _XentFn.backward's hand-over)
+
+
 class _XentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, trg, pad_index, smoothing):
@@ -32,6 +35,21 @@ class _XentFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g2):
         g = g.contiguous().float()
+        from joeys2t_amd import functional as Fn
+        want = Fn.LOGIT_GRAD_DTYPE.pop(ctx.l2.data_ptr(), None)
+        if want is not None and want != ctx.l2.dtype and ctx.l2.dtype == torch.float32:
+            # the projection that made these f32 logits multiplies in bf16 (functional.LinearFn): its backward takes the gradient
+            # in bf16 from the hand-over table - no f32 gradient [rows, V] is written and cast.  What autograd carries is a
+            # placeholder of the logits' type that nothing reads (autograd insists on one): a NaN scalar expanded to their shape.
+            d = ops.xent_bwd(ctx.l2, ctx.t1, ctx.lse, g, 1.0, ctx.pad_index, ctx.smoothing, out_dtype=want)
+            nan = _NAN.get(ctx.l2.device)
+            if nan is None:
+                nan = _NAN[ctx.l2.device] = torch.full((), float("nan"), dtype=ctx.l2.dtype, device=ctx.l2.device)
+            ph = nan.expand(ctx.shape)  # no memory, no kernel - and NaN everywhere should anything ever read it
+            if len(Fn.LOGIT_GRAD_READY) > 16:  # (entries whose consumer never ran)
+                Fn.LOGIT_GRAD_READY.clear()
+            Fn.LOGIT_GRAD_READY[ph.data_ptr()] = (d, ph)
+            return ph, None, None, None
         d = ops.xent_bwd(ctx.l2, ctx.t1, ctx.lse, g, 1.0, ctx.pad_index, ctx.smoothing)
         return d.view(ctx.shape), None, None, None
 

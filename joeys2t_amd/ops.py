@@ -730,13 +730,14 @@ def xent_fwd(logits2d, trg1d, pad_idx: int, smoothing: float):
     return loss_rows, correct_rows, lse
 
 
-def xent_bwd(logits2d, trg1d, lse, g_dev, scale: float, pad_idx: int, smoothing: float):
+def xent_bwd(logits2d, trg1d, lse, g_dev, scale: float, pad_idx: int, smoothing: float, out_dtype=None):
+    """out_dtype: torch.bfloat16 for f32 logits -> the gradient in bf16 (js2t_xent_bwd_as); default the logits' dtype."""
     _dev(logits2d, trg1d, lse, g_dev)
     rows, V = logits2d.shape
-    d = torch.empty_like(logits2d)
-    check(lib().js2t_xent_bwd(_p(logits2d), dt_code(logits2d), _p(trg1d), _p(lse), _p(g_dev), C.c_float(scale), _p(d),
-                              C.c_int64(rows), C.c_int64(V), C.c_int64(pad_idx), C.c_float(smoothing), _stream()),
-          "js2t_xent_bwd")
+    d = torch.empty(logits2d.shape, dtype=out_dtype or logits2d.dtype, device=logits2d.device)
+    check(lib().js2t_xent_bwd_as(_p(logits2d), dt_code(logits2d), _p(trg1d), _p(lse), _p(g_dev), C.c_float(scale), _p(d), dt_code(d),
+                                 C.c_int64(rows), C.c_int64(V), C.c_int64(pad_idx), C.c_float(smoothing), _stream()),
+          "js2t_xent_bwd_as")
     return d
 
 
