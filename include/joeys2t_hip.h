@@ -460,6 +460,11 @@ int js2t_fbank(const float* wave, const int64_t* sample_off, const int64_t* fram
  * over-long evaluation utterance BEFORE CMVN (tokenizers.py:474-487). */
 int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd,
                     float* fill, int32_t norm_means, int32_t norm_vars, int64_t max_frames, js2t_stream stream);
+/* The same statistics by EIGHT blocks per utterance (a 32-utterance batch otherwise keeps 32 of 256 CUs busy: 39 us) through a
+ * caller-owned workspace of js2t_cmvn_stats_workspace(U, F) doubles; fixed summation orders, bit-reproducible. */
+int64_t js2t_cmvn_stats_workspace(int32_t U, int32_t F);
+int js2t_cmvn_stats_ws(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd, float* fill,
+                       int32_t norm_means, int32_t norm_vars, int64_t max_frames, double* workspace, js2t_stream stream);
 
 /* out[u,t,c] = masked((feat - mean) * istd) for t < T_u, pad_value beyond — CMVN apply + SpecAugment masks
  * (data_augmentation.py:54-68; mask parameters drawn on the host to keep np.random parity) + pad_features

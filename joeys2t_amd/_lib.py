@@ -90,6 +90,7 @@ def lib():
         _lib.js2t_colsum_partial_rows.argtypes = [C.c_int64]
         _lib.js2t_sumsq_partials.restype = C.c_int64
         _lib.js2t_sumsq_partials.argtypes = [C.c_int64]
+        _lib.js2t_cmvn_stats_workspace.restype = C.c_int64
         _lib.js2t_gemm_grouped_blocks.restype = C.c_int64
         _lib.js2t_gemm_grouped_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)

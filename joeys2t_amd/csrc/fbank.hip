@@ -332,13 +332,74 @@ __global__ __launch_bounds__(256) void fbank512_kernel(const float* __restrict__
 // ---------------------------------------------------------------- CMVN statistics (one block per utterance)
 // mean[u,c] = mean_t x ; istd[u,c] = 1/sqrt(max(sum x^2 / T - mean^2, 1e-10)) ; fill[u] = mean of the normalised
 // spectrogram (SpecAugment's mask value).  Accumulated in f64.
-constexpr int CM_GROUPS = 12;  // frame groups per block: 12 x 80 bins = 960 threads share an utterance
+constexpr int CM_GROUPS = 12;  // frame groups per block: 12 x 80 bins = 960 threads share a piece of an utterance
+constexpr int CM_SPLIT = 8;    // pieces per utterance: 32 utterances alone would keep 32 of 256 CUs busy pulling 480 KB each (39 us)
+// phase 1: block (u, p) sums piece p of utterance u's kept frames -> part[u][p][2][F] (f64); phase 2 (cmvn_finish_kernel): one block
+// per utterance adds the pieces in order and writes mean / istd / fill.  Fixed orders: bit-reproducible.
+__global__ void cmvn_partial_kernel(const float* __restrict__ feat, const int64_t* __restrict__ frame_off, int F, double* __restrict__ part,
+                                    int64_t max_frames) {
+  extern __shared__ double sh[];  // [2][CM_GROUPS][F]
+  const int u = blockIdx.x, p = blockIdx.y;
+  // an over-long evaluation utterance is cut to max_length BEFORE CMVN (tokenizers.py:474-487): statistics over the kept frames
+  const int64_t t0 = frame_off[u], T = max_frames > 0 ? min(frame_off[u + 1] - t0, max_frames) : frame_off[u + 1] - t0;
+  const int64_t per = (T + CM_SPLIT - 1) / CM_SPLIT, ta = min(T, p * per), tb = min(T, ta + per);
+  const int c = threadIdx.x % F, gi = threadIdx.x / F;
+  double s = 0.0, q = 0.0;
+  if (gi < CM_GROUPS) {
+    for (int64_t t = ta + gi; t < tb; t += CM_GROUPS) {
+      const double v = feat[(t0 + t) * F + c];
+      s += v;
+      q += v * v;
+    }
+    sh[gi * F + c] = s;
+    sh[(CM_GROUPS + gi) * F + c] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < F) {
+    double ss = 0.0, qq = 0.0;
+    for (int g2 = 0; g2 < CM_GROUPS; ++g2) {
+      ss += sh[g2 * F + c];
+      qq += sh[(CM_GROUPS + g2) * F + c];
+    }
+    double* out = part + ((int64_t)u * CM_SPLIT + p) * 2 * F;
+    out[c] = ss;
+    out[F + c] = qq;
+  }
+}
+__global__ void cmvn_finish_kernel(const double* __restrict__ part, const int64_t* __restrict__ frame_off, int F, float* __restrict__ mean,
+                                   float* __restrict__ istd, float* __restrict__ fill, int norm_means, int norm_vars, int64_t max_frames) {
+  extern __shared__ double norm_mean[];  // [F]
+  const int u = blockIdx.x, c = threadIdx.x;
+  const int64_t t0 = frame_off[u], T = max_frames > 0 ? min(frame_off[u + 1] - t0, max_frames) : frame_off[u + 1] - t0;
+  if (c < F) {
+    double ss = 0.0, qq = 0.0;
+    for (int p = 0; p < CM_SPLIT; ++p) {
+      const double* in = part + ((int64_t)u * CM_SPLIT + p) * 2 * F;
+      ss += in[c];
+      qq += in[F + c];
+    }
+    const float m = T > 0 ? (float)(ss / (double)T) : 0.f;
+    const float sq = T > 0 ? (float)(qq / (double)T) : 0.f;
+    const float var = sq - m * m;
+    const float is = norm_vars ? 1.f / sqrtf(fmaxf(var, 1e-10f)) : 1.f;
+    mean[(int64_t)u * F + c] = norm_means ? m : 0.f;
+    istd[(int64_t)u * F + c] = is;
+    norm_mean[c] = (double)((norm_means ? 0.f : m) * is);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int k = 0; k < F; ++k) a += norm_mean[k];
+    fill[u] = (float)(a / (double)F);
+  }
+}
+
+// the round-1 form: one block per utterance, no workspace (js2t_cmvn_stats)
 __global__ void cmvn_stats_kernel(const float* __restrict__ feat, const int64_t* __restrict__ frame_off, int F,
                                   float* __restrict__ mean, float* __restrict__ istd, float* __restrict__ fill, int norm_means,
                                   int norm_vars, int64_t max_frames) {
   extern __shared__ double sh[];  // [2][CM_GROUPS][F] + [F]
   const int u = blockIdx.x;
-  // an over-long evaluation utterance is cut to max_length BEFORE CMVN (tokenizers.py:474-487): statistics over the kept frames
   const int64_t t0 = frame_off[u], T = max_frames > 0 ? min(frame_off[u + 1] - t0, max_frames) : frame_off[u + 1] - t0;
   const int c = threadIdx.x % F, gi = threadIdx.x / F;
   double s = 0.0, q = 0.0;
@@ -487,6 +548,26 @@ extern "C" int js2t_cmvn_stats(const float* feat, const int64_t* frame_off, int3
   const size_t lds = sizeof(double) * (2 * CM_GROUPS * F + F);
   hipLaunchKernelGGL(cmvn_stats_kernel, dim3(U), dim3(threads), lds, (hipStream_t)stream, feat, frame_off, F, mean, istd, fill,
                      norm_means, norm_vars, max_frames);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int64_t js2t_cmvn_stats_workspace(int32_t U, int32_t F) { return (int64_t)U * CM_SPLIT * 2 * F; }
+
+// the same through eight blocks per utterance; workspace: f64[js2t_cmvn_stats_workspace(U, F)] from the caller
+extern "C" int js2t_cmvn_stats_ws(const float* feat, const int64_t* frame_off, int32_t U, int32_t F, float* mean, float* istd, float* fill,
+                                  int32_t norm_means, int32_t norm_vars, int64_t max_frames, double* workspace, js2t_stream stream) {
+  if (U == 0) return JS2T_OK;
+  JS2T_CHECK(feat && frame_off && mean && istd && fill, "cmvn_stats: null pointer");
+  JS2T_CHECK(F > 0 && F <= 256, "cmvn_stats: 1..256 feature bins supported");
+  const int threads = ((CM_GROUPS * F + 63) / 64) * 64;
+  JS2T_CHECK(threads <= 1024, "cmvn_stats: too many feature bins");
+  JS2T_CHECK(workspace, "cmvn_stats_ws: workspace required (js2t_cmvn_stats_workspace doubles)");
+  hipLaunchKernelGGL(cmvn_partial_kernel, dim3(U, CM_SPLIT), dim3(threads), sizeof(double) * 2 * CM_GROUPS * F, (hipStream_t)stream, feat,
+                     frame_off, F, workspace, max_frames);
+  JS2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cmvn_finish_kernel, dim3(U), dim3(((F + 63) / 64) * 64), sizeof(double) * F, (hipStream_t)stream, workspace,
+                     frame_off, F, mean, istd, fill, norm_means, norm_vars, max_frames);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }

@@ -98,10 +98,11 @@ def finalize_features(feat: torch.Tensor, frame_off: torch.Tensor, frames: Seque
         mean = torch.empty((U, F), dtype=torch.float32, device=dev)
         istd = torch.empty((U, F), dtype=torch.float32, device=dev)
         fill = torch.empty((U, ), dtype=torch.float32, device=dev)
-        check(lib().js2t_cmvn_stats(_p(feat), _p(frame_off), C.c_int32(U), C.c_int32(F), _p(mean), _p(istd), _p(fill),
-                                    C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)),
-                                    C.c_int64(int(max_length) if max_length else 0), _stream()),
-              "js2t_cmvn_stats")
+        ws = torch.empty((int(lib().js2t_cmvn_stats_workspace(C.c_int32(U), C.c_int32(F))), ), dtype=torch.float64, device=dev)
+        check(lib().js2t_cmvn_stats_ws(_p(feat), _p(frame_off), C.c_int32(U), C.c_int32(F), _p(mean), _p(istd), _p(fill),
+                                       C.c_int32(int(cmvn.norm_means)), C.c_int32(int(cmvn.norm_vars)),
+                                       C.c_int64(int(max_length) if max_length else 0), _p(ws), _stream()),
+              "js2t_cmvn_stats_ws")
     if specaugment is not None:
         if masks_dev is not None:  # caller-managed static int32[U,8] buffer (hipGraph replay): already drawn
             masks = masks_dev
