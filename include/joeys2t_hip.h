@@ -119,6 +119,14 @@ typedef struct js2t_gemm_desc {
   float* c8_scale_out;
   float* fp8_state;         /* e4m3 products: delayed-scale state of the kernel that quantised A (js2t_layernorm_fwd_fp8): block 0 hands
                              * the collected maximum over, state[0] = state[1] / 448, state[1] *= 15/16 (decayed, not cleared), when the product is done */
+  /* producer out (k-contiguous bf16 products with a plain epilogue, N % 64 == 0): dot_partial[m * (N / 64) + n / 64] = the sum over
+   * the 64-column group of bf16(C[m, c]) * dot_src[m, c] (dot_src: bf16 [M, ld_dot]).  The attention output projection's input
+   * gradient dO = dY Wo is where dO and the saved attention output O meet first: with dot_src = O the partials are
+   * delta = rowsum(dO * O) per head and half head - what the attention backward needs before either of its passes
+   * (js2t_attn_desc.delta_partial), so that both run as one grid. */
+  const void* dot_src;
+  int64_t ld_dot;
+  float* dot_partial;
   float* sumsq_partial;     /* js2t_gemm_grouped only (f32 C, no split-K, N % 128 == 0): block b of the launch stores the sum of squares
                              * of the C values it wrote to sumsq_partial[b], b < js2t_gemm_grouped_blocks(M, N, count) - the weight
                              * gradients' share of clip_grad_norm_'s norm (builders.py:68-71) without a pass over them */
@@ -599,6 +607,12 @@ typedef struct js2t_attn_desc {
   int32_t rel_R;            /* clipping distance of the relative-position bias, 1..255 */
   const float* rel_bias;    /* f32[H, 2 rel_R + 1] or NULL */
   float* d_rel_bias;        /* bwd: += gradient of rel_bias (NULL: not wanted) */
+  /* bwd, optional: delta = rowsum(dO * O) arrives as partial sums over 64-column groups of the [B*Tq, H*head_dim] layout
+   * (js2t_gemm_desc.dot_partial of the product that made dO): f32 [B*Tq, delta_groups], head h owning groups h * head_dim / 64 ..;
+   * `o` and `delta` are then not read / written and the dQ and dK/dV passes run as ONE grid (two launches otherwise: the
+   * dK/dV pass waits for the delta the dQ pass computes). */
+  const float* delta_partial;
+  int32_t delta_groups;
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);

@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
         ("ln_partial", C.c_void_p), ("ln_eps", C.c_float), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("rs_partial", C.c_void_p),
         ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_state", C.c_void_p), ("c8_mul", C.c_void_p), ("c8_scale_out", C.c_void_p),
         ("fp8_state", C.c_void_p),
+        ("dot_src", C.c_void_p), ("ld_dot", C.c_int64), ("dot_partial", C.c_void_p),
         ("sumsq_partial", C.c_void_p),
     ]
 
@@ -63,6 +64,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float), ("dropout_p", C.c_float),
         ("rng_state", C.c_void_p), ("rng_stream", C.c_uint32),
         ("rel_R", C.c_int32), ("rel_bias", C.c_void_p), ("d_rel_bias", C.c_void_p),
+        ("delta_partial", C.c_void_p), ("delta_groups", C.c_int32),
     ]
 
 

@@ -52,7 +52,19 @@ struct AttnArgs {
   const float* rel;  // relative-position bias f32[H, 2R+1] (NULL: none)
   float* d_rel;
   int relR;
+  const float* dpart;  // bwd: delta as partial sums over 64-column groups of [B*Tq, H*DH] (js2t_attn_desc.delta_partial) or NULL
+  int dgroups;
 };
+// delta = rowsum(dO * O) of query row qc of head (b, h): from the partial sums the product that made dO left behind, or the
+// [B*H, Tq] array the dQ pass writes
+template <int DH>
+__device__ __forceinline__ float load_delta(const AttnArgs& a, int b, int h, int z, int qc) {
+  if (a.dpart) {
+    const float* pp = a.dpart + ((int64_t)b * a.Tq + qc) * a.dgroups + h * (DH / 64);
+    return DH == 128 ? pp[0] + pp[1] : pp[0];
+  }
+  return a.delta[(int64_t)z * a.Tq + qc];
+}
 constexpr int REL_MAX = 255;  // largest clipping distance: the per-head table (2 * 255 + 1 floats) is staged in LDS
 // the head's bias table in base-2 units, staged once per block
 __device__ __forceinline__ void stage_rel(float* rel_s, const AttnArgs& a, int h, int t) {
@@ -392,8 +404,9 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
 }
 
 // one own-query block of 16 per wave (two need ~350 registers: one wave per SIMD, slower)
+// bid / nblk: this block's index among the pass's blocks (the pass is a grid of its own, or a range of the merged grid)
 template <int DH, bool REL>
-__global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
+__device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nblk) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1], drel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int ntile = (a.Tq + 63) / 64;  // XCD-aware 1-D grid, see flash_fwd_kernel
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
   const int q0 = (lid - z * ntile) * 64 + w * 16;
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
@@ -419,17 +432,22 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
     own_frags<NKS>(Gb, a.lddo, q0, a.Tq, lane, gf);
     const int qc = min(q0 + m, a.Tq - 1);
     lse2 = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
-    // delta = rowsum(dO * O) of the own rows: the dO fragments are in registers anyway, O's are fetched once; the four
-    // lanes of a row hold a quarter of the head columns each.  Written out for the dK/dV pass, which runs after this one.
-    bf16x8_t of[NKS];
-    own_frags<NKS>(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0, a.Tq, lane, of);
-    float dsum = 0.f;
+    float dsum;
+    if (a.dpart) {
+      dsum = load_delta<DH>(a, b, h, z, qc);  // left behind by the product that made dO: nothing to compute, no O to fetch
+    } else {
+      // delta = rowsum(dO * O) of the own rows: the dO fragments are in registers anyway, O's are fetched once; the four
+      // lanes of a row hold a quarter of the head columns each.  Written out for the dK/dV pass, which runs after this one.
+      bf16x8_t of[NKS];
+      own_frags<NKS>(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0, a.Tq, lane, of);
+      dsum = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += (float)gf[ks][e] * (float)of[ks][e];
-    dsum = quad_sum(dsum);
-    if (g == 0 && q0 + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
+        for (int e = 0; e < 8; ++e) dsum += (float)gf[ks][e] * (float)of[ks][e];
+      dsum = quad_sum(dsum);
+      if (g == 0 && q0 + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
+    }
     dl2 = dsum * keep_p;
   }
   f32x4_t dq[NCT];
@@ -514,6 +532,11 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
   }
 }
 
+template <int DH, bool REL>
+__global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
+  flash_dq_body<DH, REL>(a, blockIdx.x, gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------ dK / dV
 // own rows = keys; sweeps query tiles; Q image (row + transposed reads) and dO image (row + transposed reads)
 // One (query tile, own-key block) of the dK/dV pass: probabilities and dS from the S / dP accumulators.
@@ -561,7 +584,7 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NT
 // S / dP tiles need > 400 registers - one wave per SIMD, nothing to overlap the MFMA, exp / dropout VALU work and LDS
 // latency with.  One block per wave fits 256 registers, i.e. two waves per SIMD.
 template <int DH, bool REL>
-__global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
+__device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int nblk) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;  // KT = queries per swept tile here
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int ntile = (a.Tk + 63) / 64;  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
   const int k0 = (lid - z * ntile) * 64 + w * 16;
   const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   if (t < KT) {
     const int qc = min(t, a.Tq - 1);
     lse_r = a.lse[(int64_t)z * a.Tq + qc];
-    dl_r = a.delta[(int64_t)z * a.Tq + qc];
+    dl_r = load_delta<DH>(a, b, h, z, qc);
   }
   int cur = 0;
   for (int qt = 0; qt < nqt; ++qt) {
@@ -624,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
       if (t < KT) {
         const int qc = min((qt + 1) * KT + t, a.Tq - 1);
         lse_r = a.lse[(int64_t)z * a.Tq + qc];
-        dl_r = a.delta[(int64_t)z * a.Tq + qc];
+        dl_r = load_delta<DH>(a, b, h, z, qc);
       }
     }
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
@@ -688,6 +711,22 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
   }
 }
 
+template <int DH, bool REL>
+__global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
+  flash_dkv_body<DH, REL>(a, blockIdx.x, gridDim.x);
+}
+
+// Both passes as ONE grid: two grids of 768 blocks (an encoder layer) on 512 resident slots are 2 x 1.5 rounds, one of 1536 is
+// three; on the decoder's small grids the passes run side by side.  Needs delta before either pass starts, i.e. the partial sums
+// of js2t_attn_desc.delta_partial (handing delta from the dQ blocks to the dK/dV blocks inside one grid costs more than the
+// merged grid saves: profiles/README.md, round 2).  The dK/dV blocks (the longer ones) go first; n_dkv % 8 == 0 keeps the
+// XCD-aware order of both ranges.
+template <int DH, bool REL>
+__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(AttnArgs a, int n_dkv) {
+  if ((int)blockIdx.x < n_dkv) flash_dkv_body<DH, REL>(a, blockIdx.x, n_dkv);
+  else flash_dq_body<DH, REL>(a, (int)blockIdx.x - n_dkv, (int)gridDim.x - n_dkv);
+}
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -725,10 +764,12 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.B = d->B; a.H = d->H; a.Tq = d->Tq; a.Tk = d->Tk;
   a.scale = d->scale; a.p = d->dropout_p; a.rng = d->rng_state; a.stream = d->rng_stream;
   a.rel = d->rel_bias; a.d_rel = d->d_rel_bias; a.relR = d->rel_bias ? d->rel_R : 0;
+  a.dpart = d->delta_partial; a.dgroups = d->delta_groups;
   return a;
 }
 
 int g_attn_fwd_sb = -1;  // -1: by shape, 0 / 1: forced (js2t_debug_attn_fwd_sb; measurements)
+bool g_attn_bwd_merge = true;  // js2t_debug_attn_bwd_merge(0): the two passes as two launches also with delta_partial (A/B)
 template <int DH, bool REL>
 int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
@@ -759,10 +800,18 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
     if (rc) return rc;
     rc = set_lds(flash_dkv_kernel<DH, REL>, 4 * IMG_BYTES);
     if (rc) return rc;
+    rc = set_lds(flash_bwd_kernel<DH, REL>, 4 * IMG_BYTES);
+    if (rc) return rc;
     once = true;
   }
   AttnArgs a = to_args(d);
-  hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(cdiv(d->Tq, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+  const int n_dq = cdiv(d->Tq, 64) * d->B * d->H, n_dkv = cdiv(d->Tk, 64) * d->B * d->H;
+  if (d->delta_partial && (n_dkv & 7) == 0 && g_attn_bwd_merge) {
+    hipLaunchKernelGGL((flash_bwd_kernel<DH, REL>), dim3(n_dkv + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
+  hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL((flash_dkv_kernel<DH, REL>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
@@ -775,6 +824,7 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
 extern "C" int js2t_debug_attn_prof(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 64); }
 #endif
 extern "C" void js2t_debug_attn_fwd_sb(int mode) { g_attn_fwd_sb = mode; }
+extern "C" void js2t_debug_attn_bwd_merge(int on) { g_attn_bwd_merge = on != 0; }
 extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) {
   int rc = check_common(d);
   if (rc) return rc;
@@ -787,7 +837,9 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
 extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) {
   int rc = check_common(d);
   if (rc) return rc;
-  JS2T_CHECK(d->o && d->d_o && d->dq && d->dk && d->dv && d->delta, "flash_attn_bwd: null pointer");
+  JS2T_CHECK(d->d_o && d->dq && d->dk && d->dv && (d->delta_partial || (d->o && d->delta)), "flash_attn_bwd: null pointer");
+  JS2T_CHECK(!d->delta_partial || d->delta_groups == d->H * d->head_dim / 64,
+             "flash_attn_bwd: delta_partial holds H * head_dim / 64 groups per row");
   JS2T_CHECK((d->ld_do % 8) == 0 && (d->ld_dq % 4) == 0 && (d->ld_dk % 4) == 0 && (d->ld_dv % 4) == 0 && (d->ldo % 8) == 0,
              "flash_attn_bwd: bad leading dims");
   JS2T_CHECK(((((uintptr_t)d->d_o) | ((uintptr_t)d->o)) & 15) == 0 &&

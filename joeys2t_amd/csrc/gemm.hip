@@ -862,6 +862,19 @@ __device__ __forceinline__ bool direct_tile_epilogue(const js2t_gemm_desc& d, f3
         for (int c = 0; c < 8; ++c) v[8 * h + c] = rr[c] > 0.f ? v[8 * h + c] * gate_scale : 0.f;
       }
     }
+    if (d.dot_partial) {  // sum over this lane's 16 columns of bf16(C) * dot_src, then over the 64-column group's four lanes
+      const int mm = min(m, M - 1);
+      const uint16_t* dsrc = (const uint16_t*)d.dot_src + (int64_t)mm * d.ld_dot + n;
+      float rr[8], sd = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unpack_bf16x8(*(const uint4*)(dsrc + 8 * h), rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sd = fmaf(bf16_round(v[8 * h + c]), rr[c], sd);
+      }
+      sd = col4_sum(sd);
+      if ((lane >> 4) == 0 && m < M) d.dot_partial[(int64_t)m * (N >> 6) + ((n0 >> 6) + wn)] = sd;
+    }
     if (wstats) {  // sums of what is stored (bf16-rounded) over this lane's 16 columns, then over the group's four lanes
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1381,7 +1394,7 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 // EPI < 0: every epilogue term is decided at run time; EPI >= 0: a bit mask of the terms that are present (alpha = 1),
 // so that the variants the train step uses carry no dead branches - with one wave per SIMD nothing overlaps the
 // epilogue, its instruction count is paid in full.
-constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16, PE_LNF = 32, PE_STATS = 64;
+constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16, PE_LNF = 32, PE_STATS = 64, PE_DOT = 128;
 template <int EPI>
 __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, float (&bias_r)[8]) {
   const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < d.N;  // n >= N: a column group of the N tail
@@ -1819,8 +1832,16 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
   }
   // the fold exists in the specialised instantiations only (launch_bf16_p192 refuses other combinations): the run-time
   // decided variant (EPI < 0) would otherwise carry both paths and spill
-  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0;
+  constexpr bool lnf = EPI >= 0 && (EPI & PE_LNF) != 0, wstats = EPI >= 0 && (EPI & PE_STATS) != 0, wdot = EPI >= 0 && (EPI & PE_DOT) != 0;
   const int grp = n0 >> 6, ngrp = d.N >> 6;  // this wave's 64-column group of the row, of N / 64
+  uint2 dg[3][4];  // PE_DOT: the rows of dot_src this lane's columns meet (js2t_gemm_desc.dot_partial)
+  if (wdot) {
+    const uint16_t* dsrc = (const uint16_t*)d.dot_src + n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dg[i][e] = *(const uint2*)(dsrc + (int64_t)min(mw + 16 * i + 4 * g + e, M - 1) * d.ld_dot);
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     float ln_rs[4];
@@ -1868,6 +1889,15 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
         }
         s1 = row16_sum(s1), s2 = row16_sum(s2);
         if (r == 0 && m < M) *(float2*)(d.rs_partial + 2 * ((int64_t)m * ngrp + grp)) = make_float2(s1, s2);
+      }
+      if (wdot) {
+        const uint2 q = dg[i][e];
+        float sd = bf16_round(v[0]) * __uint_as_float(q.x << 16);
+        sd = fmaf(bf16_round(v[1]), __uint_as_float(q.x & 0xffff0000u), sd);
+        sd = fmaf(bf16_round(v[2]), __uint_as_float(q.y << 16), sd);
+        sd = fmaf(bf16_round(v[3]), __uint_as_float(q.y & 0xffff0000u), sd);
+        sd = row16_sum(sd);
+        if (r == 0 && m < M) d.dot_partial[(int64_t)m * ngrp + grp] = sd;
       }
       if (m < M && (!OUT8 || d.C)) {
         uint2 pk;
@@ -2483,7 +2513,7 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
   // the row statistics (rs_*) are written by the loader / consumer form only: its multiplying waves issue no LDS-DMA, so the
   // fences of the hand-over to the finishing wave wait for nothing but the wave's own stores
-  if (g_p192_ring == 4 || (EPI >= 0 && (EPI & PE_STATS)) || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
+  if (g_p192_ring == 4 || (EPI >= 0 && (EPI & (PE_STATS | PE_DOT))) || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), PS_LDS, s, d, tm, tn);
   } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
@@ -2536,7 +2566,8 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
   // the epilogue combinations of the Transformer train step get their own instantiation, anything else the generic one
   if (d.alpha == 1.f && !d.alpha_dev) {
     const int mask = (d.bias ? PE_BIAS : 0) | (d.act == JS2T_ACT_RELU ? PE_RELU : 0) | (d.dropout_p > 0.f ? PE_DROP : 0) |
-                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_partial ? PE_LNF : 0) | (d.rs_partial ? PE_STATS : 0);
+                     (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_partial ? PE_LNF : 0) | (d.rs_partial ? PE_STATS : 0) |
+                     (d.dot_partial ? PE_DOT : 0);
     switch (mask) {
       case PE_BIAS | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_LNF>(d, s);      // q/k/v projections on the raw residual stream
       case PE_BIAS | PE_RELU | PE_DROP | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP | PE_LNF>(d, s);  // FFN layer 1, same
@@ -2548,11 +2579,13 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
       case PE_BIAS | PE_RELU | PE_DROP: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP>(d, s);  // FFN layer 1
       case PE_BIAS | PE_DROP | PE_RES: return launch_bf16_p192_epi<PE_BIAS | PE_DROP | PE_RES>(d, s);    // FFN layer 2, attention output
       case PE_GATE: return launch_bf16_p192_epi<PE_GATE>(d, s);                        // gradient through ReLU + dropout
+      case PE_DOT: return launch_bf16_p192_epi<PE_DOT>(d, s);                          // attention output projection's input gradient + delta
       default: break;
     }
   }
-  if (d.ln_partial || d.rs_partial) {
-    js2t_set_error("gemm: LayerNorm fold: bias [+ ReLU [+ dropout]] with ln_partial, bias [+ dropout] + residual with rs_partial only");
+  if (d.ln_partial || d.rs_partial || d.dot_partial) {
+    js2t_set_error("gemm: LayerNorm fold: bias [+ ReLU [+ dropout]] with ln_partial, bias [+ dropout] + residual with rs_partial only; "
+                   "dot_partial: plain epilogue only");
     return JS2T_ERR_INVALID;
   }
   return launch_bf16_p192_epi<-1>(d, s);
@@ -2616,7 +2649,7 @@ int launch_bf16_impl(const js2t_gemm_desc& d, hipStream_t s) {
 }
 template <bool TA, bool TB>
 int launch_bf16(const js2t_gemm_desc& d, hipStream_t s) {
-  if (!TA && !TB && !g_force_regstage && w256_eligible(d)) return launch_bf16_w256(d, s);
+  if (!TA && !TB && !g_force_regstage && !d.dot_partial && w256_eligible(d)) return launch_bf16_w256(d, s);
   if (!TA && !TB && !g_force_regstage && !g_force_w256 && p192_eligible(d)) return launch_bf16_p192(d, s);
   if (!d.conv && !g_force_regstage)
     return d.split_k > 1 ? launch_bf16_dma<TA, TB, true>(d, s) : launch_bf16_dma<TA, TB, false>(d, s);
@@ -2793,6 +2826,17 @@ extern "C" int js2t_gemm(const js2t_gemm_desc* dp, js2t_stream stream) {
     JS2T_CHECK(!d.ln_partial || (d.K == 64 * LNF_GROUPS && aligned16(d.ln_partial) && d.ln_eps > 0.f && (!d.ln_mean == !d.ln_rstd)),
                "gemm: ln_partial: K must be 512 (eight 64-column groups), 16-byte aligned partial sums, ln_eps > 0, ln_mean / ln_rstd both or neither");
     JS2T_CHECK(!d.rs_partial || (d.N == 64 * LNF_GROUPS && aligned16(d.rs_partial)), "gemm: rs_partial: N must be 512, 16-byte aligned partial sums");
+  }
+  if (d.dot_partial) {
+    // written by the register-direct epilogues of the k-contiguous bf16 kernels (loader / consumer form of the persistent kernel,
+    // 64 / 128-row tile kernel): every tile must take them
+    JS2T_CHECK(d.dot_src && d.dtype_ab == JS2T_BF16 && d.dtype_c == JS2T_BF16 && !d.trans_a && !d.trans_b && !d.conv && d.split_k == 1 &&
+                   d.batch == 1 && !d.preact && d.beta == 0.f && !d.a_rowsum && !d.bias && d.act == JS2T_ACT_NONE && d.dropout_p == 0.f &&
+                   !d.residual && !d.gate && d.alpha == 1.f && !d.alpha_dev && !d.ln_partial && !d.rs_partial && !g_force_regstage && !g_force_w256,
+               "gemm: dot_partial needs a plain k-contiguous bf16 product with a bf16 result (no bias / activation / dropout / residual)");
+    JS2T_CHECK((d.N & 127) == 0 && (d.K & 7) == 0 && (d.lda & 7) == 0 && (d.ldb & 7) == 0 && (d.ldc & 7) == 0 && (d.ld_dot & 7) == 0 &&
+                   aligned16(d.A) && aligned16(d.B) && aligned16(d.C) && aligned16(d.dot_src) && d.ld_dot >= d.N,
+               "gemm: dot_partial needs N % 128 == 0 and 16-byte aligned rows of A, B, C and dot_src");
   }
   if (d.dtype_ab == JS2T_FP8_E4M3) {
     // e4m3 x e4m3 -> f32 accumulate -> bf16: the persistent 192x128 kernel only (k-contiguous operands, 16-byte rows)

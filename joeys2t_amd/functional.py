@@ -130,7 +130,7 @@ def linear_fwd(x2d, w, b, *, act=None, dropout_p=0.0, rng=None, site=0, residual
 
 
 def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=None, gate_scale=1.0, dx_dtype=None,
-               dw_out=None, db_out=None, queue=None, w_t=None, dx_add=None):
+               dw_out=None, db_out=None, queue=None, w_t=None, dx_add=None, dot_src=None):
     """Gradients of y = x w^T + b given dz = dL/dy.  Returns (dx, dW_f32, db_f32).
     dw_out / db_out: fp32 gradient buffers (views of the flat gradient store) to ACCUMULATE into; the corresponding
     return value is then None (nothing left for autograd to add)."""
@@ -147,6 +147,14 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
             extra = dict(residual=dx_add, ldr=dx_add.stride(0), res_scale=1.0)
         if w_t is not None and w_t.dtype == dz2d.dtype:
             # W^T [K, N] is at hand (ParamStore.view_t): both operands k-contiguous -> plain product, register-direct epilogue
+            if (dot_src is not None and FUSE_ATTN_DELTA and gate is None and dx_add is None and K % 128 == 0 and dx.dtype == torch.bfloat16 and
+                    dot_src.dtype == torch.bfloat16 and dot_src.shape == dx.shape and dot_src.stride(1) == 1 and dot_src.stride(0) % 8 == 0 and
+                    dot_src.data_ptr() % 16 == 0 and _mfma_operand(dz2d) and _mfma_operand(w_t) and N % 8 == 0):
+                # dx is an attention block's dO and dot_src its saved output O: the epilogue leaves rowsum(dO * O) per 64-column
+                # group behind (LINEAR_BWD_DOT: read by the caller) - the attention backward then needs no pass of its own for it
+                part = torch.empty((M, K // 64), dtype=torch.float32, device=dx.device)
+                extra = dict(extra, dot=(dot_src, part))
+                LINEAR_BWD_DOT[0] = part
             ops.gemm(dz2d, w_t, dx, M=M, N=K, K=N, lda=dz2d.stride(0), ldb=w_t.stride(0), ldc=K, gate=gate,
                      ldg=0 if gate is None else gate.stride(0), gate_scale=gate_scale, **extra)
         else:
@@ -183,6 +191,12 @@ def linear_bwd(dz2d, x2d, w, *, need_dx=True, need_dw=True, need_db=True, gate=N
     if db_out is not None:
         db = None
     return dx, dw, db
+
+
+# rowsum(dO * O) of an attention block from its output projection's input-gradient product (linear_bwd(dot_src=O)): the partial
+# sums of the last such call (None: the product could not carry it), taken by the block's backward right after
+FUSE_ATTN_DELTA = os.environ.get("JS2T_FUSE_ATTN_DELTA", "1") != "0"
+LINEAR_BWD_DOT = [None]
 
 
 def _mfma_operand(t: torch.Tensor) -> bool:
@@ -247,13 +261,13 @@ def _check_rel_bias(t, H):
 
 
 def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, shp: AttnShape, P, Pd, p,
-             rng, site, ctx_out=None, mask=None, rel_bias=None, d_rel_bias=None):
+             rng, site, ctx_out=None, mask=None, rel_bias=None, d_rel_bias=None, delta_partial=None):
     """Writes dq/dk/dv into the given (row-major 2-D) gradient buffers at the given column offsets.
     Fused path: P is None, Pd carries the forward's row log-sum-exp and ctx_out its output."""
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
     if P is None:
         ops.flash_attn_bwd(dctx, ctx_out, Pd, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off,
-                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias)
+                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias, delta_partial=delta_partial)
         return
     Z = B * H
     dev, dt = dctx.device, dctx.dtype
@@ -621,7 +635,11 @@ class ResidualBlockFn(torch.autograd.Function):
                 dz1 = ops.act_bwd(dz1, sv["pre"], cfg.act)
             dn, g["w1"], g["b1"] = linear_bwd(dz1, n, wts["w1"], dw_out=sk("w1"), db_out=sk("b1"), queue=wq, w_t=wts.get("w1_t"))
         elif cfg.kind == "self":
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
+            fused = sv["P"] is None  # fused attention kernels: delta can ride on this product's epilogue
+            LINEAR_BWD_DOT[0] = None
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"),
+                                                    dot_src=c if fused else None)
+            dpart, LINEAR_BWD_DOT[0] = LINEAR_BWD_DOT[0], None
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
             rel, d_rel = wts.get("rel_bias"), None
@@ -630,10 +648,14 @@ class ResidualBlockFn(torch.autograd.Function):
                 if d_rel is None:
                     d_rel = g["rel_bias"] = torch.zeros_like(rel)
             attn_bwd(dc, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng,
-                     sites[0], ctx_out=c, mask=ctx.mask, rel_bias=rel, d_rel_bias=d_rel)
+                     sites[0], ctx_out=c, mask=ctx.mask, rel_bias=rel, d_rel_bias=d_rel, delta_partial=dpart)
             dn, g["w_in"], g["b_in"] = linear_bwd(dqkv, n, wts["w_in"], dw_out=sk("w_in"), db_out=sk("b_in"), queue=wq, w_t=wts.get("w_in_t"))
         else:  # cross
-            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"))
+            fused = sv["P"] is None
+            LINEAR_BWD_DOT[0] = None
+            dc, g["w_out"], g["b_out"] = linear_bwd(dz_o, c, wts["w_out"], dw_out=sk("w_out"), db_out=sk("b_out"), queue=wq, w_t=wts.get("w_out_t"),
+                                                    dot_src=c if fused else None)
+            dpart, LINEAR_BWD_DOT[0] = LINEAR_BWD_DOT[0], None
             q, kv, off = sv["q"], sv["kv"], sv["kv_off"]
             dq = torch.empty_like(q)
             if sv["m2"] is None:  # grouped projections: dK | dV go into this layer's columns of the gradient all layers share
@@ -646,7 +668,7 @@ class ResidualBlockFn(torch.autograd.Function):
                 else:  # nothing behind the projections wants a gradient: a scratch the kernel can write to
                     dkv = torch.empty_like(kv)
                 attn_bwd(dc, q, 0, kv, off, kv, off + d, dq, 0, dkv, off, dkv, off + d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
-                         ctx_out=c, mask=ctx.mask)
+                         ctx_out=c, mask=ctx.mask, delta_partial=dpart)
                 g["w_kv"] = g["b_kv"] = None  # MemoryKVFn's
                 if kkey is not None:
                     _KV_USERS[kkey] -= 1
@@ -655,7 +677,7 @@ class ResidualBlockFn(torch.autograd.Function):
             else:
                 dkv = torch.empty_like(kv)
                 attn_bwd(dc, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, sv["shp"], sv["P"], sv["Pd"], p, rng, sites[0],
-                         ctx_out=c, mask=ctx.mask)
+                         ctx_out=c, mask=ctx.mask, delta_partial=dpart)
                 key = sv.get("mem_key") if ctx.needs_input_grad[3] else None
                 dmem2, g["w_kv"], g["b_kv"] = linear_bwd(dkv, sv["m2"], wts["w_kv"], need_dx=ctx.needs_input_grad[3],
                                                          dw_out=sk("w_kv"), db_out=sk("b_kv"), queue=wq, w_t=wts.get("w_kv_t"),

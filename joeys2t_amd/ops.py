@@ -107,8 +107,9 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), a_off=0, b_off=0, c_off=0, alpha=1.0,
          alpha_dev=None, bias=None, act=None, preact=None, dropout_p=0.0, rng: Optional[DropoutRng] = None,
          rng_stream=0, residual=None, ldr=0, res_scale=1.0, gate=None, ldg=0, gate_scale=1.0, beta=0.0,
-         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None, fp8_state=None, c8=None):
+         conv=None, split_k=1, a_rowsum=None, ln=None, rs_partial=None, fp8_state=None, c8=None, dot=None):
     """C = epilogue(alpha * op(A) op(B)^T) — see js2t_gemm in the header.  Offsets are in elements.
+    dot = (src bf16 [M, >= N], partial f32 [M, N // 64]): partial[m, g] = sum over the 64-column group of bf16(C[m, c]) * src[m, c].
     ln = (partial f32[M,8,2], eps, mean_out f32[M] | None, rstd_out f32[M] | None): LayerNorm folded into the product (B = the
     centred, gamma-scaled weight of ParamStore.fold); rs_partial f32[M,8,2]: the stored rows' partial sums are written to it."""
     _dev(A, B, C_out, bias, preact, residual, gate, alpha_dev, a_rowsum, rs_partial)
@@ -181,6 +182,13 @@ def gemm(A, B, C_out, *, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, b
         d.c8, d.ldc8, d.c8_state = out8.data_ptr(), N, st8.data_ptr()
         d.c8_mul = None if mul8 is None else mul8.data_ptr()
         d.c8_scale_out = None if sc8 is None else sc8.data_ptr()
+    if dot is not None:
+        src, part = dot
+        _dev(src, part)
+        if (src.dtype != torch.bfloat16 or src.dim() != 2 or src.shape[0] < M or src.stride(1) != 1 or part.dtype != torch.float32 or
+                part.numel() != M * (N // 64) or not part.is_contiguous() or N % 64):
+            raise Js2tError("gemm: dot = (bf16 [M, >= N] rows, contiguous f32 [M, N // 64])")
+        d.dot_src, d.ld_dot, d.dot_partial = src.data_ptr(), int(src.stride(0)), part.data_ptr()
     if rs_partial is not None:
         if rs_partial.dtype != torch.float32 or rs_partial.numel() != M * 16 or not rs_partial.is_contiguous():
             raise Js2tError("gemm: rs_partial must be contiguous f32[M, 8, 2]")
@@ -930,17 +938,25 @@ def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p
 
 
 def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
-                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None):
-    """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating."""
-    _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask, rel_bias, d_rel_bias)
+                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None):
+    """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating.
+    delta_partial f32 [B*Tq, H*dh // 64]: rowsum(dout * out) as partial sums per 64-column group (gemm(dot=...) of the product that
+    made dout) - the two passes then run as one grid and `out` is not read."""
+    _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask, rel_bias, d_rel_bias, delta_partial)
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     if d_rel_bias is not None:
         if rel_bias is None or d_rel_bias.shape != rel_bias.shape or d_rel_bias.dtype != torch.float32 or not d_rel_bias.is_contiguous():
             raise Js2tError("d_rel_bias must be a contiguous float32 tensor shaped like rel_bias")
         d.d_rel_bias = d_rel_bias.data_ptr()
-    delta = torch.empty_like(lse)
     es = q_t.element_size()
-    d.o, d.ldo, d.lse, d.delta = out.data_ptr(), out.stride(0), lse.data_ptr(), delta.data_ptr()
+    if delta_partial is not None:
+        if delta_partial.dtype != torch.float32 or delta_partial.numel() != B * Tq * (H * dh // 64) or not delta_partial.is_contiguous():
+            raise Js2tError("flash_attn_bwd: delta_partial must be contiguous f32 [B*Tq, H*dh // 64]")
+        d.delta_partial, d.delta_groups = delta_partial.data_ptr(), H * dh // 64
+        d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
+    else:
+        delta = torch.empty_like(lse)
+        d.o, d.ldo, d.lse, d.delta = out.data_ptr(), out.stride(0), lse.data_ptr(), delta.data_ptr()
     d.d_o, d.ld_do = dout.data_ptr(), dout.stride(0)
     d.dq, d.ld_dq = dq_t.data_ptr() + dq_off * es, dq_t.stride(0)
     d.dk, d.ld_dk = dk_t.data_ptr() + dk_off * es, dk_t.stride(0)
