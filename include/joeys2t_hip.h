@@ -243,6 +243,17 @@ int64_t js2t_colsum_partial_rows(int64_t rows);
 int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows, int64_t cols, int accumulate,
                 js2t_stream stream); /* accumulate != 0: out[c] += sum (gradient accumulation in place) */
 
+/* Packed rows of a ragged batch: the encoder stack of a batch whose utterances differ in length runs on the sum(T'_i) live rows
+ * (positions behind an utterance's sub-sampled length are dead in the reference: encoders.py:348-373, transformer_layers.py:86-105,
+ * loss.py:156-161).  seg: device int32 [B + 1] row offsets (seg[0] = 0).
+ *   pack != 0: dst[seg[b] + t, :] = src[b*T + t, :] for t < seg[b+1] - seg[b]; rows seg[B] .. rows_out of dst are zeroed
+ *              (rows_out - seg[B] <= T: the caller's rounding of the packed row count);
+ *   pack == 2: only that tail of dst is zeroed (src is not read: pass dst) - buffers the packed kernels leave rows of unwritten;
+ *   pack == 0: dst[b*T + t, :] = t < seg[b+1] - seg[b] ? src[seg[b] + t, :] : 0   (rows_out unused).
+ * row_bytes % 16 == 0, 16-byte aligned buffers.  Each is the other's adjoint (the backward of pack is unpack and vice versa). */
+int js2t_pack_rows(const void* src, void* dst, const int32_t* seg, int32_t B, int32_t T, int64_t rows_out, int64_t row_bytes,
+                   int pack, js2t_stream stream);
+
 /* Conv1d weight repack: w[Cout,Cin,K] (torch layout, encoders.py:339-345) <-> wp[Cout, K*Cin] (GEMM layout). */
 int js2t_conv_weight_pack(const float* w, void* wp, int wp_dt, int64_t cout, int64_t cin, int64_t k,
                           js2t_stream stream);
@@ -613,6 +624,12 @@ typedef struct js2t_attn_desc {
    * dK/dV pass waits for the delta the dQ pass computes). */
   const float* delta_partial;
   int32_t delta_groups;
+  /* optional, self-attention over PACKED rows (the encoder of a ragged batch, encoders.py:348-373 of the reference: positions behind
+   * an utterance's length are dead): device int32 [B + 1]; batch entry b owns rows seg[b] .. seg[b+1] of q / k / v / o / d_o /
+   * dq / dk / dv and has seg[b+1] - seg[b] <= Tq positions.  Tq == Tk is then the longest entry: it shapes the grid, lse / delta
+   * ([B*H, Tq]) and the mask rows, and keeps the dropout counters those of the padded layout.  Tiles behind an entry's length
+   * are not touched; rows of the buffers no entry owns are not written. */
+  const int32_t* seg;
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);

@@ -15,6 +15,11 @@ class Batch:
                  pad_index: int, eos_index: int, is_train: bool = True, task: str = "MT", n_gpu: Optional[int] = None):
         self.src: Tensor = src
         self.src_length: Tensor = src_length
+        # the lengths as host integers, while they still are on the host: the encoder packs the live positions of a ragged batch
+        # from them without asking the device (encoders.TransformerEncoder; not in the reference, whose encoder pads)
+        self.src_length_host: Optional[List[int]] = None
+        if task == "S2T" and src_length is not None and not src_length.is_cuda:
+            self.src_length_host = [int(v) for v in src_length.tolist()]
         self.src_mask: Optional[Tensor] = None
         self.src_prompt_mask: Optional[Tensor] = src_prompt_mask
         self.trg_input: Optional[Tensor] = None
@@ -83,8 +88,11 @@ class Batch:
         """Sort by source length (descending); returns the index list that undoes the sort."""
         _, perm = self.src_length.sort(0, descending=True)
         rev = [0] * perm.size(0)
-        for new_pos, old_pos in enumerate(perm.cpu().numpy()):
+        perm_host = perm.cpu().numpy()
+        for new_pos, old_pos in enumerate(perm_host):
             rev[old_pos] = new_pos
+        if getattr(self, "src_length_host", None) is not None:
+            self.src_length_host = [self.src_length_host[int(i)] for i in perm_host]
         for name in ("src", "src_length", "src_mask", "indices", "src_prompt_mask"):
             t = getattr(self, name)
             if t is not None:

@@ -54,13 +54,25 @@ struct AttnArgs {
   int relR;
   const float* dpart;  // bwd: delta as partial sums over 64-column groups of [B*Tq, H*DH] (js2t_attn_desc.delta_partial) or NULL
   int dgroups;
+  const int32_t* seg;  // packed rows (js2t_attn_desc.seg): entry b owns rows seg[b] .. seg[b+1] of every buffer; NULL: b * Tq ..
 };
+// where batch entry b lives: first row in the query-side and key-side buffers, its own lengths.  a.Tq / a.Tk stay the PADDED
+// lengths: grid shape, [B*H, Tq] scalars (lse, delta), mask rows and the dropout counter (z * Tq + q: the packed layout draws the
+// masks of the padded one) are indexed with them
+struct Seg { int q0, k0, Tq, Tk; };
+__device__ __forceinline__ Seg seg_of(const AttnArgs& a, int b) {
+  if (a.seg) {
+    const int r0 = a.seg[b], n = a.seg[b + 1] - r0;
+    return Seg{r0, r0, n, n};
+  }
+  return Seg{b * a.Tq, b * a.Tk, a.Tq, a.Tk};
+}
 // delta = rowsum(dO * O) of query row qc of head (b, h): from the partial sums the product that made dO left behind, or the
 // [B*H, Tq] array the dQ pass writes
 template <int DH>
-__device__ __forceinline__ float load_delta(const AttnArgs& a, int b, int h, int z, int qc) {
+__device__ __forceinline__ float load_delta(const AttnArgs& a, int row0, int h, int z, int qc) {
   if (a.dpart) {
-    const float* pp = a.dpart + ((int64_t)b * a.Tq + qc) * a.dgroups + h * (DH / 64);
+    const float* pp = a.dpart + ((int64_t)row0 + qc) * a.dgroups + h * (DH / 64);
     return DH == 128 ? pp[0] + pp[1] : pp[0];
   }
   return a.delta[(int64_t)z * a.Tq + qc];
@@ -153,9 +165,9 @@ __device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) 
 // Key validity for key-padding masks (mask_sq == 0) is staged ONCE per block in LDS as bytes; per tile a lane then
 // needs NTT ds_read_b32 instead of 16-32 dependent global byte loads in the inner loop.
 constexpr int KMASK_MAX = 8192;
-__device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, int b, int nkeys_padded, int t) {
+__device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, int b, int Tk, int nkeys_padded, int t) {
   for (int k = t; k < nkeys_padded; k += 256) {
-    bool on = k < a.Tk;
+    bool on = k < Tk;
     if (on && a.mask && a.msq == 0) on = a.mask[(int64_t)b * a.msb + k] != 0;
     kmask[k] = on ? 1 : 0;
   }
@@ -219,15 +231,18 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
   const int q0 = (lid - z * ntile) * 64 + w * 16;
-  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
-  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
-  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  const Seg sg = seg_of(a, b);
+  const int Tq = sg.Tq, Tk = sg.Tk;
+  if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
+  const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
   // the first K (V) image is requested before anything else is fetched: the key mask below waits for its own loads before it can
   // write them to LDS, and a request issued behind that wait starts a second memory round trip where one would do
-  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);
-  if (!SB) img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  img_dma<DH>(Kb, a.ldk, 0, Tk, smem, t);
+  if (!SB) img_dma<DH>(Vb, a.ldv, 0, Tk, smem + IMG_BYTES, t);
   bf16x8_t qf[NKS];
-  own_frags<NKS>(Qb, a.ldq, q0, a.Tq, lane, qf);
+  own_frags<NKS>(Qb, a.ldq, q0, Tq, lane, qf);
   f32x4_t o[NCT];
   float mi = -INFINITY, li = 0.f;
 #pragma unroll
@@ -236,11 +251,11 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float drop_sc = drop ? 1.f / (1.f - a.p) : 1.f;
   const float scale2 = a.scale * 1.4426950408889634f;
-  const int nkt = (a.Tk + KT - 1) / KT;
+  const int nkt = (Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
+  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, nkt * KT, t);
+  stage_kmask(kmask, a, b, Tk, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
@@ -253,10 +268,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
     __syncthreads();
     ATT_T(1);
     if (SB) {
-      img_dma<DH>(Vb, a.ldv, kt * KT, a.Tk, smem + IMG_BYTES, t);  // every wave is through with PV of the previous tile
+      img_dma<DH>(Vb, a.ldv, kt * KT, Tk, smem + IMG_BYTES, t);  // every wave is through with PV of the previous tile
     } else if (kt + 1 < nkt) {
-      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
     ATT_T(2);
     const unsigned char* Ki = SB ? smem : smem + cur * 2 * IMG_BYTES;
@@ -287,8 +302,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
             s[tt][r] = fmaf(s[tt][r], scale2, rel_s[rel_index(KT * kt + 16 * tt + 4 * g + r, q0 + m, a.relR)]);
       }
       if (!tile_clear) {
-        const int qc = min(q0 + m, a.Tq - 1);
-        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+        const int qc = min(q0 + m, Tq - 1);
+        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, Tk);
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
     if (SB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of V(kt)
       __syncthreads();                                   // V(kt) complete; every wave is through with the K image
-      if (kt + 1 < nkt) img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem, t);
+      if (kt + 1 < nkt) img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem, t);
     }
     // O^T += V^T P^T
 #pragma unroll
@@ -357,9 +372,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
 
   {
     const int qrow = q0 + m;
-    if (qrow < a.Tq) {
+    if (qrow < Tq) {
       const float inv = li > 0.f ? drop_sc / li : NAN;  // all keys masked -> NaN, as softmax over -inf
-      uint16_t* orow = a.out + ((int64_t)b * a.Tq + qrow) * a.ldo + h * DH;
+      uint16_t* orow = a.out + ((int64_t)sg.q0 + qrow) * a.ldo + h * DH;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) store4(orow + 16 * ct + 4 * g, o[ct], inv);
       if (g == 0) a.lse[(int64_t)z * a.Tq + qrow] = mi * 0.6931471805599453f + __logf(li);  // natural-log units
@@ -417,36 +432,39 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
   const int q0 = (lid - z * ntile) * 64 + w * 16;
-  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
-  const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
-  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
-  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
+  const Seg sg = seg_of(a, b);
+  const int Tq = sg.Tq, Tk = sg.Tk;
+  if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
+  const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
+  const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
   const bool drop = a.p > 0.f;
   const float keep_p = 1.f - a.p;
-  img_dma<DH>(Kb, a.ldk, 0, a.Tk, smem, t);  // first, as in flash_fwd_kernel
-  img_dma<DH>(Vb, a.ldv, 0, a.Tk, smem + IMG_BYTES, t);
+  img_dma<DH>(Kb, a.ldk, 0, Tk, smem, t);  // first, as in flash_fwd_kernel
+  img_dma<DH>(Vb, a.ldv, 0, Tk, smem + IMG_BYTES, t);
   bf16x8_t qf[NKS], gf[NKS];
   float lse2, dl2;
   {
-    own_frags<NKS>(Qb, a.ldq, q0, a.Tq, lane, qf);
-    own_frags<NKS>(Gb, a.lddo, q0, a.Tq, lane, gf);
-    const int qc = min(q0 + m, a.Tq - 1);
+    own_frags<NKS>(Qb, a.ldq, q0, Tq, lane, qf);
+    own_frags<NKS>(Gb, a.lddo, q0, Tq, lane, gf);
+    const int qc = min(q0 + m, Tq - 1);
     lse2 = a.lse[(int64_t)z * a.Tq + qc] * 1.4426950408889634f;
     float dsum;
     if (a.dpart) {
-      dsum = load_delta<DH>(a, b, h, z, qc);  // left behind by the product that made dO: nothing to compute, no O to fetch
+      dsum = load_delta<DH>(a, sg.q0, h, z, qc);  // left behind by the product that made dO: nothing to compute, no O to fetch
     } else {
       // delta = rowsum(dO * O) of the own rows: the dO fragments are in registers anyway, O's are fetched once; the four
       // lanes of a row hold a quarter of the head columns each.  Written out for the dK/dV pass, which runs after this one.
       bf16x8_t of[NKS];
-      own_frags<NKS>(a.o + (int64_t)b * a.Tq * a.ldo + h * DH, a.ldo, q0, a.Tq, lane, of);
+      own_frags<NKS>(a.o + (int64_t)sg.q0 * a.ldo + h * DH, a.ldo, q0, Tq, lane, of);
       dsum = 0.f;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum += (float)gf[ks][e] * (float)of[ks][e];
       dsum = quad_sum(dsum);
-      if (g == 0 && q0 + m < a.Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
+      if (g == 0 && q0 + m < Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
     }
     dl2 = dsum * keep_p;
   }
@@ -455,11 +473,11 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   for (int ct = 0; ct < NCT; ++ct) dq[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float scale2 = a.scale * 1.4426950408889634f;
-  const int nkt = (a.Tk + KT - 1) / KT;
+  const int nkt = (Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, a.Tq - 1)) ^ dkey);
+  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, nkt * KT, t);
+  stage_kmask(kmask, a, b, Tk, nkt * KT, t);
   if (REL) {
     stage_rel(rel_s, a, h, t);
     for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
@@ -469,8 +487,8 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) {
-      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, a.Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
     }
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
@@ -497,11 +515,11 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
         dq_elements<false, NTT, REL>(s, dp, scale2, lse2, dl2, G::FULL, rowkey, c4base, thr, drop, rel_s, nullptr, KT * kt + 4 * g, q0 + m,
                                      a.relR);
       } else {
-        const int qc = min(q0 + m, a.Tq - 1);
+        const int qc = min(q0 + m, Tq - 1);
         uint32_t bits = kbits;
-        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, a.Tk);
+        if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, Tk);
         dq_elements<true, NTT, REL>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
-                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < a.Tq);
+                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq);
       }
 #pragma unroll
       for (int ss = 0; ss < NSS; ++ss) dsf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
@@ -524,8 +542,8 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   }
   {
     const int qrow = q0 + m;
-    if (qrow < a.Tq) {
-      uint16_t* drow = a.dq + ((int64_t)b * a.Tq + qrow) * a.lddq + h * DH;
+    if (qrow < Tq) {
+      uint16_t* drow = a.dq + ((int64_t)sg.q0 + qrow) * a.lddq + h * DH;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) store4(drow + 16 * ct + 4 * g, dq[ct], dq_sc);
     }
@@ -596,15 +614,18 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
   const int k0 = (lid - z * ntile) * 64 + w * 16;
-  const uint16_t* Qb = a.q + (int64_t)b * a.Tq * a.ldq + h * DH;
-  const uint16_t* Gb = a.d_o + (int64_t)b * a.Tq * a.lddo + h * DH;
-  const uint16_t* Kb = a.k + (int64_t)b * a.Tk * a.ldk + h * DH;
-  const uint16_t* Vb = a.v + (int64_t)b * a.Tk * a.ldv + h * DH;
-  img_dma<DH>(Qb, a.ldq, 0, a.Tq, smem, t);  // first, as in flash_fwd_kernel: the key-validity test below waits for its mask byte
-  img_dma<DH>(Gb, a.lddo, 0, a.Tq, smem + IMG_BYTES, t);
+  const Seg sg = seg_of(a, b);
+  const int Tq = sg.Tq, Tk = sg.Tk;
+  if (k0 - w * 16 >= Tk) return;  // packed rows: a tile behind this utterance's last key (block-uniform, before any barrier)
+  const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
+  const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
+  const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
+  const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
+  img_dma<DH>(Qb, a.ldq, 0, Tq, smem, t);  // first, as in flash_fwd_kernel: the key-validity test below waits for its mask byte
+  img_dma<DH>(Gb, a.lddo, 0, Tq, smem + IMG_BYTES, t);
   bf16x8_t kf[NKS], vf[NKS];
-  own_frags<NKS>(Kb, a.ldk, k0, a.Tk, lane, kf);
-  own_frags<NKS>(Vb, a.ldv, k0, a.Tk, lane, vf);
+  own_frags<NKS>(Kb, a.ldk, k0, Tk, lane, kf);
+  own_frags<NKS>(Vb, a.ldv, k0, Tk, lane, vf);
   f32x4_t dk[NCT], dv[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
@@ -619,35 +640,35 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   const bool full_mask = a.mask && a.msq != 0;
   const int key = k0 + m;
   // key-padding masks depend on the own key only: resolved once, outside the query sweep
-  const bool key_valid = key < a.Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
+  const bool key_valid = key < Tk && (!a.mask || a.msq != 0 || a.mask[(int64_t)b * a.msb + key] != 0);
   const bool all_keys = __all(key_valid) != 0;  // wave-uniform: no per-element key test needed
-  const int nqt = (a.Tq + KT - 1) / KT;
+  const int nqt = (Tq + KT - 1) / KT;
   if (REL) stage_rel(rel_s, a, h, t);  // visible after the first barrier of the sweep
   // per-query scalars of the NEXT tile (log-sum-exp, delta) travel one iteration ahead in registers: fetching
   // them at the top of the iteration they are used in put a global-load round trip in front of every tile
   float lse_r = 0.f, dl_r = 0.f;
   if (t < KT) {
-    const int qc = min(t, a.Tq - 1);
+    const int qc = min(t, Tq - 1);
     lse_r = a.lse[(int64_t)z * a.Tq + qc];
-    dl_r = load_delta<DH>(a, b, h, z, qc);
+    dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
   }
   int cur = 0;
   for (int qt = 0; qt < nqt; ++qt) {
     if (t < KT) {
-      const bool live = qt * KT + t < a.Tq;
+      const bool live = qt * KT + t < Tq;
       lse_s[cur][t] = live ? lse_r * 1.4426950408889634f : INFINITY;  // rows past Tq: exp2(-inf) = 0
       dl_s[cur][t] = dl_r * keep_p;
-      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, a.Tq - 1)) ^ dkey);
+      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, Tq - 1)) ^ dkey);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) {
-      img_dma<DH>(Qb, a.ldq, (qt + 1) * KT, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Gb, a.lddo, (qt + 1) * KT, a.Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Qb, a.ldq, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
+      img_dma<DH>(Gb, a.lddo, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
       if (t < KT) {
-        const int qc = min((qt + 1) * KT + t, a.Tq - 1);
+        const int qc = min((qt + 1) * KT + t, Tq - 1);
         lse_r = a.lse[(int64_t)z * a.Tq + qc];
-        dl_r = load_delta<DH>(a, b, h, z, qc);
+        dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
       }
     }
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
@@ -670,19 +691,19 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
           s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Qi, 4 * hf + tt, ks, lane), kf[ks], s[tt], 0, 0, 0);
           dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Gi, 4 * hf + tt, ks, lane), vf[ks], dp[tt], 0, 0, 0);
         }
-      const uint8_t* mcol = full_mask ? a.mask + (int64_t)b * a.msb + min(key, a.Tk - 1) : nullptr;
+      const uint8_t* mcol = full_mask ? a.mask + (int64_t)b * a.msb + min(key, Tk - 1) : nullptr;
       const float* lp = lse_s[cur] + 64 * hf;
       const float* dlp = dl_s[cur] + 64 * hf;
       const uint32_t* rp = rk_s[cur] + 64 * hf;
       const int qbase = qt * KT + 64 * hf;
       if (full_mask)
-        dkv_elements<true, true, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, mcol, a.msq, qbase, a.Tq, rel_s,
+        dkv_elements<true, true, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, mcol, a.msq, qbase, Tq, rel_s,
                                          a.relR);
       else if (!all_keys)
-        dkv_elements<true, false, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq, rel_s,
+        dkv_elements<true, false, 4, REL>(s, dp, lp, dlp, rp, scale2, key_valid, key, thr, drop, g, m & 1, nullptr, 0, qbase, Tq, rel_s,
                                           a.relR);
       else
-        dkv_elements<false, false, 4, REL>(s, dp, lp, dlp, rp, scale2, true, key, thr, drop, g, m & 1, nullptr, 0, qbase, a.Tq, rel_s,
+        dkv_elements<false, false, 4, REL>(s, dp, lp, dlp, rp, scale2, true, key, thr, drop, g, m & 1, nullptr, 0, qbase, Tq, rel_s,
                                            a.relR);
       pf[2 * hf] = pack8(s[0], s[1]);
       pf[2 * hf + 1] = pack8(s[2], s[3]);
@@ -700,9 +721,9 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     cur ^= 1;
   }
   const float dv_sc = drop ? 1.f / keep_p : 1.f, dk_sc = a.scale * dv_sc;
-  if (key < a.Tk) {
-    uint16_t* krow = a.dk + ((int64_t)b * a.Tk + key) * a.lddk + h * DH;
-    uint16_t* vrow = a.dv + ((int64_t)b * a.Tk + key) * a.lddv + h * DH;
+  if (key < Tk) {
+    uint16_t* krow = a.dk + ((int64_t)sg.k0 + key) * a.lddk + h * DH;
+    uint16_t* vrow = a.dv + ((int64_t)sg.k0 + key) * a.lddv + h * DH;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       store4(krow + 16 * ct + 4 * g, dk[ct], dk_sc);
@@ -750,6 +771,7 @@ int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f && (d->dropout_p == 0.f || d->rng_state), "flash_attn: bad dropout args");
   JS2T_CHECK(!d->rel_bias || (d->rel_R >= 1 && d->rel_R <= REL_MAX), "flash_attn: rel_R must be 1..%d", REL_MAX);
   JS2T_CHECK(!d->d_rel_bias || d->rel_bias, "flash_attn: d_rel_bias without rel_bias");
+  JS2T_CHECK(!d->seg || d->Tq == d->Tk, "flash_attn: packed rows (seg) are for self-attention, Tq == Tk = the longest entry");
   return JS2T_OK;
 }
 
@@ -765,6 +787,7 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.scale = d->scale; a.p = d->dropout_p; a.rng = d->rng_state; a.stream = d->rng_stream;
   a.rel = d->rel_bias; a.d_rel = d->d_rel_bias; a.relR = d->rel_bias ? d->rel_R : 0;
   a.dpart = d->delta_partial; a.dgroups = d->delta_groups;
+  a.seg = d->seg;
   return a;
 }
 

@@ -612,6 +612,63 @@ extern "C" int js2t_im2col(const void* x, void* col, int64_t B, int64_t tin, int
   return JS2T_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed rows of a ragged batch (encoders.py:348-373: positions behind an utterance's sub-sampled length are dead): the encoder
+// stack runs on the sum(T'_i) live rows only.  pack: dst[seg[b] + t] = src[b*T + t] for t < len_b, rows seg[B] .. rows_out of dst
+// zeroed (the caller rounds the packed row count up to a launch-friendly size); unpack: dst[b*T + t] = t < len_b ?
+// src[seg[b] + t] : 0.  16-byte pieces, eight rows per block; blockIdx.y = batch entry (pack: entry B = the zeroed tail).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PK_ROWS = 8;
+template <bool PACK>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int32_t* __restrict__ seg,
+                                                        int B, int T, int64_t rows_out, int chunks) {
+  const int b = blockIdx.y, t0 = blockIdx.x * PK_ROWS;
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  if (PACK && b == B) {  // the tail behind the last entry
+    const int64_t r0 = (int64_t)seg[B] + t0;
+    for (int i = threadIdx.x; i < PK_ROWS * chunks; i += 256) {
+      const int64_t r = r0 + i / chunks;
+      if (r < rows_out) dst[r * chunks + i % chunks] = zero;
+    }
+    return;
+  }
+  const int s0 = seg[b], len = seg[b + 1] - s0;
+  if (PACK && t0 >= len) return;
+  for (int i = threadIdx.x; i < PK_ROWS * chunks; i += 256) {
+    const int t = t0 + i / chunks, c = i % chunks;
+    if (t >= T) break;
+    if (PACK) {
+      if (t < len) dst[((int64_t)s0 + t) * chunks + c] = src[((int64_t)b * T + t) * chunks + c];
+    } else {
+      dst[((int64_t)b * T + t) * chunks + c] = t < len ? src[((int64_t)s0 + t) * chunks + c] : zero;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int js2t_pack_rows(const void* src, void* dst, const int32_t* seg, int32_t B, int32_t T_, int64_t rows_out, int64_t row_bytes,
+                              int pack, js2t_stream stream) {
+  JS2T_CHECK(src && dst && seg && B > 0 && T_ > 0 && row_bytes > 0 && (row_bytes % 16) == 0, "pack_rows: bad arguments");
+  JS2T_CHECK(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, "pack_rows: buffers must be 16-byte aligned");
+  JS2T_CHECK(B < 65535 && (!pack || rows_out > 0), "pack_rows: bad sizes");
+  const int chunks = (int)(row_bytes / 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (pack == 2) {  // only the tail: rows seg[B] .. rows_out of dst zeroed (src unused)
+    hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(cdiv(T_, PK_ROWS), 1), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, seg + B, 0, T_,
+                       rows_out, chunks);
+  } else if (pack) {
+    // the tail slab covers at most T rows: the caller's rounding (rows_out - seg[B]) has to stay below that
+    hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(cdiv(T_, PK_ROWS), B + 1), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, seg, B, T_,
+                       rows_out, chunks);
+  } else {
+    hipLaunchKernelGGL(pack_rows_kernel<false>, dim3(cdiv(T_, PK_ROWS), B), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, seg, B, T_,
+                       rows_out, chunks);
+  }
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 extern "C" int js2t_subsample_lengths_mask(const int64_t* lengths, int64_t* out_lengths, uint8_t* mask, int64_t B,
                                            int64_t T_out, const int32_t* kernel_sizes, int32_t n_layers, js2t_stream stream) {
   JS2T_CHECK(lengths && out_lengths && mask && B > 0 && T_out > 0, "subsample_lengths_mask: bad arguments");

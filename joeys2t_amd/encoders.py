@@ -3,8 +3,10 @@
 
 Layout note: the reference transposes to [B,C,T] for nn.Conv1d and back (:363,:368); here activations stay
 [B,T,C] end to end and each Conv1d(k, stride 2)+GLU is an implicit-im2col GEMM (functional.Conv1dGluFn)."""
+import os
 from typing import List, Tuple
 
+import torch
 from torch import Tensor, nn
 
 from joeys2t_amd import functional as Fn
@@ -12,6 +14,12 @@ from joeys2t_amd import ops
 from joeys2t_amd.helpers import freeze_params, lengths_to_padding_mask, pad
 from joeys2t_amd.runtime import runtime_of
 from joeys2t_amd.transformer_layers import ConformerEncoderLayer, PositionalEncoding, TransformerEncoderLayer
+
+
+# the encoder stack of a ragged S2T batch on its live rows only (TransformerEncoder._packing); JS2T_PACKED_ENCODER=0: padded layout
+PACK_RAGGED = os.environ.get("JS2T_PACKED_ENCODER", "1") != "0"
+PACK_MIN_SAVING = 0.04  # below this share of dead rows the two gather / scatter passes are not worth it
+PACK_ROUND = 64         # packed row count rounded up (whole 64-row groups for the row-wise kernels; the tail is kept zero)
 
 
 class Encoder(nn.Module):
@@ -110,18 +118,49 @@ class TransformerEncoder(Encoder):
             mask = lengths_to_padding_mask(src_length, src_embed.size(1)).unsqueeze(1)
         x = self.pe(src_embed, extra=kwargs.get("src_prompt_mask", None), dropout=self.emb_dropout.p,
                     training=self.training)
+        pack = self._packing(x, mask, kwargs)
+        if pack is not None:  # ragged batch: the stack runs on the live positions only, [1, sum of lengths (rounded), d]
+            x = Fn.PackRowsFn.apply(x, pack)
         for layer in self.layers:
-            x = layer(x, mask)
+            x = layer(x, mask) if pack is None else layer(x, mask, pack=pack)
         if self.layer_norm is not None:
             rt = runtime_of(self)
             sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
             x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")),
                                      rt.grads_ready)
+        if pack is not None:  # back to [B, T', d] for the decoder / CTC layer: zeros behind every length
+            x = Fn.UnpackRowsFn.apply(x, pack)
         if kwargs.get("repad", False) and "src_max_len" in kwargs and self.subsample:
             x, mask = self._repad(x, mask, kwargs["src_max_len"])
         assert src_length.size() == (x.size(0), ), (src_length.size(), x.size())
         assert mask.size() == (x.size(0), 1, x.size(1)), (mask.size(), x.size())
         return x, None, mask
+
+    def _packing(self, x: Tensor, mask: Tensor, kwargs):
+        """ops.PackedRows for this batch, or None (the padded layout).  Positions behind an utterance's sub-sampled length are dead
+        in the reference - masked as keys (transformer_layers.py:86-105), beyond the CTC input lengths (loss.py:156-161), masked in
+        the decoder's cross-attention - so an S2T encoder may drop them: every row-wise kernel then runs on sum(T'_i) rows and the
+        fused self-attention walks each utterance's own tiles (js2t_attn_desc.seg).  Needs the fused attention kernels (bf16, head
+        size 64 / 128) and lengths known on the HOST: `src_pack` (a PackedRows prepared by the caller, graphed.GraphedTrainStep)
+        or `src_length_host` (frame counts, batch.Batch).  Taken when it drops at least PACK_MIN_SAVING of the rows."""
+        if not (PACK_RAGGED and self.subsample and type(self) is TransformerEncoder and x.is_cuda and x.dtype == torch.bfloat16 and Fn.USE_FLASH):
+            return None
+        B, T, d = x.shape
+        dh = d // self.layers[0].src_src_att.num_heads
+        if dh not in (64, 128) or (d * 2) % 16 or mask is None or tuple(mask.shape) != (B, 1, T):
+            return None
+        pack = kwargs.get("src_pack", None)
+        if pack is None:
+            host = kwargs.get("src_length_host", None)
+            if host is None or len(host) != B:
+                return None
+            lens = [min(self.subsampler.out_len(int(n)), T) for n in host]
+            if sum(lens) > (1.0 - PACK_MIN_SAVING) * B * T:
+                return None
+            pack = ops.PackedRows.from_lengths(lens, T, x.device, round_to=PACK_ROUND)
+        if pack.B != B or pack.T != T:
+            raise ops.Js2tError(f"packed encoder: {pack.B} x {pack.T} prepared for a [{B}, {T}, {d}] batch")
+        return pack
 
     def _repad(self, x, mask, src_max_len):
         """Pad x / mask to the subsampled length of src_max_len (reference :290-298; mask padded with True)."""

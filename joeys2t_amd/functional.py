@@ -220,10 +220,11 @@ def wgrad_split(rows: int, cols: int, red: int, count: int = 1) -> int:
 
 
 class AttnShape:
-    __slots__ = ("B", "Tq", "Tk", "H", "dh", "ld")
+    __slots__ = ("B", "Tq", "Tk", "H", "dh", "ld", "seg")
 
-    def __init__(self, B, Tq, Tk, H, dh):
+    def __init__(self, B, Tq, Tk, H, dh, seg=None):
         self.B, self.Tq, self.Tk, self.H, self.dh = B, Tq, Tk, H, dh
+        self.seg = seg  # ops.PackedRows: self-attention over the packed rows of a ragged batch (fused kernels only)
         self.ld = ops.round_up(Tk, 8)  # score row stride: 16-byte rows for the bf16 GEMMs
 
 
@@ -239,8 +240,10 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
     Z = B * H
     if USE_FLASH and not need_probs and ops.flash_supported(q_t, k_t, v_t, dh):
         # fused kernel: scores / probabilities stay on chip; the forward keeps (out, lse) for backward
-        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
+        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, seg=shp.seg)
         return out, None, lse
+    if shp.seg is not None:
+        raise ops.Js2tError("attention over packed rows needs the fused kernels (bf16, head size 64 / 128): the encoder packs only then")
     S = torch.empty((Z, Tq, ld), dtype=dt, device=dev)
     ops.gemm(q_t, k_t, S, M=Tq, N=Tk, K=dh, lda=q_t.stride(0), ldb=k_t.stride(0), ldc=ld, batch=Z, batch_inner=H,
              a_strides=(Tq * q_t.stride(0), dh), b_strides=(Tk * k_t.stride(0), dh), c_strides=(H * Tq * ld, Tq * ld),
@@ -267,7 +270,7 @@ def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_of
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
     if P is None:
         ops.flash_attn_bwd(dctx, ctx_out, Pd, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off,
-                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias, delta_partial=delta_partial)
+                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias, delta_partial=delta_partial, seg=shp.seg)
         return
     Z = B * H
     dev, dt = dctx.device, dctx.dtype
@@ -420,6 +423,33 @@ def end_memory_chain(check: bool = True):
                            "share of the gradient is lost; set JS2T_CHAIN_MEMORY_GRADS=0")
 
 
+class PackRowsFn(torch.autograd.Function):
+    """[B, T, C] -> [1, rows, C]: the live positions of every utterance back to back (ops.pack_rows); backward scatters the
+    gradient back and leaves zeros behind every length."""
+
+    @staticmethod
+    def forward(ctx, x, pk):
+        ctx.pk, ctx.shape = pk, tuple(x.shape)
+        return ops.pack_rows(x.reshape(-1, x.shape[-1]), pk).unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.unpack_rows(dy.reshape(-1, dy.shape[-1]).contiguous(), ctx.pk).view(ctx.shape), None
+
+
+class UnpackRowsFn(torch.autograd.Function):
+    """[1, rows, C] -> [B, T, C] with zeros behind every length; backward gathers the live rows of the gradient."""
+
+    @staticmethod
+    def forward(ctx, xp, pk):
+        ctx.pk = pk
+        return ops.unpack_rows(xp.reshape(-1, xp.shape[-1]), pk).view(pk.B, pk.T, xp.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.pack_rows(dy.reshape(-1, dy.shape[-1]).contiguous(), ctx.pk).unsqueeze(0), None
+
+
 class ResidualBlockFn(torch.autograd.Function):
     """One residual block:  pre-LN:  y = drop(core(LN(x))) + alpha*x ;  post-LN: y = LN(drop(core(x)) + alpha*x).
 
@@ -490,7 +520,13 @@ class ResidualBlockFn(torch.autograd.Function):
         if cfg.kind == "self":
             H, dh = cfg.H, d // cfg.H
             qkv = linear_fwd(n, first("w_in"), first("b_in"), ln=lnf, x8=x8_first)  # columns: [k | v | q]
-            shp = AttnShape(B, T, T, H, dh)
+            pk = wts.get("pack")  # ops.PackedRows: x is [1, pk.rows, d], the live rows of a ragged batch back to back
+            if pk is not None:
+                if B != 1 or T != pk.rows or mask is None or mask.shape[0] != pk.B or mask.shape[-1] != pk.T:
+                    raise ops.Js2tError(f"self-attention over packed rows: x {tuple(x.shape)} / mask do not match {pk.B} x {pk.T} in {pk.rows} rows")
+                shp = AttnShape(pk.B, pk.T, pk.T, H, dh, seg=pk)
+            else:
+                shp = AttnShape(B, T, T, H, dh)
             c, P, Pd = attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, shp, mask, p_in, rng, sites[0], rel_bias=wts.get("rel_bias"))
             saved.update(qkv=qkv, P=P, Pd=Pd, shp=shp)
         elif cfg.kind == "cross":
@@ -642,6 +678,8 @@ class ResidualBlockFn(torch.autograd.Function):
             dpart, LINEAR_BWD_DOT[0] = LINEAR_BWD_DOT[0], None
             qkv = sv["qkv"]
             dqkv = torch.empty_like(qkv)
+            if sv["shp"].seg is not None:
+                ops.zero_tail_rows(dqkv, sv["shp"].seg)  # rows no utterance owns: not written by the kernels, read by the next product
             rel, d_rel = wts.get("rel_bias"), None
             if rel is not None:
                 d_rel = sk("rel_bias")  # the parameter's slice of the flat gradient: the kernel adds into it

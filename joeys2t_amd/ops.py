@@ -927,30 +927,111 @@ def _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rn
     return d
 
 
-def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None):
+class PackedRows:
+    """Where the utterances of a ragged batch live once their dead positions are dropped (js2t_pack_rows): entry b owns rows
+    seg[b] .. seg[b+1] of a [rows, C] buffer; B entries of at most T positions; rows >= seg[B] (rounded up by the caller, the
+    tail is kept zero)."""
+    __slots__ = ("seg", "B", "T", "rows")
+
+    def __init__(self, seg: torch.Tensor, B: int, T: int, rows: int):
+        if seg.dtype != torch.int32 or seg.numel() != B + 1 or not seg.is_contiguous():
+            raise Js2tError("PackedRows: seg must be a contiguous int32 [B + 1] tensor")
+        self.seg, self.B, self.T, self.rows = seg, int(B), int(T), int(rows)
+
+    @staticmethod
+    def from_lengths(lengths, T: int, device, round_to: int = 1) -> "PackedRows":
+        """lengths: HOST integers (no device sync), each 1..T."""
+        lens = [int(v) for v in lengths]
+        if not lens or min(lens) < 1 or max(lens) > T:
+            raise Js2tError(f"PackedRows: lengths must lie in 1..{T}")
+        off = [0]
+        for n in lens:
+            off.append(off[-1] + n)
+        round_to = max(1, min(int(round_to), T))  # the zeroed tail stays shorter than one utterance (js2t_pack_rows)
+        rows = -(-off[-1] // round_to) * round_to
+        if rows - off[-1] > T:
+            raise Js2tError("PackedRows: the rounding of the row count must stay below one utterance")
+        seg = torch.tensor(off, dtype=torch.int32).pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" \
+            else torch.tensor(off, dtype=torch.int32)
+        return PackedRows(seg, len(lens), T, rows)
+
+
+def pack_rows(x2d, pk: PackedRows):
+    """[B*T, C] -> [pk.rows, C]: the live rows of every entry, back to back; the tail zeroed."""
+    _dev(x2d, pk.seg)
+    if x2d.dim() != 2 or x2d.shape[0] != pk.B * pk.T or not x2d.is_contiguous() or (x2d.shape[1] * x2d.element_size()) % 16:
+        raise Js2tError(f"pack_rows: contiguous [{pk.B * pk.T}, C] rows of a multiple of 16 bytes, got {tuple(x2d.shape)}")
+    out = torch.empty((pk.rows, x2d.shape[1]), dtype=x2d.dtype, device=x2d.device)
+    check(lib().js2t_pack_rows(C.c_void_p(x2d.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(pk.seg.data_ptr()), pk.B, pk.T,
+                               C.c_int64(pk.rows), C.c_int64(x2d.shape[1] * x2d.element_size()), 1, _stream()), "js2t_pack_rows")
+    return out
+
+
+def unpack_rows(xp, pk: PackedRows):
+    """[pk.rows, C] -> [B*T, C]: every entry at b*T again, zeros behind its length."""
+    _dev(xp, pk.seg)
+    if xp.dim() != 2 or xp.shape[0] != pk.rows or not xp.is_contiguous() or (xp.shape[1] * xp.element_size()) % 16:
+        raise Js2tError(f"unpack_rows: contiguous [{pk.rows}, C] rows of a multiple of 16 bytes, got {tuple(xp.shape)}")
+    out = torch.empty((pk.B * pk.T, xp.shape[1]), dtype=xp.dtype, device=xp.device)
+    check(lib().js2t_pack_rows(C.c_void_p(xp.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(pk.seg.data_ptr()), pk.B, pk.T,
+                               C.c_int64(pk.rows), C.c_int64(xp.shape[1] * xp.element_size()), 0, _stream()), "js2t_pack_rows")
+    return out
+
+
+def zero_tail_rows(buf, pk: PackedRows):
+    """rows seg[B] .. pk.rows of a contiguous [pk.rows, C] buffer zeroed (what the packed attention kernels do not write)."""
+    _dev(buf, pk.seg)
+    if buf.dim() != 2 or buf.shape[0] != pk.rows or not buf.is_contiguous() or (buf.shape[1] * buf.element_size()) % 16:
+        raise Js2tError(f"zero_tail_rows: contiguous [{pk.rows}, C] rows of a multiple of 16 bytes, got {tuple(buf.shape)}")
+    check(lib().js2t_pack_rows(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_void_p(pk.seg.data_ptr()), pk.B, pk.T,
+                               C.c_int64(pk.rows), C.c_int64(buf.shape[1] * buf.element_size()), 2, _stream()), "js2t_pack_rows")
+
+
+def _seg_check(pk, q_t, B, Tq, Tk):
+    if pk.B != B or pk.T != Tq or Tq != Tk or q_t.shape[0] != pk.rows:
+        raise Js2tError(f"flash attention over packed rows: {pk.B} entries of <= {pk.T} positions in {pk.rows} rows do not match "
+                        f"B={B} Tq={Tq} Tk={Tk} rows={q_t.shape[0]}")
+    _dev(pk.seg)
+
+
+def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None, seg: PackedRows = None):
+    """seg: self-attention over packed rows (q_t / k_t / v_t are [seg.rows, ...]; B, Tq == Tk = the padded geometry)."""
     _dev(q_t, k_t, v_t, mask, rel_bias)
-    out = torch.empty((B * Tq, H * dh), dtype=q_t.dtype, device=q_t.device)
+    rows = B * Tq
+    if seg is not None:
+        _seg_check(seg, q_t, B, Tq, Tk)
+        rows = seg.rows
+    out = torch.empty((rows, H * dh), dtype=q_t.dtype, device=q_t.device)
     lse = torch.empty((B * H, Tq), dtype=torch.float32, device=q_t.device)
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
+    if seg is not None:
+        d.seg = seg.seg.data_ptr()
+        if seg.rows > 0:
+            zero_tail_rows(out, seg)
     check(lib().js2t_flash_attn_fwd(C.byref(d), _stream()), "js2t_flash_attn_fwd")
     return out, lse
 
 
 def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
-                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None):
+                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None, seg: PackedRows = None):
     """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating.
+    seg: packed rows, as in flash_attn_fwd; rows of dq / dk / dv no entry owns are NOT written (the caller zeroes them).
     delta_partial f32 [B*Tq, H*dh // 64]: rowsum(dout * out) as partial sums per 64-column group (gemm(dot=...) of the product that
     made dout) - the two passes then run as one grid and `out` is not read."""
     _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask, rel_bias, d_rel_bias, delta_partial)
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
+    nrows = B * Tq
+    if seg is not None:
+        _seg_check(seg, q_t, B, Tq, Tk)
+        d.seg, nrows = seg.seg.data_ptr(), seg.rows
     if d_rel_bias is not None:
         if rel_bias is None or d_rel_bias.shape != rel_bias.shape or d_rel_bias.dtype != torch.float32 or not d_rel_bias.is_contiguous():
             raise Js2tError("d_rel_bias must be a contiguous float32 tensor shaped like rel_bias")
         d.d_rel_bias = d_rel_bias.data_ptr()
     es = q_t.element_size()
     if delta_partial is not None:
-        if delta_partial.dtype != torch.float32 or delta_partial.numel() != B * Tq * (H * dh // 64) or not delta_partial.is_contiguous():
+        if delta_partial.dtype != torch.float32 or delta_partial.numel() != nrows * (H * dh // 64) or not delta_partial.is_contiguous():
             raise Js2tError("flash_attn_bwd: delta_partial must be contiguous f32 [B*Tq, H*dh // 64]")
         d.delta_partial, d.delta_groups = delta_partial.data_ptr(), H * dh // 64
         d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()

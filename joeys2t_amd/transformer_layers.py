@@ -73,7 +73,7 @@ class MultiHeadedAttention(nn.Module):
 
     def run_block(self, x: Tensor, memory: Optional[Tensor], mask: Optional[Tensor], *, ln: Optional[nn.LayerNorm],
                   ln_mode: str, alpha: float, out_dropout: float, need_weights: bool = False,
-                  memory_kv: Optional[Tuple[Tensor, int]] = None):
+                  memory_kv: Optional[Tuple[Tensor, int]] = None, pack=None):
         """[LN] -> attention -> output projection (+dropout) + alpha*x [-> LN] as one fused autograd node.
         `memory_kv` = (projections [B*S, L*2d] of the encoder states for all decoder layers, this layer's first column): the
         block reads its keys and values from there instead of projecting `memory` itself (functional.MemoryKVFn)."""
@@ -109,6 +109,10 @@ class MultiHeadedAttention(nn.Module):
             params = params + [self.rel_pos_bias]
             smap.update(rel_bias=[self.rel_pos_bias])
         wts["sink"], wts["notify"] = rt.sinks(smap), rt.grads_ready
+        if pack is not None:  # ops.PackedRows: x holds the live rows of a ragged batch (encoders.TransformerEncoder)
+            if kind != "self":
+                raise NotImplementedError("packed rows: self-attention blocks only")
+            wts["pack"] = pack
         if memory_kv is not None:  # k_layer / v_layer ran in MemoryKVFn, which also owns their gradients
             wts["kv_off"] = int(memory_kv[1])
             wts["notify_skip"] = {id(k_.weight), id(v_.weight), id(k_.bias), id(v_.bias)}
@@ -217,9 +221,9 @@ class TransformerEncoderLayer(nn.Module):
         self._layer_norm_position = layer_norm
         assert self._layer_norm_position in {"pre", "post"}
 
-    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+    def forward(self, x: Tensor, mask: Tensor, pack=None) -> Tensor:
         h, _ = self.src_src_att.run_block(x, None, mask, ln=self.layer_norm, ln_mode=self._layer_norm_position,
-                                          alpha=self.alpha, out_dropout=self.dropout.p)
+                                          alpha=self.alpha, out_dropout=self.dropout.p, pack=pack)
         return self.feed_forward(h)
 
 

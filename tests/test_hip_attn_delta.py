@@ -80,7 +80,7 @@ def test_train_step_gradients_with_and_without_the_hand_over(device):
     from test_hip_config_width import hip_batch, make_model, synth_batch, width_cfg
     V = 300
     torch.manual_seed(5)
-    model = make_model(width_cfg(4, 2, 2), V, None, device, torch.bfloat16, 0.0, train=True)
+    model = make_model(width_cfg(4, 2, 2), V, None, device, torch.bfloat16, 0.3, train=True)
     data = synth_batch(V, [200, 170, 150], [9, 7, 5], 1)
     step = TrainStep(model, learning_rate=1e-3, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=3)
     taken = []

@@ -1,0 +1,129 @@
+"""GPU: the encoder stack of a ragged batch on its live rows only (js2t_pack_rows, js2t_attn_desc.seg, encoders.TransformerEncoder.
+_packing).  Positions behind an utterance's sub-sampled length are dead in the reference (joeynmt/encoders.py:348-373 builds the
+padding mask, transformer_layers.py:86-105 masks them as keys, loss.py:156-161 cuts the CTC input at the lengths), so dropping them
+must change nothing: losses and gradients equal the padded path's."""
+import pytest
+import torch
+
+from joeys2t_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("lens,T,C,round_to", [([5, 3, 7, 1], 7, 64, 1), ([300, 425, 77, 250, 1], 425, 512, 64), ([9], 16, 24, 8)])
+def test_pack_unpack_rows(device, lens, T, C, round_to):
+    B = len(lens)
+    pk = ops.PackedRows.from_lengths(lens, T, device, round_to=round_to)
+    assert pk.rows % min(round_to, T) == 0 and pk.rows >= sum(lens) and pk.seg.tolist()[-1] == sum(lens)
+    x = rnd(B, T, C, seed=1).bfloat16()
+    xp = ops.pack_rows(x.view(B * T, C).to(device), pk).cpu()
+    ref = torch.cat([x[b, :n] for b, n in enumerate(lens)] + [torch.zeros(pk.rows - sum(lens), C, dtype=x.dtype)])
+    assert torch.equal(xp, ref)
+    back = ops.unpack_rows(xp.to(device), pk).cpu().view(B, T, C)
+    live = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).unsqueeze(-1)
+    assert torch.equal(back, torch.where(live, x, torch.zeros_like(x)))
+    buf = torch.full((pk.rows, C), float("nan"), dtype=torch.bfloat16, device=device)
+    ops.zero_tail_rows(buf, pk)
+    assert torch.isnan(buf[:sum(lens)].float()).all() and float(buf[sum(lens):].float().abs().sum()) == 0.0
+    f32 = rnd(B * T, C // 4 * 4, seed=2).to(device)  # any row of a multiple of 16 bytes
+    assert torch.equal(ops.unpack_rows(ops.pack_rows(f32, pk), pk).view(B, T, -1)[0, :lens[0]], f32.view(B, T, -1)[0, :lens[0]])
+
+
+@pytest.mark.parametrize("dh,H", [(128, 4), (64, 4)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_flash_attention_over_packed_rows_equals_padded(device, dh, H, p):
+    """the same keys, queries, tiles and dropout counters: bit for bit on every live row, forward and backward (also through the
+    one-grid backward with delta from partial sums)"""
+    lens, T = [375, 301, 64, 129, 1, 200], 375
+    B, d = len(lens), H * dh
+    pk = ops.PackedRows.from_lengths(lens, T, device, round_to=64)
+    live = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None])
+    qkv = rnd(B * T, 3 * d, seed=1).bfloat16().to(device)
+    go = (rnd(B * T, d, seed=2) * live.reshape(-1, 1)).bfloat16().to(device)  # dead rows carry no gradient (they are masked downstream)
+    mask = live.unsqueeze(1).to(device)
+    rng = ops.DropoutRng(device, seed=3) if p else None
+    out, lse = ops.flash_attn_fwd(qkv, 2 * d, qkv, 0, qkv, d, B, H, T, T, dh, mask, p, rng, 5)
+    qkv_p, go_p = ops.pack_rows(qkv, pk), ops.pack_rows(go, pk)
+    out_p, lse_p = ops.flash_attn_fwd(qkv_p, 2 * d, qkv_p, 0, qkv_p, d, B, H, T, T, dh, mask, p, rng, 5, seg=pk)
+    assert out_p.shape == (pk.rows, d)
+    assert torch.equal(out_p, ops.pack_rows(out, pk))  # tail rows zero on both sides
+    lv = live.to(device)[:, None, :].expand(B, H, T).reshape(B * H, T)
+    assert torch.equal(lse_p[lv], lse[lv])
+    for with_partial in (False, True):
+        kw, kw_p = {}, {}
+        if with_partial:
+            kw["delta_partial"] = (go.float() * out.float()).view(B * T, d // 64, 64).sum(-1).contiguous()
+            kw_p["delta_partial"] = (go_p.float() * out_p.float()).view(pk.rows, d // 64, 64).sum(-1).contiguous()
+        dqkv = torch.zeros_like(qkv)
+        ops.flash_attn_bwd(go, out, lse, qkv, 2 * d, qkv, 0, qkv, d, dqkv, 2 * d, dqkv, 0, dqkv, d, B, H, T, T, dh, mask, p, rng, 5, **kw)
+        dqkv_p = torch.full_like(qkv_p, float("nan"))
+        ops.zero_tail_rows(dqkv_p, pk)
+        ops.flash_attn_bwd(go_p, out_p, lse_p, qkv_p, 2 * d, qkv_p, 0, qkv_p, d, dqkv_p, 2 * d, dqkv_p, 0, dqkv_p, d, B, H, T, T, dh, mask,
+                           p, rng, 5, seg=pk, **kw_p)
+        assert torch.isfinite(dqkv_p.float()).all()
+        assert torch.equal(dqkv_p, ops.pack_rows(dqkv, pk)), with_partial
+
+
+def test_packed_rows_are_refused_where_they_cannot_work(device):
+    pk = ops.PackedRows.from_lengths([5, 3], 8, device)
+    q = torch.zeros(8, 384, dtype=torch.bfloat16, device=device)
+    mem = torch.zeros(2 * 20, 384, dtype=torch.bfloat16, device=device)
+    with pytest.raises(ops.Js2tError):  # cross-attention shapes
+        ops.flash_attn_fwd(q, 256, mem, 0, mem, 128, 2, 1, 8, 20, 128, None, 0.0, None, 0, seg=pk)
+    with pytest.raises(ops.Js2tError):
+        ops.PackedRows.from_lengths([9, 3], 8, device)
+
+
+def _grads(device, packed, data, dropout=0.0, seed=5, dtype=torch.bfloat16):
+    from joeys2t_amd import encoders
+    from joeys2t_amd.training import TrainStep
+    from test_hip_config_width import hip_batch, make_model, width_cfg
+    torch.manual_seed(seed)
+    cfg = width_cfg(4, 3, 2)
+    cfg["encoder"]["dropout"] = cfg["decoder"]["dropout"] = dropout
+    model = make_model(cfg, 300, None, device, dtype, 0.3, train=True)
+    step = TrainStep(model, learning_rate=1e-3, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=3)
+    taken = []
+    real = ops.pack_rows
+
+    def spy(x, pk):
+        taken.append(pk.rows)
+        return real(x, pk)
+
+    ops.pack_rows, encoders.PACK_RAGGED = spy, packed
+    try:
+        out = step.micro_step(hip_batch(*data, device), update=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.pack_rows, encoders.PACK_RAGGED = real, True
+    stats = step.read_stats()
+    return step.store.flat_grad.detach().clone(), stats, taken, out
+
+
+def test_train_step_on_packed_rows_equals_padded(device):
+    from test_hip_config_width import synth_batch
+    data = synth_batch(300, [400, 330, 170, 150, 90], [9, 7, 5, 6, 3], 1)  # frames: T' = 100, 83, 43, 38, 23
+    g_pad, s_pad, took_pad, _ = _grads(device, False, data)
+    g_pad2, _, _, _ = _grads(device, False, data)
+    g_pk, s_pk, took, _ = _grads(device, True, data)
+    assert took_pad == [] and len(took) >= 1 and took[0] < 5 * 100  # forward packs once (backward of the un-pack packs again)
+    assert s_pk["loss"] == pytest.approx(s_pad["loss"], rel=1e-5)
+    noise = (g_pad - g_pad2).norm().item()  # the padded path twice: split-K atomics
+    err = (g_pk - g_pad).norm().item()
+    assert torch.isfinite(g_pk).all() and err <= max(4.0 * noise, 2e-3 * g_pad.norm().item()), (err, noise, g_pad.norm().item())
+
+
+def test_packed_rows_with_dropout_stay_finite_and_close(device):
+    """dropout on: the row-wise masks differ between the layouts (the counter is the row index), the attention masks do not;
+    the loss of one step stays within the spread dropout gives it anyway"""
+    from test_hip_config_width import synth_batch
+    data = synth_batch(300, [400, 330, 170, 150, 90], [9, 7, 5, 6, 3], 1)
+    g_pk, s_pk, took, _ = _grads(device, True, data, dropout=0.1)
+    _, s_pad, _, _ = _grads(device, False, data, dropout=0.1)
+    assert took and torch.isfinite(g_pk).all()
+    assert s_pk["loss"] == pytest.approx(s_pad["loss"], rel=0.1)
