@@ -247,7 +247,7 @@ int js2t_colsum(const void* x, int dt, float* out, float* partial, int64_t rows,
  * (positions behind an utterance's sub-sampled length are dead in the reference: encoders.py:348-373, transformer_layers.py:86-105,
  * loss.py:156-161).  seg: device int32 [B + 1] row offsets (seg[0] = 0).
  *   pack != 0: dst[seg[b] + t, :] = src[b*T + t, :] for t < seg[b+1] - seg[b]; rows seg[B] .. rows_out of dst are zeroed
- *              (rows_out - seg[B] <= T: the caller's rounding of the packed row count);
+ *              (the caller's rounding of the packed row count);
  *   pack == 2: only that tail of dst is zeroed (src is not read: pass dst) - buffers the packed kernels leave rows of unwritten;
  *   pack == 0: dst[b*T + t, :] = t < seg[b+1] - seg[b] ? src[seg[b] + t, :] : 0   (rows_out unused).
  * row_bytes % 16 == 0, 16-byte aligned buffers.  Each is the other's adjoint (the backward of pack is unpack and vice versa). */

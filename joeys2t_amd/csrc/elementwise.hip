@@ -625,12 +625,12 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const uint4* __restrict_
                                                         int B, int T, int64_t rows_out, int chunks) {
   const int b = blockIdx.y, t0 = blockIdx.x * PK_ROWS;
   const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-  if (PACK && b == B) {  // the tail behind the last entry
-    const int64_t r0 = (int64_t)seg[B] + t0;
-    for (int i = threadIdx.x; i < PK_ROWS * chunks; i += 256) {
-      const int64_t r = r0 + i / chunks;
-      if (r < rows_out) dst[r * chunks + i % chunks] = zero;
-    }
+  if (PACK && b == B) {  // the tail behind the last entry, however long: the slab's blocks stride over it
+    for (int64_t r0 = (int64_t)seg[B] + t0; r0 < rows_out; r0 += (int64_t)gridDim.x * PK_ROWS)
+      for (int i = threadIdx.x; i < PK_ROWS * chunks; i += 256) {
+        const int64_t r = r0 + i / chunks;
+        if (r < rows_out) dst[r * chunks + i % chunks] = zero;
+      }
     return;
   }
   const int s0 = seg[b], len = seg[b + 1] - s0;
@@ -658,7 +658,6 @@ extern "C" int js2t_pack_rows(const void* src, void* dst, const int32_t* seg, in
     hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(cdiv(T_, PK_ROWS), 1), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, seg + B, 0, T_,
                        rows_out, chunks);
   } else if (pack) {
-    // the tail slab covers at most T rows: the caller's rounding (rows_out - seg[B]) has to stay below that
     hipLaunchKernelGGL(pack_rows_kernel<true>, dim3(cdiv(T_, PK_ROWS), B + 1), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, seg, B, T_,
                        rows_out, chunks);
   } else {

@@ -3,11 +3,12 @@
 The reference's loader cuts a new (B, T, L) every step (TokenBatchSampler, joeynmt/datasets.py:1249-1295; the step itself is
 training.py:541-596).  Launching the ~530 kernels of a step from Python costs ~19 ms against ~12 ms of GPU work, and a
 captured hipGraph only replays ONE shape.  So shapes are bucketed - frames up to the next multiple of `frame_bucket`, target
-length up to the next multiple of `target_bucket`, the utterance count as it comes - and everything that differs between two
+length up to the next multiple of `target_bucket`, the packed encoder rows (sum of the sub-sampled lengths) up to the next multiple
+of `row_bucket`, the utterance count as it comes - and everything that differs between two
 batches of a bucket lives in device memory the graph reads:
 
   * utterance offsets / frame counts of the fbank front-end (the kernels take them from device tables already),
-  * sub-sampled lengths and masks (computed on the device from the length vector),
+  * sub-sampled lengths and masks (computed on the device from the length vector), the row offsets of the packed encoder,
   * targets, target lengths, SpecAugment parameters, the learning rate of the step,
   * the crop lengths that make a batch padded to the bucket look to the sub-sampler's convolutions like the reference's
     batch, which ends at its longest utterance (js2t_feature_finalize_crop, js2t_glu_*_crop).
@@ -36,14 +37,14 @@ def _round_up(x: int, m: int) -> int:
 class _Bucket:
     """Static device inputs of one (B, T bucket, L bucket) and the graph captured over them."""
 
-    def __init__(self, key, n_conv: int, win: int, shift: int, device, pad_index: int):
-        B, Tb, Lb = key
+    def __init__(self, key, n_conv: int, win: int, shift: int, device, pad_index: int, t_sub: int = 0):
+        B, Tb, Lb, rows = key
         self.key = key
         self.n_samples_cap = win + (Tb - 1) * shift
         Lc = Lb - 1  # columns of trg_input / trg (batch.py:82-86: BOS dropped / last column dropped)
         # one packed buffer of int64 words; every static tensor is a view of its device copy
         fields = [("soff", B), ("foff", B + 1), ("src_length", B), ("crop", 1 + n_conv), ("trg_length", B), ("trg_input", B * Lc),
-                  ("trg", B * Lc), ("masks", B * 4), ("lr", 1), ("order", B)]
+                  ("trg", B * Lc), ("masks", B * 4), ("lr", 1), ("order", B), ("seg", (B + 2) // 2)]
         self.slices: Dict[str, slice] = {}
         off = 0
         for name, n in fields:
@@ -69,6 +70,9 @@ class _Bucket:
         b.nseqs, b.ntokens, b.has_trg, b.is_train, b.task = B, 0, True, True, "S2T"
         b.src_max_len, b.repad = Tb, False
         b.src_crop = self.crop[1:]  # per sub-sampler layer: output positions of the longest real utterance
+        # rows > 0: the encoder stack runs on the live sub-sampled positions, packed into `rows` rows (encoders.TransformerEncoder._packing);
+        # the row offsets of the utterances arrive with the batch like everything else
+        b.src_pack = ops.PackedRows(d[self.slices["seg"]].view(torch.int32)[:B + 1], B, t_sub, rows) if rows > 0 else None
         self.batch = b
         self.pad_index = pad_index
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -98,7 +102,8 @@ class GraphedTrainStep:
     [B, L] on the host (BOS ... EOS, padded with pad_index), trg_len: host list / tensor (including BOS and EOS)."""
 
     def __init__(self, step: TrainStep, proc: SpeechProcessor, compute_dtype=torch.bfloat16, frame_bucket: int = 64,
-                 target_bucket: int = 8, max_graphs: int = 24, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True):
+                 target_bucket: int = 8, max_graphs: int = 64, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True,
+                 row_bucket: int = 576, pack_min_saving: float = 0.04):
         if step.batch_multiplier != 1:
             raise NotImplementedError("GraphedTrainStep: one optimizer update per batch (batch_multiplier 1)")
         if step.reducer is not None:
@@ -112,6 +117,13 @@ class GraphedTrainStep:
         self.use_graphs = use_graphs
         self.ex = get_extractor(self.device, proc.sample_rate, proc.num_freq)
         self.kernel_sizes = list(step.model.encoder.subsampler.kernel_sizes)
+        # packed encoder rows (ragged batches): sum of the sub-sampled lengths up to the next multiple of row_bucket is part of the
+        # bucket key; 0 = padded layout (the encoder cannot pack, or the batch has fewer than pack_min_saving dead positions)
+        from joeys2t_amd import encoders as _enc
+        enc = step.model.encoder
+        self.row_bucket = int(row_bucket) if (_enc.PACK_RAGGED and type(enc) is _enc.TransformerEncoder and compute_dtype == torch.bfloat16 and
+                                              (enc.layers[0].size // enc.layers[0].src_src_att.num_heads) in (64, 128)) else 0
+        self.pack_min_saving = float(pack_min_saving)
         self.buckets: "OrderedDict[tuple, _Bucket]" = OrderedDict()
         self.pool = torch.cuda.graph_pool_handle()
         step.optimizer.device_schedule = True  # update count and learning rate are read from device memory
@@ -127,14 +139,20 @@ class GraphedTrainStep:
             while len(self.buckets) >= self.max_graphs:
                 self.buckets.popitem(last=False)
                 self.counts["evicted"] += 1
-            bk = _Bucket(key, len(self.kernel_sizes), self.ex.win_len, self.ex.shift, self.device, self.pad_index)
+            bk = _Bucket(key, len(self.kernel_sizes), self.ex.win_len, self.ex.shift, self.device, self.pad_index, t_sub=self._sub_len(key[1]))
             self.buckets[key] = bk
         else:
             self.buckets.move_to_end(key)
         return bk
 
+    def _sub_len(self, frames: int) -> int:
+        """Conv1dSubsampler.get_out_seq_lens_tensor (encoders.py:348-352) of one length, on the host"""
+        for k in self.kernel_sizes:
+            frames = (frames + 2 * (k // 2) - (k - 1) - 1) // 2 + 1
+        return frames
+
     def _body(self, bk: _Bucket):
-        B, Tb, _ = bk.key
+        B, Tb = bk.key[0], bk.key[1]
         step = self.step
         step.optimizer.lr_dev.copy_(bk.lr)  # the step's learning rate, as it arrived in the packed buffer
         feats = self.proc.batch_from_tables(bk.wave, bk.soff, bk.foff, B, Tb, bk.crop[0:1], is_train=True, out_dtype=self.dtype,
@@ -156,9 +174,16 @@ class GraphedTrainStep:
         order = sorted(range(B), key=lambda i: -frames[i])  # batch.sort_by_src_length() of training.py:555, on the host
         trg_len = [int(v) for v in (trg_len.tolist() if torch.is_tensor(trg_len) else trg_len)]
         L = max(trg_len)
-        key = (B, _round_up(frames[order[0]], self.frame_bucket), _round_up(L, self.target_bucket))
+        Tb = _round_up(frames[order[0]], self.frame_bucket)
+        sub = [self._sub_len(frames[i]) for i in order]  # live encoder positions per utterance
+        rows = 0
+        if self.row_bucket:
+            rows = _round_up(sum(sub), self.row_bucket)
+            if rows > (1.0 - self.pack_min_saving) * B * self._sub_len(Tb):
+                rows = 0
+        key = (B, Tb, _round_up(L, self.target_bucket), rows)
         bk = self._bucket(key)
-        Tb, Lb = key[1], key[2]
+        Lb = key[2]
         # ---- everything that varies inside the bucket, into the pinned buffer
         bk.next_host()
         fr = np.asarray([frames[i] for i in order], dtype=np.int64)
@@ -179,6 +204,9 @@ class GraphedTrainStep:
         bk.host_view("masks").view(torch.int32).copy_(torch.from_numpy(np.ascontiguousarray(masks)).reshape(-1))
         bk.host_view("lr").view(torch.float32)[0] = float(step.optimizer.param_groups[0]["lr"])
         bk.host_view("order").copy_(torch.tensor(order, dtype=torch.int64))
+        seg = np.zeros((2 * ((B + 2) // 2), ), dtype=np.int32)
+        seg[1:B + 1] = np.cumsum(sub)
+        bk.host_view("seg").view(torch.int32).copy_(torch.from_numpy(seg))
         bk.upload()
         ncol = min(wave.shape[1], bk.wave.shape[1])
         if ncol < ex.win_len + (int(fr[0]) - 1) * ex.shift:  # (samples behind an utterance's last whole frame are never read)

@@ -947,10 +947,7 @@ class PackedRows:
         off = [0]
         for n in lens:
             off.append(off[-1] + n)
-        round_to = max(1, min(int(round_to), T))  # the zeroed tail stays shorter than one utterance (js2t_pack_rows)
         rows = -(-off[-1] // round_to) * round_to
-        if rows - off[-1] > T:
-            raise Js2tError("PackedRows: the rounding of the row count must stay below one utterance")
         seg = torch.tensor(off, dtype=torch.int32).pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" \
             else torch.tensor(off, dtype=torch.int32)
         return PackedRows(seg, len(lens), T, rows)
