@@ -390,11 +390,20 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
     it = iter(PrefetchLoader(batches(), load, device))
     n_frames = 0
 
-    def one():
+    marks = []  # (how, frames, start event, end event) of every timed step: the replayed ones are also reported on their own
+
+    def one(timed=False):
         nonlocal n_frames
         item = next(it)
+        nf = sum(1 + (n - 400) // 160 for n in item["n_samples"])
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         how = gstep.run(item["wave"], item["n_samples"], torch.from_numpy(item["trg"]), item["trg_len"])
-        n_frames += sum(1 + (n - 400) // 160 for n in item["n_samples"])
+        if timed:
+            e1.record()
+            marks.append((how, nf, e0, e1))
+        n_frames += nf
         return how
 
     for _ in range(warmup):
@@ -404,14 +413,21 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
     n_frames, before = 0, dict(gstep.counts)
     t0 = time.perf_counter()
     for _ in range(steps):
-        one()
+        one(timed=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stats = gstep.read_stats()
+    rep = [(nf, e0.elapsed_time(e1)) for how, nf, e0, e1 in marks if how == "replay"]
+    rep_ms = sum(ms for _, ms in rep) / max(len(rep), 1)
+    packed = sum(1 for k in gstep.buckets if k[3] > 0)
     return {"ms_per_step": round(dt / steps * 1e3, 3), "frames_per_s_unpadded": round(n_frames / dt, 1), "steps": steps, "warmup": warmup,
+            # the replayed steps alone (GPU time between events around each): what a long run converges to once its buckets are captured
+            "ms_per_replayed_step": round(rep_ms, 3), "frames_per_s_unpadded_replayed": round(sum(nf for nf, _ in rep) / max(rep_ms * len(rep), 1e-9) * 1e3, 1),
+            "packed_encoder": {"buckets_packed": packed, "row_bucket": gstep.row_bucket,
+                               "what": "encoder stack on the live sub-sampled positions only (js2t_pack_rows, js2t_attn_desc.seg); JS2T_PACKED_ENCODER=0: padded"},
             "utterances_per_batch": round(stats["nseqs"] / steps, 2), "buckets": len(gstep.buckets),
             "timed_steps_replayed": gstep.counts["replay"] - before["replay"], "timed_steps_eager_plus_capture": gstep.counts["eager"] - before["eager"],
-            "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8) bucket" if use_graphs else "eager",
+            "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/576) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
 
@@ -1112,7 +1128,7 @@ def main():
     varying = None
     if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:
         try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
-            varying = varying_bench(device, 60, 40)
+            varying = varying_bench(device, 100, 150)
         except Exception as exc:
             varying = {"error": repr(exc)}
     decode = None
