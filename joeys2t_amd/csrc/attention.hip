@@ -396,7 +396,7 @@ template <bool MASKED, int NTT, bool REL = false>
 __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float dl2,
                                             uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop,
                                             const float* rel_s = nullptr, float* drel_s = nullptr, int key0 = 0, int query = 0, int R = 0,
-                                            bool q_live = true) {
+                                            bool q_live = true, float* edge = nullptr) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
@@ -413,7 +413,14 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
       const float tdp = hv[r] >= thr ? dp[tt][r] : 0.f;
       s[tt][r] = pv * (tdp - dl2);
       // gradient of the bias = dS (before the 1/(1-p) factor, applied when the block's histogram is flushed)
-      if (REL && drel_s && q_live && s[tt][r] != 0.f) atomicAdd(&drel_s[ri], s[tt][r]);
+      // (two thirds of the pairs of a 375-position utterance lie beyond the clipping distance: they all land in the two end
+      // bins, which are summed in registers - edge[0] / edge[1] - and posted once per wave; an LDS atomic per pair cost 135 us
+      // per layer, twice the rest of the backward pass)
+      if (REL && drel_s && q_live) {
+        if (ri == 0) edge[0] += s[tt][r];
+        else if (ri == 2 * R) edge[1] += s[tt][r];
+        else if (s[tt][r] != 0.f) atomicAdd(&drel_s[ri], s[tt][r]);
+      }
     }
   }
 }
@@ -483,6 +490,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
     for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
   }
   int cur = 0;
+  float rel_edge[2] = {0.f, 0.f};  // this lane's share of the two end bins of the bias gradient (dq_elements)
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -519,7 +527,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
         uint32_t bits = kbits;
         if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, Tk);
         dq_elements<true, NTT, REL>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
-                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq);
+                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq, rel_edge);
       }
 #pragma unroll
       for (int ss = 0; ss < NSS; ++ss) dsf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
@@ -534,6 +542,11 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   }
   const float dq_sc = a.scale * (drop ? 1.f / keep_p : 1.f);
   if (REL && a.d_rel) {  // the block's histogram of dS over relative distances -> the head's gradient row
+    const float e0 = wave_sum(rel_edge[0]), e1 = wave_sum(rel_edge[1]);
+    if (lane == 0) {
+      if (e0 != 0.f) atomicAdd(&drel_s[0], e0);
+      if (e1 != 0.f) atomicAdd(&drel_s[2 * a.relR], e1);
+    }
     __syncthreads();
     const int n = 2 * a.relR + 1;
     const float sc = drop ? 1.f / keep_p : 1.f;

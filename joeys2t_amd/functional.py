@@ -958,7 +958,7 @@ class ConvModuleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, wd, bd, gamma, beta, running_mean, running_var, w2, b2, p, rng, training, compute_dtype,
-                w1_lp=None, w2_lp=None):
+                w1_lp=None, w2_lp=None, sink=None, notify=None):
         """w1_lp / w2_lp: the two pointwise weights in the compute dtype when the flat store keeps such a shadow (stable
         addresses: the e4m3 copies of the fp8 forward mode are cached by address); otherwise they are cast here."""
         B, T, Cc = x.shape
@@ -980,6 +980,7 @@ class ConvModuleFn(torch.autograd.Function):
         y = linear_fwd(z, w2c, b2, dropout_p=p if training else 0.0, rng=rng, site=site)
         ctx.saved = (x2, w1c, h, u, wd2, v2, gamma, beta, mean, invstd, z, w2c)
         ctx.cfg = (B, T, Cc, p if training else 0.0, rng, site, training, x.dtype)
+        ctx.sink, ctx.notify, ctx.leaves = sink, notify, (w1, b1, w2, b2)
         return y.view(B, T, -1).to(x.dtype) if y.dtype != x.dtype else y.view(B, T, -1)
 
     @staticmethod
@@ -993,17 +994,25 @@ class ConvModuleFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         if p > 0:
             dy2 = ops.dropout_bwd(dy2, p, rng, site)
-        dz, dw2, db2 = linear_bwd(dy2, z, w2c)
+        sink = ctx.sink or {}
+
+        def sv(name, like):  # the parameter's slice of the flat gradient, shaped like the 2-D weight the product sees
+            t = sink.get(name)
+            return None if t is None else t.view(like.shape)
+
+        dz, dw2, db2 = linear_bwd(dy2, z, w2c, dw_out=sv("w2", w2c), db_out=sink.get("b2"), queue=sink.get("_wq"))
         dv, dgamma, dbeta = ops.bn_act_bwd(dz, v2, gamma, beta, mean, invstd, training, "hardswish")
         du, dwd = ops.dwconv_outer_bwd(dv.view(B, T, -1), u.view(B, T, -1), wd2)
         dbd = ops.colsum(dv)
         dh = ops.glu_bwd(h, du.view(B * T, -1))
-        dx, dw1, db1 = linear_bwd(dh, x2, w1c)
+        dx, dw1, db1 = linear_bwd(dh, x2, w1c, dw_out=sv("w1", w1c), db_out=sink.get("b1"), queue=sink.get("_wq"))
+        if sink and ctx.notify is not None:
+            ctx.notify(ctx.leaves)
         dx = dx.view(B, T, Cc)
         if dx.dtype != in_dtype:
             dx = dx.to(in_dtype)
-        return (dx, dw1.view(dw1.shape[0], Cc, 1), db1, dwd.view(dwd.shape[0], 1, -1), dbd, dgamma, dbeta, None, None,
-                dw2.view(dw2.shape[0], -1, 1), db2, None, None, None, None, None, None)
+        return (dx, None if dw1 is None else dw1.view(dw1.shape[0], Cc, 1), db1, dwd.view(dwd.shape[0], 1, -1), dbd, dgamma, dbeta, None, None,
+                None if dw2 is None else dw2.view(dw2.shape[0], -1, 1), db2, None, None, None, None, None, None, None, None)
 
 
 def conv_out_len(t_in: int, k: int, stride: int = 2) -> int:

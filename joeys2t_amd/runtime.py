@@ -105,7 +105,8 @@ class ParamStore:
         self._tgroups: List[Tuple[int, int, int, List[nn.Parameter]]] = []
         self._tgroup_of: Dict[int, int] = {}
         for grp in groups:
-            if all(p.dim() == 2 for p in grp) and len({p.shape[1] for p in grp}) == 1:
+            # (rows of a multiple of 16 bytes in fp32: what js2t_adamw_items takes; a [H, 2R+1] bias table is no nn.Linear weight)
+            if all(p.dim() == 2 for p in grp) and len({p.shape[1] for p in grp}) == 1 and grp[0].shape[1] % 4 == 0:
                 rows = sum(p.shape[0] for p in grp)
                 for p in grp:
                     self._tgroup_of[id(p)] = len(self._tgroups)

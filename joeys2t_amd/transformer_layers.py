@@ -24,6 +24,12 @@ def _rng(rt, x: Tensor):
     return rt.rng
 
 
+def _layer_norm(rt, ln: nn.LayerNorm, x: Tensor) -> Tensor:
+    """A stand-alone LayerNorm whose parameter gradients go straight into the flat store (as encoders.TransformerEncoder's final one)"""
+    sk = rt.sinks({"g": [ln.weight], "b": [ln.bias]})
+    return Fn.LayerNormFn.apply(x, ln.weight, ln.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")), rt.grads_ready)
+
+
 class MultiHeadedAttention(nn.Module):
     """Multi-head attention; argument order of forward is (k, v, q, mask) as in the reference (:49-56)."""
 
@@ -279,7 +285,7 @@ class ConvolutionModule(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         rt = runtime_of(self)
         x = rt.act_in(x)
-        x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None, None)
+        x = _layer_norm(rt, self.layer_norm, x)
         bn = self.batch_norm
         p = self.dropout.p
         rng = _rng(rt, x) if (self.training and p > 0) else None
@@ -290,7 +296,11 @@ class ConvolutionModule(nn.Module):
                                      self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      self.pointwise_conv2.weight, self.pointwise_conv2.bias, p, rng, self.training, rt.compute_dtype,
                                      rt.weight([self.pointwise_conv1.weight]) if lp else None,
-                                     rt.weight([self.pointwise_conv2.weight]) if lp else None)
+                                     rt.weight([self.pointwise_conv2.weight]) if lp else None,
+                                     # the two pointwise products' parameter gradients: straight into the flat store, the weight
+                                     # gradients deferred and grouped with the other layers' (runtime.WgradQueue)
+                                     rt.sinks({"w1": [self.pointwise_conv1.weight], "b1": [self.pointwise_conv1.bias],
+                                               "w2": [self.pointwise_conv2.weight], "b2": [self.pointwise_conv2.bias]}), rt.grads_ready)
 
 
 class ConformerEncoderLayer(nn.Module):
@@ -323,8 +333,8 @@ class ConformerEncoderLayer(nn.Module):
         x = Fn.AxpbyFn.apply(self.conv_module(x), 1.0, x, self.alpha)
         residual = x
         if self._layer_norm_position == "pre":
-            x = Fn.LayerNormFn.apply(x, self.final_layer_norm.weight, self.final_layer_norm.bias, None, None)
+            x = _layer_norm(rt, self.final_layer_norm, x)
         x = Fn.AxpbyFn.apply(self.final_feed_forward(x), 0.5, residual, 1.0)
         if self._layer_norm_position == "post":
-            x = Fn.LayerNormFn.apply(x, self.final_layer_norm.weight, self.final_layer_norm.bias, None, None)
+            x = _layer_norm(rt, self.final_layer_norm, x)
         return x

@@ -38,7 +38,15 @@ def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
     def bwd():
         ops.flash_attn_bwd(dout, out, lse, qkv, 2 * d, kv, 0, kv, d, dqkv, 2 * d, dkv, 0, dkv, d, B, H, Tq, Tk, dh, mask, p, rng, 5)
 
-    for fn, nm, gemms in ((fwd, "fwd", 2), (bwd, "bwd", 7)):
+    # delta = rowsum(dO * O) handed over as partial sums (in the step: from the output projection's input-gradient epilogue): both
+    # backward passes as ONE grid
+    part = (dout.float() * out.float()).view(B * Tq, d // 64, 64).sum(-1).contiguous()
+
+    def bwd1():
+        ops.flash_attn_bwd(dout, out, lse, qkv, 2 * d, kv, 0, kv, d, dqkv, 2 * d, dkv, 0, dkv, d, B, H, Tq, Tk, dh, mask, p, rng, 5,
+                           delta_partial=part)
+
+    for fn, nm, gemms in ((fwd, "fwd", 2), (bwd, "bwd (two launches)", 7), (bwd1, "bwd (one grid)", 7)):
         for _ in range(3):
             fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,7 +58,7 @@ def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
         torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1e3 / reps
         fl = gemms * 2.0 * B * H * Tq * Tk * dh
-        print(f"{name:24s} {nm} B={B} H={H} Tq={Tq} Tk={Tk} {us:8.1f} us {fl / us / 1e6:7.1f} TF", flush=True)
+        print(f"{name:24s} {nm:18s} B={B} H={H} Tq={Tq} Tk={Tk} {us:8.1f} us {fl / us / 1e6:7.1f} TF", flush=True)
 
 
 bench("encoder self", 32, 4, 375, 375, p=P_DROP)
