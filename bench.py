@@ -780,8 +780,8 @@ def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
                     "V 10000, CTC 0.3 + label-smoothed CE), 32 x 15 s, dropout 0.1, clip + AdamW, hipGraph replay",
             "flop_per_step": flop, "unit": "TFLOP/s", "bf16": out.get("bf16"), "fp8": out.get("fp8"), "peak_bf16": PEAK_BF16_TFLOPS,
             "frac_bf16": round(out["bf16"]["achieved"] / PEAK_BF16_TFLOPS, 4) if "bf16" in out else None,
-            "fp8_note": "e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8 in five of a layer's eight forward products; backward in bf16: priced "
-                        "against the bf16 peak, not the 5 PF fp8 figure",
+            "fp8_note": "e4m3 operands on the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) in five of a layer's eight forward "
+                        "products; backward in bf16: priced against the bf16 peak, not the 5 PF fp8 figure",
             "parity": "extension: no reference target for the composition (joeynmt's build_model refuses the encoder type)"}
 
 
