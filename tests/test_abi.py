@@ -74,3 +74,52 @@ def test_range_set():
     r.add(8, 16)
     r.add(16, 24)
     assert r.r == [(8, 24)] and r.contains(10, 20)
+
+
+def test_attn_desc_matches_header_layout():
+    """the ctypes mirror of js2t_attn_desc ends with the round-4 fields, in the header's order"""
+    import re
+    from joeys2t_amd._lib import HEADER_PATH, AttnDesc
+    text = HEADER_PATH.read_text()
+    body = text[text.index("typedef struct js2t_attn_desc"):text.index("} js2t_attn_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [m.group(1) for m in re.finditer(r"(\w+)\s*(?:;|,)", body)]
+    mirror = [f[0] for f in AttnDesc._fields_]
+    assert [n for n in names if n in mirror] == mirror, (names, mirror)
+    assert mirror[-3:] == ["delta_partial", "delta_groups", "seg"]
+
+
+def test_packed_rows_host_logic():
+    """ops.PackedRows.from_lengths: row offsets of a ragged batch from HOST lengths (no device involved), rounding of the row
+    count, rejection of lengths outside 1..T; Batch keeps the host lengths in step with sort_by_src_length."""
+    import torch
+    from joeys2t_amd import ops
+    from joeys2t_amd._lib import Js2tError
+    pk = ops.PackedRows.from_lengths([5, 3, 7, 1], 7, "cpu", round_to=1)
+    assert pk.seg.tolist() == [0, 5, 8, 15, 16] and (pk.B, pk.T, pk.rows) == (4, 7, 16) and pk.seg.dtype == torch.int32
+    assert ops.PackedRows.from_lengths([5, 3, 7, 1], 7, "cpu", round_to=64).rows == 64
+    assert ops.PackedRows.from_lengths([64], 64, "cpu", round_to=64).rows == 64
+    for bad in ([0, 3], [8, 3], []):
+        with pytest.raises(Js2tError):
+            ops.PackedRows.from_lengths(bad, 7, "cpu")
+    with pytest.raises(Js2tError):
+        ops.PackedRows(torch.zeros(3, dtype=torch.int64), 2, 4, 8)
+    from joeys2t_amd.batch import Batch
+    b = Batch(src=torch.zeros(3, 9, 4), src_length=torch.tensor([4, 9, 6]), src_prompt_mask=None, trg=None, trg_length=None,
+              trg_prompt_mask=None, indices=torch.arange(3), device=torch.device("cpu"), pad_index=1, eos_index=3, is_train=False,
+              task="S2T", n_gpu=1)
+    assert b.src_length_host == [4, 9, 6]
+    b.sort_by_src_length()
+    assert b.src_length_host == [9, 6, 4] == b.src_length.tolist()
+
+
+def test_sub_sampled_lengths_on_the_host():
+    """what the graphed driver and the packed encoder compute on the host equals Conv1dSubsampler.get_out_seq_lens_tensor
+    (reference encoders.py:348-352)"""
+    import torch
+    from joeys2t_amd.encoders import Conv1dSubsampler
+    for ks in ([5, 5], [3, 3], [3, 5, 3]):
+        sub = Conv1dSubsampler(80, 64, 32, ks)
+        lens = torch.arange(1, 400)
+        want = sub.get_out_seq_lens_tensor(lens).tolist()
+        assert [sub.out_len(int(n)) for n in lens] == want
