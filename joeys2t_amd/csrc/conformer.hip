@@ -8,6 +8,10 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------- depthwise conv
 constexpr int DW_MAXK = 63;
+#define DISPATCH_DT(dt, T, ...)                                   \
+  if ((dt) == JS2T_F32) { using T = float; __VA_ARGS__; }         \
+  else { using T = uint16_t; __VA_ARGS__; }
+
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_outer_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -86,6 +90,58 @@ bool dwconv_outer_lds_launch(const void* x, const float* w, const float* bias, v
   }
   hipLaunchKernelGGL(dwconv_outer_lds_kernel<FLIP>, dim3((unsigned)(C / 128), (unsigned)((N + 3) / 4)), dim3(256), lds, s,
                      (const uint16_t*)x, w, bias, (uint16_t*)y, (int)L, N, C, K);
+  return true;
+}
+
+// The same convolution from REGISTER windows (round 4): a thread owns one (n, c) column, keeps the channel's K taps and a
+// window of LC + KM - 1 inputs along l in registers and writes LC outputs per window - every input loaded once per window
+// (1 + (K-1)/LC times overall), no LDS, no barrier, any dtype / channel count.  FLIP: taps reversed (input gradient; the
+// reversed taps are loaded in reversed order, so the sum runs over k descending).  52 -> ~15 us at L = 32, N = 375, C = 512.
+template <typename T, int KM, int LC, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_outer_win_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ y, int L, int64_t N,
+                                                               int64_t C, int K, int n_per_block) {
+  const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  if (c >= C) return;
+  const int64_t n0 = (int64_t)blockIdx.y * n_per_block, n1 = min(n0 + n_per_block, N);
+  const int pad = (K - 1) / 2;
+  float wr[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) wr[k] = k < K ? w[c * K + (FLIP ? K - 1 - k : k)] : 0.f;
+  const float b = bias ? bias[c] : 0.f;
+  for (int64_t n = n0 + nl; n < n1; n += 4)
+    for (int l0 = 0; l0 < L; l0 += LC) {
+      float xr[LC + KM - 1];
+#pragma unroll
+      for (int i = 0; i < LC + KM - 1; ++i) {  // xr[i] = x[l0 + i - pad] (zero outside the sequence)
+        const int ls = l0 + i - pad;
+        xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? io<T>::ld(x + ((int64_t)ls * N + n) * C + c) : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < LC; ++j) {
+        float acc = b;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) acc = fmaf(wr[k], xr[j + k], acc);
+        if (l0 + j < L) io<T>::st(y + ((int64_t)(l0 + j) * N + n) * C + c, acc);
+      }
+    }
+}
+template <bool FLIP>
+bool dwconv_outer_win_launch(const void* x, const float* w, const float* bias, void* y, int64_t L, int64_t N, int64_t C, int K, int dt,
+                             hipStream_t s) {
+  if (K > 31 || L >= 65536 || L < 1) return false;
+  int npb = (int)cdiv(N * cdiv(C, 64), 1024);  // columns per block: about four blocks per CU
+  npb = npb < 4 ? 4 : (npb + 3) & ~3;
+  if (cdiv(N, npb) > 65535) return false;
+  const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(N, npb));
+  if (K <= 15) {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_win_kernel<T, 15, 16, FLIP>), grid, dim3(256), 0, s, (const T*)x, w, bias, (T*)y, (int)L,
+                                          N, C, K, npb));
+  } else {
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_win_kernel<T, 31, 16, FLIP>), grid, dim3(256), 0, s, (const T*)x, w, bias, (T*)y, (int)L,
+                                          N, C, K, npb));
+  }
   return true;
 }
 
@@ -292,9 +348,6 @@ __global__ void bn_param_grad_kernel(const float* s0, const float* s1, float* dg
   }
 }
 
-#define DISPATCH_DT(dt, T, ...)                                   \
-  if ((dt) == JS2T_F32) { using T = float; __VA_ARGS__; }         \
-  else { using T = uint16_t; __VA_ARGS__; }
 
 }  // namespace
 
@@ -303,7 +356,8 @@ extern "C" int js2t_dwconv_outer_fwd(const void* x, const float* w, const float*
   if (L * N * C == 0) return JS2T_OK;
   JS2T_CHECK(x && w && y, "dwconv_outer_fwd: null pointer");
   JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_fwd: kernel size must be odd and <= %d", DW_MAXK);
-  if (dwconv_outer_lds_launch<false>(x, w, bias, y, L, N, C, K, dt, (hipStream_t)stream)) {
+  if (dwconv_outer_win_launch<false>(x, w, bias, y, L, N, C, K, dt, (hipStream_t)stream) ||
+      dwconv_outer_lds_launch<false>(x, w, bias, y, L, N, C, K, dt, (hipStream_t)stream)) {
     JS2T_LAUNCH_CHECK();
     return JS2T_OK;
   }
@@ -319,7 +373,7 @@ extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float*
   JS2T_CHECK(dy && w, "dwconv_outer_bwd: null pointer");
   JS2T_CHECK(K >= 1 && (K & 1) && K <= DW_MAXK, "dwconv_outer_bwd: kernel size must be odd and <= %d", DW_MAXK);
   hipStream_t s = (hipStream_t)stream;
-  if (dx && dwconv_outer_lds_launch<true>(dy, w, nullptr, dx, L, N, C, K, dt, s)) {
+  if (dx && (dwconv_outer_win_launch<true>(dy, w, nullptr, dx, L, N, C, K, dt, s) || dwconv_outer_lds_launch<true>(dy, w, nullptr, dx, L, N, C, K, dt, s))) {
     JS2T_LAUNCH_CHECK();
   } else if (dx) {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dx_kernel<T>), dim3((unsigned)cdiv(L * N * C, 256)), dim3(256), 0, s,
@@ -329,7 +383,8 @@ extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float*
   if (dw) {
     JS2T_CHECK(x, "dwconv_outer_bwd: x needed for the weight gradient");
     JS2T_CHECK(cdiv(N, DW_SLAB) <= 65535, "dwconv_outer_bwd: too many rows");
-    // columns per block: enough blocks for two per CU (the conv axis is the BATCH index, as in the reference: L is short, N long)
+    // columns per block: enough blocks for two per CU (the conv axis is the BATCH index, as in the reference: L is short, N long);
+    // measured at L = 32, N = 375, C = 512: 4 -> 122 us, 8 -> 91, 16 -> 97, 32 -> 146 (dx + dw)
     int npb = (int)cdiv(N * cdiv(C, 64), 512);
     npb = npb < 4 ? 4 : (npb > DW_SLAB ? DW_SLAB : (npb + 3) & ~3);
     const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(N, npb));
