@@ -181,6 +181,9 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
                       trg_length=trg_len, trg_prompt_mask=None, indices=torch.arange(BATCH), device=device, pad_index=1,
                       eos_index=3, is_train=True, task="S2T", n_gpu=1)
             b.sort_by_src_length()  # batch.sort_by_src_length() of training.py:555 (all lengths equal here)
+            # the lengths as host integers (Batch keeps them when it is built from host tensors): a ragged batch then runs its
+            # encoder on the live rows only (encoders.TransformerEncoder._packing; all lengths equal: nothing to drop)
+            b.src_length_host = [int(v) for v in b.src_length.tolist()]
             state["batch"] = b
         state["batch"].src = feats
         # single GPU: the whole step incl. the update is ONE captured graph.  Data parallel: the same kernels in the same
@@ -427,7 +430,7 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
                                "what": "encoder stack on the live sub-sampled positions only (js2t_pack_rows, js2t_attn_desc.seg); JS2T_PACKED_ENCODER=0: padded"},
             "utterances_per_batch": round(stats["nseqs"] / steps, 2), "buckets": len(gstep.buckets),
             "timed_steps_replayed": gstep.counts["replay"] - before["replay"], "timed_steps_eager_plus_capture": gstep.counts["eager"] - before["eager"],
-            "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/576) bucket" if use_graphs else "eager",
+            "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/384) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
 

@@ -20,6 +20,7 @@ from joeys2t_amd.transformer_layers import ConformerEncoderLayer, PositionalEnco
 PACK_RAGGED = os.environ.get("JS2T_PACKED_ENCODER", "1") != "0"
 PACK_MIN_SAVING = 0.04  # below this share of dead rows the two gather / scatter passes are not worth it
 PACK_ROUND = 64         # packed row count rounded up (whole 64-row groups for the row-wise kernels; the tail is kept zero)
+_PACK_CACHE: dict = {}  # (lengths, T', device) -> ops.PackedRows of the last few ragged batches (TransformerEncoder._packing)
 
 
 class Encoder(nn.Module):
@@ -157,7 +158,18 @@ class TransformerEncoder(Encoder):
             lens = [min(self.subsampler.out_len(int(n)), T) for n in host]
             if sum(lens) > (1.0 - PACK_MIN_SAVING) * B * T:
                 return None
-            pack = ops.PackedRows.from_lengths(lens, T, x.device, round_to=PACK_ROUND)
+            # the row offsets reach the device by a copy from a pinned temporary: never inside a hipGraph capture (the graph would
+            # replay the copy from memory that is long gone).  A step that is captured has run eagerly on the same batch before
+            # (bench.py --ragged, GraphedTrainStep hands its own `src_pack`), so the offsets of recent batches are kept
+            key = (tuple(lens), T, str(x.device))
+            pack = _PACK_CACHE.get(key)
+            if pack is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return None
+                pack = ops.PackedRows.from_lengths(lens, T, x.device, round_to=PACK_ROUND)
+                if len(_PACK_CACHE) >= 16:
+                    _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
+                _PACK_CACHE[key] = pack
         if pack.B != B or pack.T != T:
             raise ops.Js2tError(f"packed encoder: {pack.B} x {pack.T} prepared for a [{B}, {T}, {d}] batch")
         return pack
