@@ -1131,7 +1131,7 @@ def main():
     varying = None
     if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:
         try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
-            varying = varying_bench(device, 100, 150)
+            varying = varying_bench(device, 100, 250)
         except Exception as exc:
             varying = {"error": repr(exc)}
     decode = None
