@@ -102,7 +102,7 @@ class GraphedTrainStep:
     [B, L] on the host (BOS ... EOS, padded with pad_index), trg_len: host list / tensor (including BOS and EOS)."""
 
     def __init__(self, step: TrainStep, proc: SpeechProcessor, compute_dtype=torch.bfloat16, frame_bucket: int = 64,
-                 target_bucket: int = 8, max_graphs: int = 64, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True,
+                 target_bucket: int = 8, max_graphs: int = 128, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True,
                  row_bucket: int = 384, pack_min_saving: float = 0.04):
         if step.batch_multiplier != 1:
             raise NotImplementedError("GraphedTrainStep: one optimizer update per batch (batch_multiplier 1)")
