@@ -28,6 +28,8 @@ def bench(name, B, H, Tq, Tk, p=0.1, causal=False):
     mask = torch.ones(B, Tq if causal else 1, Tk, dtype=torch.bool, device=dev)
     if causal:
         mask = torch.tril(mask)
+    elif os.environ.get("ATTN_NO_MASK"):  # how much the key-mask staging costs: no mask at all
+        mask = None
     rng = ops.dropout_rng(dev)
 
     def fwd():
