@@ -633,6 +633,11 @@ typedef struct js2t_attn_desc {
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);
+/* Measurement switches (tools/, tests): js2t_debug_attn_fwd_sb(0 / 1 / -1) forces the double- / single-buffered forward kernel or
+ * returns to the per-launch rule; js2t_debug_attn_bwd_merge(0) runs the backward as two launches also when delta_partial is given
+ * (1 = one grid, the default).  Process-wide, read at launch time; results do not depend on them. */
+void js2t_debug_attn_fwd_sb(int mode);
+void js2t_debug_attn_bwd_merge(int on);
 
 /* --------------------------------------------------------------------------------------------------
  * Gradient exchange (data parallel, one process per GPU): what DistributedDataParallel's bucketed all-reduce does for the
