@@ -947,7 +947,11 @@ class AxpbyFn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.ab
         g = g.contiguous()
-        return (ops.axpby(g, a) if ctx.needs_input_grad[0] else None, None, ops.axpby(g, b) if ctx.needs_input_grad[2] else None, None)
+
+        def part(c, wanted):  # a factor of one hands the gradient through as it is (autograd does not write into it): no pass, no copy
+            return None if not wanted else (g if c == 1.0 else ops.axpby(g, c))
+
+        return part(a, ctx.needs_input_grad[0]), None, part(b, ctx.needs_input_grad[2]), None
 
 
 class ConvModuleFn(torch.autograd.Function):
