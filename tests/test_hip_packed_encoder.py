@@ -127,3 +127,29 @@ def test_packed_rows_with_dropout_stay_finite_and_close(device):
     _, s_pad, _, _ = _grads(device, False, data, dropout=0.1)
     assert took and torch.isfinite(g_pk).all()
     assert s_pk["loss"] == pytest.approx(s_pad["loss"], rel=0.1)
+
+
+def test_inference_encode_on_packed_rows_equals_padded(device):
+    """no_grad forward (what search() runs): the encoder states of every live position are those of the padded layout, the
+    positions behind a length are zero"""
+    from joeys2t_amd import encoders
+    from test_hip_config_width import hip_batch, make_model, synth_batch, width_cfg
+    torch.manual_seed(7)
+    model = make_model(width_cfg(4, 3, 1), 300, None, device, torch.bfloat16, 0.3, train=False)
+    data = synth_batch(300, [400, 330, 170, 150, 90], [9, 7, 5, 6, 3], 1)
+    outs = {}
+    for packed in (True, False):
+        encoders.PACK_RAGGED = packed
+        try:
+            b = hip_batch(*data, device)
+            with torch.no_grad():
+                enc, _, mask, _ = model(return_type="encode", **vars(b))
+            outs[packed] = (enc.float().cpu(), mask.cpu())
+        finally:
+            encoders.PACK_RAGGED = True
+    (e_pk, m_pk), (e_pad, m_pad) = outs[True], outs[False]
+    assert torch.equal(m_pk, m_pad) and e_pk.shape == e_pad.shape
+    live = m_pad.squeeze(1).unsqueeze(-1)
+    assert float(e_pk.masked_select(~live.expand_as(e_pk)).abs().sum()) == 0.0  # zeros behind every length
+    a, r = e_pk * live, e_pad * live
+    assert (a - r).norm() <= 2e-2 * r.norm(), ((a - r).norm().item(), r.norm().item())  # bf16: the first block's LayerNorm runs stand-alone on packed rows
