@@ -160,6 +160,11 @@ void js2t_gemm_p192_mode(int mode);
  * requesting waves, anything else = chosen per launch (default: 2 when the product has at least 1.5 tiles per CU,
  * else 4).  All variants produce bit-identical results. */
 void js2t_gemm_p192_ring(int nst);
+/* Panel-resident kernel (k-contiguous bf16 operands and result, K % 128 == 0, K <= 512, N % 8 == 0, epilogue bias [+ ReLU
+ * [+ dropout]] [+ folded LayerNorm] or gate): a 96-column panel of B stays in LDS and only A is streamed, each wave through a
+ * ring of its own.  -1 = products with at least 4096 (32-row strip, panel) units (default), 0 = never, 1 = every product that
+ * qualifies (test hook).  Results are bit-identical to the persistent 192x128 kernels. */
+void js2t_gemm_panel_mode(int mode);
 
 /* --------------------------------------------------------------------------------------------------
  * Element-wise / data-movement kernels.

@@ -14,7 +14,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libjoeys2t_hip.so"
 OBJ_DIR = PKG_DIR / "build"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-inline-asm"]
 FLAGS += os.environ.get("JS2T_HIPCC_EXTRA", "").split()  # e.g. -DJS2T_P192_PROF for tools/p192_prof.py (use with --force)
 
 

@@ -85,18 +85,45 @@ __device__ __forceinline__ void stage_rel(float* rel_s, const AttnArgs& a, int h
 }
 __device__ __forceinline__ int rel_index(int key, int query, int R) { return min(max(key - query, -R), R) + R; }
 
-// HBM -> LDS image of KT rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave
+// HBM -> LDS image of KT rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave.
+// What does not change from tile to tile is computed ONCE per block (ImgSrc): this lane's tile row and column in each of its
+// wave's four pieces.  Per tile and piece that leaves one add for a whole tile, a clamp more for the last one - the first
+// version rebuilt a 64-bit address per piece and tile (two 32 x 32 multiplies, a 64-bit multiply-add, shifts: ten VALU
+// instructions x 8-16 pieces per tile, a fifth of the forward kernel's vector instructions).  ld < 2^17 (check_common) and at
+// most 8192 rows per entry keep the element offset inside 31 bits; the entry's base pointer is wave-uniform.
+template <int DH> struct ImgSrc {
+  int trow[4];  // tile row of piece q's 16 bytes
+  int col[2];   // first head column, pieces q & 1
+};
 template <int DH>
-__device__ __forceinline__ void img_dma(const uint16_t* base, int64_t ld, int row0, int rows_max, unsigned char* img, int t) {
-  const int w = t >> 6, lane = t & 63;
+__device__ __forceinline__ ImgSrc<DH> img_src(int w, int lane) {
+  ImgSrc<DH> s;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int p = (w * 4 + q) * 64 + lane;
     const int row = p >> 4, slot = p & 15;
     const int chunk = slot ^ ((row & 7) << 1);
-    const int trow = DH == 128 ? row : row + 64 * (chunk >> 3), col = DH == 128 ? chunk * 8 : (chunk & 7) * 8;
-    const uint16_t* src = base + (int64_t)min(row0 + trow, rows_max - 1) * ld + col;
-    __builtin_amdgcn_global_load_lds((g_cvoid*)src, (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+    s.trow[q] = DH == 128 ? row : row + 64 * (chunk >> 3);
+    if (q < 2) s.col[q] = DH == 128 ? chunk * 8 : (chunk & 7) * 8;
+  }
+  return s;
+}
+template <int DH>
+__device__ __forceinline__ void img_dma(const uint16_t* base, int ld, int row0, int rows_max, unsigned char* img, int w,
+                                        const ImgSrc<DH>& is) {
+  if (row0 + Geo<DH>::KT <= rows_max) {  // wave-uniform
+    const int o0 = row0 * ld;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t off = (uint32_t)(o0 + is.trow[q] * ld + is.col[q & 1]);
+      __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off), (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t off = (uint32_t)(min(row0 + is.trow[q], rows_max - 1) * ld + is.col[q & 1]);
+      __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off), (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+    }
   }
 }
 // row fragment: 8 consecutive head columns (32*ks + 8*(lane>>4) ..) of tile row 16*tt + (lane&15)
@@ -162,26 +189,33 @@ __device__ __forceinline__ void store4(uint16_t* p, const f32x4_t& v, float sc) 
   *(uint2*)p = pk;
 }
 
-// Key validity for key-padding masks (mask_sq == 0) is staged ONCE per block in LDS as bytes; per tile a lane then
-// needs NTT ds_read_b32 instead of 16-32 dependent global byte loads in the inner loop.
+// Key validity for key-padding masks (mask_sq == 0) is staged ONCE per block in LDS, already in the form the tiles want it: one
+// 16-bit word per (64-key chunk c, lane group g) with bit 4 tt + r <-> key 64 c + 16 tt + 4 g + r, the words of a tile side by
+// side - per tile a lane then reads ONE word (the byte-per-key form cost four LDS reads and ~30 bit operations per tile).  A wave
+// takes 64 consecutive keys; its ballot is the chunk, lanes 0-3 cut the four words out of it.
 constexpr int KMASK_MAX = 8192;
-__device__ __forceinline__ void stage_kmask(uint8_t* kmask, const AttnArgs& a, int b, int Tk, int nkeys_padded, int t) {
-  for (int k = t; k < nkeys_padded; k += 256) {
+template <int DH>
+__device__ __forceinline__ void stage_kbits(uint16_t* kb, const AttnArgs& a, int b, int Tk, int nkeys_padded, int t) {
+  constexpr int HV = Geo<DH>::KT / 64;  // 64-key chunks per tile
+  const int lane = t & 63;
+  for (int k0 = t & ~63; k0 < nkeys_padded; k0 += 256) {
+    const int k = k0 + lane;
     bool on = k < Tk;
     if (on && a.mask && a.msq == 0) on = a.mask[(int64_t)b * a.msb + k] != 0;
-    kmask[k] = on ? 1 : 0;
+    const uint64_t bal = __ballot(on);
+    if (lane < 4) {
+      const uint64_t v = bal >> (4 * lane);
+      const uint32_t w16 = (uint32_t)(v & 15u) | ((uint32_t)(v >> 12) & 0xf0u) | ((uint32_t)(v >> 24) & 0xf00u) | ((uint32_t)(v >> 36) & 0xf000u);
+      const int c = k0 >> 6;
+      kb[((c / HV) * 4 + lane) * HV + (c % HV)] = (uint16_t)w16;
+    }
   }
 }
 // validity bits of this lane's keys in tile kt: bit (4*tt + r) <-> key KT*kt + 16tt + 4g + r
 template <int DH>
-__device__ __forceinline__ uint32_t tile_kbits(const uint8_t* kmask, int kt, int g) {
-  uint32_t bits = 0;
-#pragma unroll
-  for (int tt = 0; tt < Geo<DH>::NTT; ++tt) {
-    const uint32_t w4 = *(const uint32_t*)(kmask + Geo<DH>::KT * kt + 16 * tt + 4 * g);  // 4 bytes, each 0/1
-    bits |= ((w4 & 1u) | ((w4 >> 7) & 2u) | ((w4 >> 14) & 4u) | ((w4 >> 21) & 8u)) << (4 * tt);
-  }
-  return bits;
+__device__ __forceinline__ uint32_t tile_kbits(const uint16_t* kb, int kt, int g) {
+  if (DH == 128) return kb[kt * 4 + g];
+  return *(const uint32_t*)(kb + (kt * 4 + g) * 2);
 }
 // per-query full mask (mask_sq != 0): AND the row's bytes into the key bits
 template <int DH>
@@ -217,13 +251,15 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x {K image, V image}; SB: K, V, key mask
-  __shared__ __attribute__((aligned(16))) uint8_t kmask_st[SB ? 16 : KMASK_MAX];
-  uint8_t* kmask = SB ? (uint8_t*)(smem + 2 * IMG_BYTES) : kmask_st;
+  __shared__ __attribute__((aligned(16))) uint16_t kmask_st[SB ? 8 : KMASK_MAX / 16];
+  uint16_t* kmask = SB ? (uint16_t*)(smem + 2 * IMG_BYTES) : kmask_st;
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
 #ifdef JS2T_ATTN_PROF
   const unsigned long long t_start_ = __builtin_readcyclecounter();
 #endif
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // wave-uniform copy: LDS-DMA destinations stay on the scalar unit
+  const ImgSrc<DH> isrc = img_src<DH>(wu, lane);
   // 1-D grid, XCD-aware: the query tiles of one (batch, head) pair are neighbours in the logical order, so they run on
   // one XCD and its L2 serves their common K / V (round-robin placement had every XCD fetch every head's K / V: six times
   // the fabric traffic, which is what bound these kernels)
@@ -239,8 +275,8 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
   // the first K (V) image is requested before anything else is fetched: the key mask below waits for its own loads before it can
   // write them to LDS, and a request issued behind that wait starts a second memory round trip where one would do
-  img_dma<DH>(Kb, a.ldk, 0, Tk, smem, t);
-  if (!SB) img_dma<DH>(Vb, a.ldv, 0, Tk, smem + IMG_BYTES, t);
+  img_dma<DH>(Kb, (int)a.ldk, 0, Tk, smem, wu, isrc);
+  if (!SB) img_dma<DH>(Vb, (int)a.ldv, 0, Tk, smem + IMG_BYTES, wu, isrc);
   bf16x8_t qf[NKS];
   own_frags<NKS>(Qb, a.ldq, q0, Tq, lane, qf);
   f32x4_t o[NCT];
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const bool full_mask = a.mask && a.msq != 0;
   const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, Tk, nkt * KT, t);
+  stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
@@ -268,10 +304,10 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
     __syncthreads();
     ATT_T(1);
     if (SB) {
-      img_dma<DH>(Vb, a.ldv, kt * KT, Tk, smem + IMG_BYTES, t);  // every wave is through with PV of the previous tile
+      img_dma<DH>(Vb, (int)a.ldv, kt * KT, Tk, smem + IMG_BYTES, wu, isrc);  // every wave is through with PV of the previous tile
     } else if (kt + 1 < nkt) {
-      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, (int)a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, wu, isrc);
+      img_dma<DH>(Vb, (int)a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, wu, isrc);
     }
     ATT_T(2);
     const unsigned char* Ki = SB ? smem : smem + cur * 2 * IMG_BYTES;
@@ -357,7 +393,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
     if (SB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of V(kt)
       __syncthreads();                                   // V(kt) complete; every wave is through with the K image
-      if (kt + 1 < nkt) img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem, t);
+      if (kt + 1 < nkt) img_dma<DH>(Kb, (int)a.ldk, (kt + 1) * KT, Tk, smem, wu, isrc);
     }
     // O^T += V^T P^T
 #pragma unroll
@@ -432,9 +468,11 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ __attribute__((aligned(16))) uint8_t kmask[KMASK_MAX];
+  __shared__ __attribute__((aligned(16))) uint16_t kmask[KMASK_MAX / 16];
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1], drel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // wave-uniform copy: LDS-DMA destinations stay on the scalar unit
+  const ImgSrc<DH> isrc = img_src<DH>(wu, lane);
   const int ntile = (a.Tq + 63) / 64;  // XCD-aware 1-D grid, see flash_fwd_kernel
   const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
@@ -448,8 +486,8 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
   const bool drop = a.p > 0.f;
   const float keep_p = 1.f - a.p;
-  img_dma<DH>(Kb, a.ldk, 0, Tk, smem, t);  // first, as in flash_fwd_kernel
-  img_dma<DH>(Vb, a.ldv, 0, Tk, smem + IMG_BYTES, t);
+  img_dma<DH>(Kb, (int)a.ldk, 0, Tk, smem, wu, isrc);  // first, as in flash_fwd_kernel
+  img_dma<DH>(Vb, (int)a.ldv, 0, Tk, smem + IMG_BYTES, wu, isrc);
   bf16x8_t qf[NKS], gf[NKS];
   float lse2, dl2;
   {
@@ -484,7 +522,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const bool full_mask = a.mask && a.msq != 0;
   const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
-  stage_kmask(kmask, a, b, Tk, nkt * KT, t);
+  stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) {
     stage_rel(rel_s, a, h, t);
     for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
@@ -495,8 +533,8 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nkt) {
-      img_dma<DH>(Kb, a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Vb, a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Kb, (int)a.ldk, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES, wu, isrc);
+      img_dma<DH>(Vb, (int)a.ldv, (kt + 1) * KT, Tk, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, wu, isrc);
     }
     const unsigned char* Ki = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Vi = Ki + IMG_BYTES;
@@ -623,6 +661,8 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   __shared__ __attribute__((aligned(16))) uint32_t rk_s[2][KT];
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
+  const int wu = __builtin_amdgcn_readfirstlane(w);  // wave-uniform copy: LDS-DMA destinations stay on the scalar unit
+  const ImgSrc<DH> isrc = img_src<DH>(wu, lane);
   const int ntile = (a.Tk + 63) / 64;  // XCD-aware 1-D grid: the key tiles of a head share its Q / dO
   const int lid = xcd_remap(bid, nblk);
   const int z = lid / ntile, b = z / a.H, h = z - b * a.H;
@@ -634,8 +674,8 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
-  img_dma<DH>(Qb, a.ldq, 0, Tq, smem, t);  // first, as in flash_fwd_kernel: the key-validity test below waits for its mask byte
-  img_dma<DH>(Gb, a.lddo, 0, Tq, smem + IMG_BYTES, t);
+  img_dma<DH>(Qb, (int)a.ldq, 0, Tq, smem, wu, isrc);  // first, as in flash_fwd_kernel: the key-validity test below waits for its mask byte
+  img_dma<DH>(Gb, (int)a.lddo, 0, Tq, smem + IMG_BYTES, wu, isrc);
   bf16x8_t kf[NKS], vf[NKS];
   own_frags<NKS>(Kb, a.ldk, k0, Tk, lane, kf);
   own_frags<NKS>(Vb, a.ldv, k0, Tk, lane, vf);
@@ -676,8 +716,8 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) {
-      img_dma<DH>(Qb, a.ldq, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, t);
-      img_dma<DH>(Gb, a.lddo, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, t);
+      img_dma<DH>(Qb, (int)a.ldq, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, wu, isrc);
+      img_dma<DH>(Gb, (int)a.lddo, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, wu, isrc);
       if (t < KT) {
         const int qc = min((qt + 1) * KT + t, Tq - 1);
         lse_r = a.lse[(int64_t)z * a.Tq + qc];
@@ -781,6 +821,8 @@ int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK(d->q && d->k && d->v && d->lse, "flash_attn: null pointer");
   JS2T_CHECK((d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0, "flash_attn: leading dims must be multiples of 8");
   JS2T_CHECK(((((uintptr_t)d->q) | ((uintptr_t)d->k) | ((uintptr_t)d->v)) & 15) == 0, "flash_attn: q/k/v must be 16-byte aligned");
+  JS2T_CHECK(d->ldq < (1 << 17) && d->ldk < (1 << 17) && d->ldv < (1 << 17) && d->ld_do < (1 << 17),
+             "flash_attn: leading dims must be below 131072 (32-bit tile offsets)");
   JS2T_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f && (d->dropout_p == 0.f || d->rng_state), "flash_attn: bad dropout args");
   JS2T_CHECK(!d->rel_bias || (d->rel_R >= 1 && d->rel_R <= REL_MAX), "flash_attn: rel_R must be 1..%d", REL_MAX);
   JS2T_CHECK(!d->d_rel_bias || d->rel_bias, "flash_attn: d_rel_bias without rel_bias");
@@ -812,16 +854,16 @@ int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   if (!once) {
     int rc = set_lds(flash_fwd_kernel<DH, REL, false>, 4 * IMG_BYTES);
     if (rc) return rc;
-    rc = set_lds(flash_fwd_kernel<DH, REL, true>, 2 * IMG_BYTES + KMASK_MAX);
+    rc = set_lds(flash_fwd_kernel<DH, REL, true>, 2 * IMG_BYTES + KMASK_MAX / 8);
     if (rc) return rc;
     once = true;
   }
   AttnArgs a = to_args(d);
   const int nblk = cdiv(d->Tq, 64) * d->B * d->H;
   constexpr int KT = Geo<DH>::KT;
-  const int kmask_bytes = (cdiv(d->Tk, KT) * KT + 15) & ~15;
+  const int kmask_bytes = (cdiv(d->Tk, KT) * KT / 8 + 15) & ~15;  // one 16-bit word per 16 keys
   // three single-buffered blocks per CU when the grid does not fit two per CU (and the key mask leaves room for three)
-  const bool sb = g_attn_fwd_sb >= 0 ? g_attn_fwd_sb != 0 : (nblk > 512 && kmask_bytes <= 4096);
+  const bool sb = g_attn_fwd_sb >= 0 ? g_attn_fwd_sb != 0 : nblk > 512;
   if (sb) hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, true>), dim3(nblk), dim3(256), 2 * IMG_BYTES + kmask_bytes, s, a);
   else hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, false>), dim3(nblk), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();

@@ -13,7 +13,7 @@
 //    This is the fp32 "parity mode" kernel and the fallback for bf16 operands the fast kernel rejects.
 //
 // Reference call sites replaced: see include/joeys2t_hip.h (js2t_gemm).
-#include "common.hpp"
+#include "gemm_shared.hpp"
 #include <type_traits>
 
 namespace {
@@ -719,7 +719,7 @@ __device__ __forceinline__ void dma_tile_epilogue(const js2t_gemm_desc& d, f32x4
 
 
 // ---- LayerNorm fold (js2t_gemm_desc::ln_partial / rs_partial) helpers of the register-direct epilogues
-constexpr int LNF_GROUPS = 8;  // row length 512 = 8 groups of 64 columns
+// LNF_GROUPS (gemm_shared.hpp): row length 512 = 8 groups of 64 columns
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -1394,7 +1394,6 @@ __device__ __forceinline__ int p192_b_granule(int n, int c) {
 // EPI < 0: every epilogue term is decided at run time; EPI >= 0: a bit mask of the terms that are present (alpha = 1),
 // so that the variants the train step uses carry no dead branches - with one wave per SIMD nothing overlaps the
 // epilogue, its instruction count is paid in full.
-constexpr int PE_BIAS = 1, PE_RELU = 2, PE_DROP = 4, PE_RES = 8, PE_GATE = 16, PE_LNF = 32, PE_STATS = 64, PE_DOT = 128;
 template <int EPI>
 __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, float (&bias_r)[8]) {
   const bool has_bias = (EPI < 0 ? d.bias != nullptr : (EPI & PE_BIAS) != 0) && n < d.N;  // n >= N: a column group of the N tail
@@ -2568,6 +2567,9 @@ int launch_bf16_p192(const js2t_gemm_desc& d, hipStream_t s) {
     const int mask = (d.bias ? PE_BIAS : 0) | (d.act == JS2T_ACT_RELU ? PE_RELU : 0) | (d.dropout_p > 0.f ? PE_DROP : 0) |
                      (d.residual ? PE_RES : 0) | (d.gate ? PE_GATE : 0) | (d.ln_partial ? PE_LNF : 0) | (d.rs_partial ? PE_STATS : 0) |
                      (d.dot_partial ? PE_DOT : 0);
+    // K <= 512 and many row strips per CU: the panel-resident kernel (gemm_panel.hip) streams A only
+    const int rc = launch_bf16_pan96(d, mask, s);
+    if (rc >= 0) return rc;
     switch (mask) {
       case PE_BIAS | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_LNF>(d, s);      // q/k/v projections on the raw residual stream
       case PE_BIAS | PE_RELU | PE_DROP | PE_LNF: return launch_bf16_p192_epi<PE_BIAS | PE_RELU | PE_DROP | PE_LNF>(d, s);  // FFN layer 1, same

@@ -342,7 +342,12 @@ class WgradQueue:
         captured stays valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches.
         mode: 1 = the products overwrite their dW (beta 0), 2 = their epilogues leave the sums of squares with the collector."""
         from joeys2t_amd.functional import wgrad_split
-        plan = sorted(self.groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * len(kv[1]))
+        # Largest first - by WEIGHT size x members, not by work: the order of the plan is the order in which the ranges of the flat
+        # gradient complete, i.e. the order of the all-reduces, and that must be the same on every rank.  The token count M differs
+        # from rank to rank (and the encoder-length memory K | V product sits in one plan with the target-length decoder products
+        # since the early exchange): sorted by N * K * M the order flipped at M_s / M_t of about 4 - two ranks would issue
+        # collectives of different ranges in different order.  Ties keep the order of arrival (the model's, rank-independent).
+        plan = sorted(self.groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
         self.groups = {}
         self.pending = 0
         cand, out, written = self.cand, [], []

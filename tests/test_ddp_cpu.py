@@ -231,3 +231,25 @@ def test_communicator_id_reaches_every_rank():
     (id0, mine0), (id1, mine1) = res[0], res[1]
     assert isinstance(id0, bytes) and len(id0) == 128 and id0 == id1 == mine0 and mine1 is None
     assert any(id0)  # not the zero buffer
+
+
+def test_wgrad_plan_order_does_not_depend_on_token_counts():
+    """The plan's order is the order in which flat-gradient ranges complete, i.e. the order of the all-reduces: it must not
+    depend on a rank's own token counts (sorted by N*K*M the encoder-length memory K|V product and the target-length
+    decoder products traded places at M_s / M_t of about 4, a ratio that differs from batch to batch and rank to rank)."""
+    from joeys2t_amd.runtime import WgradQueue
+
+    def plan_order(m_src, m_trg):
+        q = WgradQueue()
+        d = 512
+        for _ in range(6):  # decoder feed-forward layers on the target rows
+            q.add(torch.empty(m_trg, 2048), torch.empty(m_trg, d), torch.empty(2048, d), torch.empty(2048))
+            q.add(torch.empty(m_trg, d), torch.empty(m_trg, 2048), torch.empty(d, 2048), torch.empty(d))
+        q.add(torch.empty(m_src, 6 * 2 * d), torch.empty(m_src, d), torch.empty(6 * 2 * d, d), torch.empty(6 * 2 * d))  # memory K|V
+        for _ in range(6):
+            q.add(torch.empty(m_trg, 3 * d), torch.empty(m_trg, d), torch.empty(3 * d, d), None)
+        return [(k[0], k[1], len(items)) for k, items in q.take()]
+
+    ref = plan_order(12000, 2592)
+    for m_src, m_trg in ((12000, 4000), (6000, 3000), (3000, 3000), (20000, 700), (640, 640)):
+        assert plan_order(m_src, m_trg) == ref, (m_src, m_trg)
