@@ -201,11 +201,16 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         return out
 
     graphs = {}
-    # thread_local: the RCCL watchdog thread may query its events while this thread captures
-    mode = "thread_local" if ddp else "global"
+    if ddp:
+        # Data parallel: the step cut where the RCCL calls go - two captured halves of forward + backward, one small graph per
+        # completed range of the flat gradient, the update - lives in the library (graphed.GraphedDDPStep, tests/test_hip_ddp_graphed.py)
+        from joeys2t_amd.graphed import GraphedDDPStep
+        dd = GraphedDDPStep(step, body=lambda hook: body(cut_hook=hook), pre_step=pre_step,
+                            exchange=os.environ.get("JS2T_BENCH_NO_EXCHANGE") != "1")  # =1, measurement only: the cuts without the collectives
+        state["ddp_step"] = dd
+        return dd.eager_step, dd.replay_step, dd.capture, step, sum(frames_list), (model, state)
 
     def capture():
-        from joeys2t_amd.runtime import WgradQueue
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -215,81 +220,9 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         pre_step()
-        if not ddp:
-            with torch.cuda.graph(g, capture_error_mode=mode):
-                body()
-            graphs["step"] = g
-        else:
-            # Data parallel: forward + backward as TWO graphs, cut at the encoder's output (TrainStep.micro_step, cut_hook): behind
-            # the first one the decoder side's weight-gradient products run and their ranges of the flat gradient go to RCCL,
-            # which then has the whole encoder backward (the second graph) to move them.  JS2T_EARLY_EXCHANGE=0: one graph.
-            import gc
-            g2 = torch.cuda.CUDAGraph()
-            state["plan_dec"] = None
-
-            def at_cut():
-                g.capture_end()
-                state["plan_dec"] = step.rt.wgrad_queue.take(final=False)
-                g2.capture_begin(pool=g.pool(), capture_error_mode=mode)
-
-            torch.cuda.synchronize()
-            gc.collect()
-            torch.cuda.empty_cache()
-            cap = torch.cuda.Stream(device=device)
-            cap.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap):
-                g.capture_begin(capture_error_mode=mode)
-                try:
-                    body(cut_hook=at_cut)
-                finally:
-                    (g2 if state["plan_dec"] is not None else g).capture_end()
-            torch.cuda.current_stream().wait_stream(cap)
-            graphs["step"], graphs["step2"] = g, (g2 if state["plan_dec"] is not None else None)
-            # the products queued during capture reference the graphs' static buffers: they are the per-step plan.  Each
-            # group (one grouped launch per Linear shape = one range of the flat gradient) becomes a graph of its own, so
-            # that the range's all-reduce can be handed to RCCL between two replays; the update is the last piece.
-            plan = step.rt.wgrad_queue.take()
-            red = step.reducer
-
-            def cut_pieces(plan_part):
-                # one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start):
-                # groups that finish no range ride with the next one that does
-                pend = [0] * len(red.ranges)
-                for _, items in plan_part:
-                    for it in items:
-                        pend[red.bucket_of_tensor(it[2])] += 1
-                pieces, cur = [], []
-                for entry in plan_part:
-                    cur.append(entry)
-                    done = False
-                    for it in entry[1]:
-                        bi = red.bucket_of_tensor(it[2])
-                        pend[bi] -= 1
-                        done = done or pend[bi] == 0
-                    if done:
-                        pieces.append(cur)
-                        cur = []
-                if cur:
-                    pieces.append(cur)
-                return pieces
-
-            def capture_pieces(pieces):
-                out = []
-                for piece in pieces:
-                    gw = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
-                        WgradQueue.run(piece)
-                    out.append(gw)
-                return out
-
-            state["plan"], state["pieces"] = plan, cut_pieces(plan)
-            graphs["wgrad"] = capture_pieces(state["pieces"])
-            state["pieces_dec"] = cut_pieces(state["plan_dec"]) if state["plan_dec"] is not None else []
-            graphs["wgrad_dec"] = capture_pieces(state["pieces_dec"])
-            gu = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
-                step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
-            graphs["update"] = gu
+        with torch.cuda.graph(g, capture_error_mode="global"):
+            body()
+        graphs["step"] = g
         # capturing executes nothing (and the graph's buffers hold no gradients yet): one real replayed step, which also puts
         # the host-side update counter / learning-rate schedule in line with the device's
         graph_step()
@@ -297,31 +230,6 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     def graph_step():
         pre_step()
         graphs["step"].replay()
-        if ddp:
-            plan, red = state["plan"], step.reducer
-            no_exchange = os.environ.get("JS2T_BENCH_NO_EXCHANGE") == "1"  # measurement only: the price of the cuts without the collectives
-            if graphs.get("step2") is not None:  # the decoder side's products and ranges, then the encoder's backward
-                if not no_exchange:
-                    red.exchange_begin(state["plan_dec"], partial=True)
-                for piece, gw in zip(state["pieces_dec"], graphs["wgrad_dec"]):
-                    gw.replay()
-                    if not no_exchange:
-                        for _, items in piece:
-                            red.entries_done(items)
-                graphs["step2"].replay()
-            if no_exchange:
-                for gw in graphs["wgrad"]:
-                    gw.replay()
-                graphs["update"].replay()
-                step.after_update()
-                return
-            red.exchange_begin(plan)
-            for piece, gw in zip(state["pieces"], graphs["wgrad"]):
-                gw.replay()
-                for _, items in piece:
-                    red.entries_done(items)
-            red.finish()
-            graphs["update"].replay()
         step.after_update()
 
     return eager_step, graph_step, capture, step, sum(frames_list), (model, state)
@@ -1068,20 +976,13 @@ def main():
     one_step = eager_step
     capture_error = None
     if use_graph:
-        # Data parallel: a capture that fails on this node (the graph pieces around the RCCL calls have only been rehearsed on
-        # one card) must not cost the whole line - every rank then times the same kernels launched eagerly, and says so.
-        try:
+        # Data parallel: a capture that fails on this node must not cost the whole line - every rank then times the same kernels
+        # launched eagerly, and says so (GraphedDDPStep.try_capture settles the outcome over the process group)
+        dd = state.get("ddp_step")
+        if dd is not None:
+            capture_error = dd.try_capture()
+        else:
             capture()
-        except Exception as exc:  # noqa: BLE001
-            if world == 1 and not force_ddp:
-                raise
-            capture_error = repr(exc)[:300]
-            torch.cuda.synchronize()
-        if world > 1:
-            flag = torch.tensor([1.0 if capture_error else 0.0], device=device)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            if flag.item() > 0 and capture_error is None:
-                capture_error = "capture failed on another rank"
         if capture_error is None:
             one_step = graph_step
         else:

@@ -20,9 +20,10 @@
 // loads each panel its run touches (one or two) with two barriers around the load, its wave w takes the run's units
 // w, w + 8, ...  LDS: 8 stage images of the panel (96 rows x 128 B, the [row][64 k] image of gemm.hip with the XOR key
 // row & 7) = 96 KB + 8 waves x 2 slots x 4 KB = 160 KB: one 512-thread block per CU.
-// Column permutation: B fragment j of lane r is panel column 4 r + j (j < 4) or 64 + 2 r + (j - 4): a lane ends up with
-// four consecutive columns and two consecutive columns of each of its rows - one 8-byte and one 4-byte store, sixteen lanes
-// write 128 + 64 contiguous bytes; the dropout decisions of a lane are then whole words of the counter hash.
+// Column permutation: B fragment j of lane r is panel column 6 r + j: a lane ends up with six consecutive columns of each of its
+// rows - ONE 12-byte store per row (sixteen lanes write 192 contiguous bytes), and the dropout decisions of a lane are three whole
+// words of the counter hash.  (A first version gave a lane columns 4 r .. 4 r + 3 and 64 + 2 r, 64 + 2 r + 1: two stores per row,
+// sixteen per strip - the epilogue's cost is its store instructions, profiles/r05_pan96_variants.txt.)
 // Results are bit-identical to the persistent kernels (same k order, same MFMA operand positions, same epilogue arithmetic).
 #include "gemm_shared.hpp"
 
@@ -36,7 +37,7 @@ constexpr int PN_COLS = 96, PN_NJ = 6, PN_ROWS = 32, PN_IMG = PN_COLS * 128, PN_
 constexpr int PN_BPANEL = PN_NKMAX * PN_IMG;                 // 98304
 constexpr int PN_SLOT = PN_ROWS * 128, PN_WRING = 2 * PN_SLOT, PN_WAVES = 8;
 constexpr int PN_LDS = PN_BPANEL + PN_WAVES * PN_WRING;      // 163840 = the CU's whole LDS
-constexpr int PN_NSTORE = 16;                                // store instructions of a full strip's epilogue (asserted on the ISA)
+constexpr int PN_NSTORE = 8;                                 // store instructions of a full strip's epilogue (checked on the ISA)
 
 // LDS-DMA request as inline assembly (common.hpp lds_dma16, plus a memory clobber: the compiler must not move LDS reads across
 // it).  Through the builtin the compiler sees a FLAT operation that touches both VMEM and LDS, and while one is pending every wait
@@ -47,7 +48,7 @@ __device__ __forceinline__ void pan_dma16(const void* gsrc, unsigned char* lds_d
   const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "m0", "memory");
 }
-__device__ __forceinline__ int pan_col(int j, int r) { return j < 4 ? 4 * r + j : 64 + 2 * r + (j - 4); }
+__device__ __forceinline__ int pan_col(int j, int r) { return PN_NJ * r + j; }
 
 // FULL: the strip has its 32 rows and the panel its 96 columns - exactly PN_NSTORE store instructions in straight-line code (the
 // kernel's counted waits and the compiler's own count both rely on it)
@@ -64,23 +65,27 @@ __device__ __forceinline__ void pan_store(const js2t_gemm_desc& d, f32x4_t (&acc
 #endif
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, N = d.N;
-  const int cA = n0 + 4 * r, cB = n0 + 64 + 2 * r;
-  const bool okA = full || cA < N, okB = full || cB < N;  // N % 8 == 0: a lane's column groups lie inside or outside as a whole
+  const int c0 = n0 + PN_NJ * r;               // this lane's six columns c0 .. c0 + 5 (c0 even)
+  const bool okc = full || c0 + PN_NJ <= N;     // N % 8 == 0 and c0 % 2 == 0: a lane's columns end inside N or it stores the pairs that do
   constexpr bool has_bias = (EPI & PE_BIAS) != 0, relu = (EPI & PE_RELU) != 0, has_gate = (EPI & PE_GATE) != 0,
                  has_drop = (EPI & PE_DROP) != 0, lnf = (EPI & PE_LNF) != 0;
   const float keep_scale = 1.f / (1.f - d.dropout_p), gate_scale = d.gate_scale;
   const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
-  uint2 gA[2][4];
-  uint32_t gB[2][4];
+  typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+  u32x3_t gq[2][4];
   if (has_gate) {
     const uint16_t* gs = (const uint16_t*)d.gate;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int64_t ro = (int64_t)min(m0 + 16 * i + 4 * g + e, M - 1) * d.ldg;
-        gA[i][e] = *(const uint2*)(gs + ro + min(cA, N - 4));
-        gB[i][e] = *(const uint32_t*)(gs + ro + min(cB, N - 2));
+        const uint16_t* gp = gs + (int64_t)min(m0 + 16 * i + 4 * g + e, M - 1) * d.ldg;
+        if (full) {
+          gq[i][e] = *(const u32x3_t*)(gp + c0);
+        } else {  // a lane at the panel's end may own fewer than three column pairs inside N: each pair from its own (clamped) place
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gq[i][e][k] = *(const uint32_t*)(gp + min(c0 + 2 * k, N - 2));
+        }
       }
   }
   uint16_t* Cb = (uint16_t*)d.C;
@@ -103,35 +108,38 @@ __device__ __forceinline__ void pan_store(const js2t_gemm_desc& d, f32x4_t (&acc
         for (int j = 0; j < PN_NJ; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, c / 4): column c is half c & 1 of hash word c >> 1
-        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key);
-        const uint32_t h0 = hash32(rowkey + (uint32_t)(cA >> 1)), h1 = hash32(rowkey + (uint32_t)(cA >> 1) + 1u),
-                       h2 = hash32(rowkey + (uint32_t)(cB >> 1));
-        v[0] = (h0 & 0xffffu) >= thr ? v[0] * keep_scale : 0.f;
-        v[1] = (h0 >> 16) >= thr ? v[1] * keep_scale : 0.f;
-        v[2] = (h1 & 0xffffu) >= thr ? v[2] * keep_scale : 0.f;
-        v[3] = (h1 >> 16) >= thr ? v[3] * keep_scale : 0.f;
-        v[4] = (h2 & 0xffffu) >= thr ? v[4] * keep_scale : 0.f;
-        v[5] = (h2 >> 16) >= thr ? v[5] * keep_scale : 0.f;
+        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + (uint32_t)(c0 >> 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const uint32_t h = hash32(rowkey + (uint32_t)q);
+          v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * keep_scale : 0.f;
+          v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * keep_scale : 0.f;
+        }
       }
       if (has_gate) {
-        const uint2 q = gA[i][e];
-        const uint32_t q2 = gB[i][e];
-        const float rr[PN_NJ] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
-                                 __uint_as_float(q.y & 0xffff0000u), __uint_as_float(q2 << 16), __uint_as_float(q2 & 0xffff0000u)};
+        const u32x3_t q = gq[i][e];
 #pragma unroll
-        for (int j = 0; j < PN_NJ; ++j) v[j] = rr[j] > 0.f ? v[j] * gate_scale : 0.f;
+        for (int k = 0; k < 3; ++k) {
+          v[2 * k] = __uint_as_float(q[k] << 16) > 0.f ? v[2 * k] * gate_scale : 0.f;
+          v[2 * k + 1] = __uint_as_float(q[k] & 0xffff0000u) > 0.f ? v[2 * k + 1] * gate_scale : 0.f;
+        }
       }
-      uint2 pk;
-      pk.x = pack_bf16x2(v[0], v[1]);
-      pk.y = pack_bf16x2(v[2], v[3]);
-      const uint32_t pk2 = pack_bf16x2(v[4], v[5]);
-      uint16_t* crow = Cb + (int64_t)m * d.ldc;
+      const u32x3_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5])};
+      uint16_t* cp = Cb + (int64_t)m * d.ldc + c0;
+#if defined(JS2T_PAN_DBG) && (JS2T_PAN_DBG & 16)  // measurement only: the epilogue's arithmetic without its stores
+      asm volatile("" ::"v"(pk), "v"(cp));
+      continue;
+#endif
       if (full) {
-        *(uint2*)(crow + cA) = pk;
-        *(uint32_t*)(crow + cB) = pk2;
+        *(u32x3_t*)cp = pk;
       } else if (m < M) {
-        if (okA) *(uint2*)(crow + cA) = pk;
-        if (okB) *(uint32_t*)(crow + cB) = pk2;
+        if (okc) {
+          *(u32x3_t*)cp = pk;
+        } else {  // the panel's last columns: pairs inside N only
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (c0 + 2 * k < N) *(uint32_t*)(cp + 2 * k) = pk[k];
+        }
       }
     }
   }

@@ -241,3 +241,210 @@ class GraphedTrainStep:
         if reset:
             self.ntokens = 0
         return out
+
+
+class GraphedDDPStep:
+    """The DATA-PARALLEL train step over one fixed batch shape, replayed from hipGraphs that are cut where the collectives go.
+
+    The reference wraps the model in DistributedDataParallel, whose reducer sends gradient buckets while backward still runs
+    (joeynmt/prediction.py:508-515, training.py:584-588).  Here the single-GPU step (one captured graph) becomes, per update:
+
+        graph 1   front end, forward, backward down to the encoder's output        (TrainStep.micro_step, cut_hook)
+        pieces    the decoder side's deferred weight-gradient products, one small graph per point at which a range of the
+                  flat gradient completes; between two replays that range's all-reduce is handed to RCCL (side stream)
+        graph 2   the encoder's backward - while the decoder-side ranges travel
+        pieces    the encoder side's weight-gradient products, range by range as above
+        graph u   clip + AdamW behind the last collective
+
+    Collectives are never captured: RCCL calls sit between replays, so a capture can only fail on its own (memory, an
+    unsupported call) and `try_capture()` then lets EVERY rank fall back to the eager step (same kernels, same order, launched
+    from Python) - agreed over the process group, because a rank replaying graphs and a rank launching eagerly would still issue
+    the same collectives in the same order, but the caller wants to know what it timed.
+
+    `body(cut_hook)` runs ONE micro-batch over static device inputs and must end in
+    `step.micro_step(batch, sort=False, update=False, overlap=False, flush=False, cut_hook=cut_hook)`; `pre_step()` (optional)
+    refreshes those inputs before every step, outside the graphs (host-to-device copies, SpecAugment draws)."""
+
+    def __init__(self, step: TrainStep, body, pre_step=None, exchange: bool = True, inject_failure: Optional[str] = None):
+        if step.reducer is None:
+            raise ops.Js2tError("GraphedDDPStep: the TrainStep has no gradient reducer (no process group is up)")
+        if step.rt.wgrad_queue is None:
+            raise ops.Js2tError("GraphedDDPStep: needs the deferred weight-gradient products (TrainStep(defer_wgrads=True))")
+        if step.batch_multiplier != 1:
+            raise NotImplementedError("GraphedDDPStep: one optimizer update per batch (batch_multiplier 1)")
+        self.step, self.body, self.pre_step = step, body, (pre_step or (lambda: None))
+        self.exchange = bool(exchange)         # False: measurement only - the price of the cuts without the collectives
+        self.inject_failure = inject_failure   # tests: "forward" / "pieces" / "update" make capture() raise at that stage
+        self.device = step.store.device
+        self.graphs: Dict[str, object] = {}
+        self.plan = self.plan_dec = None
+        self.pieces: List[list] = []
+        self.pieces_dec: List[list] = []
+        self.capture_error: Optional[str] = None
+        self.counts = {"eager": 0, "replay": 0}
+        step.optimizer.device_schedule = True  # update count and learning rate are read from device memory (replayable)
+        step.optimizer.step_dev.fill_(step.optimizer.t)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def eager_step(self):
+        """The step launched from Python: micro-batch, overlapped exchange + deferred products, update."""
+        step = self.step
+        self.pre_step()
+        out = self.body(None)
+        step.exchange_and_flush()
+        step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+        step.after_update()
+        self.counts["eager"] += 1
+        return out
+
+    def _cut_pieces(self, plan_part):
+        """one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start): groups
+        that finish no range ride with the next one that does"""
+        red = self.step.reducer
+        pend = [0] * len(red.ranges)
+        for _, items in plan_part:
+            for it in items:
+                pend[red.bucket_of_tensor(it[2])] += 1
+        pieces, cur = [], []
+        for entry in plan_part:
+            cur.append(entry)
+            done = False
+            for it in entry[1]:
+                bi = red.bucket_of_tensor(it[2])
+                pend[bi] -= 1
+                done = done or pend[bi] == 0
+            if done:
+                pieces.append(cur)
+                cur = []
+        if cur:
+            pieces.append(cur)
+        return pieces
+
+    def _fail(self, stage: str):
+        if self.inject_failure == stage:
+            raise RuntimeError(f"GraphedDDPStep: injected capture failure at '{stage}'")
+
+    def capture(self, warm: int = 2):
+        """`warm` eager steps (real training steps: allocator, autotuned choices, RCCL's first calls), then the captures.  Capturing
+        executes nothing and issues no collective - a rank whose capture fails has made exactly the collective calls of the ranks whose
+        capture went through (try_capture relies on that)."""
+        import gc
+        from joeys2t_amd.runtime import WgradQueue
+        step, red = self.step, self.step.reducer
+        # thread_local: the RCCL watchdog thread may query its events while this thread captures
+        mode = "thread_local"
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        st = {"plan_dec": None}
+
+        def at_cut():
+            g.capture_end()
+            st["plan_dec"] = step.rt.wgrad_queue.take(final=False)
+            g2.capture_begin(pool=g.pool(), capture_error_mode=mode)
+
+        self.pre_step()
+        gc.collect()
+        torch.cuda.empty_cache()
+        micro, t_opt = step.micro, step.optimizer.t  # the capture pass is not a step: host-side counters stay
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(cap):
+                g.capture_begin(capture_error_mode=mode)
+                try:
+                    self._fail("forward")
+                    self.body(at_cut)
+                finally:
+                    (g2 if st["plan_dec"] is not None else g).capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
+            # the products queued during capture reference the graphs' static buffers: they are the per-step plan
+            plan = step.rt.wgrad_queue.take()
+
+            def capture_pieces(pieces):
+                out = []
+                for piece in pieces:
+                    gw = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
+                        self._fail("pieces")
+                        WgradQueue.run(piece)
+                    out.append(gw)
+                return out
+
+            pieces = self._cut_pieces(plan)
+            pieces_dec = self._cut_pieces(st["plan_dec"]) if st["plan_dec"] is not None else []
+            gw, gw_dec = capture_pieces(pieces), capture_pieces(pieces_dec)
+            gu = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
+                self._fail("update")
+                step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+        except BaseException:
+            # leave the step usable for eager_step(): nothing of a half-made capture may stay queued or counted
+            step.rt.wgrad_queue.take()
+            step.micro, step.optimizer.t = micro, t_opt
+            torch.cuda.synchronize()
+            raise
+        step.micro, step.optimizer.t = micro, t_opt
+        self.plan, self.plan_dec, self.pieces, self.pieces_dec = plan, st["plan_dec"], pieces, pieces_dec
+        self.graphs = {"step": g, "step2": g2 if st["plan_dec"] is not None else None, "wgrad": gw, "wgrad_dec": gw_dec, "update": gu}
+
+    def try_capture(self, warm: int = 2) -> Optional[str]:
+        """capture(); on failure - here or on ANY rank - drop the graphs everywhere and return what went wrong (None: captured).
+        Every rank must call it (one small all-reduce settles the outcome)."""
+        err = None
+        try:
+            self.capture(warm)
+        except Exception as exc:  # noqa: BLE001 - whatever the capture trips over, the eager step is still there
+            err = repr(exc)[:300]
+            torch.cuda.synchronize()
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            flag = torch.tensor([1.0 if err else 0.0], device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if flag.item() > 0 and err is None:
+                err = "capture failed on another rank"
+        if err is not None:
+            self.graphs = {}
+        self.capture_error = err
+        return err
+
+    @property
+    def captured(self) -> bool:
+        return bool(self.graphs)
+
+    def replay_step(self):
+        step, red, gr = self.step, self.step.reducer, self.graphs
+        self.pre_step()
+        gr["step"].replay()
+        if gr.get("step2") is not None:  # the decoder side's products and ranges, then the encoder's backward
+            if self.exchange:
+                red.exchange_begin(self.plan_dec, partial=True)
+            for piece, gw in zip(self.pieces_dec, gr["wgrad_dec"]):
+                gw.replay()
+                if self.exchange:
+                    for _, items in piece:
+                        red.entries_done(items)
+            gr["step2"].replay()
+        if self.exchange:
+            red.exchange_begin(self.plan)
+        for piece, gw in zip(self.pieces, gr["wgrad"]):
+            gw.replay()
+            if self.exchange:
+                for _, items in piece:
+                    red.entries_done(items)
+        if self.exchange:
+            red.finish()
+        gr["update"].replay()
+        step.optimizer.t += 1  # the replayed kernel counts on the device; checkpoints write the host's count
+        step.after_update()
+        self.counts["replay"] += 1
+
+    def run(self):
+        """One training step: replayed if the capture stands, else eager."""
+        if self.graphs:
+            return self.replay_step()
+        return self.eager_step()

@@ -926,6 +926,62 @@ def golden_frontend_general():
     print("frontend_general:", sorted(cases))
 
 
+def golden_predict_loss(name="predict_loss", V=20):
+    """The validation-loss / reference-scoring leg of the reference's `predict` batch loop (prediction.py:165-200) on the tiny
+    golden model (weights of model_pre.npz), two batches, eval mode, no process group (ddp_reduce / ddp_merge are identities then,
+    helpers_for_ddp.py:88-174; their 2-rank behaviour is pinned by ddp.npz).  What the loop computes per batch:
+      batch.sort_by_src_length(); model(return_type="loss", return_prob=..., return_attention=..., **vars(batch)) under no_grad;
+      ddp_reduce of the loss, n_correct and batch.ntokens; batch.normalize(x, "sum", n_gpu); running totals;
+      return_prob == "ref": ddp_merge(log_probs), ddp_merge(batch.trg) -> Batch.score(log_probs, trg, pad_index).
+    NOTE (reference quirk, kept out of the fixture's expectations): the loop asks for return_type="loss", whose 4-tuple carries the
+    loss components in slots 1-2, not log-probabilities - `Batch.score` on them cannot work; log-probabilities come with
+    return_type="loss_probs" (model.py:148-150).  The fixture stores both calls' outputs; the scoring uses "loss_probs"."""
+    from joeynmt.batch import Batch
+    from joeynmt.helpers_for_ddp import ddp_merge, ddp_reduce
+    from joeynmt.model import build_model
+    g0 = dict(np.load(OUT / "model_pre.npz"))
+    cfg = tiny_cfg("pre")
+    model = build_model(cfg, src_vocab=None, trg_vocab=make_vocab(V))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g0.items() if k.startswith("sd.")})
+    model.eval()
+    dev = torch.device("cpu")
+    out = {}
+    totals = dict(loss=0.0, n_correct=0, ntokens=0, nseqs=0)
+    for bi, (B, T, seed) in enumerate([(3, 37, 7), (4, 29, 21)]):
+        src, lengths, trg, trg_len = synth_batch(B, T, cfg["encoder"]["in_channels"], V, 3, 6, seed)
+        batch = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=trg, trg_length=trg_len, trg_prompt_mask=None,
+                      indices=torch.arange(B), device=dev, pad_index=1, eos_index=3, is_train=False, task="S2T")
+        out.update({f"b{bi}.src": src.numpy(), f"b{bi}.src_length": lengths.numpy(), f"b{bi}.trg_full": trg.numpy(),
+                    f"b{bi}.trg_length_full": trg_len.numpy()})
+        batch_nseqs = ddp_reduce(batch.nseqs, dev, torch.long).item()
+        reverse_index = batch.sort_by_src_length()
+        with torch.no_grad():
+            batch_loss, s1, s2, n_correct = model(return_type="loss", return_prob="ref", return_attention=False, **vars(batch))
+            _, log_probs, ctc_log_probs, n_correct2 = model(return_type="loss_probs", return_prob="ref", return_attention=False, **vars(batch))
+        assert int(n_correct) == int(n_correct2)
+        batch_loss, n_correct = ddp_reduce(batch_loss), ddp_reduce(n_correct)
+        batch_ntokens = ddp_reduce(batch.ntokens, dev, torch.long)
+        batch_loss = batch.normalize(batch_loss, "sum", n_gpu=1)
+        n_correct = batch.normalize(n_correct, "sum", n_gpu=1)
+        log_probs_m, trg_m = ddp_merge(log_probs, 0.0), ddp_merge(batch.trg, model.pad_index)
+        ref_scores = batch.score(log_probs_m, trg_m, model.pad_index)
+        totals["loss"] += batch_loss.item()
+        totals["n_correct"] += n_correct.item()
+        totals["ntokens"] += batch_ntokens.item()
+        totals["nseqs"] += batch_nseqs
+        out.update({f"b{bi}.reverse_index": np.asarray(reverse_index), f"b{bi}.loss": np.float64(batch_loss.item()),
+                    f"b{bi}.slot1": np.float64(s1.item()), f"b{bi}.slot2": np.float64(s2.item()),
+                    f"b{bi}.n_correct": np.int64(n_correct.item()), f"b{bi}.ntokens": np.int64(batch_ntokens.item()),
+                    f"b{bi}.log_probs": log_probs.numpy(), f"b{bi}.ctc_log_probs": ctc_log_probs.numpy(),
+                    f"b{bi}.trg_sorted": batch.trg.numpy(), f"b{bi}.n_rows": np.int64(len(ref_scores))})
+        for i, row in enumerate(ref_scores):  # ragged: one array per sentence, in the SORTED order (un-sorted by the caller)
+            out[f"b{bi}.ref_scores.{i}"] = np.asarray(row, dtype=np.float64)
+    out.update({f"total.{k}": np.float64(v) for k, v in totals.items()})
+    np.savez_compressed(OUT / f"{name}.npz", **out)
+    print(name, totals)
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     import_reference()
@@ -937,6 +993,7 @@ def main():
         "model_deepnet": lambda: golden_model("model_deepnet", tiny_cfg("pre", initializer="xavier_normal", heads=4), ctc_weight=0.1),
         "train_steps": golden_train_steps, "conformer": golden_conformer, "search_options": golden_search_options, "ddp": golden_ddp, "text_tail": golden_text_tail,
         "ref_unit_tests": golden_ref_unit_tests, "model_mt": golden_model_mt, "frontend_general": golden_frontend_general, "search_wrapper": golden_search_wrapper,
+        "predict_loss": golden_predict_loss,
     }
     for name in (sys.argv[1:] or list(jobs)):  # `python oracle/make_golden.py search_options ddp` regenerates only those
         jobs[name]()

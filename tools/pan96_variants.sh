@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 B=joeys2t_amd/build
-VARIANTS="1 2 3 8 9 6 15"
+VARIANTS="${PAN_VARIANTS:-1 2 3 8 9 6 15}"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-inline-asm -DJS2T_PAN_DBG=$v -x hip -c joeys2t_amd/csrc/gemm_panel.hip -o $B/pan_dbg$v.o
