@@ -191,6 +191,17 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
         # flush=False), then one piece per weight-gradient group, then the update (see capture()).
         return step.micro_step(state["batch"], sort=False, update=not ddp, overlap=False, flush=not ddp, cut_hook=cut_hook)
 
+    def grad_only():
+        """forward + backward + the deferred weight-gradient products of the bench batch, no update: the flat gradient stays"""
+        pre_step()
+        feats, lengths = proc.batch_from_waveforms(wave, n_samples, is_train=True, out_dtype=dtype, masks_dev=masks_dev)
+        if state["batch"] is None:
+            body()  # builds the batch (and takes a step)
+        state["batch"].src = feats
+        return step.micro_step(state["batch"], sort=False, update=False, overlap=False, flush=True)
+
+    state["grad_only"] = grad_only
+
     def eager_step():
         pre_step()
         out = body()
@@ -1035,6 +1046,12 @@ def main():
             varying = varying_bench(device, 100, 250)
         except Exception as exc:
             varying = {"error": repr(exc)}
+    fp32_mode = None
+    if rank == 0 and world == 1 and roofline is not None and not args.no_extras:
+        try:
+            fp32_mode = fp32_parity_mode(device)
+        except Exception as exc:
+            fp32_mode = {"error": repr(exc)[:300]}
     decode = None
     if rank == 0 and world == 1 and not args.no_decode:
         try:
@@ -1076,11 +1093,66 @@ def main():
                        "capture_error": capture_error,
                        "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else ("bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32"),
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
+            "precision": "bf16 products, fp32 accumulation / master weights / statistics; parity with the fp32 reference at bf16 tolerance "
+                         "(tests/test_hip_config_width.py), at 1e-4 in the fp32 mode below",
+            "fp32_parity_mode": fp32_mode,
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode, "varying_batches": varying,
         }
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def fp32_parity_mode(device, n_steps=3):
+    """The SAME train step in the fp32 parity mode (compute_dtype float32: f32 MFMA products, materialised attention - the mode whose
+    outputs meet the reference at 1e-4, tests/test_hip_model.py) timed beside the bf16 headline, and how far the bf16 step's numbers
+    are from it on the bench batch: relative L2 of the decoder logits (eval mode) and of the flat gradient (train mode, same dropout
+    decisions: the masks are a function of seed, step, call site, row and column, not of the dtype).  The CPU baseline beside the
+    headline is fp32 arithmetic (configs/librispeech_100h.yaml:6): this is the same-arithmetic GPU figure."""
+    res = {}
+    grads, logits = {}, {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        es, _, _, st, frames, (m, state) = build_step(device, 1, dtype=dt, ddp=False)
+        st.optimizer.param_groups[0]["lr"] = 0.0  # the comparison wants both models ON the initial weights: steps that move nothing
+        st.scheduler = None
+        st.optimizer.lr_dev.fill_(0.0)
+        st.optimizer.device_schedule = True
+        state["grad_only"]()  # first call builds the batch (one zero-rate update) ...
+        st.store.flat_grad.zero_()
+        if st.optimizer.keep is not None:
+            for lo, hi in list(st.optimizer.keep.r):
+                st.optimizer.keep.remove(lo, hi)
+        st.micro = 0
+        st.rt.rng.state[1:2].zero_()  # ... and both dtypes then draw the masks of step 0
+        state["grad_only"]()
+        torch.cuda.synchronize()
+        grads[name] = st.store.flat_grad.detach().float().clone()
+        m.eval()
+        with torch.no_grad():
+            out, _, _ = m._encode_decode(**vars(state["batch"]))
+        logits[name] = out.detach().float().clone()
+        m.train()
+        if name == "fp32":
+            for _ in range(1):
+                es()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                es()
+            torch.cuda.synchronize()
+            dt_s = (time.perf_counter() - t0) / n_steps
+            res["ms_per_step"] = round(dt_s * 1e3, 2)
+            res["frames_per_s"] = round(frames / dt_s, 1)
+            res["launch"] = "eager (the step's GPU time exceeds its launch time in this mode)"
+        del es, st, m, state
+        torch.cuda.empty_cache()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    res["bf16_vs_fp32"] = {"logits_rel_l2": round(rel(logits["bf16"], logits["fp32"]), 5),
+                           "flat_gradient_rel_l2": round(rel(grads["bf16"], grads["fp32"]), 5),
+                           "flat_gradient_cosine": round(float(torch.dot(grads["bf16"], grads["fp32"]) / (grads["bf16"].norm() * grads["fp32"].norm())), 6),
+                           "grad_norm_bf16": round(float(grads["bf16"].norm()), 4), "grad_norm_fp32": round(float(grads["fp32"].norm()), 4)}
+    res["note"] = "fp32 mode: what the 1e-4 parity tests run; the headline value is the bf16 mode (BASELINE.json config: bf16)"
+    return res
 
 
 def self_launch(n, backend):

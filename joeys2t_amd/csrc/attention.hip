@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
         uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
         if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
           const uint32_t c4 = (uint32_t)((KT / 4) * kt + 4 * tt + g);
-          h0 = hash32(rowkey + 2u * c4), h1 = hash32(rowkey + 2u * c4 + 1u);
+          h0 = hash32w(rowkey + 2u * c4), h1 = hash32w(rowkey + 2u * c4 + 1u);
         }
         const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
@@ -438,7 +438,7 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
     if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
       const uint32_t c4 = c4base + 4u * tt;
-      h0 = hash32(rowkey + 2u * c4), h1 = hash32(rowkey + 2u * c4 + 1u);
+      h0 = hash32w(rowkey + 2u * c4), h1 = hash32w(rowkey + 2u * c4 + 1u);
     }
     const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
 //   pv  = exp2(s * scale*log2e - lse*log2e)        (lse_s holds lse*log2e, +inf for rows past Tq -> pv = 0)
 //   pd  = keep ? pv : 0                             (dV gets the 1/(1-p) factor once, at the end)
 //   ds' = pv * ((keep ? dp : 0) - delta*(1-p))      (dK gets scale/(1-p) once, at the end)
-// Dropout: the decision of (query row, key) is the half (key & 1) of hash32(rowhash + (key >> 1)) - the same value for
+// Dropout: the decision of (query row, key) is the half (key & 1) of hash32w(rowhash + (key >> 1)) - the same value for
 // the two neighbouring lanes of a key pair, so each lane hashes two of the four rows and swaps with its neighbour (DPP).
 template <bool KEYCHECK, bool FULLMASK, int NTT, bool REL = false>
 __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NTT], const float* lse2, const float* dl2,
@@ -627,7 +627,7 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NT
     if (drop) {
       const uint2 rk2 = *(const uint2*)(rkp + 16 * tt + 4 * g + 2 * par);  // row hashes of this lane's two rows
       const uint32_t c2 = (uint32_t)(key >> 1);
-      const uint32_t ha = hash32(rk2.x + c2), hb = hash32(rk2.y + c2);
+      const uint32_t ha = hash32w(rk2.x + c2), hb = hash32w(rk2.y + c2);
       const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)ha, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
       const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)hb, 0xB1, 0xf, 0xf, true);
       h[0] = par ? na : ha, h[1] = par ? nb : hb, h[2] = par ? ha : na, h[3] = par ? hb : nb;

@@ -160,6 +160,17 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
+// Second level of the dropout RNG: the word of (row, column pair) from the row's key, rowkey = hash32(row ^ key).  The row key is
+// fully mixed already and the words of a row are rowkey + 0, 1, 2, ...: multiply - fold - multiply without the two outer folds of
+// hash32 decorrelates them (two vector instructions fewer per word).  Chosen by measurement, not by taste: ONE multiply round
+// (fold, multiply, fold) leaves neighbouring words anti-correlated at hundreds of sigma on a 4096 x 4096 mask; this form and
+// hash32 itself stay within 3 sigma on rates and on every neighbour correlation (tests/test_hip_ops.py::test_dropout_rng_statistics,
+// and its numpy twin tools/rng_stats.py for other keys and rates).
+__device__ __forceinline__ uint32_t hash32w(uint32_t x) {
+  x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  return x;
+}
 __device__ __forceinline__ uint32_t dropout_key(const uint64_t* rng_state, uint32_t stream) {
   const uint64_t seed = rng_state[0], off = rng_state[1];
   return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) + 0x9E3779B9u) ^ hash32((uint32_t)off * 0x85EBCA6Bu + 1u) ^
@@ -170,7 +181,7 @@ __device__ __forceinline__ uint32_t dropout_key(const uint64_t* rng_state, uint3
 // `key` = dropout_key(...) is call-invariant: kernels compute it ONCE per thread and pass it in.
 __device__ __forceinline__ uint32_t dropout_keep4_key(uint32_t key, uint32_t row, uint32_t col4, float p) {
   const uint32_t rowkey = hash32(row ^ key);
-  const uint32_t h0 = hash32(rowkey + 2u * col4), h1 = hash32(rowkey + 2u * col4 + 1u);
+  const uint32_t h0 = hash32w(rowkey + 2u * col4), h1 = hash32w(rowkey + 2u * col4 + 1u);
   const uint32_t thr = (uint32_t)(p * 65536.0f);
   return ((h0 & 0xffffu) >= thr ? 1u : 0u) | ((h0 >> 16) >= thr ? 2u : 0u) | ((h1 & 0xffffu) >= thr ? 4u : 0u) |
          ((h1 >> 16) >= thr ? 8u : 0u);

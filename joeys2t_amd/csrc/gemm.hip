@@ -1486,7 +1486,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint32_t h = hash32(rowkey + (uint32_t)q);
+          const uint32_t h = hash32w(rowkey + (uint32_t)q);
           v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * keep_scale : 0.f;
           v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * keep_scale : 0.f;
         }
@@ -1865,7 +1865,7 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
       }
       if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, n / 4)
         const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
-        const uint32_t h0 = hash32(rowkey), h1 = hash32(rowkey + 1u);
+        const uint32_t h0 = hash32w(rowkey), h1 = hash32w(rowkey + 1u);
         v[0] = (h0 & 0xffffu) >= thr ? v[0] * keep_scale : 0.f;
         v[1] = (h0 >> 16) >= thr ? v[1] * keep_scale : 0.f;
         v[2] = (h1 & 0xffffu) >= thr ? v[2] * keep_scale : 0.f;

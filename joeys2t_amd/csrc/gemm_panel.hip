@@ -13,7 +13,10 @@
 //    acknowledgement of its stores) runs under the other waves' stages;
 //  * a wave's requests run two stages ahead of its multiplies, also across the end of a strip: the stores of a strip's
 //    epilogue are YOUNGER than the requests of the next strip's first two stages, so the counted wait for those stages does not
-//    wait for the stores (the in-order vmcnt problem of the ring kernels, profiles/r04_epilogue_store_experiments.txt);
+//    wait for the stores (the in-order vmcnt problem of the ring kernels, profiles/r04_epilogue_store_experiments.txt).
+//    (Measured and dropped: holding a strip's packed results in registers and storing them INSIDE the next strip's first stage,
+//    behind its requests - two and a half stages before any counted wait covers them: no faster, 24 more registers;
+//    profiles/r05_pan96_bench.txt.  What the epilogue costs is not the wait for its stores' acknowledgement.)
 //  * blocks with equal blockIdx % 8 (one XCD under round-robin placement: speed only) share one eighth of the rows, so A is
 //    pulled through the fabric once and every XCD reads all of B (1.5-2 MB).
 // Work: unit = (panel, strip).  The blocks of a group cut the group's units, in panel-major order, into equal runs; a block
@@ -111,7 +114,7 @@ __device__ __forceinline__ void pan_store(const js2t_gemm_desc& d, f32x4_t (&acc
         const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + (uint32_t)(c0 >> 1);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const uint32_t h = hash32(rowkey + (uint32_t)q);
+          const uint32_t h = hash32w(rowkey + (uint32_t)q);
           v[2 * q] = (h & 0xffffu) >= thr ? v[2 * q] * keep_scale : 0.f;
           v[2 * q + 1] = (h >> 16) >= thr ? v[2 * q + 1] * keep_scale : 0.f;
         }
@@ -396,6 +399,10 @@ int launch_bf16_pan96(const js2t_gemm_desc& d, int mask, hipStream_t s) {
   // worth it from two units per wave on (a block loads 96 KB of B before its first multiply)
   const int64_t units = (int64_t)((d.M + PN_ROWS - 1) / PN_ROWS) * ((d.N + PN_COLS - 1) / PN_COLS);
   if (g_pan_mode < 0 && units < 16 * 256) return -1;
+  // ... and not with dropout in the epilogue: the strip's hash arithmetic (13 vector instructions per element) sits in the same wave
+  // as its multiplies and the partner wave does not cover it - FFN layer 1 takes 36-37 us here against 32-33 on the persistent kernel
+  // (profiles/r05_pan96_bench.txt); the projections and the gated input gradient gain 4-15 %
+  if (g_pan_mode < 0 && (mask & PE_DROP)) return -1;
   switch (mask) {
     case 0: return launch_pan96_epi<0>(d, s);
     case PE_BIAS: return launch_pan96_epi<PE_BIAS>(d, s);

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_vec_kernel(const T* __rest
           const uint32_t rowkey = hash32((uint32_t)row ^ dkey) + 4u * (uint32_t)c;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const uint32_t h = hash32(rowkey + (uint32_t)q);
+            const uint32_t h = hash32w(rowkey + (uint32_t)q);
             od[2 * q] = (h & 0xffffu) >= dthr ? o[2 * q] * dsc : 0.f;
             od[2 * q + 1] = (h >> 16) >= dthr ? o[2 * q + 1] * dsc : 0.f;
           }

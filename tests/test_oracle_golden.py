@@ -374,3 +374,38 @@ def test_frontend_orders_and_mask_counts_beside_the_configured_one():
         for i in range(3):
             got = oracle_frontend(g[f"in{i}"].copy(), case["cmvn"], case["specaugment"], case["max_length"], rng)
             np.testing.assert_allclose(got, g[f"{name}_{i}"], rtol=1e-5, atol=1e-5, err_msg=f"{name} {i}")
+
+
+def test_predict_validation_leg():
+    """The validation-loss / reference-scoring leg of the reference's `predict` loop (prediction.py:165-200), captured per batch
+    in predict_loss.npz: the oracle's eval-mode loss, n_correct, log-probabilities and the scores of the reference tokens."""
+    g = load_golden("predict_loss")
+    sd = golden_sd(load_golden("model_pre"))
+    cfg = oracle_cfg(FIXTURES["model_pre"]["cfg"])
+    tot = dict(loss=0.0, n_correct=0, ntokens=0, nseqs=0)
+    for bi in (0, 1):
+        pre = f"b{bi}."
+        b = O.make_batch(torch.from_numpy(g[pre + "src"]), torch.from_numpy(g[pre + "src_length"]), torch.from_numpy(g[pre + "trg_full"]),
+                         torch.from_numpy(g[pre + "trg_length_full"]), SPECIALS["pad"], SPECIALS["eos"])
+        order = torch.argsort(b["src_length"], descending=True, stable=True)
+        rev = g[pre + "reverse_index"]
+        assert np.array_equal(np.argsort(order.numpy()), rev)  # batch.sort_by_src_length(): position of every original row
+        b = {k: v[order] for k, v in b.items()}
+        total, xent, ctc, ncor, out, ctc_out = O.model_loss(sd, cfg, b, SPECIALS, 0.1, 0.3)
+        assert abs(total.item() - g[pre + "loss"]) <= 1e-4 * abs(g[pre + "loss"])
+        # the 4-tuple of return_type="loss": slots 1-2 are the two loss components (what the reference's loop calls log_probs / attn)
+        assert abs(xent.item() - g[pre + "slot1"]) <= 1e-4 * abs(g[pre + "slot1"]) and abs(ctc.item() - g[pre + "slot2"]) <= 1e-4 * abs(g[pre + "slot2"])
+        assert int(ncor) == int(g[pre + "n_correct"])
+        lp = torch.log_softmax(out, -1)
+        torch.testing.assert_close(lp, torch.from_numpy(g[pre + "log_probs"]), **TOL)
+        torch.testing.assert_close(torch.log_softmax(ctc_out, -1), torch.from_numpy(g[pre + "ctc_log_probs"]), **TOL)
+        assert np.array_equal(b["trg"].numpy(), g[pre + "trg_sorted"])
+        for i in range(int(g[pre + "n_rows"])):  # Batch.score (batch.py:210-223): log-probability of every non-pad reference token
+            row = np.array([lp[i, j, t].item() for j, t in enumerate(b["trg"][i]) if t != SPECIALS["pad"]])
+            np.testing.assert_allclose(row, g[pre + f"ref_scores.{i}"], rtol=1e-4, atol=1e-4)
+        tot["loss"] += total.item()
+        tot["n_correct"] += int(ncor)
+        tot["ntokens"] += int((b["trg"] != SPECIALS["pad"]).sum())
+        tot["nseqs"] += b["src"].shape[0]
+    for k, v in tot.items():
+        assert abs(v - float(g["total." + k])) <= 1e-4 * max(1.0, abs(float(g["total." + k]))), k
