@@ -584,6 +584,23 @@ int js2t_beam_step_logp(const float* log_probs, const float* beam_log_probs, flo
                         float* out_lse, int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids,
                         int32_t n_forbid, float length_penalty, js2t_stream stream);
 
+/* EXTENSION (the reference returns ctc_out for return_type="decode_ctc", joeynmt/model.py:162-166, and has no
+ * consumer): joint CTC / attention decoding after Watanabe et al., IEEE JSTSP 2017, Algorithm 2.
+ * js2t_beam_pick: for every row of logits [rows, V] the n_pick (<= 8) best tokens by log-softmax (forbidden ids masked) +
+ * row_scores[row]: out_scores / out_ids [rows, n_pick] (score descending, id ascending among ties), out_lse [rows].
+ * js2t_ctc_prefix_step: one extension step of the CTC prefix score for every (hypothesis row, candidate) pair.  ctc_log_probs f32
+ * [B, T, V] (B = rows / beam utterances), in_len [B]; r_prev f32 [rows, T, 2] forward variables (non-blank, blank) of the
+ * hypotheses (log 0 = -1e30), last_tok [rows] their last tokens, n_out = tokens emitted so far (0: only BOS); cand / cand_lp
+ * [rows, n_cand] candidate ids and attention log-probabilities; psi_prev [rows] prefix scores of the hypotheses.  Writes psi_out
+ * [rows, n_cand], r_new [rows, n_cand, T, 2] and local [rows, n_cand] = (1 - weight) * cand_lp + weight * (psi - psi_prev)
+ * (-inf where either probability is 0) - the step score js2t_beam_step_logp then selects on. */
+int js2t_beam_pick(const float* logits, const float* row_scores, float* out_scores, int64_t* out_ids, float* out_lse, int64_t rows,
+                   int32_t n_pick, int64_t V, const int32_t* forbid_ids, int32_t n_forbid, js2t_stream stream);
+int js2t_ctc_prefix_step(const float* ctc_log_probs, const int64_t* in_len, const float* r_prev, const int64_t* last_tok,
+                         const int64_t* cand, const float* cand_lp, const float* psi_prev, float* local, float* psi_out, float* r_new,
+                         int64_t rows, int32_t beam, int32_t n_cand, int32_t T, int64_t V, int32_t n_out, int32_t blank, int32_t eos,
+                         float weight, js2t_stream stream);
+
 /* penalize_repetition (search.py:972-1001): for every id in tokens[row, 0..L) (int64[rows, L]; hypothesis prefix or
  * source tokens) log_probs[row, id] := x * penalty if x < 0 else x / penalty, x = the value BEFORE this call (gather,
  * scale, scatter: an id that occurs several times is penalised once).  In place on f32[rows, V].

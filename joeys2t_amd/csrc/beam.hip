@@ -102,7 +102,7 @@ constexpr int BS_LK = 8;
 __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float* __restrict__ logits, const float* __restrict__ beam_lp,
                                                                    float* __restrict__ out_scores, int64_t* __restrict__ out_ids,
                                                                    float* __restrict__ out_lse, int k, int V, ForbidList fb, float len_pen,
-                                                                   int use_pen, int normalized) {
+                                                                   int use_pen, int normalized, int n_pick) {
   __shared__ float red[BS_THREADS / 64];
   __shared__ int redi[BS_THREADS / 64];
   __shared__ int redt[BS_THREADS / 64];
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float*
       }
     }
   }
-  // k rounds over the list heads
-  for (int rank = 0; rank < k; ++rank) {
+  // n_pick (the beam search: k) rounds over the list heads
+  for (int rank = 0; rank < n_pick; ++rank) {
     float bs = ls[0];
     int bi = li[0], bt = t;
 #pragma unroll
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(BS_THREADS) void beam_step_fast_kernel(const float*
       for (int ww = 1; ww < BS_THREADS / 64; ++ww)
         if (better(red[ww], redi[ww], fs, fi)) { fs = red[ww]; fi = redi[ww]; ft = redt[ww]; }
       pick_t = ft;
-      out_scores[(int64_t)b * k + rank] = fs;
-      out_ids[(int64_t)b * k + rank] = fi == 0x7fffffff ? 0 : fi;
+      out_scores[(int64_t)b * n_pick + rank] = fs;
+      out_ids[(int64_t)b * n_pick + rank] = fi == 0x7fffffff ? 0 : fi;
     }
     __syncthreads();
     if (t == pick_t) {  // pop the winner's list
@@ -230,7 +230,101 @@ int beam_step_launch(const float* logits, const float* beam_log_probs, float* ou
                      int64_t n_batch, int32_t beam, int64_t V, const int32_t* forbid_ids, int32_t n_forbid, float length_penalty,
                      int normalized, js2t_stream stream);
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Joint CTC / attention decoding (EXTENSION: the reference returns ctc_out for return_type="decode_ctc", model.py:162-166,
+// and has no consumer).  One step of the CTC prefix score of Watanabe et al., "Hybrid CTC/Attention Architecture for End-to-End
+// Speech Recognition" (IEEE JSTSP 2017, Algorithm 2), for every (live hypothesis, candidate token) pair - one thread each, the
+// recursion over the utterance's frames is sequential:
+//   r_n[t] = logaddexp(r_n[t-1], phi[t-1]) + x[t, c]      phi = r_n + r_b of the hypothesis, or its r_b alone when c repeats its last label
+//   r_b[t] = logaddexp(r_n[t-1], r_b[t-1]) + x[t, blank]
+//   psi    = logaddexp over t of (phi[t-1] + x[t, c])      (c = EOS: r_n[T-1] + r_b[T-1] of the hypothesis - it ends here)
+// and the step's local score  (1 - w) * log p_att(c) + w * (psi - psi of the hypothesis)  that the beam selection adds to the
+// accumulated one.  log 0 is carried as -1e30 (no inf - inf).  oracle: oracle/s2t_oracle.py ctc_prefix_score, pinned by enumeration.
+constexpr float CTC_LOG0 = -1.0e30f;
+__device__ __forceinline__ float ctc_lae(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m <= 0.5f * CTC_LOG0 ? CTC_LOG0 : m + log1pf(__expf(-fabsf(a - b)));
+}
+__global__ __launch_bounds__(64) void ctc_prefix_step_kernel(const float* __restrict__ x, const int64_t* __restrict__ in_len,
+                                                            const float* __restrict__ r_prev, const int64_t* __restrict__ last_tok,
+                                                            const int64_t* __restrict__ cand, const float* __restrict__ cand_lp,
+                                                            const float* __restrict__ psi_prev, float* __restrict__ local,
+                                                            float* __restrict__ psi_out, float* __restrict__ r_new, int64_t n_pairs, int k, int C,
+                                                            int T, int64_t V, int n_out, int blank, int eos, float w) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= n_pairs) return;
+  const int64_t row = idx / C, b = row / k;
+  const int Tb = (int)min((int64_t)T, in_len[b]);
+  const float* xb = x + b * (int64_t)T * V;
+  const float* rp = r_prev + row * (int64_t)T * 2;
+  float* rn = r_new + idx * (int64_t)T * 2;
+  const int64_t c = cand[idx];
+  const bool repeat = n_out > 0 && c == last_tok[row];
+  for (int t = 0; t < T; ++t) rn[2 * t] = CTC_LOG0, rn[2 * t + 1] = CTC_LOG0;
+  float r_n = CTC_LOG0, r_b = CTC_LOG0, psi = CTC_LOG0;
+  const int start = max(n_out, 1);
+  if (n_out == 0 && Tb > 0) {
+    r_n = xb[c];
+    rn[0] = r_n;
+  }
+  if (start - 1 < Tb) psi = n_out == 0 ? r_n : CTC_LOG0;  // r[start - 1, 0]: only the first label can have been emitted by frame 0
+  const int t0 = min(start - 1, T - 1);  // (a hypothesis longer than the input has frames: the loop below does not run)
+  float pn = rp[2 * t0], pb = rp[2 * t0 + 1];  // the hypothesis' variables at t - 1
+  for (int t = start; t < Tb; ++t) {
+    const float phi = repeat ? pb : ctc_lae(pn, pb);
+    const float xt = xb[(int64_t)t * V + c], xblank = xb[(int64_t)t * V + blank];
+    const float nn = ctc_lae(r_n, phi) + xt;
+    const float nb = ctc_lae(r_n, r_b) + xblank;
+    psi = ctc_lae(psi, phi + xt);
+    r_n = fmaxf(nn, CTC_LOG0), r_b = fmaxf(nb, CTC_LOG0);
+    rn[2 * t] = r_n, rn[2 * t + 1] = r_b;
+    pn = rp[2 * t], pb = rp[2 * t + 1];
+  }
+  if (c == eos) psi = Tb > 0 ? ctc_lae(rp[2 * (Tb - 1)], rp[2 * (Tb - 1) + 1]) : CTC_LOG0;
+  if (c == blank) psi = CTC_LOG0;
+  psi = fmaxf(psi, CTC_LOG0);
+  psi_out[idx] = psi;
+  const float att = cand_lp[idx], pp = psi_prev[row];
+  float loc = (1.f - w) * att;
+  if (w > 0.f) loc = (psi <= 0.5f * CTC_LOG0 || pp <= 0.5f * CTC_LOG0) ? -INFINITY : loc + w * (psi - pp);
+  if (!(att > -INFINITY)) loc = -INFINITY;
+  local[idx] = loc;
+}
+
 }  // namespace
+
+// The n_pick best tokens of EVERY row (log-softmax, forbidden ids masked, + the row's entry of row_scores): the candidate
+// pre-selection of joint CTC / attention decoding - the fast beam kernel with one row per entry
+extern "C" int js2t_beam_pick(const float* logits, const float* row_scores, float* out_scores, int64_t* out_ids, float* out_lse, int64_t rows,
+                              int32_t n_pick, int64_t V, const int32_t* forbid_ids, int32_t n_forbid, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(logits && row_scores && out_scores && out_ids && out_lse, "beam_pick: null pointer");
+  JS2T_CHECK(n_pick >= 1 && n_pick <= BS_LK && n_pick <= V, "beam_pick: 1..%d candidates (at most the vocabulary)", BS_LK);
+  JS2T_CHECK(n_forbid >= 0 && n_forbid <= BS_MAX_FORBID && (n_forbid == 0 || forbid_ids), "beam_pick: at most %d forbidden ids", BS_MAX_FORBID);
+  JS2T_CHECK(V < 0x7fffffff, "beam_pick: vocabulary too large");
+  ForbidList fb;
+  fb.n = n_forbid;
+  for (int i = 0; i < BS_MAX_FORBID; ++i) fb.ids[i] = i < n_forbid ? forbid_ids[i] : -1;
+  hipLaunchKernelGGL(beam_step_fast_kernel, dim3((unsigned)rows), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, row_scores, out_scores,
+                     out_ids, out_lse, 1, (int)V, fb, 1.f, 0, 0, n_pick);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
+extern "C" int js2t_ctc_prefix_step(const float* ctc_log_probs, const int64_t* in_len, const float* r_prev, const int64_t* last_tok,
+                                    const int64_t* cand, const float* cand_lp, const float* psi_prev, float* local, float* psi_out,
+                                    float* r_new, int64_t rows, int32_t beam, int32_t n_cand, int32_t T, int64_t V, int32_t n_out,
+                                    int32_t blank, int32_t eos, float weight, js2t_stream stream) {
+  if (rows == 0) return JS2T_OK;
+  JS2T_CHECK(ctc_log_probs && in_len && r_prev && last_tok && cand && cand_lp && psi_prev && local && psi_out && r_new, "ctc_prefix_step: null pointer");
+  JS2T_CHECK(beam >= 1 && n_cand >= 1 && T >= 1 && V >= 1 && rows % beam == 0 && n_out >= 0, "ctc_prefix_step: bad sizes");
+  JS2T_CHECK(blank >= 0 && blank < V && eos >= 0 && eos < V && weight >= 0.f && weight <= 1.f, "ctc_prefix_step: bad blank / eos / weight");
+  const int64_t n = rows * n_cand;
+  hipLaunchKernelGGL(ctc_prefix_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, ctc_log_probs, in_len, r_prev,
+                     last_tok, cand, cand_lp, psi_prev, local, psi_out, r_new, n, beam, n_cand, T, V, n_out, blank, eos, weight);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
 
 extern "C" int js2t_rep_penalty(float* log_probs, const int64_t* tokens, int64_t rows, int64_t V, int64_t L, float penalty,
                                 js2t_stream stream) {
@@ -284,7 +378,7 @@ int beam_step_launch(const float* logits, const float* beam_log_probs, float* ou
   const int use_pen = length_penalty > 0.f ? 1 : 0;
   if (beam <= BS_LK) {
     hipLaunchKernelGGL(beam_step_fast_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
-                       out_scores, out_ids, out_lse, beam, (int)V, fb, use_pen ? length_penalty : 1.f, use_pen, normalized);
+                       out_scores, out_ids, out_lse, beam, (int)V, fb, use_pen ? length_penalty : 1.f, use_pen, normalized, beam);
   } else {
     hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)n_batch), dim3(BS_THREADS), 0, (hipStream_t)stream, logits, beam_log_probs,
                        out_scores, out_ids, out_lse, beam, V, fb, use_pen ? length_penalty : 1.f, use_pen, normalized);

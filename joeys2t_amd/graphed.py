@@ -162,6 +162,43 @@ class GraphedTrainStep:
         b.trg_mask = (b.trg != self.pad_index).unsqueeze(1)
         return step.micro_step(b, sort=False, update=True, overlap=False)
 
+    def bucket_key(self, n_samples: Sequence[int], trg_len) -> tuple:
+        """The bucket a batch falls into - host arithmetic on lengths only, so a loader that knows its epoch (samplers are
+        deterministic given their seed) can ask for every bucket ahead of time and have them captured before they are needed."""
+        frames = [self.ex.n_frames(int(n)) for n in n_samples]
+        trg_len = [int(v) for v in (trg_len.tolist() if torch.is_tensor(trg_len) else trg_len)]
+        B = len(frames)
+        Tb = _round_up(max(frames), self.frame_bucket)
+        rows = 0
+        if self.row_bucket:
+            rows = _round_up(sum(self._sub_len(f) for f in frames), self.row_bucket)
+            if rows > (1.0 - self.pack_min_saving) * B * self._sub_len(Tb):
+                rows = 0
+        return (B, Tb, _round_up(max(trg_len), self.target_bucket), rows)
+
+    def precapture(self, key: tuple) -> bool:
+        """Capture the graph of a bucket BEFORE its first batch arrives.  Capturing executes nothing (no kernel runs, the model, the
+        optimizer and the RNG stay where they are - the host-side counters the capture pass touches are put back), so it can be done
+        at any point between two steps; it needs one earlier eager step of any shape (lazily built tables, the allocator's pools).
+        Returns False when the bucket was captured already."""
+        if not self.use_graphs:
+            return False
+        if not self.counts["eager"]:
+            raise ops.Js2tError("GraphedTrainStep.precapture: run one batch first (the first step of a run builds what captures reuse)")
+        bk = self._bucket(tuple(key))
+        if bk.graph is not None:
+            return False
+        step = self.step
+        g = torch.cuda.CUDAGraph()
+        micro, t, steps = step.micro, step.optimizer.t, step.steps
+        with torch.cuda.graph(g, pool=self.pool):
+            self._body(bk)
+        step.micro, step.optimizer.t, step.steps = micro, t, steps
+        bk.graph = g
+        self.counts["captured"] += 1
+        self.counts["precaptured"] = self.counts.get("precaptured", 0) + 1
+        return True
+
     def run(self, wave: torch.Tensor, n_samples: Sequence[int], trg: torch.Tensor, trg_len) -> str:
         """One training step on this batch; returns how it ran ("eager" on a bucket's first sight, else "replay")."""
         ex, step = self.ex, self.step
@@ -174,14 +211,9 @@ class GraphedTrainStep:
         order = sorted(range(B), key=lambda i: -frames[i])  # batch.sort_by_src_length() of training.py:555, on the host
         trg_len = [int(v) for v in (trg_len.tolist() if torch.is_tensor(trg_len) else trg_len)]
         L = max(trg_len)
-        Tb = _round_up(frames[order[0]], self.frame_bucket)
         sub = [self._sub_len(frames[i]) for i in order]  # live encoder positions per utterance
-        rows = 0
-        if self.row_bucket:
-            rows = _round_up(sum(sub), self.row_bucket)
-            if rows > (1.0 - self.pack_min_saving) * B * self._sub_len(Tb):
-                rows = 0
-        key = (B, Tb, _round_up(L, self.target_bucket), rows)
+        key = self.bucket_key(n_samples, trg_len)
+        Tb = key[1]
         bk = self._bucket(key)
         Lb = key[2]
         # ---- everything that varies inside the bucket, into the pinned buffer

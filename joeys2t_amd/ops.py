@@ -888,6 +888,60 @@ def beam_step(logits2d: torch.Tensor, beam_log_probs: torch.Tensor, n_batch: int
     return scores, ids, lse
 
 
+def beam_pick(logits2d: torch.Tensor, n_pick: int, forbid_ids, row_scores: Optional[torch.Tensor] = None):
+    """For every row the n_pick (<= 8) best tokens by log-softmax (forbidden ids masked) + row_scores[row] (js2t_beam_pick): the
+    candidate pre-selection of joint CTC / attention decoding.  Returns (scores [rows, n_pick], ids [rows, n_pick] int64, lse [rows])."""
+    _dev(logits2d, row_scores)
+    if logits2d.dtype != torch.float32 or not logits2d.is_contiguous():
+        raise Js2tError("beam_pick: logits must be contiguous float32")
+    rows, V = logits2d.shape
+    dev = logits2d.device
+    if row_scores is None:
+        row_scores = torch.zeros((rows, ), dtype=torch.float32, device=dev)
+    scores = torch.empty((rows, n_pick), dtype=torch.float32, device=dev)
+    ids = torch.empty((rows, n_pick), dtype=torch.int64, device=dev)
+    lse = torch.empty((rows, ), dtype=torch.float32, device=dev)
+    fb = (C.c_int32 * max(1, len(forbid_ids)))(*forbid_ids)
+    check(lib().js2t_beam_pick(_p(logits2d), _p(row_scores.contiguous().float()), _p(scores), _p(ids), _p(lse), C.c_int64(rows), C.c_int32(n_pick),
+                               C.c_int64(V), fb, C.c_int32(len(forbid_ids)), _stream()), "js2t_beam_pick")
+    return scores, ids, lse
+
+
+CTC_LOG0 = -1.0e30  # log 0 of the CTC prefix variables (js2t_ctc_prefix_step carries no infinities)
+
+
+def ctc_prefix_init(ctc_log_probs: torch.Tensor, in_len: torch.Tensor, beam: int, blank: int) -> torch.Tensor:
+    """Forward variables of the EMPTY prefix for every hypothesis slot: [B * beam, T, 2] = (log 0, running sum of the blank's
+    log-probabilities inside the utterance's frames)."""
+    B, T, _ = ctc_log_probs.shape
+    rb = torch.cumsum(ctc_log_probs[:, :, blank].float(), dim=1)
+    live = torch.arange(T, device=ctc_log_probs.device).unsqueeze(0) < in_len.view(-1, 1)
+    r = torch.full((B, T, 2), CTC_LOG0, dtype=torch.float32, device=ctc_log_probs.device)
+    r[:, :, 1] = torch.where(live, rb, torch.full_like(rb, CTC_LOG0))
+    return r.repeat_interleave(beam, dim=0).contiguous()
+
+
+def ctc_prefix_step(ctc_log_probs, in_len, r_prev, last_tok, cand, cand_lp, psi_prev, n_out: int, beam: int, blank: int, eos: int,
+                    weight: float):
+    """One extension step of the CTC prefix score for every (hypothesis, candidate) pair (js2t_ctc_prefix_step; Watanabe et al. 2017,
+    Algorithm 2).  Returns (local [rows, C] step scores, psi [rows, C], r_new [rows, C, T, 2])."""
+    _dev(ctc_log_probs, in_len, r_prev, last_tok, cand, cand_lp, psi_prev)
+    B, T, V = ctc_log_probs.shape
+    rows, Cn = cand.shape
+    if (ctc_log_probs.dtype != torch.float32 or not ctc_log_probs.is_contiguous() or r_prev.shape != (rows, T, 2) or not r_prev.is_contiguous()
+            or rows != B * beam or cand.dtype != torch.int64 or in_len.dtype != torch.int64 or last_tok.dtype != torch.int64):
+        raise Js2tError("ctc_prefix_step: ctc_log_probs f32 [B, T, V], r_prev f32 [B * beam, T, 2], int64 cand / in_len / last_tok")
+    dev = cand.device
+    local = torch.empty((rows, Cn), dtype=torch.float32, device=dev)
+    psi = torch.empty((rows, Cn), dtype=torch.float32, device=dev)
+    r_new = torch.empty((rows, Cn, T, 2), dtype=torch.float32, device=dev)
+    check(lib().js2t_ctc_prefix_step(_p(ctc_log_probs), _p(in_len.contiguous()), _p(r_prev), _p(last_tok.contiguous()), _p(cand.contiguous()),
+                                     _p(cand_lp.contiguous().float()), _p(psi_prev.contiguous().float()), _p(local), _p(psi), _p(r_new),
+                                     C.c_int64(rows), C.c_int32(beam), C.c_int32(Cn), C.c_int32(T), C.c_int64(V), C.c_int32(n_out),
+                                     C.c_int32(blank), C.c_int32(eos), C.c_float(weight), _stream()), "js2t_ctc_prefix_step")
+    return local, psi, r_new
+
+
 # ----------------------------------------------------------------------------------------- fused attention
 def _mask_strides(mask, B, Tq, Tk):
     if mask is None:

@@ -239,6 +239,25 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
     # plain decoding (no option that edits the scores on the host) with the key/value cache: the search runs without a
     # device -> host round trip per step, see `if fast:` below
     fast = inc is not None and not opt.edits and kwargs.get("sync_free", True)
+    # EXTENSION (the reference has no consumer for its CTC head at decoding time, model.py:162-166): joint CTC /
+    # attention decoding after Watanabe et al. 2017.  ctc_weight w > 0: per live hypothesis the `ctc_candidates` best next tokens by
+    # attention log-probability, each scored (1 - w) * log p_att + w * (CTC prefix score of the extension - of the hypothesis);
+    # the beam keeps the best beam_size of beam_size * ctc_candidates per utterance.  w = 0: the reference's beam search, untouched.
+    ctc_w = float(kwargs.get("ctc_weight", 0.0) or 0.0)
+    n_cand = 0
+    if ctc_w > 0.0:
+        if not fast:
+            raise ops.Js2tError("beam_search: ctc_weight needs the key/value-cached search without score-editing options")
+        if getattr(model.decoder, "ctc_output_layer", None) is None:
+            raise ops.Js2tError("beam_search: ctc_weight > 0 but the model has no CTC output layer")
+        n_cand = int(kwargs.get("ctc_candidates", 8))
+        if not (beam_size <= n_cand <= min(8, V)):
+            raise ops.Js2tError("beam_search: ctc_candidates must lie in beam_size .. min(8, vocabulary)")
+        with torch.no_grad():
+            ctc_lp = ops.log_softmax(model.decoder.project(model.decoder.ctc_output_layer, encoder_output, model.runtime.compute_dtype).float())
+        ctc_in_len = src_mask.view(B, -1).sum(-1).long()
+        ctc_r = ops.ctc_prefix_init(ctc_lp, ctc_in_len, beam_size, bos)  # blank = BOS (loss.py:156-161)
+        ctc_psi = torch.zeros((B * beam_size, ), dtype=torch.float32, device=dev)
     if fast:
         # what a step leaves behind is its picks (token + the beam it extends), its flags and its scores: O(L * B * k); the
         # hypotheses themselves are rebuilt on the host from the back-pointers, only for those that get filed
@@ -257,7 +276,13 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
         forced_rows = None
         if not opt.edits:
             logits = inc.step(alive_seq[:, -1]) if inc is not None else _decode_last(model, alive_seq, encoder_output, src_mask, trg_mask)
-            topk_scores, topk_flat, _ = ops.beam_step(logits, topk_log_probs.reshape(-1), nb, beam_size, forbid, length_penalty)
+            if ctc_w > 0.0:
+                cand_lp, cand_id, _ = ops.beam_pick(logits, n_cand, forbid)
+                local, psi_new, r_new = ops.ctc_prefix_step(ctc_lp, ctc_in_len, ctc_r, alive_seq[:, -1].contiguous(), cand_id, cand_lp, ctc_psi,
+                                                           step, beam_size, bos, eos, ctc_w)
+                topk_scores, topk_flat, _ = ops.beam_step(local, topk_log_probs.reshape(-1), nb, beam_size, [], length_penalty, normalized=True)
+            else:
+                topk_scores, topk_flat, _ = ops.beam_step(logits, topk_log_probs.reshape(-1), nb, beam_size, forbid, length_penalty)
         else:
             # forced tokens of this step (:489-499): hypotheses whose prompt mask is set at position step + 1
             has_mask = pmask is not None and pmask.size(1) > step + 1
@@ -280,8 +305,15 @@ def beam_search(model, beam_size: int, encoder_output: Tensor, encoder_hidden: T
             topk_scores, topk_flat, _ = ops.beam_step(log_probs, topk_log_probs.reshape(-1), nb, beam_size, [], length_penalty,
                                                       normalized=True)
         topk_log_probs = topk_scores * length_penalty if alpha > 0 else topk_scores.clone()
-        topk_beam_index = topk_flat.div(V, rounding_mode="floor")
-        topk_ids = topk_flat.fmod(V)
+        if ctc_w > 0.0:  # flat index over beam * candidates: which hypothesis, which of its candidates
+            topk_beam_index = topk_flat.div(n_cand, rounding_mode="floor")
+            pair = ((topk_beam_index + beam_offset[:nb].unsqueeze(1)) * n_cand + topk_flat.fmod(n_cand)).view(-1)
+            topk_ids = cand_id.view(-1).index_select(0, pair).view(nb, beam_size)
+            ctc_r = r_new.view(rows * n_cand, -1).index_select(0, pair).view(rows, -1, 2)  # the winners' forward variables
+            ctc_psi = psi_new.view(-1).index_select(0, pair)
+        else:
+            topk_beam_index = topk_flat.div(V, rounding_mode="floor")
+            topk_ids = topk_flat.fmod(V)
         if forced_rows is not None:
             # forced decoding overwrites the picks themselves as well (:648-655): flat position r of [nb, k] <- hypothesis r
             topk_ids = topk_ids.view(-1).index_put((forced_rows, ), forced_tok.index_select(0, forced_rows)).view(-1, beam_size)

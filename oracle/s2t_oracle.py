@@ -801,3 +801,173 @@ def ctc_best_path(logits, in_len, blank, pad):
         lens[b] = n
     return ids, lens
 
+
+
+# --------------------------------------------------------------------------------------------------
+# joint CTC / attention decoding (EXTENSION: the reference returns `ctc_out` for return_type="decode_ctc",
+# model.py:162-166, and has no consumer).  The algorithm is the published one: Watanabe, Hori, Kim, Hershey, Hayashi, "Hybrid
+# CTC/Attention Architecture for End-to-End Speech Recognition", IEEE JSTSP 2017, section IV-B / Algorithm 2 (CTC prefix score),
+# with the forward variables r^n_t(g), r^b_t(g) of Graves' prefix search.  Pinned by enumeration: ctc_prefix_brute() below sums
+# the probability of every alignment of a tiny input by brute force (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------------------------------
+def _collapse(path, blank):
+    out, prev = [], None
+    for s in path:
+        if s != blank and s != prev:
+            out.append(s)
+        prev = s
+    return out
+
+
+def ctc_prefix_brute(logp: np.ndarray, prefix: List[int], blank: int, whole: bool = False) -> float:
+    """log of the total probability of all length-T alignments whose collapsed labelling STARTS WITH `prefix` (whole=False: the
+    CTC prefix probability psi of the paper, eq. 44-51) or IS `prefix` (whole=True: what a hypothesis ending in EOS scores).
+    Exponential in T: for T <= 6, V <= 4."""
+    import itertools
+    T, V = logp.shape
+    tot = -np.inf
+    for path in itertools.product(range(V), repeat=T):
+        lab = _collapse(path, blank)
+        ok = lab == list(prefix) if whole else lab[:len(prefix)] == list(prefix)
+        if ok:
+            tot = np.logaddexp(tot, sum(logp[t, s] for t, s in enumerate(path)))
+    return float(tot)
+
+
+def ctc_prefix_init(logp: np.ndarray, in_len: int, blank: int) -> np.ndarray:
+    """forward variables of the EMPTY prefix: r[t] = (r^n_t, r^b_t) = (log 0, sum of the blank log-probabilities up to t)"""
+    T = logp.shape[0]
+    r = np.full((T, 2), -np.inf)
+    r[:in_len, 1] = np.cumsum(logp[:in_len, blank])
+    return r
+
+
+def ctc_prefix_score(logp: np.ndarray, in_len: int, y: List[int], cands: List[int], r_prev: np.ndarray, blank: int, eos: int):
+    """One extension step of the CTC prefix score (Algorithm 2 of the paper): y = the hypothesis so far INCLUDING its leading BOS,
+    r_prev [T, 2] = its forward variables -> (log psi [C] of y + c for every candidate c, r_new [T, 2, C])."""
+    T = logp.shape[0]
+    C = len(cands)
+    n_out = len(y) - 1
+    xs = logp[:, cands]
+    r = np.full((T, 2, C), -np.inf)
+    if n_out == 0 and in_len > 0:
+        r[0, 0] = xs[0]
+    r_sum = np.logaddexp(r_prev[:, 0], r_prev[:, 1])
+    log_phi = np.repeat(r_sum[:, None], C, axis=1)
+    if n_out > 0:
+        for i, c in enumerate(cands):
+            if c == y[-1]:
+                log_phi[:, i] = r_prev[:, 1]  # a repeated label needs a blank in between
+    start = max(n_out, 1)
+    # (a hypothesis with more labels than the input has frames cannot be emitted at all: every extension scores log 0)
+    log_psi = r[start - 1, 0].copy() if start - 1 < in_len else np.full((C, ), -np.inf)
+    for t in range(start, in_len):
+        r[t, 0] = np.logaddexp(r[t - 1, 0], log_phi[t - 1]) + xs[t]
+        r[t, 1] = np.logaddexp(r[t - 1, 0], r[t - 1, 1]) + logp[t, blank]
+        log_psi = np.logaddexp(log_psi, log_phi[t - 1] + xs[t])
+    for i, c in enumerate(cands):
+        if c == eos:
+            log_psi[i] = r_sum[in_len - 1]  # the hypothesis ends here: probability of the labelling itself
+        if c == blank:
+            log_psi[i] = -np.inf
+    return log_psi, r
+
+
+def joint_ctc_beam_search(sd: SD, cfg: dict, specials: dict, enc: Tensor, src_mask: Tensor, beam_size: int, max_output_length: int,
+                          alpha: float, ctc_weight: float, n_cand: int = 8, n_best: int = 1, min_output_length: int = 1,
+                          generate_unk: bool = True):
+    """beam_search() above with the CTC prefix score mixed into every step (EXTENSION, see the section header):
+      per live hypothesis: the n_cand best next tokens by attention log-probability; for each, local score
+      (1 - w) * log p_att + w * (log psi_ctc(y + c) - log psi_ctc(y)); per utterance the beam_size best of beam_size * n_cand
+      by (accumulated score + local) / length penalty.  Bookkeeping of finished hypotheses as in the reference's beam search.
+    -> (ids [B*n_best, L], scores [B*n_best, 1])"""
+    bos, eos, pad, unk = specials["bos"], specials["eos"], specials["pad"], specials["unk"]
+    B = src_mask.size(0)
+    V = sd["decoder.output_layer.weight"].size(0)
+    ctc_lp = F.log_softmax(linear(sd, "decoder.ctc_output_layer", enc), dim=-1).double().numpy()  # [B, T', V], blank = BOS (loss.py:156-161)
+    in_len = src_mask.squeeze(1).sum(-1).tolist()
+    k = beam_size
+    enc = enc.repeat_interleave(k, dim=0)
+    src_mask = src_mask.repeat_interleave(k, dim=0)
+    trg_mask = torch.ones(1, 1, 1, dtype=torch.bool)
+    alive_seq = torch.full((B * k, 1), bos, dtype=torch.long)
+    topk_log_probs = torch.zeros(B, k, dtype=torch.float64)
+    topk_log_probs[:, 1:] = float("-inf")
+    r_state = [ctc_prefix_init(ctc_lp[b], int(in_len[b]), bos) for b in range(B) for _ in range(k)]
+    ctc_prev = [0.0] * (B * k)
+    hypotheses = [[] for _ in range(B)]
+    results = {"predictions": [[] for _ in range(B)], "scores": [[] for _ in range(B)]}
+    is_finished = torch.zeros(B, k, dtype=torch.bool)
+    live = list(range(B))  # every utterance stays in the batch until the search ends (utterances do not interact)
+    done = [False] * B
+    for step in range(max_output_length):
+        logits, _, _, _ = decoder_forward(sd, cfg, alive_seq, enc, src_mask, trg_mask)
+        att = F.log_softmax(logits[:, -1], dim=-1).double()
+        _forbid(att, [bos, pad, specials.get("sep")])
+        if not generate_unk:
+            att[:, unk] = float("-inf")
+        if step < min_output_length:
+            att[:, eos] = float("-inf")
+        length_penalty = ((5.0 + (step + 1)) / 6.0)**alpha if alpha > 0 else 1.0
+        cand_lp, cand_id = att.topk(n_cand, dim=-1)
+        joint = torch.full((B * k, n_cand), float("-inf"), dtype=torch.float64)
+        new_r, new_psi = [None] * (B * k), [None] * (B * k)
+        for row in range(B * k):
+            b = row // k
+            psi, r_new = ctc_prefix_score(ctc_lp[b], int(in_len[b]), alive_seq[row].tolist(), cand_id[row].tolist(), r_state[row], bos, eos)
+            new_r[row], new_psi[row] = r_new, psi
+            loc = (1.0 - ctc_weight) * cand_lp[row].numpy()
+            if ctc_weight > 0:  # log 0 stays log 0: an extension (or a hypothesis) CTC rules out is out, whatever the weight
+                with np.errstate(invalid="ignore"):
+                    inc = np.where(np.isfinite(psi) & np.isfinite(ctc_prev[row]), psi - ctc_prev[row], -np.inf)
+                loc = loc + ctc_weight * inc
+            loc[~np.isfinite(cand_lp[row].numpy())] = -np.inf
+            joint[row] = torch.from_numpy(topk_log_probs.view(-1)[row].item() + loc)
+        curr = (joint / length_penalty).reshape(B, k * n_cand)
+        topk_scores, flat = curr.topk(k, dim=-1)
+        topk_log_probs = topk_scores * length_penalty if alpha > 0 else topk_scores.clone()
+        beam_idx = flat.div(n_cand, rounding_mode="floor")
+        slot = flat.fmod(n_cand)
+        rows_from = (beam_idx + torch.arange(B).unsqueeze(1) * k).view(-1)
+        topk_ids = cand_id[rows_from, slot.view(-1)].view(B, k)
+        r_state = [new_r[int(rf)][:, :, int(s)] for rf, s in zip(rows_from, slot.view(-1))]
+        ctc_prev = [float(new_psi[int(rf)][int(s)]) for rf, s in zip(rows_from, slot.view(-1))]
+        alive_seq = torch.cat([alive_seq.index_select(0, rows_from), topk_ids.view(-1, 1)], -1)
+        is_finished = topk_ids.eq(eos) | is_finished | topk_scores.eq(-np.inf)
+        if step + 1 == max_output_length:
+            is_finished.fill_(True)
+        end_condition = is_finished.all(-1)
+        predictions = alive_seq.view(B, k, -1)
+        for i in range(B):
+            if done[i] or not is_finished[i].any():
+                continue
+            if end_condition[i]:
+                is_finished[i].fill_(True)
+            for j in is_finished[i].nonzero(as_tuple=False).view(-1):
+                n_eos = (predictions[i, j, 1:] == eos).count_nonzero().item()
+                if n_eos > 1:
+                    continue
+                if (n_eos == 0 and step + 1 == max_output_length) or (n_eos == 1 and predictions[i, j, -1] == eos):
+                    hypotheses[i].append((topk_scores[i, j].item(), predictions[i, j, 1:].clone()))
+            if end_condition[i]:
+                for n, (score, pred) in enumerate(sorted(hypotheses[i], key=lambda x: x[0], reverse=True)):
+                    if n >= n_best:
+                        break
+                    results["scores"][i].append(score)
+                    results["predictions"][i].append(pred)
+                done[i] = True
+        if all(done):
+            break
+        enc = enc.index_select(0, rows_from)
+        src_mask = src_mask.index_select(0, rows_from)
+    for b in range(B):
+        for _ in range(n_best - len(results["predictions"][b])):
+            results["predictions"][b].append(torch.tensor([unk]).long())
+            results["scores"][b].append(-1.0)
+    preds = [u for r in results["predictions"] for u in r]
+    max_len = max(p.shape[0] for p in preds)
+    out = torch.full((len(preds), max_len), pad, dtype=torch.int64)
+    for j, p in enumerate(preds):
+        out[j, :p.shape[0]] = p
+    scores = torch.tensor([[float(u)] for r in results["scores"] for u in r])
+    return out, scores

@@ -244,3 +244,46 @@ def test_graphed_steps_on_packed_encoder_rows(device):
         assert r[4] == gt[4]
     rel = ((flat - flat_ref).norm() / flat_ref.norm()).item()
     assert rel < 8e-3, rel
+
+
+def test_precaptured_bucket_replays_on_first_sight(device):
+    """GraphedTrainStep.precapture: a bucket captured before any batch of it has arrived - capturing runs nothing (parameters, step
+    count, RNG untouched) - and the bucket's first batch is a replay with the plain step's numbers."""
+    from test_hip_config_width import make_model
+    torch.manual_seed(3)
+    base = make_model(_cfg(), V, None, None, None, 0.3)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    dtype = torch.float32
+    first = _batches(5, 1)                          # ~ 30000-41000 samples: frame bucket 256
+    later = _batches(6, 2, lo=52000, hi=60000)      # longer utterances: another bucket
+    proc = _proc()
+    ref, flat_ref = _plain_run(_make(sd, device, dtype), proc, first + later, device, dtype)
+    from joeys2t_amd.graphed import GraphedTrainStep
+    np.random.seed(11)
+    step = _make(sd, device, dtype)
+    gs = GraphedTrainStep(step, proc, compute_dtype=dtype, frame_bucket=128, target_bucket=16)
+    with pytest.raises(Exception):
+        gs.precapture(gs.bucket_key(later[0][1], later[0][3]))  # nothing has run yet
+    assert gs.run(first[0][0].to(device), first[0][1], first[0][2], first[0][3]) == "eager"
+    s0 = gs.read_stats()
+    keys = {gs.bucket_key(ns, tl) for _, ns, _, tl in later}
+    assert gs.bucket_key(first[0][1], first[0][3]) not in keys
+    before = step.store.flat.detach().clone()
+    t_before = (step.optimizer.t, step.steps, step.micro, int(step.optimizer.step_dev.item()))
+    for key in keys:
+        assert gs.precapture(key) and not gs.precapture(key)  # the second call finds it captured
+    torch.cuda.synchronize()
+    assert torch.equal(before, step.store.flat) and t_before == (step.optimizer.t, step.steps, step.micro, int(step.optimizer.step_dev.item()))
+    got = [(s0["loss"], s0["nll"], s0["ctc"])]
+    for wave, ns, trg, tl in later:
+        assert gs.run(wave.to(device), ns, trg, tl) == "replay"  # first sight of the bucket, and no eager step
+        s = gs.read_stats()
+        got.append((s["loss"], s["nll"], s["ctc"]))
+    assert gs.counts["eager"] == 1 and gs.counts["precaptured"] == len(keys)
+    for r, g in zip(ref, got):
+        for k in range(3):
+            assert abs(r[k] - g[k]) <= 2e-5 * abs(r[k]), (r, g)
+    torch.cuda.synchronize()
+    diff = (step.store.flat - flat_ref).abs()
+    apart = diff > 1e-5
+    assert float(apart.float().mean()) < 5e-4 and ((((step.store.flat - flat_ref) * ~apart).norm() / flat_ref.norm()).item() < 1e-5)

@@ -409,3 +409,52 @@ def test_predict_validation_leg():
         tot["nseqs"] += b["src"].shape[0]
     for k, v in tot.items():
         assert abs(v - float(g["total." + k])) <= 1e-4 * max(1.0, abs(float(g["total." + k]))), k
+
+
+def test_ctc_prefix_score_against_enumeration():
+    """Known-answer pin of the CTC prefix score (EXTENSION f3; Watanabe et al. 2017, Algorithm 2): on tiny random inputs the
+    recursion's log psi(g + c) equals the summed probability of EVERY alignment whose labelling starts with g + c (EOS: is exactly
+    g), found by brute-force enumeration - for chains of extensions, repeated labels and ragged input lengths."""
+    rng = np.random.RandomState(5)
+    blank, eos = 0, 3
+    for trial in range(6):
+        T, V = 5, 4
+        in_len = T if trial % 2 == 0 else T - 1
+        logp = np.log(rng.dirichlet(np.ones(V), size=T))
+        lp_live = logp[:in_len]
+        # hand-checkable corner: the empty prefix extended by c = probability that the first non-blank label is c
+        r0 = O.ctc_prefix_init(logp, in_len, blank)
+        psi, r1 = O.ctc_prefix_score(logp, in_len, [blank], [1, 2, eos], r0, blank, eos)
+        for i, c in enumerate([1, 2]):
+            assert abs(psi[i] - O.ctc_prefix_brute(lp_live, [c], blank)) < 1e-9
+        assert abs(psi[2] - O.ctc_prefix_brute(lp_live, [], blank, whole=True)) < 1e-9  # EOS right away: the all-blank alignment
+        assert abs(psi[2] - logp[:in_len, blank].sum()) < 1e-9
+        # chains: g = [1], [1, 1] (a repeat: needs a blank in between), [1, 2], [1, 2, 1]
+        state = {(): (r0, 0.0)}
+        for g in [(1, ), (1, 1), (1, 2), (1, 2, 1), (2, ), (2, 2)]:
+            parent = g[:-1]
+            r_prev, _ = state[parent]
+            cands = [1, 2, eos, blank]
+            psi, r_new = O.ctc_prefix_score(logp, in_len, [blank] + list(parent), cands, r_prev, blank, eos)
+            i = cands.index(g[-1])
+            want = O.ctc_prefix_brute(lp_live, list(g), blank)
+            assert abs(psi[i] - want) < 1e-9 or (np.isinf(want) and psi[i] < -1e8), (trial, g, psi[i], want)
+            assert abs(psi[2] - O.ctc_prefix_brute(lp_live, list(parent), blank, whole=True)) < 1e-9  # parent + EOS
+            assert np.isinf(psi[3]) and psi[3] < 0  # the blank is never a label
+            state[g] = (r_new[:, :, i], psi[i])
+
+
+@pytest.mark.parametrize("name", list(FIXTURES))
+def test_joint_ctc_beam_search_reduces_to_beam_search(name):
+    """weight 0: the candidate pre-selection (n_cand >= beam) cannot lose a winner - the joint search IS the reference's beam search"""
+    g = load_golden(name)
+    cfg = oracle_cfg(FIXTURES[name]["cfg"])
+    sd = golden_sd(g)
+    b = _batch(g)
+    enc, mask, _ = O.encoder_forward(sd, cfg, b["src"], b["src_length"])
+    k, alpha = int(g["beam_size"]), float(g["beam_alpha"])
+    ids, scores = O.joint_ctc_beam_search(sd, cfg, SPECIALS, enc, mask, k, 12, alpha, ctc_weight=0.0, n_cand=8, n_best=k)
+    assert np.array_equal(ids.numpy(), g["beam_ids"])
+    np.testing.assert_allclose(scores.numpy(), g["beam_scores"], rtol=1e-4, atol=1e-4)
+    ids2, scores2 = O.joint_ctc_beam_search(sd, cfg, SPECIALS, enc, mask, k, 12, alpha, ctc_weight=0.3, n_cand=8, n_best=1)
+    assert ids2.shape[0] == b["src"].shape[0] and np.isfinite(scores2.numpy()).all()
