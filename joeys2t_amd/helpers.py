@@ -20,9 +20,14 @@ def subsequent_mask(size: int, device=None) -> Tensor:
     key = (int(size), str(device))
     m = _SUBSEQUENT_MASKS.get(key)
     if m is None:
-        if len(_SUBSEQUENT_MASKS) > 256:
-            _SUBSEQUENT_MASKS.clear()
-        m = _SUBSEQUENT_MASKS[key] = torch.ones(size, size, dtype=torch.bool, device=device).tril_().unsqueeze(0)
+        m = torch.ones(size, size, dtype=torch.bool, device=device).tril_().unsqueeze(0)
+        # Built while a hipGraph is captured, the mask is filled only when THAT graph replays: cached, a graph captured later (another
+        # bucket of graphed.GraphedTrainStep.precapture, same target length) would read it before anything has written it.  So a mask
+        # made under capture belongs to its graph alone, and only eagerly built ones are shared.
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            if len(_SUBSEQUENT_MASKS) > 256:
+                _SUBSEQUENT_MASKS.clear()
+            _SUBSEQUENT_MASKS[key] = m
     return m
 
 

@@ -160,7 +160,9 @@ class TrainStep:
         inv_norm = self._inv_normalizer(batch)
         seed = self._grad_seeds.get(inv_norm)
         if seed is None:
-            seed = self._grad_seeds[inv_norm] = torch.full((), inv_norm, dtype=torch.float32, device=total.device)
+            seed = torch.full((), inv_norm, dtype=torch.float32, device=total.device)
+            if not torch.cuda.is_current_stream_capturing():  # made under capture it is filled by THAT graph's replays only: not shared
+                self._grad_seeds[inv_norm] = seed
         # Data parallel: the backward pass in two halves, cut at the encoder's output.  Behind it (decoder, target embedding, both
         # output layers, the CTC branch) every gradient is complete after the first half: the decoder side's weight-gradient
         # products run there and their ranges of the flat gradient (ParamStore.late_ranges) travel while the encoder's backward

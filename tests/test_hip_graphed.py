@@ -255,7 +255,11 @@ def test_precaptured_bucket_replays_on_first_sight(device):
     sd = {k: v.clone() for k, v in base.state_dict().items()}
     dtype = torch.float32
     first = _batches(5, 1)                          # ~ 30000-41000 samples: frame bucket 256
-    later = _batches(6, 2, lo=52000, hi=60000)      # longer utterances: another bucket
+    # two further buckets (longer utterances) that share their target-length bucket and their utterance count: what a capture builds
+    # lazily per target length / per normaliser (causal mask, backward seed) must not be handed from one captured graph to the next -
+    # the batches below arrive in the REVERSE of the capture order, so a constant filled only by the first graph's replays would be
+    # read before it was ever written (bench.py --varying showed exactly that as a NaN loss)
+    later = _batches(7, 1, lo=72000, hi=80000) + _batches(6, 2, lo=52000, hi=60000)
     proc = _proc()
     ref, flat_ref = _plain_run(_make(sd, device, dtype), proc, first + later, device, dtype)
     from joeys2t_amd.graphed import GraphedTrainStep
@@ -267,10 +271,11 @@ def test_precaptured_bucket_replays_on_first_sight(device):
     assert gs.run(first[0][0].to(device), first[0][1], first[0][2], first[0][3]) == "eager"
     s0 = gs.read_stats()
     keys = {gs.bucket_key(ns, tl) for _, ns, _, tl in later}
-    assert gs.bucket_key(first[0][1], first[0][3]) not in keys
+    assert gs.bucket_key(first[0][1], first[0][3]) not in keys and len(keys) == 2 and len({k[2] for k in keys}) == 1
+    assert gs.bucket_key(later[0][1], later[0][3]) == max(keys)  # captured last, replayed first
     before = step.store.flat.detach().clone()
     t_before = (step.optimizer.t, step.steps, step.micro, int(step.optimizer.step_dev.item()))
-    for key in keys:
+    for key in sorted(keys):
         assert gs.precapture(key) and not gs.precapture(key)  # the second call finds it captured
     torch.cuda.synchronize()
     assert torch.equal(before, step.store.flat) and t_before == (step.optimizer.t, step.steps, step.micro, int(step.optimizer.step_dev.item()))
