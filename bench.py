@@ -270,7 +270,9 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
                            specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
                            cmvn=dict(norm_means=True, norm_vars=True, before=True))
-    gstep = GraphedTrainStep(step, proc, compute_dtype=dtype, use_graphs=use_graphs)
+    # bucket widths (measurement knobs): finer buckets pad less and need more graphs - affordable since they are captured ahead
+    gstep = GraphedTrainStep(step, proc, compute_dtype=dtype, use_graphs=use_graphs, frame_bucket=int(os.environ.get("JS2T_VARY_FRAME_BUCKET", 64)),
+                             row_bucket=int(os.environ.get("JS2T_VARY_ROW_BUCKET", 384)), max_graphs=256)
     # the corpus: pool_utts utterances of 10-17 s in pinned host memory (slices of one noise buffer), targets of 40-80 tokens
     g = torch.Generator().manual_seed(4321)
     n_samples = torch.randint(160000, 272001, (pool_utts, ), generator=g).tolist()
@@ -639,7 +641,7 @@ def measure_hbm_kernels(eager_step, step):
     return {"bound": "hbm", "peak": PEAK_HBM_TBS, "unit": "TB/s", "event_pair_overhead_us": round(pair * 1e6, 2), "kernels": out}
 
 
-def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
+def conformer_train_step(device, reps=10, modes=("bf16", )):
     """BASELINE.json configs[4] as a TRAIN step: build_model(encoder.type: conformer, rel_pos_clip 64, depthwise kernel 31; 16 + 6
     layers, d 512, V 10000 as librispeech_960h) -> TrainStep (forward, CTC + label-smoothed CE, backward, clip + AdamW), 32 x 15 s
     of synthetic features, dropout on, hipGraph replay; in bf16 and with e4m3 forward products (functional.FP8_FORWARD; backward
@@ -674,9 +676,13 @@ def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
                 for layer in model.encoder.layers:
                     layer.src_src_att.rel_pos_bias.normal_(0.0, 0.1)
             model.finalize(device, torch.bfloat16, seed=42)
-            # (the reference's schedule runs the FIRST update at the un-warmed peak rate, training.py:438-456: 2e-3 blows a randomly
-            # initialised Conformer up; a timing figure on synthetic data, so a rate it survives)
-            step = TrainStep(model, learning_rate=3.0e-4, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=10000,
+            # the rate and warm-up of the 1000-update soak runs (tools/conformer_soak.py, profiles/r05_conformer_soak_*.txt): the loss
+            # falls steadily there.  The encoder has no final LayerNorm (encoders.py:376-445), so the CTC head starts on un-normalised
+            # activations and the initial CTC term is ~30 x the uniform level: with the gradient clipped to norm 1 the first updates
+            # are sign-like and two runs that differ in the last bit of one atomic sum drift apart within tens of updates - the spread
+            # of same-seed mean losses round 4 reported.  js2t_set_deterministic now covers the extension kernels: same-seed runs agree
+            # bit for bit (tests/test_hip_config5_train.py).  Reported: the loss in front of and behind the timed window, not a mean.
+            step = TrainStep(model, learning_rate=1.0e-4, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=200,
                              normalization="batch", overlap_ctc=True)
             step.optimizer.device_schedule = True
             src = torch.randn(BATCH, frames, 80, device=device).bfloat16()
@@ -697,9 +703,11 @@ def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
-            for _ in range(3):
+            for _ in range(2):
                 g.replay()
             step.read_stats(reset=True)
+            g.replay()
+            loss_first = step.read_stats()["loss"]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             s.record()
@@ -708,9 +716,12 @@ def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
             e.record()
             torch.cuda.synchronize()
             ms = s.elapsed_time(e) / reps
-            loss = step.read_stats()["loss"] / reps
+            step.read_stats(reset=True)
+            g.replay()
+            loss_last = step.read_stats()["loss"]
             out[mode] = {"ms_per_step": round(ms, 3), "frames_per_s": round(BATCH * frames / (ms * 1e-3), 1),
-                         "achieved": round(flop / (ms * 1e-3) / 1e12, 1), "loss": round(loss, 3)}
+                         "achieved": round(flop / (ms * 1e-3) / 1e12, 1), "loss_before_timed_window": round(loss_first, 3),
+                         "loss_after_timed_window": round(loss_last, 3), "updates_between": reps + 1}
             del g, step, model
             torch.cuda.empty_cache()
         finally:
@@ -719,8 +730,10 @@ def conformer_train_step(device, reps=10, modes=("bf16", "fp8")):
                     "V 10000, CTC 0.3 + label-smoothed CE), 32 x 15 s, dropout 0.1, clip + AdamW, hipGraph replay",
             "flop_per_step": flop, "unit": "TFLOP/s", "bf16": out.get("bf16"), "fp8": out.get("fp8"), "peak_bf16": PEAK_BF16_TFLOPS,
             "frac_bf16": round(out["bf16"]["achieved"] / PEAK_BF16_TFLOPS, 4) if "bf16" in out else None,
-            "fp8_note": "e4m3 operands on the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) in five of a layer's eight forward "
-                        "products; backward in bf16: priced against the bf16 peak, not the 5 PF fp8 figure",
+            "fp8_note": "e4m3 forward products are reported as INFERENCE-only (roofline.conformer_fp8_forward): as a train step they save less "
+                        "than keeping both operand copies for the bf16 backward costs (round 4: 27.3 against 26.1 ms); "
+                        "conformer_train_step(modes=('bf16', 'fp8')) still measures both, tools/conformer_soak.py trains both",
+            "soak": "profiles/r05_conformer_soak_bf16.txt, _fp8.txt: 1000 updates at peak rate 1e-4 (200 warm-up): total loss 44.8 k -> 1.8 k; at 3e-4 the CTC term diverges after ~250 updates (profiles/r05_conformer_soak_bf16_lr3e-4_diverges.txt)",
             "parity": "extension: no reference target for the composition (joeynmt's build_model refuses the encoder type)"}
 
 

@@ -518,8 +518,12 @@ int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int
  *   js2t_layernorm_bwd*: accumulate mode goes through the partial slab + the fixed-order final kernel instead of atomics;
  *   js2t_embed_bwd: the first position of a token id owns the table row and adds the later ones in position order;
  *   js2t_ctc_bwd: the first occurrence of a label in the extended target sums its later occurrences in order.
- * Not covered (extension kernels off that path): the relative-position bias gradient, the Conformer's depthwise-convolution
- * and BatchNorm parameter gradients.  A process-wide switch, read at launch time. */
+ * Round 5 - the extension kernels (BASELINE config 5) as well:
+ *   js2t_flash_attn_bwd / js2t_rel_bias_grad: the relative-position bias gradient is collected as a histogram of 2^-32 fixed-point
+ *     integers (integer atomics commute) in a scratch buffer the library owns, then converted and added into d_rel_bias;
+ *   js2t_dwconv_outer_bwd (weight gradient), js2t_bn_act_fwd / _bwd (batch statistics, parameter-gradient sums): ONE block per
+ *     64 columns walks all rows, so every output receives a single sum formed in a fixed order - slower, deterministic.
+ * A process-wide switch, read at launch time.  The first call in this mode allocates the scratch (never inside a hipGraph capture). */
 void js2t_set_deterministic(int on);
 int js2t_get_deterministic(void);
 

@@ -129,6 +129,8 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(store.flat)
         self.exp_avg_sq = torch.zeros_like(store.flat)
         self.t = 0
+        self._retired_plans = []   # item / fold tables of earlier plans: captured graphs may still point at them (see _fused_plan)
+        self.plan_generation = 0   # bumped whenever a plan that may have been captured is replaced
         from joeys2t_amd._lib import lib
         n = store.total
         self._partial = torch.empty((max(1, lib().js2t_sumsq_partials(_C.c_int64(n))), ), dtype=torch.float32,
@@ -211,6 +213,13 @@ class FlatAdamW:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("FlatAdamW: the store changed (new LayerNorm folds / shadows) after the last eager update: "
                                "run one eager step before capturing")
+        # A rebuilt plan does not free the old one: hipGraphs captured earlier hold raw pointers to its tables (replay never comes
+        # through here), and reused memory read as an item table would send the kernel's writes anywhere.  Every table ever handed to
+        # a launch stays alive (a few KB each); `plan_generation` tells holders of captured graphs that their graphs carry the OLD
+        # keep flags / folds and must be re-captured (graphed.GraphedTrainStep checks it before every replay).
+        if self._plan is not None:
+            self._retired_plans.append(self._plan)
+            self.plan_generation += 1
         self._plan_key, self._plan = key, None
         from joeys2t_amd._lib import lib
         geo = [_C.c_int32() for _ in range(3)]

@@ -55,6 +55,7 @@ struct AttnArgs {
   const float* dpart;  // bwd: delta as partial sums over 64-column groups of [B*Tq, H*DH] (js2t_attn_desc.delta_partial) or NULL
   int dgroups;
   const int32_t* seg;  // packed rows (js2t_attn_desc.seg): entry b owns rows seg[b] .. seg[b+1] of every buffer; NULL: b * Tq ..
+  unsigned long long* d_rel_fix;  // deterministic mode: the bias gradient as 2^-32 fixed-point sums [H, 2R+1] (common.hpp), else NULL
 };
 // where batch entry b lives: first row in the query-side and key-side buffers, its own lengths.  a.Tq / a.Tk stay the PADDED
 // lengths: grid shape, [B*H, Tq] scalars (lse, delta), mask rows and the dropout counter (z * Tq + q: the packed layout draws the
@@ -432,7 +433,7 @@ template <bool MASKED, int NTT, bool REL = false>
 __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float dl2,
                                             uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop,
                                             const float* rel_s = nullptr, float* drel_s = nullptr, int key0 = 0, int query = 0, int R = 0,
-                                            bool q_live = true, float* edge = nullptr) {
+                                            bool q_live = true, float* edge = nullptr, unsigned long long* drel_i = nullptr) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
@@ -455,7 +456,10 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
       if (REL && drel_s && q_live) {
         if (ri == 0) edge[0] += s[tt][r];
         else if (ri == 2 * R) edge[1] += s[tt][r];
-        else if (s[tt][r] != 0.f) atomicAdd(&drel_s[ri], s[tt][r]);
+        else if (s[tt][r] != 0.f) {
+          if (drel_i) atomicAdd(&drel_i[ri], js2t_to_fixed(s[tt][r]));  // deterministic mode: integer sums commute
+          else atomicAdd(&drel_s[ri], s[tt][r]);
+        }
       }
     }
   }
@@ -470,6 +474,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ __attribute__((aligned(16))) uint16_t kmask[KMASK_MAX / 16];
   __shared__ float rel_s[REL ? 2 * REL_MAX + 1 : 1], drel_s[REL ? 2 * REL_MAX + 1 : 1];
+  __shared__ unsigned long long drel_i[REL ? 2 * REL_MAX + 1 : 1];  // the same histogram in fixed point (deterministic mode)
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, m = lane & 15;
   const int wu = __builtin_amdgcn_readfirstlane(w);  // wave-uniform copy: LDS-DMA destinations stay on the scalar unit
   const ImgSrc<DH> isrc = img_src<DH>(wu, lane);
@@ -525,7 +530,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) {
     stage_rel(rel_s, a, h, t);
-    for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f;
+    for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f, drel_i[i] = 0ull;
   }
   int cur = 0;
   float rel_edge[2] = {0.f, 0.f};  // this lane's share of the two end bins of the bias gradient (dq_elements)
@@ -565,7 +570,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
         uint32_t bits = kbits;
         if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, Tk);
         dq_elements<true, NTT, REL>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
-                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq, rel_edge);
+                                    KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq, rel_edge, a.d_rel_fix ? drel_i : nullptr);
       }
 #pragma unroll
       for (int ss = 0; ss < NSS; ++ss) dsf[ss] = pack8(s[2 * ss], s[2 * ss + 1]);
@@ -580,16 +585,26 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   }
   const float dq_sc = a.scale * (drop ? 1.f / keep_p : 1.f);
   if (REL && a.d_rel) {  // the block's histogram of dS over relative distances -> the head's gradient row
-    const float e0 = wave_sum(rel_edge[0]), e1 = wave_sum(rel_edge[1]);
-    if (lane == 0) {
-      if (e0 != 0.f) atomicAdd(&drel_s[0], e0);
-      if (e1 != 0.f) atomicAdd(&drel_s[2 * a.relR], e1);
-    }
-    __syncthreads();
+    const float e0 = wave_sum(rel_edge[0]), e1 = wave_sum(rel_edge[1]);  // (a lane's own sum and the wave's butterfly: fixed orders)
     const int n = 2 * a.relR + 1;
-    const float sc = drop ? 1.f / keep_p : 1.f;
-    for (int i = t; i < n; i += 256)
-      if (drel_s[i] != 0.f) atomicAdd(a.d_rel + (int64_t)h * n + i, drel_s[i] * sc);
+    if (a.d_rel_fix) {  // deterministic mode: the block's histogram and the head's row as integer sums (1 / (1 - p) at the conversion)
+      if (lane == 0) {
+        if (e0 != 0.f) atomicAdd(&drel_i[0], js2t_to_fixed(e0));
+        if (e1 != 0.f) atomicAdd(&drel_i[2 * a.relR], js2t_to_fixed(e1));
+      }
+      __syncthreads();
+      for (int i = t; i < n; i += 256)
+        if (drel_i[i] != 0ull) atomicAdd(a.d_rel_fix + (int64_t)h * n + i, drel_i[i]);
+    } else {
+      if (lane == 0) {
+        if (e0 != 0.f) atomicAdd(&drel_s[0], e0);
+        if (e1 != 0.f) atomicAdd(&drel_s[2 * a.relR], e1);
+      }
+      __syncthreads();
+      const float sc = drop ? 1.f / keep_p : 1.f;
+      for (int i = t; i < n; i += 256)
+        if (drel_s[i] != 0.f) atomicAdd(a.d_rel + (int64_t)h * n + i, drel_s[i] * sc);
+    }
   }
   {
     const int qrow = q0 + m;
@@ -843,6 +858,7 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.rel = d->rel_bias; a.d_rel = d->d_rel_bias; a.relR = d->rel_bias ? d->rel_R : 0;
   a.dpart = d->delta_partial; a.dgroups = d->delta_groups;
   a.seg = d->seg;
+  a.d_rel_fix = nullptr;
   return a;
 }
 
@@ -884,15 +900,25 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
   }
   AttnArgs a = to_args(d);
   const int n_dq = cdiv(d->Tq, 64) * d->B * d->H, n_dkv = cdiv(d->Tk, 64) * d->B * d->H;
+  // deterministic mode (js2t_set_deterministic): the bias gradient's histogram as integer sums in a library scratch, converted
+  // (x 1 / (1 - p)) and added into d_rel_bias behind the kernels
+  const int64_t n_fix = (REL && g_js2t_deterministic && d->d_rel_bias) ? (int64_t)d->H * (2 * d->rel_R + 1) : 0;
+  if (n_fix) {
+    long long* fix = js2t_fixed_scratch((size_t)n_fix);
+    JS2T_CHECK(fix != nullptr, "flash_attn_bwd: scratch allocation failed");
+    JS2T_CHECK(hipMemsetAsync(fix, 0, (size_t)n_fix * sizeof(long long), s) == hipSuccess, "flash_attn_bwd: memset failed");
+    a.d_rel_fix = (unsigned long long*)fix;
+  }
   if (d->delta_partial && (n_dkv & 7) == 0 && g_attn_bwd_merge) {
     hipLaunchKernelGGL((flash_bwd_kernel<DH, REL>), dim3(n_dkv + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv);
     JS2T_LAUNCH_CHECK();
-    return JS2T_OK;
+  } else {
+    hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+    JS2T_LAUNCH_CHECK();
+    hipLaunchKernelGGL((flash_dkv_kernel<DH, REL>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+    JS2T_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
-  JS2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL((flash_dkv_kernel<DH, REL>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
-  JS2T_LAUNCH_CHECK();
+  if (n_fix) return js2t_fixed_to_float_add((const long long*)a.d_rel_fix, d->d_rel_bias, n_fix, d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f, s);
   return JS2T_OK;
 }
 

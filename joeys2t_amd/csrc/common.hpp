@@ -31,6 +31,15 @@ void js2t_set_error(const char* fmt, ...);
 
 extern int g_js2t_deterministic;  // js2t_set_deterministic (core.cpp): ordered sums instead of floating-point atomics
 
+// Deterministic mode of the histogram-shaped sums (relative-position bias gradient): the addends are rounded ONCE to 2^-32 fixed
+// point and summed as 64-bit integers - integer atomics commute, so LDS and global atomics in any order give the same bits.
+// js2t_fixed_scratch: a device buffer of n zeroed-by-the-caller int64 words owned by the library (allocated at first use - which
+// must not be inside a hipGraph capture: the first step of a run is eager); js2t_fixed_to_float_add: dst[i] += src[i] * 2^-32 * scale.
+constexpr float JS2T_FIX_SCALE = 4294967296.0f;
+long long* js2t_fixed_scratch(size_t n);
+int js2t_fixed_to_float_add(const long long* src, float* dst, int64_t n, float scale, hipStream_t s);
+__device__ __forceinline__ unsigned long long js2t_to_fixed(float v) { return (unsigned long long)__float2ll_rn(v * JS2T_FIX_SCALE); }
+
 // ---------------------------------------------------------------- dtype helpers
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);

@@ -252,20 +252,22 @@ __global__ __launch_bounds__(256) void dwconv_outer_dw_win_kernel(const T* __res
 // column reductions over a row slab: MODE 0: (sum x, -) ; 1: (sum (x-mean)^2, -) ; 2: (sum dz, sum dz*xhat) with
 // dz = dy * act'(z), z = xhat*gamma + beta.  Block = 64 columns x 4 row lanes; atomics onto out0 / out1 (pre-zeroed).
 constexpr int BN_SLAB = 64;
+// `slab`: rows per block (BN_SLAB; deterministic mode: all of them - ONE block per 64 columns, so every output receives a single
+// sum formed in a fixed order)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_colreduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* out0, float* out1, int64_t rows,
-                                                           int64_t C, int act) {
+                                                           int64_t C, int act, int64_t slab) {
   __shared__ float red[2][4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + cl;
-  const int64_t r0 = (int64_t)blockIdx.y * BN_SLAB;
+  const int64_t r0 = (int64_t)blockIdx.y * slab;
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     const float mu = MODE >= 1 ? mean[c] : 0.f;
     const float is = MODE == 2 ? invstd[c] : 0.f, ga = MODE == 2 ? gamma[c] : 0.f, be = MODE == 2 ? beta[c] : 0.f;
-    for (int64_t r = r0 + rl; r < min(r0 + BN_SLAB, rows); r += 4) {
+    for (int64_t r = r0 + rl; r < min(r0 + slab, rows); r += 4) {
       const float v = io<T>::ld(x + r * C + c);
       if (MODE == 0) {
         a0 += v;
@@ -387,8 +389,11 @@ extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float*
     // measured at L = 32, N = 375, C = 512: 4 -> 122 us, 8 -> 91, 16 -> 97, 32 -> 146 (dx + dw)
     int npb = (int)cdiv(N * cdiv(C, 64), 512);
     npb = npb < 4 ? 4 : (npb > DW_SLAB ? DW_SLAB : (npb + 3) & ~3);
+    // deterministic mode (js2t_set_deterministic): ONE block per 64 channels walks every column, so each dw[c, k] receives a single
+    // sum formed in a fixed order (the slabs' atomics arrive in any order otherwise)
+    if (g_js2t_deterministic && N < (1 << 30)) npb = (int)N;
     const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(N, npb));
-    if (L >= 65536) {  // (int arithmetic of the window kernel)
+    if (L >= 65536 && !g_js2t_deterministic) {  // (int arithmetic of the window kernel)
       DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_kernel<T>), dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(N, DW_SLAB)), dim3(256),
                                             0, s, (const T*)dy, (const T*)x, dw, L, N, C, K));
     } else if (K <= 15) {
@@ -417,16 +422,17 @@ extern "C" int js2t_bn_act_fwd(const void* x, const float* gamma, const float* b
   if (train) {
     JS2T_CHECK(ws, "bn_act_fwd: workspace required in train mode");
     JS2T_CHECK(cdiv(rows, BN_SLAB) <= 65535, "bn_act_fwd: too many rows");
-    const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, BN_SLAB));
+    const int64_t slab = g_js2t_deterministic ? rows : BN_SLAB;  // deterministic mode: one block, one ordered sum per column
+    const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, slab));
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, s);
     JS2T_CHECK(e == hipSuccess, "bn_act_fwd: memset failed: %s", hipGetErrorString(e));
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 0>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, nullptr,
-                                          nullptr, nullptr, nullptr, ws, nullptr, rows, C, act));
+                                          nullptr, nullptr, nullptr, ws, nullptr, rows, C, act, slab));
     JS2T_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_mean_kernel, cgrid, dim3(256), 0, s, ws, mean, rows, C);
     JS2T_LAUNCH_CHECK();
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 1>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)nullptr, mean, nullptr,
-                                          nullptr, nullptr, ws + C, nullptr, rows, C, act));
+                                          nullptr, nullptr, ws + C, nullptr, rows, C, act, slab));
     JS2T_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finalize_kernel, cgrid, dim3(256), 0, s, ws + C, mean, invstd, running_mean, running_var, rows, C, eps,
                        momentum);
@@ -450,9 +456,10 @@ extern "C" int js2t_bn_act_bwd(const void* dy, const void* x, const float* gamma
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, s);
   JS2T_CHECK(e == hipSuccess, "bn_act_bwd: memset failed: %s", hipGetErrorString(e));
-  const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, BN_SLAB));
+  const int64_t slab = g_js2t_deterministic ? rows : BN_SLAB;
+  const dim3 rgrid((unsigned)cdiv(C, 64), (unsigned)cdiv(rows, slab));
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_colreduce_kernel<T, 2>), rgrid, dim3(256), 0, s, (const T*)x, (const T*)dy, mean, invstd, gamma,
-                                        beta, ws, ws + C, rows, C, act));
+                                        beta, ws, ws + C, rows, C, act, slab));
   JS2T_LAUNCH_CHECK();
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((bn_act_dx_kernel<T>), dim3((unsigned)cdiv(rows * C, 256)), dim3(256), 0, s, (const T*)dy,
                                         (const T*)x, mean, invstd, gamma, beta, ws, ws + C, (T*)dx, rows, C, act, train));

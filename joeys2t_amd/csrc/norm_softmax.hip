@@ -769,11 +769,68 @@ extern "C" int js2t_rel_bias_add(void* S, const float* rel_bias, int64_t B, int6
   return JS2T_OK;
 }
 
+namespace {
+__global__ void fixed_to_float_add_kernel(const long long* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && src[i] != 0) dst[i] += (float)((double)src[i] * (1.0 / 4294967296.0) * (double)scale);
+}
+// deterministic form of rel_bias_grad_kernel: the same histogram in 2^-32 fixed point (integer atomics commute)
+template <typename T>
+__global__ void rel_bias_grad_fixed_kernel(const T* __restrict__ dS, unsigned long long* __restrict__ d_fix, int64_t B, int64_t H, int64_t Tq,
+                                           int64_t Tk, int64_t ld, int R, int64_t rows_per_block) {
+  extern __shared__ unsigned long long hist_i[];
+  const int W = 2 * R + 1;
+  const int64_t h = blockIdx.y;
+  for (int i = threadIdx.x; i < W; i += blockDim.x) hist_i[i] = 0ull;
+  __syncthreads();
+  const int64_t r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, B * Tq);
+  for (int64_t i = r0 * Tk + threadIdx.x; i < r1 * Tk; i += blockDim.x) {
+    const int64_t bq = i / Tk, k = i - bq * Tk, b = bq / Tq, q = bq - b * Tq;
+    const float g = io<T>::ld(dS + ((b * H + h) * Tq + q) * ld + k);
+    const int64_t dlt = k - q;
+    const int r = (int)(dlt < -R ? -R : (dlt > R ? R : dlt)) + R;
+    if (g != 0.f) atomicAdd(&hist_i[r], js2t_to_fixed(g));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += blockDim.x)
+    if (hist_i[i] != 0ull) atomicAdd(d_fix + h * W + i, hist_i[i]);
+}
+}  // namespace
+
+long long* js2t_fixed_scratch(size_t n) {
+  static long long* buf = nullptr;
+  static size_t cap = 0;
+  if (n > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr, cap = 0;
+    const size_t want = n < 65536 ? 65536 : n;
+    if (hipMalloc(&buf, want * sizeof(long long)) != hipSuccess) return nullptr;
+    cap = want;
+  }
+  return buf;
+}
+int js2t_fixed_to_float_add(const long long* src, float* dst, int64_t n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fixed_to_float_add_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, src, dst, n, scale);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 extern "C" int js2t_rel_bias_grad(const void* dS, float* d_rel_bias, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t ld,
                                   int32_t R, int dt, js2t_stream stream) {
   if (B * H * Tq * Tk == 0) return JS2T_OK;
   JS2T_CHECK(dS && d_rel_bias && R >= 0 && R <= 4096 && ld >= Tk && H <= 65535, "rel_bias_grad: bad arguments");
   const int64_t rows = B * Tq, rpb = 64;
+  if (g_js2t_deterministic) {  // js2t_set_deterministic: fixed-point histogram, then one conversion pass
+    const int64_t n = H * (2 * R + 1);
+    long long* fix = js2t_fixed_scratch((size_t)n);
+    JS2T_CHECK(fix != nullptr, "rel_bias_grad: scratch allocation failed");
+    JS2T_CHECK(hipMemsetAsync(fix, 0, (size_t)n * sizeof(long long), (hipStream_t)stream) == hipSuccess, "rel_bias_grad: memset failed");
+    DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_grad_fixed_kernel<T>), dim3((unsigned)cdiv(rows, rpb), (unsigned)H), dim3(256),
+                                          (size_t)(2 * R + 1) * sizeof(unsigned long long), (hipStream_t)stream, (const T*)dS,
+                                          (unsigned long long*)fix, B, H, Tq, Tk, ld, (int)R, rpb));
+    JS2T_LAUNCH_CHECK();
+    return js2t_fixed_to_float_add(fix, d_rel_bias, n, 1.f, (hipStream_t)stream);
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_grad_kernel<T>), dim3((unsigned)cdiv(rows, rpb), (unsigned)H), dim3(256),
                                         (size_t)(2 * R + 1) * sizeof(float), (hipStream_t)stream, (const T*)dS, d_rel_bias, B, H,
                                         Tq, Tk, ld, (int)R, rpb));

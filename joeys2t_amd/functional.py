@@ -877,14 +877,23 @@ class LinearFn(torch.autograd.Function):
             if len(LOGIT_GRAD_DTYPE) > 16:
                 LOGIT_GRAD_DTYPE.clear()
             LOGIT_GRAD_DTYPE[y.data_ptr()] = x2.dtype
+            ctx.y_ptr = y.data_ptr()
         return y.view(*shape[:-1], w_compute.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w = ctx.x2, ctx.w
-        ready = LOGIT_GRAD_READY.pop(dy.data_ptr(), None)
-        if ready is not None and ready[1].shape == dy.shape and ready[0].dtype == x2.dtype:
-            dy = ready[0].view(dy.shape)  # the loss wrote its gradient in this node's compute type (loss._XentFn.backward)
+        ready = LOGIT_GRAD_READY.pop(ctx.y_ptr, None) if getattr(ctx, "y_ptr", None) is not None else None
+        if ready is not None:
+            d_lp, ph = ready
+            is_placeholder = dy.data_ptr() == ph.data_ptr() and dy.shape == ph.shape and all(st == 0 for st in dy.stride())
+            if is_placeholder and d_lp.dtype == x2.dtype:
+                dy = d_lp.view(dy.shape)  # the loss wrote its gradient in this node's compute type (loss._XentFn.backward)
+            else:
+                # the loss handed its gradient over on the side and gave autograd a NaN placeholder; what arrived here is not that
+                # placeholder (a second consumer of the logits, a copy or a cast in between): its NaNs must not reach dX and dW
+                raise ops.Js2tError("LinearFn.backward: the loss handed its logit gradient over in the projection's compute type, but autograd "
+                                    "delivered a different tensor - the logits have another consumer or a copy sits between projection and loss")
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()

@@ -131,6 +131,7 @@ class GraphedTrainStep:
         step.external_lr = True                # ... and the rate arrives with the batch (one copy), not by a fill per step
         self.ntokens = 0
         self.counts = {"eager": 0, "replay": 0, "captured": 0, "evicted": 0}
+        self._plan_generation = step.optimizer.plan_generation  # update plan the captured graphs were made with (builders._fused_plan)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _bucket(self, key) -> _Bucket:
@@ -246,6 +247,14 @@ class GraphedTrainStep:
         bk.wave[:, :ncol].copy_(wave.index_select(0, bk.order)[:, :ncol])  # rows in sorted order (samples past an utterance are never read)
         self.ntokens += int((t[:, 1:] != self.pad_index).sum())
         # ---- run
+        if step.optimizer.plan_generation != self._plan_generation:
+            # the optimizer rebuilt its update plan (a new LayerNorm fold, another set of un-cleared gradient ranges) after graphs were
+            # captured: those graphs bake in the old tables and keep flags - a stale-plus-new gradient waiting to happen.  Drop them;
+            # every bucket is captured again at its next batch.
+            for other in self.buckets.values():
+                other.graph = None
+            self.counts["recaptured_after_plan_change"] = self.counts.get("recaptured_after_plan_change", 0) + 1
+            self._plan_generation = step.optimizer.plan_generation
         if bk.graph is not None:
             bk.graph.replay()
             bk.replays += 1

@@ -48,7 +48,9 @@ class _XentFn(torch.autograd.Function):
             ph = nan.expand(ctx.shape)  # no memory, no kernel - and NaN everywhere should anything ever read it
             if len(Fn.LOGIT_GRAD_READY) > 16:  # (entries whose consumer never ran)
                 Fn.LOGIT_GRAD_READY.clear()
-            Fn.LOGIT_GRAD_READY[ph.data_ptr()] = (d, ph)
+            # keyed by the LOGITS (the projection's output storage), not by the placeholder: the cached NaN scalar has one address for
+            # every call, and two losses of one backward pass would collide on it
+            Fn.LOGIT_GRAD_READY[ctx.l2.data_ptr()] = (d, ph)
             return ph, None, None, None
         d = ops.xent_bwd(ctx.l2, ctx.t1, ctx.lse, g, 1.0, ctx.pad_index, ctx.smoothing)
         return d.view(ctx.shape), None, None, None
@@ -59,6 +61,11 @@ class _CtcFn(torch.autograd.Function):
     def forward(ctx, logits, targets, in_len, tgt_len, blank, zero_infinity):
         B, T, V = logits.shape
         l3 = logits.contiguous()
+        # f32 logits of a bf16 projection are registered for the cross-entropy's bf16 hand-over (functional.LOGIT_GRAD_DTYPE); this
+        # loss takes its gradient the ordinary way, so the entry goes now - left behind, the address could be reused by f32 logits of
+        # another producer within the step and send THEIR cross-entropy onto the hand-over path
+        from joeys2t_amd import functional as Fn
+        Fn.LOGIT_GRAD_DTYPE.pop(logits.data_ptr(), None)
         targets = targets.contiguous()
         in_len = in_len.to(torch.int64).contiguous()
         tgt_len = tgt_len.to(torch.int64).contiguous()

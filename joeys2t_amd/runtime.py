@@ -129,6 +129,7 @@ class ParamStore:
         # LayerNorm folds (fold()): derived weights per (LayerNorm, Linear group) pair + the table js2t_fold_ln_weights walks
         self._folds: Dict[Tuple, LnFold] = {}
         self._fold_rows: List[List[int]] = []
+        self._retired_fold_tables: List[torch.Tensor] = []
         self._fold_table: Optional[torch.Tensor] = None
         self._fold_max_rows = 0
 
@@ -155,6 +156,8 @@ class ParamStore:
         self._fold_rows.append([w32.data_ptr(), gamma.data.data_ptr(), beta.data.data_ptr(), b32.data_ptr(), f.w.data_ptr(),
                                 f.bias.data_ptr(), N, K])
         self._fold_max_rows = max(self._fold_max_rows, N)
+        if self._fold_table is not None:  # a captured refresh_folds() launch may still read it: kept, not freed (builders._fused_plan)
+            self._retired_fold_tables.append(self._fold_table)
         self._fold_table = None
         row = torch.tensor([self._fold_rows[-1]], dtype=torch.int64, device=self.device)
         ops.fold_ln_weights(row, 1, N)  # this pair now; all pairs together after every update (refresh_folds)

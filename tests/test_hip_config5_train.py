@@ -241,3 +241,62 @@ def test_conformer_train_step_bf16_and_fp8_forward(device):
     for a, b in zip(l8, l16):
         assert abs(a - b) <= 6e-2 * abs(b), (l8, l16)
     assert l16[-1] < l16[0] and l8[-1] < l8[0] and all(np.isfinite(l8))
+
+
+def _soak(device, dtype, steps=10, deterministic=True):
+    """a small config-5 model (head size 64: the fused attention kernels with the relative-position bias; depthwise convolution,
+    BatchNorm) trained for a few updates on two fixed batches -> (losses per update, parameters, Adam moments)"""
+    from joeys2t_amd._lib import lib
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    V = 40
+    torch.manual_seed(11)
+    cfg = conformer_cfg(d=128, ff=256, heads=2, layers=2, in_ch=16, conv_ch=48, dwk=7, rel=6, dropout=0.1, dec_layers=1)
+    model = build_model(copy.deepcopy(cfg), None, Vocabulary.synthetic(V))
+    model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+    with torch.no_grad():
+        for layer in model.encoder.layers:
+            layer.src_src_att.rel_pos_bias.normal_(0.0, 0.1, generator=torch.Generator().manual_seed(3))
+    model.finalize(device, dtype, seed=11)
+    g = torch.Generator().manual_seed(23)
+    data = []
+    for s in range(2):
+        lengths = torch.tensor([150, 141, 120, 97, 96])
+        src = torch.randn(5, 150, 16, generator=g)
+        for b in range(5):
+            src[b, lengths[b]:] = 1.0
+        data.append(_batch_from(src if dtype == torch.float32 else src.to(dtype).float(), lengths, V, 40 + s, device)[0])
+    try:
+        step = TrainStep(model, learning_rate=2e-3, adam_betas=(0.9, 0.98), clip_grad_norm=1.0, learning_rate_warmup=4, overlap_ctc=True,
+                         deterministic=deterministic)
+        losses = []
+        for i in range(steps):
+            b = copy.copy(data[i % 2])
+            if dtype != torch.float32:
+                b.src = data[i % 2].src.to(dtype)
+            step.micro_step(b)
+            losses.append(step.read_stats()["loss"])
+        torch.cuda.synchronize()
+        return losses, step.store.flat.clone(), step.optimizer.exp_avg.clone(), step.optimizer.exp_avg_sq.clone()
+    finally:
+        lib().js2t_set_deterministic(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_config5_deterministic_runs_agree_and_train(device, dtype):
+    """js2t_set_deterministic now also orders the extension kernels' sums - the relative-position bias gradient (2^-32 fixed-point
+    histogram: integer atomics commute), the depthwise-convolution weight gradient and the BatchNorm statistics / parameter
+    gradients (one block per column group): two runs of ten updates agree BIT FOR BIT (bf16: the fused attention kernels; fp32: the
+    materialised path), and the loss goes down."""
+    a = _soak(device, dtype)
+    b = _soak(device, dtype)
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, name in zip(a[1:], b[1:], ("parameters", "exp_avg", "exp_avg_sq")):
+        assert torch.equal(x, y), (name, (x - y).abs().max().item(), int((x != y).sum()))
+    losses = a[0]
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < 0.8 * max(losses[:2]), losses
+    # the ordered forms compute the default step's numbers (other orders of the same sums)
+    c = _soak(device, dtype, deterministic=False)
+    for u, v in zip(a[0][:3], c[0][:3]):
+        assert abs(u - v) <= (2e-2 if dtype == torch.bfloat16 else 1e-4) * abs(v), (a[0], c[0])

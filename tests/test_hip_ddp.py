@@ -228,8 +228,9 @@ def _cabi_step_worker(rank, port, ret):
     try:
         step, got = run("cabi")
         used = step.reducer is not None and step.reducer.comm is not None and len(step.reducer.works) == len(step.reducer.ranges)
+        ranges = [tuple(r) for r in step.reducer.ranges]
         step.reducer.comm.close()
-        ret["res"] = (plain, got, used)
+        ret["res"] = (plain, got, used, ranges)
     finally:
         dist.destroy_process_group()
 
@@ -238,12 +239,17 @@ def test_train_step_with_the_exchange_through_the_c_boundary(device):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_cabi_step_worker, args=(_free_port(), ret), nprocs=1, join=True)
-    plain, got, used = ret["res"]
+    plain, got, used, ranges = ret["res"]
     assert used  # every range of the flat gradient went through js2t_comm_allreduce_async
     # two runs of the same two steps differ where an f32 atomic in backward flips the sign of a near-zero gradient (Adam's first steps move
     # every coordinate by ~lr whatever its gradient's size): a handful of coordinates, each by less than the learning rate.  A range that
     # went out before its products had run would be off by the learning rate everywhere in it.
     diff = (plain - got).abs()
-    assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 2e-2  # (0.1 - 0.5 % of the coordinates, run to run)
+    assert diff.max().item() < 1e-2 and (diff > 1e-6).float().mean().item() < 1e-2  # (0.1 - 0.5 % of the coordinates, run to run)
     # (1e-4 - 4e-4 run to run; a range exchanged too early is off by the learning rate in every coordinate: > 1e-2 of the norm)
     assert (diff.norm() / plain.norm()).item() < 2e-3
+    # ... and range by range, so that a SHORT range that left before its products had run cannot hide under the global bounds: in
+    # such a range (nearly) every coordinate is off by about the learning rate (1e-2); run-to-run noise touches well under a percent
+    for lo, hi in ranges:
+        off = (diff[lo:hi] > 1e-3).float().mean().item()
+        assert off < 0.05, (lo, hi, off)

@@ -721,6 +721,56 @@ def test_gemm_p192_variants_agree_on_random_shapes(device, seed):
         torch.testing.assert_close(outs[3].float().cpu(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(12000, 1536, 512, "qkv"), (12000, 2048, 512, "ffn1"), (12000, 2048, 512, "gate"), (11975, 1000, 256, "bias"),
+                                       (4111, 2048, 512, "ffn1_eval"), (8200, 200, 384, "gate"), (9000, 5000, 512, "bias"), (3000, 2048, 128, "ffn1_nofold"),
+                                       (12000, 512, 512, "plain")])
+def test_gemm_panel_identical_to_persistent(device, M, N, K, kind):
+    """The panel-resident kernel (csrc/gemm_panel.hip: a 96-column panel of B in LDS, every wave streams its own rows) against the
+    persistent 192 x 128 kernels: BIT-identical results - ragged last strip, partial last panel (also one whose lanes own fewer than
+    three column pairs), K = 128 .. 512, every epilogue it carries (bias, folded LayerNorm + its mean / rstd side outputs, ReLU,
+    dropout, gate)."""
+    from joeys2t_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(device)
+    B = (torch.randn(N, K, generator=g) / K**0.5).bfloat16().to(device)
+    kw = {}
+    if kind in ("bias", "qkv", "ffn1", "ffn1_eval", "ffn1_nofold"):
+        kw["bias"] = torch.randn(N, generator=g).to(device)
+    if kind in ("ffn1", "ffn1_eval", "ffn1_nofold"):
+        kw["act"] = "relu"
+    if kind in ("ffn1", "ffn1_nofold"):
+        kw.update(dropout_p=0.1, rng=ops.dropout_rng(device), rng_stream=5)
+    if kind in ("qkv", "ffn1", "ffn1_eval"):
+        part = (torch.randn(M, 8, 2, generator=g).abs() * 30.0 + 40.0).to(device)  # sums / sums of squares of a plausible row
+        part[:, :, 0] *= 0.01
+        kw["ln"] = (part, 1e-6, torch.zeros(M, device=device), torch.zeros(M, device=device))
+    if kind == "gate":
+        kw.update(gate=torch.randn(M, N, generator=g).bfloat16().to(device), ldg=N, gate_scale=1.0 / 0.9)
+    outs, stats = [], []
+    try:
+        lib().js2t_gemm_p192_mode(1)
+        for mode in (1, 0):
+            lib().js2t_gemm_panel_mode(mode)
+            Cc = torch.full((M, N), float("nan"), device=device, dtype=torch.bfloat16)
+            if "ln" in kw:
+                kw["ln"][2].zero_(), kw["ln"][3].zero_()
+            ops.gemm(A, B, Cc, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, **kw)
+            torch.cuda.synchronize()
+            outs.append(Cc)
+            if "ln" in kw:
+                stats.append((kw["ln"][2].clone(), kw["ln"][3].clone()))
+    finally:
+        lib().js2t_gemm_panel_mode(-1)
+        lib().js2t_gemm_p192_mode(-1)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), (M, N, K, kind, int((outs[0] != outs[1]).sum()))
+    for a, b in zip(*stats) if stats else []:
+        assert torch.equal(a, b)
+    if kind == "plain":
+        ref = A.float().cpu() @ B.float().cpu().t()
+        torch.testing.assert_close(outs[0].float().cpu(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
+
+
 def test_transposed_weight_shadow(device):
     """ParamStore.view_t: the transposed bf16 shadow of fused / single 2-D weights follows the parameters (also after an update)."""
     from joeys2t_amd.runtime import ParamStore
