@@ -155,6 +155,12 @@ void js2t_gemm_force_w256(int on);
  * js2t_gemm_grouped (f32 result, N % 128 == 0, M % 8 == 0, no split-K; only in mode 1): 0 = never, 1 = every product
  * that qualifies (test hook), -1 = k-contiguous products that qualify and have >= 200 tiles (default). */
 void js2t_gemm_p192_mode(int mode);
+/* Kernel selection inside js2t_gemm_grouped for the 256x128 three-slot-ring kernel (reduction-major bf16 operands, f32 result,
+ * M % 256 == 0, N % 128 == 0, no split-K, 16-byte aligned C; rowsum / sumsq_partial / beta as the 128x128 kernel, products
+ * bit-identical to it): 0 = never, 1 = every launch that qualifies (test hook), -1 = launches of >= 160 such tiles over
+ * K >= 1024 (default: the deferred weight gradients of the FFN / QKV layers, training.py:570-588 of the reference -
+ * loss.backward() forms them one by one). */
+void js2t_gemm_wg256_mode(int mode);
 /* Variant of the persistent 192x128 kernel: 3 = one block per CU with two stages in flight, 2 = two blocks per CU
  * with one stage in flight each (80 KB of LDS per block), 4 = one block per CU of eight multiplying and four
  * requesting waves, anything else = chosen per launch (default: 2 when the product has at least 1.5 tiles per CU,
@@ -654,8 +660,11 @@ typedef struct js2t_attn_desc {
    * an utterance's length are dead): device int32 [B + 1]; batch entry b owns rows seg[b] .. seg[b+1] of q / k / v / o / d_o /
    * dq / dk / dv and has seg[b+1] - seg[b] <= Tq positions.  Tq == Tk is then the longest entry: it shapes the grid, lse / delta
    * ([B*H, Tq]) and the mask rows, and keeps the dropout counters those of the padded layout.  Tiles behind an entry's length
-   * are not touched; rows of the buffers no entry owns are not written. */
+   * are not touched.  seg_rows = rows of the packed buffers (>= seg[B]; callers round it up to a bucket): rows seg[B] .. seg_rows of
+   * o (forward) / dq, dk, dv (backward), which no entry owns, are ZEROED by the kernels - they are read by the products behind
+   * (whose column sums - weight gradients, bias gradients - run over all rows); 0: not written, the caller's business. */
   const int32_t* seg;
+  int64_t seg_rows;
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);

@@ -64,7 +64,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float), ("dropout_p", C.c_float),
         ("rng_state", C.c_void_p), ("rng_stream", C.c_uint32),
         ("rel_R", C.c_int32), ("rel_bias", C.c_void_p), ("d_rel_bias", C.c_void_p),
-        ("delta_partial", C.c_void_p), ("delta_groups", C.c_int32), ("seg", C.c_void_p),
+        ("delta_partial", C.c_void_p), ("delta_groups", C.c_int32), ("seg", C.c_void_p), ("seg_rows", C.c_int64),
     ]
 
 
@@ -97,6 +97,8 @@ def lib():
         _lib.js2t_gemm_grouped_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)
             _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
+        if "JS2T_WG256" in os.environ:  # 0 / 1 / -1: the 256x128 kernel of the grouped weight gradients (js2t_gemm_wg256_mode)
+            _lib.js2t_gemm_wg256_mode(int(os.environ["JS2T_WG256"]))
         if "JS2T_P192_RING" in os.environ:  # 2 = two blocks per CU with a two-slot ring (js2t_gemm_p192_ring)
             _lib.js2t_gemm_p192_ring(int(os.environ["JS2T_P192_RING"]))
     return _lib

@@ -56,6 +56,7 @@ struct AttnArgs {
   int dgroups;
   const int32_t* seg;  // packed rows (js2t_attn_desc.seg): entry b owns rows seg[b] .. seg[b+1] of every buffer; NULL: b * Tq ..
   unsigned long long* d_rel_fix;  // deterministic mode: the bias gradient as 2^-32 fixed-point sums [H, 2R+1] (common.hpp), else NULL
+  int seg_rows;  // packed rows: rows of the buffers; seg[B] .. seg_rows belong to nobody and are zeroed (0: left alone)
 };
 // where batch entry b lives: first row in the query-side and key-side buffers, its own lengths.  a.Tq / a.Tk stay the PADDED
 // lengths: grid shape, [B*H, Tq] scalars (lse, delta), mask rows and the dropout counter (z * Tq + q: the packed layout draws the
@@ -77,6 +78,12 @@ __device__ __forceinline__ float load_delta(const AttnArgs& a, int row0, int h, 
     return DH == 128 ? pp[0] + pp[1] : pp[0];
   }
   return a.delta[(int64_t)z * a.Tq + qc];
+}
+// packed rows: the rows behind the last entry (js2t_attn_desc.seg_rows), zeroed by the grid as a whole - block bid of nblk takes
+// rows seg[B] + bid, + nblk, ..: at most one row each for an encoder layer's grid (a launch of its own cost 4.8 us, 32 times a step)
+__device__ __forceinline__ void zero_tail_rows(const AttnArgs& a, uint16_t* base, int64_t ld, int width, int bid, int nblk) {
+  for (int row = a.seg[a.B] + bid; row < a.seg_rows; row += nblk)
+    for (int c = 4 * (int)threadIdx.x; c < width; c += 1024) *(uint2*)(base + (int64_t)row * ld + c) = make_uint2(0u, 0u);
 }
 constexpr int REL_MAX = 255;  // largest clipping distance: the per-head table (2 * 255 + 1 floats) is staged in LDS
 // the head's bias table in base-2 units, staged once per block
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const int q0 = (lid - z * ntile) * 64 + w * 16;
   const Seg sg = seg_of(a, b);
   const int Tq = sg.Tq, Tk = sg.Tk;
+  if (a.seg_rows) zero_tail_rows(a, a.out, a.ldo, a.H * DH, blockIdx.x, gridDim.x);
   if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
   const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
@@ -484,6 +492,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const int q0 = (lid - z * ntile) * 64 + w * 16;
   const Seg sg = seg_of(a, b);
   const int Tq = sg.Tq, Tk = sg.Tk;
+  if (a.seg_rows) zero_tail_rows(a, a.dq, a.lddq, a.H * DH, bid, nblk);
   if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
   const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
@@ -684,6 +693,10 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   const int k0 = (lid - z * ntile) * 64 + w * 16;
   const Seg sg = seg_of(a, b);
   const int Tq = sg.Tq, Tk = sg.Tk;
+  if (a.seg_rows) {
+    zero_tail_rows(a, a.dk, a.lddk, a.H * DH, bid, nblk);
+    zero_tail_rows(a, a.dv, a.lddv, a.H * DH, bid, nblk);
+  }
   if (k0 - w * 16 >= Tk) return;  // packed rows: a tile behind this utterance's last key (block-uniform, before any barrier)
   const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
@@ -842,6 +855,7 @@ int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK(!d->rel_bias || (d->rel_R >= 1 && d->rel_R <= REL_MAX), "flash_attn: rel_R must be 1..%d", REL_MAX);
   JS2T_CHECK(!d->d_rel_bias || d->rel_bias, "flash_attn: d_rel_bias without rel_bias");
   JS2T_CHECK(!d->seg || d->Tq == d->Tk, "flash_attn: packed rows (seg) are for self-attention, Tq == Tk = the longest entry");
+  JS2T_CHECK(!d->seg || (d->seg_rows >= 0 && d->seg_rows < (1ll << 31) && ((d->H * d->head_dim) & 3) == 0), "flash_attn: bad seg_rows");
   return JS2T_OK;
 }
 
@@ -858,6 +872,7 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.rel = d->rel_bias; a.d_rel = d->d_rel_bias; a.relR = d->rel_bias ? d->rel_R : 0;
   a.dpart = d->delta_partial; a.dgroups = d->delta_groups;
   a.seg = d->seg;
+  a.seg_rows = d->seg ? (int)d->seg_rows : 0;
   a.d_rel_fix = nullptr;
   return a;
 }

@@ -2471,6 +2471,210 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192t_kernel(js2t_gemm_desc 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x128x64 tile, 8 multiplying waves of 64x64 + 4 requesting waves, three-slot DMA ring: the big grouped weight gradients
+// C_g[M,N] (f32) = alpha * A_g[K,M]^T B_g[K,N] + beta * C_g, optional row sums of A_g^T, optional tile sums of squares
+// ------------------------------------------------------------------------------------------------
+// The two-stage 128x128 kernel pulls 32 KB from L2 per 2.1 MFLOP and every wave requests its share of a stage itself.  This tile
+// moves 48 KB per 4.2 MFLOP (0.75 x the bytes per flop), keeps TWO stages in flight behind the one being multiplied, and
+// separates the roles: a first version whose eight waves requested their own pieces (six each, in the second k-half) ran at
+// 2150 clocks per stage against 1024 of MFMA work - a global_load_lds occupies its wave for ~18 clocks per KB while the CU's
+// one address path serialises the 48 requests of a stage, so the wave served first stood 650 clocks at the barrier waiting for
+// the one served last, and nobody multiplied meanwhile (profiles/r05_wg256_v1_selfloading_*.txt: x1.00 - 1.09 over 128x128).
+//  * stage = two [64 k][128 m] images of A^T (columns m0.. and m0 + 128..) + one [64 k][128 n] image of B^T, the 256-byte-row
+//    layout of the two-stage kernel (XOR key tr_g(k) on the 32-byte column groups, two ds_read_b64_tr_b16 per fragment);
+//    requesting wave l of 4 sends the four 1 KB pieces 4l .. 4l + 3 of each image (12 requests per stage); rows k >= K of a
+//    partial last stage come from a 16-byte zero constant;
+//  * one raw s_barrier per stage for all twelve waves, in the MIDDLE of the multiplying waves' stage (the scheme of
+//    gemm_bf16_p192t_kernel): by then they hold the second k-half of stage s in registers, and a requesting wave arrives once
+//    its counted vmcnt has retired its pieces of stage s + 1; behind the barrier slot s % 3 takes stage s + 3 while the second
+//    half of s and the first half of s + 1 are multiplied;
+//  * fragments are double-buffered by k-half, the order "four products, four transposing reads" is pinned by scheduling barriers
+//    (left alone the compiler issues sixteen products, then sixteen reads, and waits); requests past the last stage re-read
+//    stage 0 into a dead slot so that the counted waits need no branches;
+//  * multiplying wave (wm, wn) of 4 x 2 owns C rows 64 wm .. + 63, columns 64 wn .. + 63: the accumulator layout, the MFMA
+//    operand order and the k order are those of the 128x128 kernel, so the products are bit-identical to it; a tile is >= 100 us
+//    of work, its epilogue (16-byte f32 pieces straight from the registers, read-modify-write for beta) does not matter.
+// M % 256 == 0, N % 128 == 0 (weight shapes); one tile per block, blocks of a member neighbours in the XCD-aware order.
+constexpr int WG_IMG = 16384, WG_STAGE = 3 * WG_IMG, WG_NST = 3, WG_LDS = WG_NST * WG_STAGE, WG_PER = 12;
+
+template <bool RS>
+__global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tiles = tiles_m * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mem = lid / tiles, tile = lid - mem * tiles;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+  const int K = d.K, nk = (K + 63) >> 6;
+  float ss = 0.f;
+
+  if (w >= 8) {
+    // ---- requesting waves
+    const int l = w - 8;
+    const int64_t lda = d.lda, ldb = d.ldb;
+    const uint16_t* zsrc = (const uint16_t*)&g_zero16;
+    const uint16_t* src[12];  // this lane's 16 bytes of pieces 4l + q of A0 (0-3), A1 (4-7), B (8-11) at k = 0
+    int krow[4];
+    {
+      const uint16_t* Ab = (const uint16_t*)grp.A[mem];
+      const uint16_t* Bb = (const uint16_t*)grp.B[mem];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = (l * 4 + q) * 64 + lane, kr = p >> 4, col = (((p & 15) ^ (tr_g(kr) << 1)) << 3);
+        krow[q] = kr;
+        src[q] = Ab + (int64_t)kr * lda + m0 + col;
+        src[4 + q] = Ab + (int64_t)kr * lda + m0 + 128 + col;
+        src[8 + q] = Bb + (int64_t)kr * ldb + n0 + col;
+      }
+    }
+    auto issue_stage = [&](int st, int slot) {  // st, slot wave-uniform
+      const int k0 = st < nk ? st << 6 : 0;    // past the end: stage 0 again, into a slot nobody reads
+      const int64_t ka = (int64_t)k0 * lda, kb = (int64_t)k0 * ldb;
+      const int klim = K - k0;
+      unsigned char* stp = smem + slot * WG_STAGE + l * 4096;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const uint16_t* sp = src[q] + (q < 8 ? ka : kb);
+        if (klim < 64) {  // partial last stage (wave-uniform test)
+          if (krow[q & 3] >= klim) sp = zsrc;
+        }
+        lds_dma16(sp, stp + (q >> 2) * WG_IMG + (q & 3) * 1024);
+      }
+    };
+    issue_stage(0, 0);
+    issue_stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_PER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_stage(2, 2);
+    int cslot = 0;
+    for (int s = 0; s < nk; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_PER) : "memory");  // own pieces of stage s + 1 (stage s + 2 stays in flight)
+      __builtin_amdgcn_s_barrier();                                  // the multiplying waves are through with slot s % 3
+      asm volatile("" ::: "memory");
+      issue_stage(s + 3, cslot);
+      cslot = cslot == WG_NST - 1 ? 0 : cslot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the end
+  } else {
+    // ---- multiplying waves
+    const int wm = w >> 1, wn = w & 1;
+    const int a_img = (wm >> 1) * WG_IMG, a_sub = (wm & 1) * 64, b_sub = wn * 64;
+    bf16x8_t fm0[4], fn0[4], fm1[4], fn1[4];
+    f32x4_t acc[4][4], racc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      racc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_rs = RS && n0 == 0 && wn == 0 && grp.rowsum[mem] != nullptr;
+    typedef __attribute__((ext_vector_type(8))) short s16x8_ones_t;
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, s16x8_ones_t{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80});
+
+    __builtin_amdgcn_s_barrier();  // stage 0 has landed
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fm0[i] = frag_load2<true>(smem + a_img, a_sub + 16 * i, 0, lane);
+      fn0[i] = frag_load2<true>(smem + 2 * WG_IMG, b_sub + 16 * i, 0, lane);
+    }
+    int cslot = 0;
+#ifdef JS2T_P192_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
+    for (int s = 0; s < nk; ++s) {
+      const unsigned char* cst = smem + cslot * WG_STAGE;
+      // first k-half of stage s; its second half's fragments are read underneath, B's first: the next half's first products want
+      // all of B and one block of A
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn0[j], fm0[i], acc[i][j], 0, 0, 0);
+        if (i < 2) {
+          fn1[2 * i] = frag_load2<true>(cst + 2 * WG_IMG, b_sub + 32 * i, 1, lane);
+          fn1[2 * i + 1] = frag_load2<true>(cst + 2 * WG_IMG, b_sub + 32 * i + 16, 1, lane);
+        } else {
+          fm1[2 * i - 4] = frag_load2<true>(cst + a_img, a_sub + 32 * (i - 2), 1, lane);
+          fm1[2 * i - 3] = frag_load2<true>(cst + a_img, a_sub + 32 * (i - 2) + 16, 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (RS && do_rs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm0[i], racc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      P192_T(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own reads of slot s % 3
+      P192_T(1);
+      __builtin_amdgcn_s_barrier();                       // stage s + 1 has landed; slot s % 3 goes to the requesting waves
+      asm volatile("" ::: "memory");
+      P192_T(2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int nslot = cslot == WG_NST - 1 ? 0 : cslot + 1;
+      const unsigned char* nst = smem + nslot * WG_STAGE;
+      // second k-half of stage s; the first half of stage s + 1 is read underneath
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn1[j], fm1[i], acc[i][j], 0, 0, 0);
+        if (i < 2) {
+          fn0[2 * i] = frag_load2<true>(nst + 2 * WG_IMG, b_sub + 32 * i, 0, lane);
+          fn0[2 * i + 1] = frag_load2<true>(nst + 2 * WG_IMG, b_sub + 32 * i + 16, 0, lane);
+        } else {
+          fm0[2 * i - 4] = frag_load2<true>(nst + a_img, a_sub + 32 * (i - 2), 0, lane);
+          fm0[2 * i - 3] = frag_load2<true>(nst + a_img, a_sub + 32 * (i - 2) + 16, 0, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (RS && do_rs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fm1[i], racc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      P192_T(3);
+      cslot = nslot;
+    }
+#ifdef JS2T_P192_PROF
+    if (blockIdx.x == 0 && t == 0)
+      for (int i = 0; i < 8; ++i) g_p192_prof[i] = prof_[i];
+#endif
+
+    // ---- epilogue: lane (g = lane >> 4, r = lane & 15) holds C[16 i + r][16 j + 4 g .. + 3] of its wave's 64 x 64
+    const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f), beta = d.beta;
+    float* Cb = (float*)grp.C[mem] + (int64_t)(m0 + wm * 64 + (lane & 15)) * d.ldc + n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* crow = Cb + (int64_t)(16 * i) * d.ldc;
+      float4 old[4];
+      if (beta != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) old[j] = *(const float4*)(crow + 16 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = make_float4(acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+        if (beta != 0.f) v.x += beta * old[j].x, v.y += beta * old[j].y, v.z += beta * old[j].z, v.w += beta * old[j].w;
+        *(float4*)(crow + 16 * j) = v;
+        ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+      }
+    }
+    if (RS && do_rs && (lane >> 4) == 0) {  // every output row of the ones-product holds the same sums: take row 0
+      typedef __attribute__((address_space(1))) float gfloat;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)grp.rowsum[mem] + m0 + wm * 64 + 16 * i + lane, racc[i][0]);
+    }
+  }
+  if (d.sumsq_partial) {  // two entries per block: the launch is accounted in 128 x 128 tiles (js2t_gemm_grouped_blocks)
+    ss = block_sum(ss, (float*)smem);  // (starts with a barrier: every wave's requests have landed, every fragment has been read)
+    if (t == 0) d.sumsq_partial[2 * blockIdx.x] = ss, d.sumsq_partial[2 * blockIdx.x + 1] = 0.f;
+  }
+}
+
 // 0 = never, 1 = whenever the product qualifies, -1 = when it qualifies and fills the chip (default)
 int g_p192_mode = -1;
 inline bool p192_eligible(const js2t_gemm_desc& d) {
@@ -2731,6 +2935,33 @@ static int launch_grouped_p192t(const js2t_gemm_desc& d, const GemmGroup& grp, i
   return JS2T_OK;
 }
 
+// -1 (default): the grouped launches that fill the chip with 256x128 tiles over a long reduction; 0: never; 1: whenever the shape allows
+int g_wg256_mode = -1;
+extern "C" void js2t_gemm_wg256_mode(int mode) { g_wg256_mode = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+static bool wg256_eligible(const js2t_gemm_desc& d, int count) {
+  if (g_wg256_mode == 0 || d.split_k > 1 || d.dtype_c != JS2T_F32) return false;
+  if ((d.M & 255) || (d.N & 127) || (d.ldc & 3) || d.K < 192) return false;
+  if (g_wg256_mode == 1) return true;
+  const int64_t tiles = (int64_t)(d.M >> 8) * (d.N >> 7) * count;
+  return d.K >= 1024 && tiles >= 160;  // one block per CU: below that most of the chip idles, the 128x128 tiles spread further
+}
+template <bool RS>
+static int launch_grouped_wg256(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_wg256_kernel<RS>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    if (e != hipSuccess) {
+      js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return JS2T_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int tm = d.M >> 8, tn = d.N >> 7;
+  hipLaunchKernelGGL(gemm_bf16_wg256_kernel<RS>, dim3(tm * tn * count), dim3(768), WG_LDS, s, d, grp, tm, tn);
+  JS2T_LAUNCH_CHECK();
+  return JS2T_OK;
+}
+
 extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const void* const* A, const void* const* B, void* const* C,
                                  float* const* a_rowsum, js2t_stream stream) {
   JS2T_CHECK(dp != nullptr && count >= 0, "gemm_grouped: bad arguments");
@@ -2764,7 +2995,11 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
     }
     d.A = grp.A[0], d.B = grp.B[0], d.C = grp.C[0];
     int rc;
-    if (!d.sumsq_partial && p192t_eligible(d, n)) {
+    bool c16 = true;  // (the 256x128 kernel stores 16-byte pieces)
+    for (int i = 0; i < n; ++i) c16 = c16 && aligned16(grp.C[i]);
+    if (c16 && wg256_eligible(d, n)) {
+      rc = a_rowsum ? launch_grouped_wg256<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_wg256<false>(d, grp, n, (hipStream_t)stream);
+    } else if (!d.sumsq_partial && p192t_eligible(d, n)) {
       rc = a_rowsum ? launch_grouped_p192t<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_p192t<false>(d, grp, n, (hipStream_t)stream);
     } else {
       rc = d.split_k > 1 ? launch_grouped_tt<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_tt<false>(d, grp, n, (hipStream_t)stream);

@@ -677,9 +677,7 @@ class ResidualBlockFn(torch.autograd.Function):
                                                     dot_src=c if fused else None)
             dpart, LINEAR_BWD_DOT[0] = LINEAR_BWD_DOT[0], None
             qkv = sv["qkv"]
-            dqkv = torch.empty_like(qkv)
-            if sv["shp"].seg is not None:
-                ops.zero_tail_rows(dqkv, sv["shp"].seg)  # rows no utterance owns: not written by the kernels, read by the next product
+            dqkv = torch.empty_like(qkv)  # (packed rows: the kernels zero the rows no utterance owns - the next product reads them)
             rel, d_rel = wts.get("rel_bias"), None
             if rel is not None:
                 d_rel = sk("rel_bias")  # the parameter's slice of the flat gradient: the kernel adds into it

@@ -1057,9 +1057,7 @@ def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
     if seg is not None:
-        d.seg = seg.seg.data_ptr()
-        if seg.rows > 0:
-            zero_tail_rows(out, seg)
+        d.seg, d.seg_rows = seg.seg.data_ptr(), seg.rows  # rows no entry owns are zeroed by the kernel
     check(lib().js2t_flash_attn_fwd(C.byref(d), _stream()), "js2t_flash_attn_fwd")
     return out, lse
 
@@ -1067,7 +1065,7 @@ def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p
 def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
                    dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None, seg: PackedRows = None):
     """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating.
-    seg: packed rows, as in flash_attn_fwd; rows of dq / dk / dv no entry owns are NOT written (the caller zeroes them).
+    seg: packed rows, as in flash_attn_fwd; rows of dq / dk / dv no entry owns are zeroed by the kernels (js2t_attn_desc.seg_rows).
     delta_partial f32 [B*Tq, H*dh // 64]: rowsum(dout * out) as partial sums per 64-column group (gemm(dot=...) of the product that
     made dout) - the two passes then run as one grid and `out` is not read."""
     _dev(dout, out, lse, q_t, k_t, v_t, dq_t, dk_t, dv_t, mask, rel_bias, d_rel_bias, delta_partial)
@@ -1075,7 +1073,7 @@ def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_
     nrows = B * Tq
     if seg is not None:
         _seg_check(seg, q_t, B, Tq, Tk)
-        d.seg, nrows = seg.seg.data_ptr(), seg.rows
+        d.seg, d.seg_rows, nrows = seg.seg.data_ptr(), seg.rows, seg.rows
     if d_rel_bias is not None:
         if rel_bias is None or d_rel_bias.shape != rel_bias.shape or d_rel_bias.dtype != torch.float32 or not d_rel_bias.is_contiguous():
             raise Js2tError("d_rel_bias must be a contiguous float32 tensor shaped like rel_bias")

@@ -77,7 +77,7 @@ def test_range_set():
 
 
 def test_attn_desc_matches_header_layout():
-    """the ctypes mirror of js2t_attn_desc ends with the round-4 fields, in the header's order"""
+    """the ctypes mirror of js2t_attn_desc ends with the round-4 / round-5 fields, in the header's order"""
     import re
     from joeys2t_amd._lib import HEADER_PATH, AttnDesc
     text = HEADER_PATH.read_text()
@@ -86,7 +86,7 @@ def test_attn_desc_matches_header_layout():
     names = [m.group(1) for m in re.finditer(r"(\w+)\s*(?:;|,)", body)]
     mirror = [f[0] for f in AttnDesc._fields_]
     assert [n for n in names if n in mirror] == mirror, (names, mirror)
-    assert mirror[-3:] == ["delta_partial", "delta_groups", "seg"]
+    assert mirror[-4:] == ["delta_partial", "delta_groups", "seg", "seg_rows"]
 
 
 def test_packed_rows_host_logic():

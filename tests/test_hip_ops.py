@@ -770,6 +770,43 @@ def test_gemm_panel_identical_to_persistent(device, M, N, K, kind):
         ref = A.float().cpu() @ B.float().cpu().t()
         torch.testing.assert_close(outs[0].float().cpu(), ref.bfloat16().float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
 
+@pytest.mark.parametrize("n,M,N,K,beta,extras", [(3, 512, 256, 1000, 0.0, True), (2, 256, 128, 200, 1.0, False), (5, 768, 384, 4130, 1.0, True),
+                                                 (16, 2048, 512, 6000, 0.0, True), (4, 512, 2048, 2592, 1.0, True)])
+def test_grouped_wgrad_256_tile_identical_to_128_tile(device, n, M, N, K, beta, extras):
+    """The 256 x 128 kernel of js2t_gemm_grouped (csrc/gemm.hip gemm_bf16_wg256_kernel: eight multiplying + four requesting waves, a
+    three-slot ring) against the two-stage 128 x 128 kernel: the products BIT-identical (partial last K stage, K of a few stages,
+    beta 0 / 1, several members), the row sums to the order of their atomics, the tile sums of squares summing to the same total;
+    against an fp32 product of the same operands."""
+    from joeys2t_amd._lib import lib
+    g = torch.Generator().manual_seed(n + M + N + K)
+    As = [(torch.randn(K, M, generator=g) * (torch.rand(K, M, generator=g) > 0.5)).bfloat16().to(device) for _ in range(n)]
+    Bs = [torch.randn(K, N, generator=g).bfloat16().to(device) for _ in range(n)]
+    c0 = [torch.randn(M, N, generator=g).to(device) for _ in range(n)]
+    res = []
+    try:
+        for mode in (1, 0):
+            lib().js2t_gemm_wg256_mode(mode)
+            Cs = [c.clone() for c in c0]
+            rs = [torch.zeros(M, device=device) for _ in range(n)] if extras else None
+            ss = torch.full((ops.grouped_blocks(M, N, n),), float("nan"), device=device) if extras else None
+            ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, beta=beta, alpha=0.5, a_rowsums=rs, sumsq_partial=ss)
+            torch.cuda.synchronize()
+            res.append((Cs, rs, ss))
+    finally:
+        lib().js2t_gemm_wg256_mode(-1)
+    (C1, r1, s1), (C0, r0, s0) = res
+    for a, b in zip(C1, C0):
+        assert torch.equal(a, b)
+    ref = 0.5 * (As[-1].float().T @ Bs[-1].float()) + beta * c0[-1]
+    assert ((C1[-1] - ref).norm() / ref.norm()).item() < 1e-5
+    if extras:
+        for a, b, A in zip(r1, r0, As):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-3) and torch.allclose(a, A.float().sum(0), rtol=1e-4, atol=1e-2)
+        want = sum((c.double() ** 2).sum().item() for c in C1)
+        assert torch.isfinite(s1).all() and abs(s1.double().sum().item() - want) <= 1e-5 * want
+        assert abs(s0.double().sum().item() - want) <= 1e-5 * want
+
+
 
 def test_transposed_weight_shadow(device):
     """ParamStore.view_t: the transposed bf16 shadow of fused / single 2-D weights follows the parameters (also after an update)."""
