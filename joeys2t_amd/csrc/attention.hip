@@ -734,6 +734,9 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
   }
   int cur = 0;
+#ifdef JS2T_ATTN_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
   for (int qt = 0; qt < nqt; ++qt) {
     if (t < KT) {
       const bool live = qt * KT + t < Tq;
@@ -741,8 +744,11 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
       dl_s[cur][t] = dl_r * keep_p;
       rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, Tq - 1)) ^ dkey);
     }
+    ATT_T(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATT_T(1);
     __syncthreads();
+    ATT_T(2);
     if (qt + 1 < nqt) {
       img_dma<DH>(Qb, (int)a.ldq, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, wu, isrc);
       img_dma<DH>(Gb, (int)a.lddo, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, wu, isrc);
@@ -752,6 +758,7 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
         dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
       }
     }
+    ATT_T(3);
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
     const unsigned char* Gi = Qi + IMG_BYTES;
     // S = Q K^T and dP = dO V^T with D rows = tile queries, D cols = own keys:
@@ -791,6 +798,8 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
       dsf[2 * hf] = pack8(dp[0], dp[1]);
       dsf[2 * hf + 1] = pack8(dp[2], dp[3]);
     }
+    ATT_PIN(dsf[NSS - 1]);
+    ATT_T(4);
     // dV^T += dO^T Pd ; dK^T += Q^T dS   (contraction over the tile's queries)
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -800,7 +809,13 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
         dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Qi, ss, ct, lane), dsf[ss], dk[ct], 0, 0, 0);
       }
     cur ^= 1;
+    ATT_PIN(dk[NCT - 1][3]);
+    ATT_T(5);
   }
+#ifdef JS2T_ATTN_PROF
+  if (bid == 0 && t == 0)
+    for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
+#endif
   const float dv_sc = drop ? 1.f / keep_p : 1.f, dk_sc = a.scale * dv_sc;
   if (key < Tk) {
     uint16_t* krow = a.dk + ((int64_t)sg.k0 + key) * a.lddk + h * DH;

@@ -2550,14 +2550,24 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
     asm volatile("" ::: "memory");
     issue_stage(2, 2);
     int cslot = 0;
+#ifdef JS2T_P192_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < nk; ++s) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WG_PER) : "memory");  // own pieces of stage s + 1 (stage s + 2 stays in flight)
+      P192_T(4);
       __builtin_amdgcn_s_barrier();                                  // the multiplying waves are through with slot s % 3
       asm volatile("" ::: "memory");
+      P192_T(5);
       issue_stage(s + 3, cslot);
+      P192_T(6);
       cslot = cslot == WG_NST - 1 ? 0 : cslot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests past the end
+#ifdef JS2T_P192_PROF
+    if (blockIdx.x == 0 && t == 512)
+      for (int i = 4; i < 8; ++i) g_p192_prof[i] = prof_[i];
+#endif
   } else {
     // ---- multiplying waves
     const int wm = w >> 1, wn = w & 1;
@@ -2640,7 +2650,7 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
     }
 #ifdef JS2T_P192_PROF
     if (blockIdx.x == 0 && t == 0)
-      for (int i = 0; i < 8; ++i) g_p192_prof[i] = prof_[i];
+      for (int i = 0; i < 4; ++i) g_p192_prof[i] = prof_[i];
 #endif
 
     // ---- epilogue: lane (g = lane >> 4, r = lane & 15) holds C[16 i + r][16 j + 4 g .. + 3] of its wave's 64 x 64

@@ -25,8 +25,9 @@ fn = lib().js2t_debug_p192_prof
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(out) == 0
 steps = -(-T // 64)
-names = ["first half: 16 MFMA + 16 reads", "lgkmcnt wait", "barrier", "second half: 16 MFMA + 16 reads"]
+names = ["multiplying wave 0: first half: 16 MFMA + 16 reads", "  lgkmcnt wait", "  barrier", "  second half: 16 MFMA + 16 reads",
+         "requesting wave 8: vmcnt wait (stage s + 1)", "  barrier", "  12 requests"]
 print(f"{L} x dW[{rows},{cols}] over {T}: {(rows // 256) * (cols // 128) * L} tiles")
 for i, n in enumerate(names):
-    print(f"{n:48s} {out[i] / steps:9.1f} ticks")
-print(f"per stage {sum(out[:4]) / steps:9.1f} ticks (s_memtime, 100 MHz: x 24 = core clocks at 2.4 GHz; MFMA-bound: 1024 clocks per SIMD)")
+    print(f"{n:52s} {out[i] / steps:9.1f} ticks")
+print(f"per stage {sum(out[:4]) / steps:9.1f} / {sum(out[4:7]) / steps:9.1f} ticks (s_memtime, 100 MHz: x 24 = core clocks at 2.4 GHz; MFMA-bound: 1024 clocks per SIMD)")
