@@ -316,17 +316,22 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
 
     marks = []  # (how, frames, start event, end event) of every timed step: the replayed ones are also reported on their own
 
+    host = []  # (first launch of its graph?, host ms inside run()) per timed step
     def one(timed=False):
         nonlocal n_frames
         item = next(it)
         nf = sum(1 + (n - 400) // 160 for n in item["n_samples"])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            bk = gstep.buckets.get(gstep.bucket_key(item["n_samples"], item["trg_len"])) if use_graphs else None
+            first = bk is not None and bk.graph is not None and bk.replays == 0  # captured ahead, never launched: the launch uploads it
+            h0 = time.perf_counter()
             e0.record()
         how = gstep.run(item["wave"], item["n_samples"], torch.from_numpy(item["trg"]), item["trg_len"])
         if timed:
             e1.record()
             marks.append((how, nf, e0, e1))
+            host.append((first, (time.perf_counter() - h0) * 1e3))
         n_frames += nf
         return how
 
@@ -359,6 +364,8 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
     dt = time.perf_counter() - t0
     stats = gstep.read_stats()
     rep = [(nf, e0.elapsed_time(e1)) for how, nf, e0, e1 in marks if how == "replay"]
+    first_ms = sorted(ms for f, ms in host if f)
+    later_ms = sorted(ms for f, ms in host if not f)
     rep_ms = sum(ms for _, ms in rep) / max(len(rep), 1)
     packed = sum(1 for k in gstep.buckets if k[3] > 0)
     return {"ms_per_step": round(dt / steps * 1e3, 3), "frames_per_s_unpadded": round(n_frames / dt, 1), "steps": steps, "warmup": warmup,
@@ -368,6 +375,11 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
                                "what": "encoder stack on the live sub-sampled positions only (js2t_pack_rows, js2t_attn_desc.seg); JS2T_PACKED_ENCODER=0: padded"},
             "utterances_per_batch": round(stats["nseqs"] / steps, 2), "buckets": len(gstep.buckets), "buckets_captured_ahead": n_pre,
             "timed_steps_replayed": gstep.counts["replay"] - before["replay"], "timed_steps_eager_plus_capture": gstep.counts["eager"] - before["eager"],
+            # host time inside run() per step: a graph captured ahead is uploaded by its FIRST launch (once per bucket and process)
+            "host_ms_in_run": {"first_launch_of_a_graph": {"steps": len(first_ms), "median": round(first_ms[len(first_ms) // 2], 2) if first_ms else None,
+                                                           "sum": round(sum(first_ms), 1)},
+                               "later_launches": {"steps": len(later_ms), "median": round(later_ms[len(later_ms) // 2], 2) if later_ms else None,
+                                                  "max": round(later_ms[-1], 2) if later_ms else None}},
             "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/384) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
@@ -427,7 +439,8 @@ def measure_roofline(eager_step, model):
                        "current_gemm_hip_sha16": sha, "stale": tj.get("gemm_hip_sha16") != sha}
         if not traffic_src["stale"]:
             traffic = tj.get("hbm_bytes_per_launch")
-    key = "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>"
+    key = ("gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_pan96_kernel<*> + gemm_bf16_dma_kernel<*> + "
+           "gemm_bf16_wg256_kernel<*> + gemm_bf16_dma_grouped_kernel<*>")
     roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(algo_bytes),

@@ -237,7 +237,9 @@ def gemm_grouped(As, Bs, Cs, *, M, N, K, lda, ldb, ldc, split_k=1, beta=0.0, alp
     pa, pb, pc = arr(*[t.data_ptr() for t in As]), arr(*[t.data_ptr() for t in Bs]), arr(*[t.data_ptr() for t in Cs])
     pr = None if a_rowsums is None else arr(*[t.data_ptr() for t in a_rowsums])
     if GEMM_TIMER is not None:
-        GEMM_TIMER.wrap(f"gemm_bf16_dma_grouped_kernel<1,1,{int(d.split_k > 1)}>", 2.0 * d.M * d.N * d.K * n,
+        # (which kernel a launch takes is the library's choice: the 256x128 one for >= 160 such tiles without split-K, else 128x128)
+        GEMM_TIMER.wrap(f"js2t_gemm_grouped<split_k {'>' if d.split_k > 1 else '='} 1> (gemm_bf16_wg256_kernel | gemm_bf16_dma_grouped_kernel)",
+                        2.0 * d.M * d.N * d.K * n,
                         lambda: check(lib().js2t_gemm_grouped(C.byref(d), n, pa, pb, pc, pr, _stream()), "js2t_gemm_grouped"),
                         nbytes=n * (2 * (d.M * d.K + d.N * d.K) + Cs[0].element_size() * d.M * d.N * (2 if d.beta else 1)))
     else:

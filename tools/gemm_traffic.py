@@ -17,11 +17,12 @@ def load(name):
 
 
 fetch, write = load("pmc_fetch_by_kernel.csv"), load("pmc_write_by_kernel.csv")
-fam = [k for k in fetch if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_", "gemm_bf16_p192s_"))]
+fam = [k for k in fetch if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_", "gemm_bf16_p192s_", "gemm_bf16_pan96_", "gemm_bf16_wg256_", "gemm_bf16_w256_"))]
 n = sum(fetch[k][0] for k in fam)
 fb = sum(fetch[k][1] for k in fam) * 1024 * 2
 wb = sum(write[k][1] for k in fam if k in write) * 1024
-res = {"kernel_family": "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_dma_grouped_kernel<*>", "launches_measured": n,
+res = {"kernel_family": "gemm_bf16_p192_kernel<*> + gemm_bf16_p192s_kernel<*> + gemm_bf16_pan96_kernel<*> + gemm_bf16_dma_kernel<*> + gemm_bf16_wg256_kernel<*> + "
+                        "gemm_bf16_dma_grouped_kernel<*>", "launches_measured": n,
        "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "hbm_bytes_per_launch": round((fb + wb) / n),
        "per_kernel": {k: {"launches": fetch[k][0], "fetch_bytes_per_launch": fetch[k][1] * 2048 / fetch[k][0],
                           "write_bytes_per_launch": (write[k][1] * 1024 / write[k][0]) if k in write else None} for k in fam},
