@@ -1086,7 +1086,16 @@ def main():
     varying = None
     if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:
         try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
-            varying = varying_bench(device, 100, 250)
+            import gc
+            # the legs above leave millions of dead Python objects and a fragmented allocator cache behind: a full collection or a
+            # hipMalloc inside the 100 timed steps is a stall of this process's history, not of the loader -> graph path being timed
+            gc.collect()
+            torch.cuda.empty_cache()
+            gc.freeze()
+            try:
+                varying = varying_bench(device, 100, 250)
+            finally:
+                gc.unfreeze()
         except Exception as exc:
             varying = {"error": repr(exc)}
     fp32_mode = None

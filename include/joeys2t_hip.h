@@ -156,10 +156,11 @@ void js2t_gemm_force_w256(int on);
  * that qualifies (test hook), -1 = k-contiguous products that qualify and have >= 200 tiles (default). */
 void js2t_gemm_p192_mode(int mode);
 /* Kernel selection inside js2t_gemm_grouped for the 256x128 three-slot-ring kernel (reduction-major bf16 operands, f32 result,
- * M % 256 == 0, N % 128 == 0, no split-K, 16-byte aligned C; rowsum / sumsq_partial / beta as the 128x128 kernel, products
- * bit-identical to it): 0 = never, 1 = every launch that qualifies (test hook), -1 = launches of >= 160 such tiles over
- * K >= 1024 (default: the deferred weight gradients of the FFN / QKV layers, training.py:570-588 of the reference -
- * loss.backward() forms them one by one). */
+ * M % 256 == 0, N % 128 == 0, 16-byte aligned C; rowsum / sumsq_partial / beta / split_k as the 128x128 kernel, products
+ * bit-identical to it - with split_k > 2 to the order of the slices' atomic additions): 0 = never, 1 = every launch that
+ * qualifies (test hook), -1 = launches of >= 160 blocks (tiles x members x slices) over K >= 1024 per slice (default: the
+ * deferred weight gradients of the encoder and decoder layers, training.py:570-588 of the reference - loss.backward() forms
+ * them one by one). */
 void js2t_gemm_wg256_mode(int mode);
 /* Variant of the persistent 192x128 kernel: 3 = one block per CU with two stages in flight, 2 = two blocks per CU
  * with one stage in flight each (80 KB of LDS per block), 4 = one block per CU of eight multiplying and four

@@ -2498,16 +2498,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_p192t_kernel(js2t_gemm_desc 
 // M % 256 == 0, N % 128 == 0 (weight shapes); one tile per block, blocks of a member neighbours in the XCD-aware order.
 constexpr int WG_IMG = 16384, WG_STAGE = 3 * WG_IMG, WG_NST = 3, WG_LDS = WG_NST * WG_STAGE, WG_PER = 12;
 
-template <bool RS>
-__global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n) {
+// SPLITK: the launch is (member, K slice, tile); a block multiplies stages kt0 .. kt0 + nk of its slice and ADDS alpha * partial
+// into a zero-filled C with row-contiguous f32 atomics (tile staged through the idle ring), like the 128x128 kernel's slices.
+template <bool RS, bool SPLITK>
+__global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc d, GemmGroup grp, int tiles_m, int tiles_n, int split_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int tiles = tiles_m * tiles_n;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mem = lid / tiles, tile = lid - mem * tiles;
+  const int vm = lid / tiles, tile = lid - vm * tiles;  // vm = member * split_k + slice
+  const int mem = SPLITK ? vm / split_k : vm, slice = SPLITK ? vm - mem * split_k : 0;
   const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
-  const int K = d.K, nk = (K + 63) >> 6;
+  const int K = d.K, nk_all = (K + 63) >> 6;
+  const int per = SPLITK ? (nk_all + split_k - 1) / split_k : nk_all;
+  const int kt0 = slice * per;
+  const int nk = min(per, nk_all - kt0);  // >= 1: the launcher keeps split_k <= nk_all / 4
   float ss = 0.f;
 
   if (w >= 8) {
@@ -2530,7 +2536,7 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
       }
     }
     auto issue_stage = [&](int st, int slot) {  // st, slot wave-uniform
-      const int k0 = st < nk ? st << 6 : 0;    // past the end: stage 0 again, into a slot nobody reads
+      const int k0 = st < nk ? (kt0 + st) << 6 : 0;  // past the end: the matrix's stage 0 again, into a slot nobody reads
       const int64_t ka = (int64_t)k0 * lda, kb = (int64_t)k0 * ldb;
       const int klim = K - k0;
       unsigned char* stp = smem + slot * WG_STAGE + l * 4096;
@@ -2653,6 +2659,25 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
       for (int i = 0; i < 4; ++i) g_p192_prof[i] = prof_[i];
 #endif
 
+    if (RS && do_rs && (lane >> 4) == 0) {  // every output row of the ones-product holds the same sums: take row 0
+      typedef __attribute__((address_space(1))) float gfloat;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)grp.rowsum[mem] + m0 + wm * 64 + 16 * i + lane, racc[i][0]);
+    }
+    if constexpr (SPLITK) {
+      // the partial tile goes through the ring (idle by now) as [256 rows][32 float4 slots, slot ^= row & 7]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();  // (with the requesting waves, which have drained their requests: nothing lands in the ring any more)
+      float* Cs = (float*)smem;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ml = wm * 64 + 16 * i + (lane & 15), n4 = wn * 16 + 4 * j + (lane >> 4);
+          *(f32x4_t*)(Cs + ml * 128 + ((n4 ^ (ml & 7)) << 2)) = acc[i][j];
+        }
+    } else {
     // ---- epilogue: lane (g = lane >> 4, r = lane & 15) holds C[16 i + r][16 j + 4 g .. + 3] of its wave's 64 x 64
     const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f), beta = d.beta;
     float* Cb = (float*)grp.C[mem] + (int64_t)(m0 + wm * 64 + (lane & 15)) * d.ldc + n0 + wn * 64 + 4 * (lane >> 4);
@@ -2672,12 +2697,23 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
         ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
       }
     }
-    if (RS && do_rs && (lane >> 4) == 0) {  // every output row of the ones-product holds the same sums: take row 0
-      typedef __attribute__((address_space(1))) float gfloat;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)grp.rowsum[mem] + m0 + wm * 64 + 16 * i + lane, racc[i][0]);
     }
+  }
+  if constexpr (SPLITK) {
+    // f32 atomics as whole 256-byte row segments, one row half per wave-instruction, all twelve waves (scattered 4-byte atomics
+    // run an order of magnitude below the contiguous rate)
+    if (w >= 8) __syncthreads();  // the requesting waves' side of the barrier in front of the staging writes
+    __syncthreads();
+    const float alpha = d.alpha * (d.alpha_dev ? *d.alpha_dev : 1.f);
+    const float* Cs = (const float*)smem;
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat* cg = (gfloat*)grp.C[mem] + (int64_t)m0 * d.ldc + n0;
+    for (int idx = w; idx < 512; idx += 12) {
+      const int ml = idx >> 1, nl = (idx & 1) * 64 + lane;
+      const float v = Cs[ml * 128 + ((((nl >> 2) ^ (ml & 7)) << 2) | (nl & 3))];
+      __builtin_amdgcn_global_atomic_fadd_f32(cg + (int64_t)ml * d.ldc + nl, v * alpha);
+    }
+    return;
   }
   if (d.sumsq_partial) {  // two entries per block: the launch is accounted in 128 x 128 tiles (js2t_gemm_grouped_blocks)
     ss = block_sum(ss, (float*)smem);  // (starts with a barrier: every wave's requests have landed, every fragment has been read)
@@ -2949,17 +2985,17 @@ static int launch_grouped_p192t(const js2t_gemm_desc& d, const GemmGroup& grp, i
 int g_wg256_mode = -1;
 extern "C" void js2t_gemm_wg256_mode(int mode) { g_wg256_mode = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
 static bool wg256_eligible(const js2t_gemm_desc& d, int count) {
-  if (g_wg256_mode == 0 || d.split_k > 1 || d.dtype_c != JS2T_F32) return false;
-  if ((d.M & 255) || (d.N & 127) || (d.ldc & 3) || d.K < 192) return false;
+  if (g_wg256_mode == 0 || d.dtype_c != JS2T_F32 || (d.split_k > 1 && d.sumsq_partial)) return false;
+  if ((d.M & 255) || (d.N & 127) || (d.ldc & 3) || d.K < 192 * d.split_k || d.split_k > ((d.K + 63) >> 6) / 4) return false;
   if (g_wg256_mode == 1) return true;
-  const int64_t tiles = (int64_t)(d.M >> 8) * (d.N >> 7) * count;
-  return d.K >= 1024 && tiles >= 160;  // one block per CU: below that most of the chip idles, the 128x128 tiles spread further
+  const int64_t blocks = (int64_t)(d.M >> 8) * (d.N >> 7) * count * d.split_k;
+  return d.K >= 1024 * d.split_k && blocks >= 160;  // one block per CU: below that most of the chip idles, the 128x128 tiles spread further
 }
-template <bool RS>
+template <bool RS, bool SPLITK>
 static int launch_grouped_wg256(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_wg256_kernel<RS>, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)(gemm_bf16_wg256_kernel<RS, SPLITK>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
     if (e != hipSuccess) {
       js2t_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
       return JS2T_ERR_LAUNCH;
@@ -2967,7 +3003,8 @@ static int launch_grouped_wg256(const js2t_gemm_desc& d, const GemmGroup& grp, i
     attr_set = true;
   }
   const int tm = d.M >> 8, tn = d.N >> 7;
-  hipLaunchKernelGGL(gemm_bf16_wg256_kernel<RS>, dim3(tm * tn * count), dim3(768), WG_LDS, s, d, grp, tm, tn);
+  hipLaunchKernelGGL((gemm_bf16_wg256_kernel<RS, SPLITK>), dim3(tm * tn * count * (SPLITK ? d.split_k : 1)), dim3(768), WG_LDS, s, d, grp, tm, tn,
+                     d.split_k);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
@@ -3008,7 +3045,10 @@ extern "C" int js2t_gemm_grouped(const js2t_gemm_desc* dp, int32_t count, const 
     bool c16 = true;  // (the 256x128 kernel stores 16-byte pieces)
     for (int i = 0; i < n; ++i) c16 = c16 && aligned16(grp.C[i]);
     if (c16 && wg256_eligible(d, n)) {
-      rc = a_rowsum ? launch_grouped_wg256<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_wg256<false>(d, grp, n, (hipStream_t)stream);
+      if (d.split_k > 1)
+        rc = a_rowsum ? launch_grouped_wg256<true, true>(d, grp, n, (hipStream_t)stream) : launch_grouped_wg256<false, true>(d, grp, n, (hipStream_t)stream);
+      else
+        rc = a_rowsum ? launch_grouped_wg256<true, false>(d, grp, n, (hipStream_t)stream) : launch_grouped_wg256<false, false>(d, grp, n, (hipStream_t)stream);
     } else if (!d.sumsq_partial && p192t_eligible(d, n)) {
       rc = a_rowsum ? launch_grouped_p192t<true>(d, grp, n, (hipStream_t)stream) : launch_grouped_p192t<false>(d, grp, n, (hipStream_t)stream);
     } else {

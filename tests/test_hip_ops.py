@@ -807,6 +807,34 @@ def test_grouped_wgrad_256_tile_identical_to_128_tile(device, n, M, N, K, beta, 
         assert abs(s0.double().sum().item() - want) <= 1e-5 * want
 
 
+@pytest.mark.parametrize("n,M,N,K,sk", [(4, 512, 512, 6000, 2), (3, 256, 256, 2592, 4), (2, 512, 128, 1100, 3)])
+def test_grouped_wgrad_256_tile_split_k(device, n, M, N, K, sk):
+    """K slices of the 256 x 128 kernel (a block per (member, slice, tile), partial tiles added into a zero-filled C by row-contiguous
+    atomics): the slices are cut where the 128 x 128 kernel cuts them - two slices are bit-identical to it (a + b = b + a), more
+    agree to the order of their additions; row sums and an fp32 product as yardsticks."""
+    from joeys2t_amd._lib import lib
+    g = torch.Generator().manual_seed(n + M + N + K)
+    As = [torch.randn(K, M, generator=g).bfloat16().to(device) for _ in range(n)]
+    Bs = [torch.randn(K, N, generator=g).bfloat16().to(device) for _ in range(n)]
+    res = []
+    try:
+        for mode in (1, 0):
+            lib().js2t_gemm_wg256_mode(mode)
+            Cs = [torch.zeros(M, N, device=device) for _ in range(n)]
+            rs = [torch.zeros(M, device=device) for _ in range(n)]
+            ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, split_k=sk, a_rowsums=rs)
+            torch.cuda.synchronize()
+            res.append((Cs, rs))
+    finally:
+        lib().js2t_gemm_wg256_mode(-1)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b) if sk == 2 else torch.allclose(a, b, rtol=1e-5, atol=1e-3)
+    ref = As[-1].float().T @ Bs[-1].float()
+    assert ((res[0][0][-1] - ref).norm() / ref.norm()).item() < 1e-5
+    for a, A in zip(res[0][1], As):
+        assert torch.allclose(a, A.float().sum(0), rtol=1e-4, atol=1e-2)
+
+
 
 def test_transposed_weight_shadow(device):
     """ParamStore.view_t: the transposed bf16 shadow of fused / single 2-D weights follows the parameters (also after an update)."""

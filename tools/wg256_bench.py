@@ -26,13 +26,13 @@ def operands(n, M, N, K, seed, sparse=False):
     return As, Bs
 
 
-def run(mode, As, Bs, M, N, K, beta, rowsum, sumsq, c0):
+def run(mode, As, Bs, M, N, K, beta, rowsum, sumsq, c0, split_k=1):
     lib().js2t_gemm_wg256_mode(C.c_int(mode))
     n = len(As)
     Cs = [c.clone() for c in c0]
     rs = [torch.zeros(M, device=dev) for _ in range(n)] if rowsum else None
     ss = torch.full((ops.grouped_blocks(M, N, n),), float("nan"), device=dev) if sumsq else None
-    ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, beta=beta, alpha=0.5, a_rowsums=rs, sumsq_partial=ss)
+    ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, beta=beta, alpha=0.5, a_rowsums=rs, sumsq_partial=ss, split_k=split_k)
     torch.cuda.synchronize()
     lib().js2t_gemm_wg256_mode(C.c_int(-1))
     return Cs, rs, ss
@@ -58,6 +58,18 @@ for (n, M, N, K, beta, rowsum, sumsq) in [(3, 512, 256, 1000, 0.0, True, True), 
         ss_ok = abs(tot1 - want) <= 1e-5 * want and abs(tot0 - want) <= 1e-5 * want and bool(torch.isfinite(s1).all())
     print(f"check {n:2d} x dW[{M},{N}] over {K}: beta={beta} identical={same} vs_f32 {err:.2e} rowsum={rs_ok} sumsq={ss_ok}", flush=True)
     ok &= same and err < 1e-5 and rs_ok and ss_ok
+for (n, M, N, K, sk) in [(16, 512, 512, 12000, 2), (8, 1024, 512, 12000, 2), (3, 256, 256, 2592, 4), (2, 512, 128, 1100, 3)]:
+    As, Bs = operands(n, M, N, K, 11 + M)
+    c0 = [torch.zeros(M, N, device=dev) for _ in range(n)]
+    C1, r1, _ = run(1, As, Bs, M, N, K, 0.0, True, False, c0, split_k=sk)
+    C0, r0, _ = run(0, As, Bs, M, N, K, 0.0, True, False, c0, split_k=sk)
+    same = all(torch.equal(a, b) for a, b in zip(C1, C0))
+    close = all(torch.allclose(a, b, rtol=1e-5, atol=1e-3) for a, b in zip(C1, C0))
+    ref = 0.5 * (As[-1].float().T @ Bs[-1].float())
+    err = ((C1[-1] - ref).norm() / ref.norm()).item()
+    rs_ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-3) for a, b in zip(r1, r0)) and torch.allclose(r1[0], As[0].float().sum(0), rtol=1e-4, atol=1e-2)
+    print(f"check {n:2d} x dW[{M},{N}] over {K} in {sk} slices: identical={same} close={close} vs_f32 {err:.2e} rowsum={rs_ok}", flush=True)
+    ok &= close and err < 1e-5 and rs_ok and (same or sk > 2)
 print("ALL OK" if ok else "MISMATCH", flush=True)
 
 
@@ -84,12 +96,15 @@ for name, n, M, N, sparse in [("FFN1 16 x dW[2048,512]", 16, 2048, 512, True), (
     Cs = [torch.zeros(M, N, device=dev) for _ in range(n)]
     rs = [torch.zeros(M, device=dev) for _ in range(n)]
     ss = torch.zeros(ops.grouped_blocks(M, N, n), device=dev)
-    us = {}
-    for rnd in range(2):
-        for mode in (0, 1):
-            lib().js2t_gemm_wg256_mode(C.c_int(mode))
-            t = timed(lambda: ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, a_rowsums=rs, sumsq_partial=ss))
-            us[mode] = min(us.get(mode, 1e9), t)
-    lib().js2t_gemm_wg256_mode(C.c_int(-1))
     fl = 2e-6 * n * M * N * K
-    print(f"{name:26s}: 128x128 {us[0]:7.1f} us {fl / us[0]:5.0f} TF/s | 256x128 {us[1]:7.1f} us {fl / us[1]:5.0f} TF/s | x{us[0] / us[1]:.2f}", flush=True)
+    for sk in ((1,) if n * (M // 256) * (N // 128) > 128 else (1, 2)):
+        us = {}
+        kw = dict(a_rowsums=rs, sumsq_partial=ss) if sk == 1 else dict(a_rowsums=rs, split_k=sk)
+        for rnd in range(2):
+            for mode in (0, 1):
+                lib().js2t_gemm_wg256_mode(C.c_int(mode))
+                t = timed(lambda: ops.gemm_grouped(As, Bs, Cs, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, **kw))
+                us[mode] = min(us.get(mode, 1e9), t)
+        lib().js2t_gemm_wg256_mode(C.c_int(-1))
+        print(f"{name:26s} split {sk}: 128x128 {us[0]:7.1f} us {fl / us[0]:5.0f} TF/s | 256x128 {us[1]:7.1f} us {fl / us[1]:5.0f} TF/s | x{us[0] / us[1]:.2f}",
+              flush=True)
