@@ -254,7 +254,9 @@ __device__ unsigned long long g_attn_prof[8];
 // blocks fit a CU (three waves per SIMD at <= 168 registers) and the 768 blocks of an encoder layer are resident at once.
 // V(kt) is requested when K(kt) has landed and lands under QK^T + softmax; K(kt+1) is requested when every wave is through
 // with QK^T and lands under PV (what of it is exposed, the other two blocks of the CU cover): two barriers per tile.
-template <int DH, bool REL, bool SB = false>
+// DROP: dropout compiled in or out - as a run-time flag every 16-key block of the element loops had its own branch around the hashes,
+// i.e. its own basic block with an LDS wait at its head, and nothing of one block's arithmetic could hide under another's products
+template <int DH, bool REL, bool SB = false, bool DROP = true>
 __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
@@ -292,13 +294,14 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   float mi = -INFINITY, li = 0.f;
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bool drop = a.p > 0.f;
+  constexpr bool drop = DROP;  // (launched with DROP = dropout_p > 0)
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float drop_sc = drop ? 1.f / (1.f - a.p) : 1.f;
   const float scale2 = a.scale * 1.4426950408889634f;
   const int nkt = (Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
+  // the dropout word of (row, col4 c4, half w) is hash32w(rowkey + 2 c4 + w): kept as (..) * M1 and advanced by adds (hash32w_pre)
+  const uint32_t rowkeym = (hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey) + 2u * (uint32_t)g) * HASH32W_M1;
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
@@ -373,9 +376,9 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
         uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
-        if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
-          const uint32_t c4 = (uint32_t)((KT / 4) * kt + 4 * tt + g);
-          h0 = hash32w(rowkey + 2u * c4), h1 = hash32w(rowkey + 2u * c4 + 1u);
+        if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4 = (KT/4) kt + 4 tt + g) with the row hash hoisted out of the key loop
+          const uint32_t xm = rowkeym + (uint32_t)kt * ((KT / 2) * HASH32W_M1) + (uint32_t)tt * (8u * HASH32W_M1);
+          h0 = hash32w_pre(xm), h1 = hash32w_pre(xm + HASH32W_M1);
         }
         const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
@@ -437,17 +440,19 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
 // own rows = queries (like forward); sweeps key tiles; needs K image (row + transposed reads) and V image (row reads)
 // dS' of one (own query block, key tile): pv * ((keep ? dp : 0) - delta*(1-p)); the common factor scale/(1-p) is applied to
 // dQ once at the end.  lse2 = lse*log2e, scale2 = scale*log2e.  MASKED = some key of the tile is padded / masked out.
+// The subtraction rides on the product: the caller starts the dP accumulators at ndl2 = -delta*(1-p), so `dp` arrives as
+// dP - delta*(1-p) and a dropped element takes ndl2 itself (one vector instruction per element less).
 template <bool MASKED, int NTT, bool REL = false>
-__device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float dl2,
-                                            uint32_t bits, uint32_t rowkey, uint32_t c4base, uint32_t thr, bool drop,
+__device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&dp)[NTT], float scale2, float lse2, float ndl2,
+                                            uint32_t bits, uint32_t rowkeym, uint32_t thr, bool drop,
                                             const float* rel_s = nullptr, float* drel_s = nullptr, int key0 = 0, int query = 0, int R = 0,
                                             bool q_live = true, float* edge = nullptr, unsigned long long* drel_i = nullptr) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
     uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
-    if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4) with the row hash hoisted out of the key loop
-      const uint32_t c4 = c4base + 4u * tt;
-      h0 = hash32w(rowkey + 2u * c4), h1 = hash32w(rowkey + 2u * c4 + 1u);
+    if (drop) {  // == dropout_keep4_key(dkey, z*Tq + q, col4 = c4base + 4 tt): rowkeym = (row hash + 2 c4base) * M1, see flash_fwd_kernel
+      const uint32_t xm = rowkeym + (uint32_t)tt * (8u * HASH32W_M1);
+      h0 = hash32w_pre(xm), h1 = hash32w_pre(xm + HASH32W_M1);
     }
     const uint32_t hv[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
 #pragma unroll
@@ -455,8 +460,7 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
       const int ri = REL ? rel_index(key0 + 16 * tt + r, query, R) : 0;
       float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale2, (REL ? rel_s[ri] : 0.f) - lse2));
       if (MASKED) pv = ((bits >> (4 * tt + r)) & 1u) ? pv : 0.f;
-      const float tdp = hv[r] >= thr ? dp[tt][r] : 0.f;
-      s[tt][r] = pv * (tdp - dl2);
+      s[tt][r] = pv * (hv[r] >= thr ? dp[tt][r] : ndl2);
       // gradient of the bias = dS (before the 1/(1-p) factor, applied when the block's histogram is flushed)
       // (two thirds of the pairs of a 375-position utterance lie beyond the clipping distance: they all land in the two end
       // bins, which are summed in registers - edge[0] / edge[1] - and posted once per wave; an LDS atomic per pair cost 135 us
@@ -475,7 +479,7 @@ __device__ __forceinline__ void dq_elements(f32x4_t (&s)[NTT], const f32x4_t (&d
 
 // one own-query block of 16 per wave (two need ~350 registers: one wave per SIMD, slower)
 // bid / nblk: this block's index among the pass's blocks (the pass is a grid of its own, or a range of the merged grid)
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nblk) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;
@@ -498,12 +502,12 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
   const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
   const uint16_t* Vb = a.v + (int64_t)sg.k0 * a.ldv + h * DH;
-  const bool drop = a.p > 0.f;
+  constexpr bool drop = DROP;  // (launched with DROP = dropout_p > 0)
   const float keep_p = 1.f - a.p;
   img_dma<DH>(Kb, (int)a.ldk, 0, Tk, smem, wu, isrc);  // first, as in flash_fwd_kernel
   img_dma<DH>(Vb, (int)a.ldv, 0, Tk, smem + IMG_BYTES, wu, isrc);
   bf16x8_t qf[NKS], gf[NKS];
-  float lse2, dl2;
+  float lse2, ndl2;
   {
     own_frags<NKS>(Qb, a.ldq, q0, Tq, lane, qf);
     own_frags<NKS>(Gb, a.lddo, q0, Tq, lane, gf);
@@ -525,7 +529,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
       dsum = quad_sum(dsum);
       if (g == 0 && q0 + m < Tq) a.delta[(int64_t)z * a.Tq + q0 + m] = dsum;
     }
-    dl2 = dsum * keep_p;
+    ndl2 = -dsum * keep_p;
   }
   f32x4_t dq[NCT];
 #pragma unroll
@@ -534,7 +538,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const float scale2 = a.scale * 1.4426950408889634f;
   const int nkt = (Tk + KT - 1) / KT;
   const bool full_mask = a.mask && a.msq != 0;
-  const uint32_t rowkey = hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey);
+  const uint32_t rowkeym0 = (hash32((uint32_t)(z * a.Tq + min(q0 + m, Tq - 1)) ^ dkey) + 2u * (uint32_t)g) * HASH32W_M1;
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) {
@@ -561,7 +565,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
         s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = f32x4_t{ndl2, ndl2, ndl2, ndl2};  // dP - delta*(1-p) comes out of the product (dq_elements)
       }
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
@@ -570,15 +574,15 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
           s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Ki, tt, ks, lane), qf[ks], s[tt], 0, 0, 0);
           dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Vi, tt, ks, lane), gf[ks], dp[tt], 0, 0, 0);
         }
-      const uint32_t c4base = (uint32_t)((KT / 4) * kt + g);
+      const uint32_t rowkeym = rowkeym0 + (uint32_t)kt * ((KT / 2) * HASH32W_M1);  // col4 base (KT/4) kt + g of this tile
       if (tile_clear) {
-        dq_elements<false, NTT, REL>(s, dp, scale2, lse2, dl2, G::FULL, rowkey, c4base, thr, drop, rel_s, nullptr, KT * kt + 4 * g, q0 + m,
+        dq_elements<false, NTT, REL>(s, dp, scale2, lse2, ndl2, G::FULL, rowkeym, thr, drop, rel_s, nullptr, KT * kt + 4 * g, q0 + m,
                                      a.relR);
       } else {
         const int qc = min(q0 + m, Tq - 1);
         uint32_t bits = kbits;
         if (full_mask) bits = row_kbits<DH>(bits, a.mask + (int64_t)b * a.msb + (int64_t)qc * a.msq, kt, g, Tk);
-        dq_elements<true, NTT, REL>(s, dp, scale2, lse2, dl2, bits, rowkey, c4base, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
+        dq_elements<true, NTT, REL>(s, dp, scale2, lse2, ndl2, bits, rowkeym, thr, drop, rel_s, a.d_rel ? drel_s : nullptr,
                                     KT * kt + 4 * g, q0 + m, a.relR, q0 + m < Tq, rel_edge, a.d_rel_fix ? drel_i : nullptr);
       }
 #pragma unroll
@@ -625,50 +629,56 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   }
 }
 
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_dq_kernel(AttnArgs a) {
-  flash_dq_body<DH, REL>(a, blockIdx.x, gridDim.x);
+  flash_dq_body<DH, REL, DROP>(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------ dK / dV
 // own rows = keys; sweeps query tiles; Q image (row + transposed reads) and dO image (row + transposed reads)
 // One (query tile, own-key block) of the dK/dV pass: probabilities and dS from the S / dP accumulators.
-//   pv  = exp2(s * scale*log2e - lse*log2e)        (lse_s holds lse*log2e, +inf for rows past Tq -> pv = 0)
+//   pv  = exp2(s * scale*log2e - lse*log2e)        (nlse2 holds -lse*log2e, -inf for rows past Tq -> pv = 0)
 //   pd  = keep ? pv : 0                             (dV gets the 1/(1-p) factor once, at the end)
 //   ds' = pv * ((keep ? dp : 0) - delta*(1-p))      (dK gets scale/(1-p) once, at the end)
-// Dropout: the decision of (query row, key) is the half (key & 1) of hash32w(rowhash + (key >> 1)) - the same value for
-// the two neighbouring lanes of a key pair, so each lane hashes two of the four rows and swaps with its neighbour (DPP).
+// Both per-query scalars arrive NEGATED (ndl2 = -delta*(1-p)): the caller starts the dP accumulators at ndl2, so `dp` is already
+// dP - delta*(1-p) and a dropped element takes ndl2 itself; -lse goes into the fma as it is (two vector instructions per element
+// less than negating / subtracting here).
+// Dropout: the decision of (query row, key) is the half (key & 1) of hash32w(rowhash + (key >> 1)).  A lane's key is fixed, so
+// (i) (key >> 1) * M1 is a per-lane constant and the row hashes arrive pre-multiplied (hash32w_pre: one multiply per word),
+// (ii) which half it wants is a per-lane constant, folded into the hash's last multiply: mulsel = M2 for the high half,
+// M2 << 16 for the low one (x * (M2 << 16) = (the low half of x * M2) << 16), and the decision is one unsigned compare of the
+// product with thr << 16 - no extraction per element.  (A first version shared each word between the two lanes of a key pair -
+// two hashes + two DPP moves + four selects per four elements: more instructions than the four hashes.)
 template <bool KEYCHECK, bool FULLMASK, int NTT, bool REL = false>
-__device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NTT], const float* lse2, const float* dl2,
+__device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NTT], const float* nlse2, const float* ndl2,
                                              const uint32_t* rkp, float scale2, bool key_ok, int key, uint32_t thr, bool drop, int g,
                                              int par, const uint8_t* mcol, int64_t msq, int qbase, int Tq, const float* rel_s = nullptr,
                                              int R = 0) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
-    const f32x4_t l4 = *(const f32x4_t*)(lse2 + 16 * tt + 4 * g);
-    const f32x4_t d4 = *(const f32x4_t*)(dl2 + 16 * tt + 4 * g);
+    const f32x4_t l4 = *(const f32x4_t*)(nlse2 + 16 * tt + 4 * g);
+    const f32x4_t d4 = *(const f32x4_t*)(ndl2 + 16 * tt + 4 * g);
     uint32_t h[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     if (drop) {
-      const uint2 rk2 = *(const uint2*)(rkp + 16 * tt + 4 * g + 2 * par);  // row hashes of this lane's two rows
-      const uint32_t c2 = (uint32_t)(key >> 1);
-      const uint32_t ha = hash32w(rk2.x + c2), hb = hash32w(rk2.y + c2);
-      const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)ha, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-      const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)hb, 0xB1, 0xf, 0xf, true);
-      h[0] = par ? na : ha, h[1] = par ? nb : hb, h[2] = par ? ha : na, h[3] = par ? hb : nb;
+      const uint4 rk4 = *(const uint4*)(rkp + 16 * tt + 4 * g);  // (row hash) * M1 of this lane's four rows
+      const uint32_t c2m = (uint32_t)(key >> 1) * HASH32W_M1;     // per-lane constant: hoisted out of the sweep
+      const uint32_t mulsel = par ? HASH32W_M2 : HASH32W_M2 << 16;  // (par = key & 1)
+      h[0] = hash32w_pre(rk4.x + c2m, mulsel), h[1] = hash32w_pre(rk4.y + c2m, mulsel);
+      h[2] = hash32w_pre(rk4.z + c2m, mulsel), h[3] = hash32w_pre(rk4.w + c2m, mulsel);
     }
+    const uint32_t thr_hi = thr << 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float pv = __builtin_amdgcn_exp2f(
-          fmaf(s[tt][r], scale2, (REL ? rel_s[rel_index(key, qbase + 16 * tt + 4 * g + r, R)] : 0.f) - l4[r]));
+          REL ? fmaf(s[tt][r], scale2, rel_s[rel_index(key, qbase + 16 * tt + 4 * g + r, R)] + l4[r]) : fmaf(s[tt][r], scale2, l4[r]));
       if (KEYCHECK) pv = key_ok ? pv : 0.f;
       if (FULLMASK) {
         const int qrow = min(qbase + 16 * tt + 4 * g + r, Tq - 1);
         pv = mcol[(int64_t)qrow * msq] ? pv : 0.f;
       }
-      const bool keep = ((h[r] >> (16 * (key & 1))) & 0xffffu) >= thr;
-      const float tdp = keep ? dp[tt][r] : 0.f;
+      const bool keep = h[r] >= thr_hi;  // the wanted half sits in the upper 16 bits (thr <= 0xffff; no dropout: h = all ones, thr = 0)
       s[tt][r] = keep ? pv : 0.f;
-      dp[tt][r] = pv * (tdp - d4[r]);
+      dp[tt][r] = pv * (keep ? dp[tt][r] : d4[r]);
     }
   }
 }
@@ -676,7 +686,7 @@ __device__ __forceinline__ void dkv_elements(f32x4_t (&s)[NTT], f32x4_t (&dp)[NT
 // one own-key block of 16 per wave: with two (32 keys per wave) the dK / dV accumulators, the own K / V fragments and the
 // S / dP tiles need > 400 registers - one wave per SIMD, nothing to overlap the MFMA, exp / dropout VALU work and LDS
 // latency with.  One block per wave fits 256 registers, i.e. two waves per SIMD.
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int nblk) {
   using G = Geo<DH>;
   constexpr int KT = G::KT, NTT = G::NTT, NKS = G::NKS, NCT = G::NCT, NSS = G::NSS;  // KT = queries per swept tile here
@@ -713,7 +723,7 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     dk[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     dv[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const bool drop = a.p > 0.f;
+  constexpr bool drop = DROP;  // (launched with DROP = dropout_p > 0)
   const uint32_t dkey = drop ? dropout_key(a.rng, a.stream) : 0u;
   const float keep_p = 1.f - a.p;  // delta is pre-multiplied by it so that dS carries a common 1/(1-p)
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
@@ -740,9 +750,9 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   for (int qt = 0; qt < nqt; ++qt) {
     if (t < KT) {
       const bool live = qt * KT + t < Tq;
-      lse_s[cur][t] = live ? lse_r * 1.4426950408889634f : INFINITY;  // rows past Tq: exp2(-inf) = 0
-      dl_s[cur][t] = dl_r * keep_p;
-      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, Tq - 1)) ^ dkey);
+      lse_s[cur][t] = live ? -lse_r * 1.4426950408889634f : -INFINITY;  // negated (dkv_elements); rows past Tq: exp2(-inf) = 0
+      dl_s[cur][t] = -dl_r * keep_p;
+      rk_s[cur][t] = hash32((uint32_t)(z * a.Tq + min(qt * KT + t, Tq - 1)) ^ dkey) * HASH32W_M1;  // pre-multiplied: hash32w_pre
     }
     ATT_T(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -770,7 +780,7 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[tt] = *(const f32x4_t*)(dl_s[cur] + 64 * hf + 16 * tt + 4 * g);  // -delta*(1-p) of the element's query: the product adds dP
       }
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
@@ -828,9 +838,9 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
   }
 }
 
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
-  flash_dkv_body<DH, REL>(a, blockIdx.x, gridDim.x);
+  flash_dkv_body<DH, REL, DROP>(a, blockIdx.x, gridDim.x);
 }
 
 // Both passes as ONE grid: two grids of 768 blocks (an encoder layer) on 512 resident slots are 2 x 1.5 rounds, one of 1536 is
@@ -838,10 +848,10 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
 // of js2t_attn_desc.delta_partial (handing delta from the dQ blocks to the dK/dV blocks inside one grid costs more than the
 // merged grid saves: profiles/README.md, round 2).  The dK/dV blocks (the longer ones) go first; n_dkv % 8 == 0 keeps the
 // XCD-aware order of both ranges.
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(AttnArgs a, int n_dkv) {
-  if ((int)blockIdx.x < n_dkv) flash_dkv_body<DH, REL>(a, blockIdx.x, n_dkv);
-  else flash_dq_body<DH, REL>(a, (int)blockIdx.x - n_dkv, (int)gridDim.x - n_dkv);
+  if ((int)blockIdx.x < n_dkv) flash_dkv_body<DH, REL, DROP>(a, blockIdx.x, n_dkv);
+  else flash_dq_body<DH, REL, DROP>(a, (int)blockIdx.x - n_dkv, (int)gridDim.x - n_dkv);
 }
 
 template <typename K>
@@ -894,13 +904,13 @@ AttnArgs to_args(const js2t_attn_desc* d) {
 
 int g_attn_fwd_sb = -1;  // -1: by shape, 0 / 1: forced (js2t_debug_attn_fwd_sb; measurements)
 bool g_attn_bwd_merge = true;  // js2t_debug_attn_bwd_merge(0): the two passes as two launches also with delta_partial (A/B)
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
   if (!once) {
-    int rc = set_lds(flash_fwd_kernel<DH, REL, false>, 4 * IMG_BYTES);
+    int rc = set_lds(flash_fwd_kernel<DH, REL, false, DROP>, 4 * IMG_BYTES);
     if (rc) return rc;
-    rc = set_lds(flash_fwd_kernel<DH, REL, true>, 2 * IMG_BYTES + KMASK_MAX / 8);
+    rc = set_lds(flash_fwd_kernel<DH, REL, true, DROP>, 2 * IMG_BYTES + KMASK_MAX / 8);
     if (rc) return rc;
     once = true;
   }
@@ -910,21 +920,21 @@ int launch_fwd(const js2t_attn_desc* d, hipStream_t s) {
   const int kmask_bytes = (cdiv(d->Tk, KT) * KT / 8 + 15) & ~15;  // one 16-bit word per 16 keys
   // three single-buffered blocks per CU when the grid does not fit two per CU (and the key mask leaves room for three)
   const bool sb = g_attn_fwd_sb >= 0 ? g_attn_fwd_sb != 0 : nblk > 512;
-  if (sb) hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, true>), dim3(nblk), dim3(256), 2 * IMG_BYTES + kmask_bytes, s, a);
-  else hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, false>), dim3(nblk), dim3(256), 4 * IMG_BYTES, s, a);
+  if (sb) hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, true, DROP>), dim3(nblk), dim3(256), 2 * IMG_BYTES + kmask_bytes, s, a);
+  else hipLaunchKernelGGL((flash_fwd_kernel<DH, REL, false, DROP>), dim3(nblk), dim3(256), 4 * IMG_BYTES, s, a);
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;
 }
 
-template <int DH, bool REL>
+template <int DH, bool REL, bool DROP>
 int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
   static bool once = false;
   if (!once) {
-    int rc = set_lds(flash_dq_kernel<DH, REL>, 4 * IMG_BYTES);
+    int rc = set_lds(flash_dq_kernel<DH, REL, DROP>, 4 * IMG_BYTES);
     if (rc) return rc;
-    rc = set_lds(flash_dkv_kernel<DH, REL>, 4 * IMG_BYTES);
+    rc = set_lds(flash_dkv_kernel<DH, REL, DROP>, 4 * IMG_BYTES);
     if (rc) return rc;
-    rc = set_lds(flash_bwd_kernel<DH, REL>, 4 * IMG_BYTES);
+    rc = set_lds(flash_bwd_kernel<DH, REL, DROP>, 4 * IMG_BYTES);
     if (rc) return rc;
     once = true;
   }
@@ -940,12 +950,12 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
     a.d_rel_fix = (unsigned long long*)fix;
   }
   if (d->delta_partial && (n_dkv & 7) == 0 && g_attn_bwd_merge) {
-    hipLaunchKernelGGL((flash_bwd_kernel<DH, REL>), dim3(n_dkv + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv);
+    hipLaunchKernelGGL((flash_bwd_kernel<DH, REL, DROP>), dim3(n_dkv + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv);
     JS2T_LAUNCH_CHECK();
   } else {
-    hipLaunchKernelGGL((flash_dq_kernel<DH, REL>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
+    hipLaunchKernelGGL((flash_dq_kernel<DH, REL, DROP>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
     JS2T_LAUNCH_CHECK();
-    hipLaunchKernelGGL((flash_dkv_kernel<DH, REL>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
+    hipLaunchKernelGGL((flash_dkv_kernel<DH, REL, DROP>), dim3(cdiv(d->Tk, 64) * d->B * d->H), dim3(256), 4 * IMG_BYTES, s, a);
     JS2T_LAUNCH_CHECK();
   }
   if (n_fix) return js2t_fixed_to_float_add((const long long*)a.d_rel_fix, d->d_rel_bias, n_fix, d->dropout_p > 0.f ? 1.f / (1.f - d->dropout_p) : 1.f, s);
@@ -964,8 +974,12 @@ extern "C" int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream) 
   if (rc) return rc;
   JS2T_CHECK(d->o && (d->ldo % 4) == 0 && ((((uintptr_t)d->o)) & 7) == 0, "flash_attn_fwd: bad output");
   hipStream_t s = (hipStream_t)stream;
-  if (d->rel_bias) return d->head_dim == 128 ? launch_fwd<128, true>(d, s) : launch_fwd<64, true>(d, s);
-  return d->head_dim == 128 ? launch_fwd<128, false>(d, s) : launch_fwd<64, false>(d, s);
+  if (d->dropout_p > 0.f) {
+    if (d->rel_bias) return d->head_dim == 128 ? launch_fwd<128, true, true>(d, s) : launch_fwd<64, true, true>(d, s);
+    return d->head_dim == 128 ? launch_fwd<128, false, true>(d, s) : launch_fwd<64, false, true>(d, s);
+  }
+  if (d->rel_bias) return d->head_dim == 128 ? launch_fwd<128, true, false>(d, s) : launch_fwd<64, true, false>(d, s);
+  return d->head_dim == 128 ? launch_fwd<128, false, false>(d, s) : launch_fwd<64, false, false>(d, s);
 }
 
 extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) {
@@ -980,6 +994,10 @@ extern "C" int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream) 
                  ((((uintptr_t)d->dq) | ((uintptr_t)d->dk) | ((uintptr_t)d->dv)) & 7) == 0,
              "flash_attn_bwd: misaligned gradient buffers");
   hipStream_t s = (hipStream_t)stream;
-  if (d->rel_bias) return d->head_dim == 128 ? launch_bwd<128, true>(d, s) : launch_bwd<64, true>(d, s);
-  return d->head_dim == 128 ? launch_bwd<128, false>(d, s) : launch_bwd<64, false>(d, s);
+  if (d->dropout_p > 0.f) {
+    if (d->rel_bias) return d->head_dim == 128 ? launch_bwd<128, true, true>(d, s) : launch_bwd<64, true, true>(d, s);
+    return d->head_dim == 128 ? launch_bwd<128, false, true>(d, s) : launch_bwd<64, false, true>(d, s);
+  }
+  if (d->rel_bias) return d->head_dim == 128 ? launch_bwd<128, true, false>(d, s) : launch_bwd<64, true, false>(d, s);
+  return d->head_dim == 128 ? launch_bwd<128, false, false>(d, s) : launch_bwd<64, false, false>(d, s);
 }

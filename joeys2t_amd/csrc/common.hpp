@@ -180,6 +180,15 @@ __device__ __forceinline__ uint32_t hash32w(uint32_t x) {
   x ^= x >> 15; x *= 0x846ca68bu;
   return x;
 }
+// The same word from xm = x * HASH32W_M1 (mod 2^32), for callers whose x advances by constants: the first multiply distributes
+// over the sum (rowkey + counter) * M1 = rowkey * M1 + counter * M1, so a loop keeps rowkey * M1 and adds multiples of M1 - one
+// multiply per word instead of two (attention.hip).  last_mul: HASH32W_M2 gives hash32w(x); HASH32W_M2 << 16 gives
+// hash32w(x) << 16, i.e. the LOW half of the word in the upper 16 bits - for a lane that only ever wants one half of its words.
+constexpr uint32_t HASH32W_M1 = 0x7feb352du, HASH32W_M2 = 0x846ca68bu;
+__device__ __forceinline__ uint32_t hash32w_pre(uint32_t xm, uint32_t last_mul = HASH32W_M2) {
+  xm ^= xm >> 15;
+  return xm * last_mul;
+}
 __device__ __forceinline__ uint32_t dropout_key(const uint64_t* rng_state, uint32_t stream) {
   const uint64_t seed = rng_state[0], off = rng_state[1];
   return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) + 0x9E3779B9u) ^ hash32((uint32_t)off * 0x85EBCA6Bu + 1u) ^
