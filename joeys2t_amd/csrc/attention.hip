@@ -134,6 +134,17 @@ __device__ __forceinline__ void img_dma(const uint16_t* base, int ld, int row0, 
     }
   }
 }
+// ONE of a wave's four pieces, as a request the compiler does not see (lds_dma16, common.hpp): for kernels that spread the next
+// tile's requests over the current tile's products - a burst of eight behind the barrier holds its wave for ~1100 ticks while the
+// CU's one address path takes the requests of eight waves in turn (profiles/r05_attn_bwd_ticks.txt), and the builtin form makes the
+// compiler drain every request in front of the first transposing read.  The caller orders requests and reads itself (counted
+// vmcnt + barrier at the top of its loop).
+template <int DH>
+__device__ __forceinline__ void img_dma_piece(const uint16_t* base, int ld, int row0, int rows_max, unsigned char* img, int w,
+                                              const ImgSrc<DH>& is, int q) {
+  const int row = min(row0 + is.trow[q], rows_max - 1);  // (no fast path: a branch here cuts the caller's product loop into blocks)
+  lds_dma16(base + (uint32_t)(row * ld + is.col[q & 1]), img + (w * 4 + q) * 1024);
+}
 // row fragment: 8 consecutive head columns (32*ks + 8*(lane>>4) ..) of tile row 16*tt + (lane&15)
 template <int DH>
 __device__ __forceinline__ bf16x8_t img_row(const unsigned char* img, int tt, int ks, int lane) {
@@ -759,14 +770,19 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     ATT_T(1);
     __syncthreads();
     ATT_T(2);
-    if (qt + 1 < nqt) {
-      img_dma<DH>(Qb, (int)a.ldq, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES, wu, isrc);
-      img_dma<DH>(Gb, (int)a.lddo, (qt + 1) * KT, Tq, smem + (cur ^ 1) * 2 * IMG_BYTES + IMG_BYTES, wu, isrc);
-      if (t < KT) {
-        const int qc = min((qt + 1) * KT + t, Tq - 1);
-        lse_r = a.lse[(int64_t)z * a.Tq + qc];
-        dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
-      }
+    // the next tile's images are requested in pairs under this tile's products; behind the last tile the requests go on (tile 0
+    // again, into the idle buffer: nobody reads it) - a branch around them would cut the product loops into blocks
+    const bool more = qt + 1 < nqt;
+    const int nrow0 = more ? (qt + 1) * KT : 0;
+    unsigned char* nQ = smem + (cur ^ 1) * 2 * IMG_BYTES;
+    auto request = [&](const uint16_t* base, int ld, unsigned char* img, int q) {
+      img_dma_piece<DH>(base, ld, nrow0, Tq, img, wu, isrc, q);
+      img_dma_piece<DH>(base, ld, nrow0, Tq, img, wu, isrc, q + 1);
+    };
+    if (more && t < KT) {
+      const int qc = min((qt + 1) * KT + t, Tq - 1);
+      lse_r = a.lse[(int64_t)z * a.Tq + qc];
+      dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
     }
     ATT_T(3);
     const unsigned char* Qi = smem + cur * 2 * IMG_BYTES;
@@ -782,13 +798,32 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
         s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         dp[tt] = *(const f32x4_t*)(dl_s[cur] + 64 * hf + 16 * tt + 4 * g);  // -delta*(1-p) of the element's query: the product adds dP
       }
+      // every product takes a fresh 1 KB fragment from LDS (a wave owns 16 keys: nothing is reused): the reads run ONE PAIR AHEAD
+      // of the products, pinned by scheduling groups - left alone the compiler (230 registers) issued read, wait, product, 32 times
+      bf16x8_t fq[2], fg[2];
+      fq[0] = img_row<DH>(Qi, 4 * hf, 0, lane);
+      fg[0] = img_row<DH>(Gi, 4 * hf, 0, lane);
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Qi, 4 * hf + tt, ks, lane), kf[ks], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Gi, 4 * hf + tt, ks, lane), vf[ks], dp[tt], 0, 0, 0);
+          const int i = tt * NKS + ks, nt = (i + 1) / NKS, nks = (i + 1) % NKS;
+          if (i + 1 < 4 * NKS) {
+            fq[(i + 1) & 1] = img_row<DH>(Qi, 4 * hf + nt, nks, lane);
+            fg[(i + 1) & 1] = img_row<DH>(Gi, 4 * hf + nt, nks, lane);
+          }
+          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i & 1], kf[ks], s[tt], 0, 0, 0);
+          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i & 1], vf[ks], dp[tt], 0, 0, 0);
         }
+        if (hf == 0 && (tt & 1) == 0) request(Qb, (int)a.ldq, nQ, tt);  // pieces 0-1 behind tt = 0, 2-3 behind tt = 2
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 4 * NKS - 1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next pair of fragments
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // this pair's products
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       const uint8_t* mcol = full_mask ? a.mask + (int64_t)b * a.msb + min(key, Tk - 1) : nullptr;
       const float* lp = lse_s[cur] + 64 * hf;
       const float* dlp = dl_s[cur] + 64 * hf;
@@ -812,16 +847,19 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     ATT_T(4);
     // dV^T += dO^T Pd ; dK^T += Q^T dS   (contraction over the tile's queries)
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+    for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
       for (int ss = 0; ss < NSS; ++ss) {
         dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Gi, ss, ct, lane), pf[ss], dv[ct], 0, 0, 0);
         dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr<DH>(Qi, ss, ct, lane), dsf[ss], dk[ct], 0, 0, 0);
       }
+      if (ct == 0 || ct == NCT / 2) request(Gb, (int)a.lddo, nQ + IMG_BYTES, ct == 0 ? 0 : 2);
+    }
     cur ^= 1;
     ATT_PIN(dk[NCT - 1][3]);
     ATT_T(5);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests behind the last tile
 #ifdef JS2T_ATTN_PROF
   if (bid == 0 && t == 0)
     for (int i = 0; i < 8; ++i) g_attn_prof[i] = prof_[i];
