@@ -94,6 +94,9 @@ __device__ __forceinline__ void stage_rel(float* rel_s, const AttnArgs& a, int h
 __device__ __forceinline__ int rel_index(int key, int query, int R) { return min(max(key - query, -R), R) + R; }
 
 // HBM -> LDS image of KT rows starting at row0 (rows clamped to rows_max-1), 4 DMA pieces per wave.
+// The requests are hidden from the compiler (lds_dma16, common.hpp): with the builtin in a block every wait the compiler places
+// for its LDS reads becomes lgkmcnt(0) - a full drain of the fragment reads in flight in front of every other product - and every
+// transposing read gets a vmcnt(0).  The kernels order requests and reads themselves: vmcnt(0) + barrier where an image is first read.
 // What does not change from tile to tile is computed ONCE per block (ImgSrc): this lane's tile row and column in each of its
 // wave's four pieces.  Per tile and piece that leaves one add for a whole tile, a clamp more for the last one - the first
 // version rebuilt a 64-bit address per piece and tile (two 32 x 32 multiplies, a 64-bit multiply-add, shifts: ten VALU
@@ -124,13 +127,13 @@ __device__ __forceinline__ void img_dma(const uint16_t* base, int ld, int row0, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t off = (uint32_t)(o0 + is.trow[q] * ld + is.col[q & 1]);
-      __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off), (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+      lds_dma16(base + off, img + (w * 4 + q) * 1024);
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t off = (uint32_t)(min(row0 + is.trow[q], rows_max - 1) * ld + is.col[q & 1]);
-      __builtin_amdgcn_global_load_lds((g_cvoid*)(base + off), (l_void*)(img + (w * 4 + q) * 1024), 16, 0, 0);
+      lds_dma16(base + off, img + (w * 4 + q) * 1024);
     }
   }
 }
@@ -169,6 +172,14 @@ __device__ __forceinline__ void own_frags(const uint16_t* base, int64_t ld, int 
   const int row = min(rb + (lane & 15), rows_max - 1);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) f[ks] = *(const bf16x8_t*)(base + (int64_t)row * ld + 32 * ks + 8 * (lane >> 4));
+}
+// The compiler waits for a global load where its result is first used.  With the LDS-DMA requests hidden from it (img_dma) such a
+// wait inside a tile loop - vmcnt(N) for "its" loads - would also wait for the younger requests of the tile in flight: the own-row
+// fragments are therefore "used" once in front of the loop, which moves their wait there.
+template <int N>
+__device__ __forceinline__ void pin_loaded(bf16x8_t (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x4_t& a, const f32x4_t& b) {
   const uint4 v = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const uint32_t thr = (uint32_t)(a.p * 65536.0f);
   stage_kbits<DH>(kmask, a, b, Tk, nkt * KT, t);
   if (REL) stage_rel(rel_s, a, h, t);
+  pin_loaded(qf);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = t_start_;
@@ -340,11 +352,25 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
     f32x4_t s[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {  // every product takes a fresh K fragment from LDS: the reads run two fragments ahead of the products (pinned by scheduling
+       // groups; left alone the compiler drained the LDS queue - lgkmcnt(0) - in front of every other product)
+      constexpr int NF = NTT * NKS;
+      bf16x8_t fk[3];
+      fk[0] = img_row<DH>(Ki, 0, 0, lane);
+      fk[1] = img_row<DH>(Ki, 1 / NKS, 1 % NKS, lane);
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
+      for (int i = 0; i < NF; ++i) {
+        if (i + 2 < NF) fk[(i + 2) % 3] = img_row<DH>(Ki, (i + 2) / NKS, (i + 2) % NKS, lane);
+        s[i / NKS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i % 3], qf[i % NKS], s[i / NKS], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Ki, tt, ks, lane), qf[ks], s[tt], 0, 0, 0);
+      for (int i = 0; i < NF - 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
     // online softmax in base 2: mi = running max of s*scale*log2e, li = running sum of exp2(.. - mi); the dropped
     // probabilities go to the PV product unscaled, 1/(1-p) is applied with 1/li at the end
     const bool tile_clear = !full_mask && __all(kbits == G::FULL) != 0;  // wave-uniform: every key of the tile is live
@@ -556,6 +582,9 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
     stage_rel(rel_s, a, h, t);
     for (int i = t; i < 2 * a.relR + 1; i += 256) drel_s[i] = 0.f, drel_i[i] = 0ull;
   }
+  pin_loaded(qf);
+  pin_loaded(gf);
+  asm volatile("" : "+v"(lse2), "+v"(ndl2));
   int cur = 0;
   float rel_edge[2] = {0.f, 0.f};  // this lane's share of the two end bins of the bias gradient (dq_elements)
   for (int kt = 0; kt < nkt; ++kt) {
@@ -578,13 +607,28 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
         s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         dp[tt] = f32x4_t{ndl2, ndl2, ndl2, ndl2};  // dP - delta*(1-p) comes out of the product (dq_elements)
       }
+      {  // fragment reads one pair ahead of their products, as in the dK/dV pass
+        constexpr int NF = NTT * NKS;
+        bf16x8_t fk[2], fv[2];
+        fk[0] = img_row<DH>(Ki, 0, 0, lane);
+        fv[0] = img_row<DH>(Vi, 0, 0, lane);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Ki, tt, ks, lane), qf[ks], s[tt], 0, 0, 0);
-          dp[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row<DH>(Vi, tt, ks, lane), gf[ks], dp[tt], 0, 0, 0);
+        for (int i = 0; i < NF; ++i) {
+          if (i + 1 < NF) {
+            fk[(i + 1) & 1] = img_row<DH>(Ki, (i + 1) / NKS, (i + 1) % NKS, lane);
+            fv[(i + 1) & 1] = img_row<DH>(Vi, (i + 1) / NKS, (i + 1) % NKS, lane);
+          }
+          s[i / NKS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i & 1], qf[i % NKS], s[i / NKS], 0, 0, 0);
+          dp[i / NKS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[i & 1], gf[i % NKS], dp[i / NKS], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int i = 0; i < NF - 1; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
       const uint32_t rowkeym = rowkeym0 + (uint32_t)kt * ((KT / 2) * HASH32W_M1);  // col4 base (KT/4) kt + g of this tile
       if (tile_clear) {
         dq_elements<false, NTT, REL>(s, dp, scale2, lse2, ndl2, G::FULL, rowkeym, thr, drop, rel_s, nullptr, KT * kt + 4 * g, q0 + m,
@@ -754,6 +798,8 @@ __device__ __forceinline__ void flash_dkv_body(const AttnArgs& a, int bid, int n
     lse_r = a.lse[(int64_t)z * a.Tq + qc];
     dl_r = load_delta<DH>(a, sg.q0, h, z, qc);
   }
+  pin_loaded(kf);
+  pin_loaded(vf);
   int cur = 0;
 #ifdef JS2T_ATTN_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
