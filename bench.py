@@ -417,10 +417,11 @@ def measure_roofline(eager_step, model):
     agg = timer.summary()
     for v in agg.values():
         v[2] = max(v[2] - v[0] * pair_overhead, 1e-9)
-    # dominant kernel = the bf16 LDS-DMA MFMA GEMM family: the persistent 192x128 kernel (forward and input-gradient
-    # products of the encoder-sized layers), the 128/64-row tile kernel (everything else) and its grouped launch
-    # form (the deferred weight gradients); per-kernel figures are listed beside it
-    fam = {k: v for k, v in agg.items() if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_"))}
+    # dominant kernel = the bf16 LDS-DMA MFMA GEMM family: the persistent 192x128 / panel kernels (forward and input-gradient
+    # products of the encoder-sized layers), the 128/64-row tile kernel (everything else) and the grouped launches (the deferred
+    # weight gradients: 256x128 or 128x128 tiles); per-kernel figures are listed beside it (labels are the host's: which kernel a
+    # js2t_gemm / js2t_gemm_grouped call takes is the library's choice)
+    fam = {k: v for k, v in agg.items() if k.startswith(("gemm_bf16_dma_", "gemm_bf16_p192_", "js2t_gemm_grouped"))}
     n = sum(v[0] for v in fam.values())
     flops = sum(v[1] for v in fam.values())
     secs = sum(v[2] for v in fam.values())
@@ -1062,7 +1063,37 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = step.read_stats()
+    # how much of a step the HOST spends inside the launch of its graph(s): with the GPU idle (synchronised before each launch) the
+    # call returns when the ~900 nodes are enqueued.  A step cannot be shorter than this on this runtime.
+    launch_host_ms = None
+    if use_graph and rank == 0:
+        ts = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            one_step()
+            ts.append((time.perf_counter() - h0) * 1e3)
+        torch.cuda.synchronize()
+        launch_host_ms = round(sorted(ts)[len(ts) // 2], 3)
+        step.read_stats(reset=True)
 
+    varying = None
+    if rank == 0 and world == 1 and not args.no_roofline and not args.no_extras and use_graph:
+        try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
+            import gc
+            # This leg runs right behind the headline, in front of the roofline / extension legs: behind their allocations and graphs the
+            # host side of a varying step (loader + bucket bookkeeping + graph launch, config.graph_launch_host_ms) ran ~1 ms slower
+            # and the line turned host-bound (12.8 ms per step against 11.9 ms on the GPU; stand-alone `--varying`: 11.8 against 11.8).
+            # A full collection or a hipMalloc inside the 100 timed steps would be a stall of this process's history, not of the path timed.
+            gc.collect()
+            torch.cuda.empty_cache()
+            gc.freeze()
+            try:
+                varying = varying_bench(device, 100, 250)
+            finally:
+                gc.unfreeze()
+        except Exception as exc:
+            varying = {"error": repr(exc)}
     roofline = None
     if rank == 0 and world == 1 and not args.no_roofline:  # N = 1: on the step that was just timed
         roofline = measure_roofline(eager_step, model)
@@ -1083,21 +1114,6 @@ def main():
         except Exception as exc:
             roofline["conformer_train_step"] = {"error": repr(exc)}
 
-    varying = None
-    if rank == 0 and world == 1 and roofline is not None and not args.no_extras and use_graph:
-        try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
-            import gc
-            # the legs above leave millions of dead Python objects and a fragmented allocator cache behind: a full collection or a
-            # hipMalloc inside the 100 timed steps is a stall of this process's history, not of the loader -> graph path being timed
-            gc.collect()
-            torch.cuda.empty_cache()
-            gc.freeze()
-            try:
-                varying = varying_bench(device, 100, 250)
-            finally:
-                gc.unfreeze()
-        except Exception as exc:
-            varying = {"error": repr(exc)}
     fp32_mode = None
     if rank == 0 and world == 1 and roofline is not None and not args.no_extras:
         try:
@@ -1139,6 +1155,7 @@ def main():
                        "global_batch": BATCH * world, "frames_per_utt": frames_per_step // BATCH, "encoder_len": ((int(state["batch"].src.shape[1]) - 1) // 2) // 2 + 1,
                        "lengths": "ragged 10-17 s, un-padded frames counted" if args.ragged else "fixed 15 s",
                        "vocab": VOCAB, "batch_multiplier": 1, "dropout": 0.1, "parallelism": f"dp{world}",
+                       "graph_launch_host_ms": launch_host_ms,
                        "launch": ("hipGraph replay" if world == 1 and not force_ddp else
                                   "hipGraph replay in pieces (fwd + decoder-side bwd | decoder-side weight-gradient groups | encoder bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
