@@ -1066,7 +1066,7 @@ def main():
     # how much of a step the HOST spends inside the launch of its graph(s): with the GPU idle (synchronised before each launch) the
     # call returns when the ~900 nodes are enqueued.  A step cannot be shorter than this on this runtime.
     launch_host_ms = None
-    if use_graph and rank == 0:
+    if use_graph and world == 1 and not force_ddp:  # (N > 1: a step is collectives too - never run one on a subset of the ranks)
         ts = []
         for _ in range(8):
             torch.cuda.synchronize()

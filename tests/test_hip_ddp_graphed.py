@@ -160,3 +160,26 @@ def test_graphed_ddp_step_capture_failure_falls_back_everywhere(device, stage):
         assert not r["captured"] and r["counts"] == {"eager": 5, "replay": 0}, r["counts"]
         assert torch.equal(r["graph"], r["eager"])  # five eager data-parallel updates: the reference run's parameters
     assert torch.equal(r0["graph"], r1["graph"])
+
+
+def test_bench_two_ranks_end_to_end(device):
+    """`python bench.py --gpus 2` as the driver runs it (bench.py starts its ranks itself), two ranks on one card over gloo: every
+    rank must make the same collective calls from start to finish - a step run by rank 0 alone (a side measurement, say) leaves
+    the other rank's collectives unmatched and the line is lost.  One JSON line, two ranks seen, graphs replayed, a finite loss."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, JS2T_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-decode",
+                          "--no-extras", "--no-roofline"], cwd=str(root), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["config"]["capture_error"] is None and "hipGraph replay in pieces" in out["config"]["launch"]
+    assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]  # finite, not NaN
