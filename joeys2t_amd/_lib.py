@@ -86,6 +86,11 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
             )
+        # torch first: its wheel carries its own libamdhip64, and a process that has loaded /opt/rocm's copy through this library
+        # BEFORE torch ends up with two HIP runtimes - the kernels' one then reports "no ROCm-capable device" (seen with
+        # __graft_entry__.build() followed by smoke() in one process).  Loaded after torch, the library binds to torch's runtime:
+        # one runtime, one set of streams and allocations.
+        import torch  # noqa: F401
         _lib = C.CDLL(str(LIB_PATH))
         _lib.js2t_last_error.restype = C.c_char_p
         _lib.js2t_colsum_partial_rows.restype = C.c_int64
