@@ -110,27 +110,36 @@ __global__ __launch_bounds__(256) void dwconv_outer_win_kernel(const T* __restri
 #pragma unroll
   for (int k = 0; k < KM; ++k) wr[k] = k < K ? w[c * K + (FLIP ? K - 1 - k : k)] : 0.f;
   const float b = bias ? bias[c] : 0.f;
-  for (int64_t n = n0 + nl; n < n1; n += 4)
+  const int64_t NC = N * C;
+  for (int64_t n = n0 + nl; n < n1; n += 4) {
+    const int off = (int)(n * C + c);  // this thread's column inside a row l (N * C < 2^30: checked by the launcher)
     for (int l0 = 0; l0 < L; l0 += LC) {
       float xr[LC + KM - 1];
 #pragma unroll
       for (int i = 0; i < LC + KM - 1; ++i) {  // xr[i] = x[l0 + i - pad] (zero outside the sequence)
+        // Every load is issued - from a clamped row where the window leaves the sequence - and zeroed by a select (as
+        // `cond ? load : 0` each of the 46 loads was a basic block of its own), and its address is a wave-uniform row base
+        // plus the thread's 32-bit column offset: formed per load as ((l * N + n) * C + c) in 64 bits the address arithmetic
+        // was half of the loop's vector instructions.
         const int ls = l0 + i - pad;
-        xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? io<T>::ld(x + ((int64_t)ls * N + n) * C + c) : 0.f;
+        const T* row = x + (int64_t)min(max(ls, 0), L - 1) * NC;
+        const float v = io<T>::ld(row + off);
+        xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? v : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < LC; ++j) {
         float acc = b;
 #pragma unroll
         for (int k = 0; k < KM; ++k) acc = fmaf(wr[k], xr[j + k], acc);
-        if (l0 + j < L) io<T>::st(y + ((int64_t)(l0 + j) * N + n) * C + c, acc);
+        if (l0 + j < L) io<T>::st(y + (int64_t)(l0 + j) * NC + off, acc);
       }
     }
+  }
 }
 template <bool FLIP>
 bool dwconv_outer_win_launch(const void* x, const float* w, const float* bias, void* y, int64_t L, int64_t N, int64_t C, int K, int dt,
                              hipStream_t s) {
-  if (K > 31 || L >= 65536 || L < 1) return false;
+  if (K > 31 || L >= 65536 || L < 1 || N * C >= (int64_t(1) << 30)) return false;
   int npb = (int)cdiv(N * cdiv(C, 64), 1024);  // columns per block: about four blocks per CU
   npb = npb < 4 ? 4 : (npb + 3) & ~3;
   if (cdiv(N, npb) > 65535) return false;
@@ -208,9 +217,13 @@ __global__ __launch_bounds__(256) void dwconv_outer_dw_kernel(const T* __restric
 // LC of dy along l in registers and forms all K lags from them (the kernel above fetches x K times per dy element and runs 96
 // blocks at L = 32, N = 375, C = 512: 1.06 ms per Conformer layer, a third of the config-5 train step).  Block = 64 channels x
 // 4 columns at a time over a slab of n; lags combined over the four waves in LDS, one atomic per (c, k) and block.
+// `part` != nullptr: the block's sums go to part[blockIdx.y][c][k] with plain stores and dwconv_dw_reduce_kernel adds the slabs up in
+// order - the 47 atomics per (c, k) of the other form (746 k on 15.9 k addresses at L = 32, N = 375, C = 512) were HALF of this
+// kernel's time (68 -> 37 us without them), and the order of the additions is then fixed (deterministic mode needs no special grid).
 template <typename T, int KM, int LC>
 __global__ __launch_bounds__(256) void dwconv_outer_dw_win_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw,
-                                                                  int L, int64_t N, int64_t C, int K, int n_per_block) {
+                                                                  int L, int64_t N, int64_t C, int K, int n_per_block,
+                                                                  float* __restrict__ part) {
   __shared__ float red[4][KM][64];
   const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + cl;
@@ -220,32 +233,67 @@ __global__ __launch_bounds__(256) void dwconv_outer_dw_win_kernel(const T* __res
 #pragma unroll
   for (int k = 0; k < KM; ++k) acc[k] = 0.f;
   if (c < C) {
-    for (int64_t n = n0 + nl; n < n1; n += 4)
+    const int64_t NC = N * C;
+    for (int64_t n = n0 + nl; n < n1; n += 4) {
+      const int off = (int)(n * C + c);  // (N * C < 2^30: checked by the launcher)
       for (int l0 = 0; l0 < L; l0 += LC) {
         float xr[LC + KM - 1];
 #pragma unroll
         for (int i = 0; i < LC + KM - 1; ++i) {  // xr[i] = x[l0 + i - pad] (zero outside the sequence)
-          const int ls = l0 + i - pad;
-          xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? io<T>::ld(x + ((int64_t)ls * N + n) * C + c) : 0.f;
+          const int ls = l0 + i - pad;  // (unconditional loads from clamped, wave-uniform rows + selects: see dwconv_outer_win_kernel)
+          const float v = io<T>::ld(x + (int64_t)min(max(ls, 0), L - 1) * NC + off);
+          xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? v : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < LC; ++j) {
-          const float g = l0 + j < L ? io<T>::ld(dy + ((int64_t)(l0 + j) * N + n) * C + c) : 0.f;
+          const float gv = io<T>::ld(dy + (int64_t)min(l0 + j, L - 1) * NC + off);
+          const float g = l0 + j < L ? gv : 0.f;
 #pragma unroll
           for (int k = 0; k < KM; ++k) acc[k] = fmaf(g, xr[j + k], acc[k]);  // x[l + k - pad] = xr[(l - l0) + k]
         }
       }
+    }
   }
 #pragma unroll
   for (int k = 0; k < KM; ++k) red[nl][k][cl] = acc[k];
   __syncthreads();
   typedef __attribute__((address_space(1))) float gfloat;
+  if (part) {  // contiguous run of 64 x K floats per block: thread i writes element i (channel i / K, lag i % K)
+    float* pb = part + ((int64_t)blockIdx.y * C + (int64_t)blockIdx.x * 64) * K;
+    for (int i = threadIdx.x; i < K * 64; i += 256) {
+      const int cc = i / K, k = i - cc * K;
+      if ((int64_t)blockIdx.x * 64 + cc < C) pb[i] = (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < K * 64; i += 256) {
     const int k = i >> 6, cc = i & 63;
     const int64_t co = (int64_t)blockIdx.x * 64 + cc;
     if (co < C)
       __builtin_amdgcn_global_atomic_fadd_f32((gfloat*)dw + co * K + k, (red[0][k][cc] + red[1][k][cc]) + (red[2][k][cc] + red[3][k][cc]));
   }
+}
+// dw[i] += part[0][i] + part[1][i] + ... (slabs in order)
+__global__ __launch_bounds__(256) void dwconv_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t n, int slabs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int sidx = 0; sidx < slabs; ++sidx) a += part[(int64_t)sidx * n + i];
+  dw[i] += a;
+}
+// Library-owned scratch for the slab sums: allocated ONCE, at the first call (an eager call: hipMalloc is not capturable, and a buffer
+// that moved later would leave captured graphs with a dangling pointer), never grown; a call that needs more takes the atomic form.
+float* dw_partial_scratch(size_t n_floats) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const size_t want = n_floats < (size_t(4) << 20) ? (size_t(4) << 20) : n_floats;  // >= 16 MB: 256 slabs of a 512 x 31 weight
+    if (hipMalloc(&buf, want * sizeof(float)) == hipSuccess) cap = want;
+    else buf = nullptr;
+  }
+  return n_floats <= cap ? buf : nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------- batch norm + activation
@@ -389,24 +437,40 @@ extern "C" int js2t_dwconv_outer_bwd(const void* dy, const void* x, const float*
     // measured at L = 32, N = 375, C = 512: 4 -> 122 us, 8 -> 91, 16 -> 97, 32 -> 146 (dx + dw)
     int npb = (int)cdiv(N * cdiv(C, 64), 512);
     npb = npb < 4 ? 4 : (npb > DW_SLAB ? DW_SLAB : (npb + 3) & ~3);
-    // deterministic mode (js2t_set_deterministic): ONE block per 64 channels walks every column, so each dw[c, k] receives a single
-    // sum formed in a fixed order (the slabs' atomics arrive in any order otherwise)
-    if (g_js2t_deterministic && N < (1 << 30)) npb = (int)N;
+    // the slabs' sums go through the library's scratch and are added up in order (also what deterministic mode wants); without the
+    // scratch (first call under capture, or a problem larger than it): atomics, and in deterministic mode (js2t_set_deterministic)
+    // ONE block per 64 channels that walks every column
+    hipStreamCaptureStatus cap_state = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap_state);
+    static bool scratch_ready = false;  // (the first, allocating call must be an eager one)
+    float* part = nullptr;
+    if (L < 65536 && N * C < (int64_t(1) << 30) && (scratch_ready || cap_state == hipStreamCaptureStatusNone)) {
+      const char* e = getenv("JS2T_DW_NPB");
+      const int npb_part = e ? atoi(e) : npb;
+      part = dw_partial_scratch((size_t)cdiv(N, npb_part) * (size_t)C * (size_t)K);
+      scratch_ready = true;
+      if (part) npb = npb_part;
+    }
+    if (!part && g_js2t_deterministic && N < (1 << 30)) npb = (int)N;
     const dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(N, npb));
-    if (L >= 65536 && !g_js2t_deterministic) {  // (int arithmetic of the window kernel)
+    if ((L >= 65536 || N * C >= (int64_t(1) << 30)) && !g_js2t_deterministic) {  // (int arithmetic of the window kernel)
       DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_kernel<T>), dim3((unsigned)cdiv(C, 64), (unsigned)cdiv(N, DW_SLAB)), dim3(256),
                                             0, s, (const T*)dy, (const T*)x, dw, L, N, C, K));
     } else if (K <= 15) {
       DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_win_kernel<T, 15, 32>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, dw,
-                                            (int)L, N, C, K, npb));
+                                            (int)L, N, C, K, npb, part));
     } else if (K <= 31) {
       DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_win_kernel<T, 31, 16>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, dw,
-                                            (int)L, N, C, K, npb));
+                                            (int)L, N, C, K, npb, part));
     } else {
       DISPATCH_DT(dt, T, hipLaunchKernelGGL((dwconv_outer_dw_win_kernel<T, 63, 16>), grid, dim3(256), 0, s, (const T*)dy, (const T*)x, dw,
-                                            (int)L, N, C, K, npb));
+                                            (int)L, N, C, K, npb, part));
     }
     JS2T_LAUNCH_CHECK();
+    if (part) {
+      hipLaunchKernelGGL(dwconv_dw_reduce_kernel, dim3((unsigned)cdiv(C * K, 256)), dim3(256), 0, s, part, dw, C * (int64_t)K, (int)grid.y);
+      JS2T_LAUNCH_CHECK();
+    }
   }
   return JS2T_OK;
 }
