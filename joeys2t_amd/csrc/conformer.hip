@@ -126,12 +126,22 @@ __global__ __launch_bounds__(256) void dwconv_outer_win_kernel(const T* __restri
         const float v = io<T>::ld(row + off);
         xr[i] = (i < LC + K - 1 && ls >= 0 && ls < L) ? v : 0.f;
       }
+      if (l0 + LC <= L) {  // whole chunk (wave-uniform): no test per store, one basic block for the 16 outputs
 #pragma unroll
-      for (int j = 0; j < LC; ++j) {
-        float acc = b;
+        for (int j = 0; j < LC; ++j) {
+          float acc = b;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) acc = fmaf(wr[k], xr[j + k], acc);
-        if (l0 + j < L) io<T>::st(y + (int64_t)(l0 + j) * NC + off, acc);
+          for (int k = 0; k < KM; ++k) acc = fmaf(wr[k], xr[j + k], acc);
+          io<T>::st(y + (int64_t)(l0 + j) * NC + off, acc);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < LC; ++j) {
+          float acc = b;
+#pragma unroll
+          for (int k = 0; k < KM; ++k) acc = fmaf(wr[k], xr[j + k], acc);
+          if (l0 + j < L) io<T>::st(y + (int64_t)(l0 + j) * NC + off, acc);
+        }
       }
     }
   }
