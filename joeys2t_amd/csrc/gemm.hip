@@ -2762,10 +2762,13 @@ int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   const int tm = cdiv(d.M, P_BM), tn = cdiv(d.N, 128);
   // the row statistics (rs_*) are written by the loader / consumer form only: its multiplying waves issue no LDS-DMA, so the
   // fences of the hand-over to the finishing wave wait for nothing but the wave's own stores
-  if (g_p192_ring == 4 || (EPI >= 0 && (EPI & (PE_STATS | PE_DOT))) || (g_p192_ring < 0 && 2 * tm * tn < 3 * n_cu)) {
+  // one block of twelve waves per CU while the tiles fit ONE round (<= one per CU); between one and one and a half tiles per CU that
+  // form needs a second round for the few tiles left over (12288 < M <= 18432 rows at N = 512: the memory K | V input gradient on
+  // the padded rows of a ragged batch, 284 tiles, took two tile times) - the two-block form has them all resident at once
+  if (g_p192_ring == 4 || (EPI >= 0 && (EPI & (PE_STATS | PE_DOT))) || (g_p192_ring < 0 && tm * tn <= n_cu)) {
     const int grid = tm * tn < n_cu ? tm * tn : n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192s_kernel<EPI>), dim3(grid), dim3(768), PS_LDS, s, d, tm, tn);
-  } else if (g_p192_ring == 2 || (g_p192_ring < 0 && 2 * tm * tn >= 3 * n_cu)) {
+  } else if (g_p192_ring == 2 || (g_p192_ring < 0 && tm * tn > n_cu)) {
     const int grid = tm * tn < 2 * n_cu ? tm * tn : 2 * n_cu;
     hipLaunchKernelGGL((gemm_bf16_p192_kernel<EPI, 2>), dim3(grid), dim3(256), 2 * P_STAGE, s, d, tm, tn);
   } else {
