@@ -930,12 +930,14 @@ __global__ __launch_bounds__(256, 2) void flash_dkv_kernel(AttnArgs a) {
 // Both passes as ONE grid: two grids of 768 blocks (an encoder layer) on 512 resident slots are 2 x 1.5 rounds, one of 1536 is
 // three; on the decoder's small grids the passes run side by side.  Needs delta before either pass starts, i.e. the partial sums
 // of js2t_attn_desc.delta_partial (handing delta from the dQ blocks to the dK/dV blocks inside one grid costs more than the
-// merged grid saves: profiles/README.md, round 2).  The dK/dV blocks (the longer ones) go first; n_dkv % 8 == 0 keeps the
-// XCD-aware order of both ranges.
+// merged grid saves: profiles/README.md, round 2).  The dK/dV blocks (the longer ones) go first; their range is padded to a
+// multiple of 8 blocks, which keeps the XCD-aware order of both ranges.
 template <int DH, bool REL, bool DROP>
-__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(AttnArgs a, int n_dkv) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(AttnArgs a, int n_dkv, int n_dkv_pad) {
+  // n_dkv_pad = n_dkv rounded up to a multiple of 8: up to seven idle blocks between the ranges keep the dQ range's block ids
+  // congruent to their XCDs (a batch of 33 utterances x 4 heads x 7 tiles used to fall back to two launches)
   if ((int)blockIdx.x < n_dkv) flash_dkv_body<DH, REL, DROP>(a, blockIdx.x, n_dkv);
-  else flash_dq_body<DH, REL, DROP>(a, (int)blockIdx.x - n_dkv, (int)gridDim.x - n_dkv);
+  else if ((int)blockIdx.x >= n_dkv_pad) flash_dq_body<DH, REL, DROP>(a, (int)blockIdx.x - n_dkv_pad, (int)gridDim.x - n_dkv_pad);
 }
 
 template <typename K>
@@ -1033,8 +1035,9 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
     JS2T_CHECK(hipMemsetAsync(fix, 0, (size_t)n_fix * sizeof(long long), s) == hipSuccess, "flash_attn_bwd: memset failed");
     a.d_rel_fix = (unsigned long long*)fix;
   }
-  if (d->delta_partial && (n_dkv & 7) == 0 && g_attn_bwd_merge) {
-    hipLaunchKernelGGL((flash_bwd_kernel<DH, REL, DROP>), dim3(n_dkv + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv);
+  if (d->delta_partial && g_attn_bwd_merge) {
+    const int n_dkv_pad = (n_dkv + 7) & ~7;
+    hipLaunchKernelGGL((flash_bwd_kernel<DH, REL, DROP>), dim3(n_dkv_pad + n_dq), dim3(256), 4 * IMG_BYTES, s, a, n_dkv, n_dkv_pad);
     JS2T_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL((flash_dq_kernel<DH, REL, DROP>), dim3(n_dq), dim3(256), 4 * IMG_BYTES, s, a);  // also writes delta
