@@ -666,6 +666,11 @@ typedef struct js2t_attn_desc {
    * (whose column sums - weight gradients, bias gradients - run over all rows); 0: not written, the caller's business. */
   const int32_t* seg;
   int64_t seg_rows;
+  /* seg_keys != 0: CROSS-attention over packed keys (the decoder reading the encoder states of a ragged batch, transformer_layers.py:
+   * 383-396 of the reference): seg describes k / v / dk / dv only - entry b's keys are rows seg[b] .. seg[b+1] and it has
+   * seg[b+1] - seg[b] <= Tk of them; q / o / d_o / dq stay in the padded [B * Tq] layout.  Tk is the longest entry (grid shape, mask
+   * rows, dropout counters of the padded layout); seg_rows zeroes the tails of dk / dv. */
+  int32_t seg_keys;
 } js2t_attn_desc;
 int js2t_flash_attn_fwd(const js2t_attn_desc* d, js2t_stream stream);
 int js2t_flash_attn_bwd(const js2t_attn_desc* d, js2t_stream stream);

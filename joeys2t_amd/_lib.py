@@ -65,6 +65,7 @@ class AttnDesc(C.Structure):
         ("rng_state", C.c_void_p), ("rng_stream", C.c_uint32),
         ("rel_R", C.c_int32), ("rel_bias", C.c_void_p), ("d_rel_bias", C.c_void_p),
         ("delta_partial", C.c_void_p), ("delta_groups", C.c_int32), ("seg", C.c_void_p), ("seg_rows", C.c_int64),
+        ("seg_keys", C.c_int32),
     ]
 
 

@@ -57,6 +57,7 @@ struct AttnArgs {
   const int32_t* seg;  // packed rows (js2t_attn_desc.seg): entry b owns rows seg[b] .. seg[b+1] of every buffer; NULL: b * Tq ..
   unsigned long long* d_rel_fix;  // deterministic mode: the bias gradient as 2^-32 fixed-point sums [H, 2R+1] (common.hpp), else NULL
   int seg_rows;  // packed rows: rows of the buffers; seg[B] .. seg_rows belong to nobody and are zeroed (0: left alone)
+  int seg_keys;  // seg describes the key side only (cross-attention over packed keys): queries stay padded
 };
 // where batch entry b lives: first row in the query-side and key-side buffers, its own lengths.  a.Tq / a.Tk stay the PADDED
 // lengths: grid shape, [B*H, Tq] scalars (lse, delta), mask rows and the dropout counter (z * Tq + q: the packed layout draws the
@@ -65,6 +66,7 @@ struct Seg { int q0, k0, Tq, Tk; };
 __device__ __forceinline__ Seg seg_of(const AttnArgs& a, int b) {
   if (a.seg) {
     const int r0 = a.seg[b], n = a.seg[b + 1] - r0;
+    if (a.seg_keys) return Seg{b * a.Tq, r0, a.Tq, n};
     return Seg{r0, r0, n, n};
   }
   return Seg{b * a.Tq, b * a.Tk, a.Tq, a.Tk};
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, SB ? 3 : 2) void flash_fwd_kernel(AttnArgs a) 
   const int q0 = (lid - z * ntile) * 64 + w * 16;
   const Seg sg = seg_of(a, b);
   const int Tq = sg.Tq, Tk = sg.Tk;
-  if (a.seg_rows) zero_tail_rows(a, a.out, a.ldo, a.H * DH, blockIdx.x, gridDim.x);
+  if (a.seg_rows && !a.seg_keys) zero_tail_rows(a, a.out, a.ldo, a.H * DH, blockIdx.x, gridDim.x);
   if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
   const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
   const uint16_t* Kb = a.k + (int64_t)sg.k0 * a.ldk + h * DH;
@@ -533,7 +535,7 @@ __device__ __forceinline__ void flash_dq_body(const AttnArgs& a, int bid, int nb
   const int q0 = (lid - z * ntile) * 64 + w * 16;
   const Seg sg = seg_of(a, b);
   const int Tq = sg.Tq, Tk = sg.Tk;
-  if (a.seg_rows) zero_tail_rows(a, a.dq, a.lddq, a.H * DH, bid, nblk);
+  if (a.seg_rows && !a.seg_keys) zero_tail_rows(a, a.dq, a.lddq, a.H * DH, bid, nblk);
   if (q0 - w * 16 >= Tq) return;  // packed rows: a tile behind this utterance's last query (block-uniform, before any barrier)
   const uint16_t* Qb = a.q + (int64_t)sg.q0 * a.ldq + h * DH;
   const uint16_t* Gb = a.d_o + (int64_t)sg.q0 * a.lddo + h * DH;
@@ -965,7 +967,8 @@ int check_common(const js2t_attn_desc* d) {
   JS2T_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f && (d->dropout_p == 0.f || d->rng_state), "flash_attn: bad dropout args");
   JS2T_CHECK(!d->rel_bias || (d->rel_R >= 1 && d->rel_R <= REL_MAX), "flash_attn: rel_R must be 1..%d", REL_MAX);
   JS2T_CHECK(!d->d_rel_bias || d->rel_bias, "flash_attn: d_rel_bias without rel_bias");
-  JS2T_CHECK(!d->seg || d->Tq == d->Tk, "flash_attn: packed rows (seg) are for self-attention, Tq == Tk = the longest entry");
+  JS2T_CHECK(!d->seg || d->seg_keys || d->Tq == d->Tk, "flash_attn: packed rows (seg) are for self-attention, Tq == Tk = the longest entry");
+  JS2T_CHECK(!d->seg_keys || d->seg, "flash_attn: seg_keys without seg");
   JS2T_CHECK(!d->seg || (d->seg_rows >= 0 && d->seg_rows < (1ll << 31) && ((d->H * d->head_dim) & 3) == 0), "flash_attn: bad seg_rows");
   return JS2T_OK;
 }
@@ -984,6 +987,7 @@ AttnArgs to_args(const js2t_attn_desc* d) {
   a.dpart = d->delta_partial; a.dgroups = d->delta_groups;
   a.seg = d->seg;
   a.seg_rows = d->seg ? (int)d->seg_rows : 0;
+  a.seg_keys = d->seg ? d->seg_keys : 0;
   a.d_rel_fix = nullptr;
   return a;
 }

@@ -1040,32 +1040,39 @@ def zero_tail_rows(buf, pk: PackedRows):
                                C.c_int64(pk.rows), C.c_int64(buf.shape[1] * buf.element_size()), 2, _stream()), "js2t_pack_rows")
 
 
-def _seg_check(pk, q_t, B, Tq, Tk):
-    if pk.B != B or pk.T != Tq or Tq != Tk or q_t.shape[0] != pk.rows:
+def _seg_check(pk, q_t, B, Tq, Tk, k_t=None):
+    """k_t given: cross-attention over packed KEYS (js2t_attn_desc.seg_keys) - the queries stay [B * Tq]."""
+    if k_t is not None:
+        if pk.B != B or pk.T != Tk or k_t.shape[0] != pk.rows or q_t.shape[0] != B * Tq:
+            raise Js2tError(f"flash attention over packed keys: {pk.B} entries of <= {pk.T} keys in {pk.rows} rows do not match "
+                            f"B={B} Tq={Tq} Tk={Tk} key rows={k_t.shape[0]} query rows={q_t.shape[0]}")
+    elif pk.B != B or pk.T != Tq or Tq != Tk or q_t.shape[0] != pk.rows:
         raise Js2tError(f"flash attention over packed rows: {pk.B} entries of <= {pk.T} positions in {pk.rows} rows do not match "
                         f"B={B} Tq={Tq} Tk={Tk} rows={q_t.shape[0]}")
     _dev(pk.seg)
 
 
-def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None, seg: PackedRows = None):
-    """seg: self-attention over packed rows (q_t / k_t / v_t are [seg.rows, ...]; B, Tq == Tk = the padded geometry)."""
+def flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias=None, seg: PackedRows = None,
+                   seg_keys: bool = False):
+    """seg: self-attention over packed rows (q_t / k_t / v_t are [seg.rows, ...]; B, Tq == Tk = the padded geometry); with seg_keys
+    cross-attention over packed KEYS (k_t / v_t are [seg.rows, ...], q_t stays [B * Tq, ...]; Tk = the longest entry)."""
     _dev(q_t, k_t, v_t, mask, rel_bias)
     rows = B * Tq
     if seg is not None:
-        _seg_check(seg, q_t, B, Tq, Tk)
-        rows = seg.rows
+        _seg_check(seg, q_t, B, Tq, Tk, k_t if seg_keys else None)
+        rows = B * Tq if seg_keys else seg.rows
     out = torch.empty((rows, H * dh), dtype=q_t.dtype, device=q_t.device)
     lse = torch.empty((B * H, Tq), dtype=torch.float32, device=q_t.device)
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     d.o, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
     if seg is not None:
-        d.seg, d.seg_rows = seg.seg.data_ptr(), seg.rows  # rows no entry owns are zeroed by the kernel
+        d.seg, d.seg_rows, d.seg_keys = seg.seg.data_ptr(), seg.rows, int(bool(seg_keys))  # rows no entry owns are zeroed by the kernel
     check(lib().js2t_flash_attn_fwd(C.byref(d), _stream()), "js2t_flash_attn_fwd")
     return out, lse
 
 
 def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off, B, H, Tq, Tk,
-                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None, seg: PackedRows = None):
+                   dh, mask, p, rng, site, rel_bias=None, d_rel_bias=None, delta_partial=None, seg: PackedRows = None, seg_keys: bool = False):
     """d_rel_bias (f32, shape of rel_bias): the bias gradient is ADDED into it (atomics): zero it unless accumulating.
     seg: packed rows, as in flash_attn_fwd; rows of dq / dk / dv no entry owns are zeroed by the kernels (js2t_attn_desc.seg_rows).
     delta_partial f32 [B*Tq, H*dh // 64]: rowsum(dout * out) as partial sums per 64-column group (gemm(dot=...) of the product that
@@ -1074,8 +1081,10 @@ def flash_attn_bwd(dout, out, lse, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_
     d = _attn_desc(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias)
     nrows = B * Tq
     if seg is not None:
-        _seg_check(seg, q_t, B, Tq, Tk)
-        d.seg, d.seg_rows, nrows = seg.seg.data_ptr(), seg.rows, seg.rows
+        _seg_check(seg, q_t, B, Tq, Tk, k_t if seg_keys else None)
+        d.seg, d.seg_rows, d.seg_keys = seg.seg.data_ptr(), seg.rows, int(bool(seg_keys))
+        if not seg_keys:
+            nrows = seg.rows
     if d_rel_bias is not None:
         if rel_bias is None or d_rel_bias.shape != rel_bias.shape or d_rel_bias.dtype != torch.float32 or not d_rel_bias.is_contiguous():
             raise Js2tError("d_rel_bias must be a contiguous float32 tensor shaped like rel_bias")

@@ -86,7 +86,7 @@ def test_attn_desc_matches_header_layout():
     names = [m.group(1) for m in re.finditer(r"(\w+)\s*(?:;|,)", body)]
     mirror = [f[0] for f in AttnDesc._fields_]
     assert [n for n in names if n in mirror] == mirror, (names, mirror)
-    assert mirror[-4:] == ["delta_partial", "delta_groups", "seg", "seg_rows"]
+    assert mirror[-5:] == ["delta_partial", "delta_groups", "seg", "seg_rows", "seg_keys"]
 
 
 def test_packed_rows_host_logic():

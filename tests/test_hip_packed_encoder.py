@@ -68,6 +68,39 @@ def test_flash_attention_over_packed_rows_equals_padded(device, dh, H, p):
         assert torch.equal(dqkv_p, ops.pack_rows(dqkv, pk)), with_partial
 
 
+@pytest.mark.parametrize("dh,H", [(128, 4), (64, 8)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_cross_attention_over_packed_keys_equals_padded(device, dh, H, p):
+    """js2t_attn_desc.seg_keys: the decoder's cross-attention reading the encoder states of a ragged batch as packed rows - the same
+    keys, tiles, masks and dropout counters as over the padded memory: output, log-sum-exp, dQ bit for bit, dK / dV bit for bit on
+    every live key row, the rows behind the last entry zeroed by the kernels (NaN-prefilled buffers); one grid and two launches."""
+    lens, Tk, Tq = [375, 301, 64, 129, 1, 200], 375, 27
+    B, d = len(lens), H * dh
+    pk = ops.PackedRows.from_lengths(lens, Tk, device, round_to=64)
+    live = (torch.arange(Tk)[None, :] < torch.tensor(lens)[:, None])
+    q = rnd(B * Tq, d, seed=1).bfloat16().to(device)
+    kv = (rnd(B * Tk, 2 * d, seed=2) * live.reshape(-1, 1)).bfloat16().to(device)
+    go = rnd(B * Tq, d, seed=3).bfloat16().to(device)
+    mask = live.unsqueeze(1).to(device)
+    rng = ops.DropoutRng(device, seed=3) if p else None
+    out, lse = ops.flash_attn_fwd(q, 0, kv, 0, kv, d, B, H, Tq, Tk, dh, mask, p, rng, 5)
+    kv_p = ops.pack_rows(kv, pk)
+    out_p, lse_p = ops.flash_attn_fwd(q, 0, kv_p, 0, kv_p, d, B, H, Tq, Tk, dh, mask, p, rng, 5, seg=pk, seg_keys=True)
+    assert out_p.shape == out.shape and torch.equal(out_p, out) and torch.equal(lse_p, lse)
+    part = (go.float() * out.float()).view(B * Tq, d // 64, 64).sum(-1).contiguous()
+    for kw in ({}, {"delta_partial": part}):
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        ops.flash_attn_bwd(go, out, lse, q, 0, kv, 0, kv, d, dq, 0, dkv, 0, dkv, d, B, H, Tq, Tk, dh, mask, p, rng, 5, **kw)
+        dq_p, dkv_p = torch.full_like(q, float("nan")), torch.full_like(kv_p, float("nan"))
+        ops.flash_attn_bwd(go, out_p, lse_p, q, 0, kv_p, 0, kv_p, d, dq_p, 0, dkv_p, 0, dkv_p, d, B, H, Tq, Tk, dh, mask, p, rng, 5,
+                           seg=pk, seg_keys=True, **kw)
+        assert torch.isfinite(dq_p.float()).all() and torch.isfinite(dkv_p.float()).all()
+        assert torch.equal(dq_p, dq), bool(kw)
+        assert torch.equal(dkv_p, ops.pack_rows(dkv, pk)), bool(kw)  # (pack_rows zeroes the tail: so did the kernels)
+    with pytest.raises(ops.Js2tError):  # the key buffer must be the packed one
+        ops.flash_attn_fwd(q, 0, kv, 0, kv, d, B, H, Tq, Tk, dh, mask, p, rng, 5, seg=pk, seg_keys=True)
+
+
 def test_packed_rows_are_refused_where_they_cannot_work(device):
     pk = ops.PackedRows.from_lengths([5, 3], 8, device)
     q = torch.zeros(8, 384, dtype=torch.bfloat16, device=device)
