@@ -19,6 +19,9 @@ class Decoder(nn.Module):
         return self._output_size
 
 
+PACK_MEMORY = True  # the decoder reads the encoder states of a ragged batch as packed rows when the encoder packed them (tests flip this)
+
+
 class TransformerDecoder(Decoder):
     def __init__(self, num_layers: int = 4, num_heads: int = 8, hidden_size: int = 512, ff_size: int = 2048,
                  dropout: float = 0.1, emb_dropout: float = 0.1, vocab_size: int = 1, freeze: bool = False, **kwargs):
@@ -99,12 +102,25 @@ class TransformerDecoder(Decoder):
         last_layer = len(self.layers) - 1
         return_attention = kwargs.get("return_attention", False)
         att = None
-        kv_all = self.memory_kv(encoder_output)
+        # Ragged batch whose encoder ran on packed rows (encoders.TransformerEncoder, `memory_pack` = its ops.PackedRows): the K | V
+        # projections of all layers, their gradients and the cross-attention keys stay on the LIVE positions too - the padded
+        # [B, T', d] states are packed again right here (a 12 MB copy; the tensor the backward pass is cut at stays the padded
+        # one), the cross-attention kernels read each utterance's own row range (js2t_attn_desc.seg_keys).  Needs the grouped
+        # projections and the fused kernels (no attention weights to return).
+        mem_pack = kwargs.get("memory_pack")
+        kv_all = None
+        if (mem_pack is not None and not return_attention and Fn.USE_FLASH and rt.compute_dtype == torch.bfloat16 and PACK_MEMORY and
+                encoder_output.dim() == 3 and (mem_pack.B, mem_pack.T) == tuple(encoder_output.shape[:2]) and
+                (self._hidden_size // self.layers[0].src_trg_att.num_heads) in (64, 128)):
+            kv_all = self.memory_kv(Fn.PackRowsFn.apply(rt.act_in(encoder_output), mem_pack))
+        if kv_all is None:
+            mem_pack = None
+            kv_all = self.memory_kv(encoder_output)
         d2 = 2 * self._hidden_size
         for i, layer in enumerate(self.layers):
             x, att = layer(x=x, memory=encoder_output, src_mask=src_mask, trg_mask=trg_mask,
                            return_attention=(return_attention and i == last_layer),
-                           memory_kv=None if kv_all is None else (kv_all, i * d2))
+                           memory_kv=None if kv_all is None else (kv_all, i * d2), mem_pack=mem_pack)
         if self.layer_norm is not None:
             sk = rt.sinks({"g": [self.layer_norm.weight], "b": [self.layer_norm.bias]})
             x = Fn.LayerNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, None if sk is None else (sk["g"], sk["b"], sk.get("_copies")),

@@ -120,6 +120,7 @@ class TransformerEncoder(Encoder):
         x = self.pe(src_embed, extra=kwargs.get("src_prompt_mask", None), dropout=self.emb_dropout.p,
                     training=self.training)
         pack = self._packing(x, mask, kwargs)
+        self.last_pack = pack  # for the decoder of the same forward (model.py hands it on as `memory_pack`)
         if pack is not None:  # ragged batch: the stack runs on the live positions only, [1, sum of lengths (rounded), d]
             x = Fn.PackRowsFn.apply(x, pack)
         for layer in self.layers:

@@ -220,11 +220,12 @@ def wgrad_split(rows: int, cols: int, red: int, count: int = 1) -> int:
 
 
 class AttnShape:
-    __slots__ = ("B", "Tq", "Tk", "H", "dh", "ld", "seg")
+    __slots__ = ("B", "Tq", "Tk", "H", "dh", "ld", "seg", "seg_keys")
 
-    def __init__(self, B, Tq, Tk, H, dh, seg=None):
+    def __init__(self, B, Tq, Tk, H, dh, seg=None, seg_keys=False):
         self.B, self.Tq, self.Tk, self.H, self.dh = B, Tq, Tk, H, dh
         self.seg = seg  # ops.PackedRows: self-attention over the packed rows of a ragged batch (fused kernels only)
+        self.seg_keys = bool(seg_keys)  # seg describes the KEY side only: cross-attention over packed encoder states
         self.ld = ops.round_up(Tk, 8)  # score row stride: 16-byte rows for the bf16 GEMMs
 
 
@@ -240,7 +241,8 @@ def attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, shp: AttnShape, mask, p, rng, s
     Z = B * H
     if USE_FLASH and not need_probs and ops.flash_supported(q_t, k_t, v_t, dh):
         # fused kernel: scores / probabilities stay on chip; the forward keeps (out, lse) for backward
-        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, seg=shp.seg)
+        out, lse = ops.flash_attn_fwd(q_t, q_off, k_t, k_off, v_t, v_off, B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, seg=shp.seg,
+                                      seg_keys=shp.seg_keys)
         return out, None, lse
     if shp.seg is not None:
         raise ops.Js2tError("attention over packed rows needs the fused kernels (bf16, head size 64 / 128): the encoder packs only then")
@@ -270,7 +272,8 @@ def attn_bwd(dctx, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_of
     B, Tq, Tk, H, dh, ld = shp.B, shp.Tq, shp.Tk, shp.H, shp.dh, shp.ld
     if P is None:
         ops.flash_attn_bwd(dctx, ctx_out, Pd, q_t, q_off, k_t, k_off, v_t, v_off, dq_t, dq_off, dk_t, dk_off, dv_t, dv_off,
-                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias, delta_partial=delta_partial, seg=shp.seg)
+                           B, H, Tq, Tk, dh, mask, p, rng, site, rel_bias, d_rel_bias, delta_partial=delta_partial, seg=shp.seg,
+                           seg_keys=shp.seg_keys)
         return
     Z = B * H
     dev, dt = dctx.device, dctx.dtype
@@ -540,8 +543,10 @@ class ResidualBlockFn(torch.autograd.Function):
                 kv_off = 0
             else:  # `memory` IS the projections of all layers (MemoryKVFn) [B*S, L*2d]: this layer's [k | v] start at column kv_off
                 kv, m2 = memory, None
-                S = kv.shape[0] // B
-                if kv.dim() != 2 or kv.shape[0] != B * S or kv_off + 2 * d > kv.shape[1]:
+                mem_pack = wts.get("mem_pack")  # ops.PackedRows: the projections of the PACKED encoder states, [rows, L*2d]
+                S = kv.shape[0] // B if mem_pack is None else mem_pack.T
+                rows = B * S if mem_pack is None else mem_pack.rows
+                if kv.dim() != 2 or kv.shape[0] != rows or kv_off + 2 * d > kv.shape[1] or (mem_pack is not None and mem_pack.B != B):
                     raise ops.Js2tError(f"cross block: grouped projections {tuple(kv.shape)} do not hold [k | v] at column {kv_off}")
                 if kv.requires_grad:
                     if not _CHAIN_ACTIVE:
@@ -549,7 +554,8 @@ class ResidualBlockFn(torch.autograd.Function):
                     key = kv.data_ptr()
                     _KV_USERS[key] = _KV_USERS.get(key, 0) + 1
                     saved["kv_key"] = key
-            shp = AttnShape(B, T, S, H, dh)
+            mem_pack = wts.get("mem_pack") if wts.get("kv_off") is not None else None
+            shp = AttnShape(B, T, S, H, dh, seg=mem_pack, seg_keys=mem_pack is not None)
             c, P, Pd = attn_fwd(q, 0, kv, kv_off, kv, kv_off + d, shp, mask, p_in, rng, sites[0], need_probs=cfg.need_weights)
             if cfg.need_weights:
                 att_w = ops.attn_head_mean(P, B, H, T, S, shp.ld)

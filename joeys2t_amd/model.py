@@ -173,7 +173,8 @@ class Model(nn.Module):
         encoder_output = self._mark_cut(encoder_output)
         decoder_output, _, _, _, ctc_output = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden,
                                                            src_mask=src_mask, trg_input=trg_input,
-                                                           unroll_steps=trg_input.size(1), trg_mask=trg_mask, **kwargs)
+                                                           unroll_steps=trg_input.size(1), trg_mask=trg_mask,
+                                                           memory_pack=getattr(self.encoder, "last_pack", None), **kwargs)
         return decoder_output, ctc_output, src_mask
 
     def _encode_decode_ctc_aside(self, lf, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
@@ -194,7 +195,7 @@ class Model(nn.Module):
             tns.record_stream(side)
         decoder_output, _, _, _, _ = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden, src_mask=src_mask,
                                                   trg_input=trg_input, unroll_steps=trg_input.size(1), trg_mask=trg_mask,
-                                                  compute_ctc=False, **kwargs)
+                                                  compute_ctc=False, memory_pack=getattr(self.encoder, "last_pack", None), **kwargs)
         return decoder_output, ctc_out, src_mask, ctc_loss
 
     def _mark_cut(self, encoder_output: Tensor) -> Tensor:

@@ -79,7 +79,7 @@ class MultiHeadedAttention(nn.Module):
 
     def run_block(self, x: Tensor, memory: Optional[Tensor], mask: Optional[Tensor], *, ln: Optional[nn.LayerNorm],
                   ln_mode: str, alpha: float, out_dropout: float, need_weights: bool = False,
-                  memory_kv: Optional[Tuple[Tensor, int]] = None, pack=None):
+                  memory_kv: Optional[Tuple[Tensor, int]] = None, pack=None, mem_pack=None):
         """[LN] -> attention -> output projection (+dropout) + alpha*x [-> LN] as one fused autograd node.
         `memory_kv` = (projections [B*S, L*2d] of the encoder states for all decoder layers, this layer's first column): the
         block reads its keys and values from there instead of projecting `memory` itself (functional.MemoryKVFn)."""
@@ -119,6 +119,10 @@ class MultiHeadedAttention(nn.Module):
             if kind != "self":
                 raise NotImplementedError("packed rows: self-attention blocks only")
             wts["pack"] = pack
+        if mem_pack is not None:  # ops.PackedRows: memory_kv are the projections of the PACKED encoder states (decoders.py)
+            if memory_kv is None:
+                raise NotImplementedError("packed encoder states: grouped K | V projections only")
+            wts["mem_pack"] = mem_pack
         if memory_kv is not None:  # k_layer / v_layer ran in MemoryKVFn, which also owns their gradients
             wts["kv_off"] = int(memory_kv[1])
             wts["notify_skip"] = {id(k_.weight), id(v_.weight), id(k_.bias), id(v_.bias)}
@@ -257,7 +261,8 @@ class TransformerDecoderLayer(nn.Module):
                                            alpha=self.alpha, out_dropout=self.dropout.p)
         h2, att = self.src_trg_att.run_block(h1, memory, src_mask, ln=self.dec_layer_norm,
                                              ln_mode=self._layer_norm_position, alpha=self.alpha,
-                                             out_dropout=self.dropout.p, need_weights=return_attention, memory_kv=memory_kv)
+                                             out_dropout=self.dropout.p, need_weights=return_attention, memory_kv=memory_kv,
+                                             mem_pack=kwargs.get("mem_pack"))
         out = self.feed_forward(h2)
         return out, (att if return_attention else None)
 

@@ -150,6 +150,38 @@ def test_train_step_on_packed_rows_equals_padded(device):
     assert torch.isfinite(g_pk).all() and err <= max(4.0 * noise, 2e-3 * g_pad.norm().item()), (err, noise, g_pad.norm().item())
 
 
+def test_decoder_reads_packed_encoder_states(device):
+    """The decoder side of a ragged batch: K | V projections of all layers, their gradients and the cross-attention keys on the live
+    positions (decoders.PACK_MEMORY, js2t_attn_desc.seg_keys) against the same step reading the padded [B, T', d] states: the cross-
+    attention calls really take packed keys, the loss agrees to 1e-5, the flat gradient within the padded path's run-to-run noise."""
+    from joeys2t_amd import decoders
+    from test_hip_config_width import synth_batch
+    data = synth_batch(300, [400, 330, 170, 150, 90], [9, 7, 5, 6, 3], 1)
+    seen = []
+    real = ops.flash_attn_fwd
+
+    def spy(*a, **kw):
+        seen.append((bool(kw.get("seg_keys", False)), None if kw.get("seg") is None else kw["seg"].rows, a[2].shape[0]))
+        return real(*a, **kw)
+
+    ops.flash_attn_fwd = spy
+    try:
+        g_pk, s_pk, _, _ = _grads(device, True, data)
+        n_keys_packed = sum(1 for k, rows, krows in seen if k and rows == krows)
+        del seen[:]
+        decoders.PACK_MEMORY = False
+        g_pad, s_pad, _, _ = _grads(device, True, data)
+        g_pad2, _, _, _ = _grads(device, True, data)
+        assert not any(k for k, _, _ in seen)
+    finally:
+        ops.flash_attn_fwd, decoders.PACK_MEMORY = real, True
+    assert n_keys_packed == 2  # width_cfg(4, 3, 2): two decoder layers, each cross-attention once
+    assert s_pk["loss"] == pytest.approx(s_pad["loss"], rel=1e-5)
+    noise = (g_pad - g_pad2).norm().item()
+    err = (g_pk - g_pad).norm().item()
+    assert torch.isfinite(g_pk).all() and err <= max(4.0 * noise, 2e-3 * g_pad.norm().item()), (err, noise, g_pad.norm().item())
+
+
 def test_packed_rows_with_dropout_stay_finite_and_close(device):
     """dropout on: the row-wise masks differ between the layouts (the counter is the row index), the attention masks do not;
     the loss of one step stays within the spread dropout gives it anyway"""
