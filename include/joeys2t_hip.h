@@ -411,16 +411,20 @@ int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream stream);
  * nll: f32[B] raw negative log-likelihoods (inf when infeasible), loss_rows: f32[B] after zero_infinity.
  * beta (optional, f32[B,T,2*Lmax+1]): when given, the backward recursion runs in the same launch (it does not depend on
  * alpha) so that js2t_ctc_bwd(beta_ready = 1) only has the gradient pass left. */
+/* row_offsets (optional, device int32 [B]): the logits / lse / dlogits are PACKED rows (js2t_pack_rows: the CTC branch of a ragged
+ * batch on its live positions) - utterance b's frames are rows row_offsets[b] .. + in_len[b]; alpha / beta keep their [B,T,S]
+ * layout (row_offsets then has B + 1 entries: the last one = the first row nobody owns); js2t_ctc_bwd writes the rows of live frames
+ * and zeroes rows row_offsets[B] .. packed_rows of dlogits.  NULL: [B,T,V] as above. */
 int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                    const int64_t* tgt_len, float* alpha, float* beta, float* nll, float* loss_rows, int64_t B, int64_t T,
-                   int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream);
+                   int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, const int32_t* row_offsets, js2t_stream stream);
 /* beta recursion (skipped when beta_ready != 0) + dlogits[b,t,v] = scale*(*g_dev)*(softmax_t(v) -
  * sum_{s:ext(s)=v} exp(alpha+beta-lp+nll)), zero for t >= in_len[b] and for infeasible utterances when zero_infinity.
  * beta: f32[B,T,2*Lmax+1] workspace, or the result of js2t_ctc_alpha. */
 int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                  const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
                  float scale, void* dlogits, int64_t B, int64_t T, int64_t V, int64_t Lmax, int64_t blank,
-                 int zero_infinity, int beta_ready, js2t_stream stream);
+                 int zero_infinity, int beta_ready, const int32_t* row_offsets, int64_t packed_rows, js2t_stream stream);
 
 /* Single-query attention for KV-cached decoding (replaces the per-step full-prefix decoder pass of search.py:518-534 and
  * the per-step re-projection of the encoder states, transformer_layers.py:75-107 under beam search):

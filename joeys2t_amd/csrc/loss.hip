@@ -234,11 +234,12 @@ __device__ __forceinline__ void ctc_recursion_body(
     float (&a)[2][CTC_MAX_S + 2], int (&ext)[CTC_MAX_S], float (&em)[CTC_CHUNK_FLOATS],
     const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
     const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ out /*alpha|beta*/,
-    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank, const int32_t* __restrict__ rowoff) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t Tb = min(in_len[b], Tmax);
   const int L = (int)min(tgt_len[b], Lmax);
   const int S = 2 * L + 1;
+  const int64_t r0 = rowoff ? (int64_t)rowoff[b] : (int64_t)b * Tmax;  // first logits / lse row of the utterance (packed rows: js2t_ctc_alpha)
   for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? (int)targets[b * Lmax + (s >> 1)] : (int)blank;
   float* ob = out + (int64_t)b * Tmax * Smax;
   // rows t >= Tb are never read by the gradient kernel; keep them defined
@@ -257,8 +258,7 @@ __device__ __forceinline__ void ctc_recursion_body(
       const int tt = i / S, s = i - tt * S;
       const int64_t t = BACKWARD ? (Tb - 1 - (c0 + tt)) : (c0 + tt);
       const int lab = ext[s];
-      const float v = (lab >= 0 && lab < V) ? io<T>::ld(x + ((int64_t)b * Tmax + t) * V + lab) - lse[(int64_t)b * Tmax + t]
-                                            : -INFINITY;
+      const float v = (lab >= 0 && lab < V) ? io<T>::ld(x + (r0 + t) * V + lab) - lse[r0 + t] : -INFINITY;
       em[i] = v;
     }
     __syncthreads();
@@ -303,11 +303,11 @@ template <typename T, bool BACKWARD>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_recursion_kernel(
     const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
     const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ out, float* __restrict__ nll,
-    int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+    int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank, const int32_t* __restrict__ rowoff) {
   __shared__ float a[2][CTC_MAX_S + 2];
   __shared__ int ext[CTC_MAX_S];
   __shared__ float em[CTC_CHUNK_FLOATS];
-  ctc_recursion_body<T, BACKWARD>(a, ext, em, x, lse, targets, in_len, tgt_len, out, nll, Tmax, V, Lmax, Smax, blank);
+  ctc_recursion_body<T, BACKWARD>(a, ext, em, x, lse, targets, in_len, tgt_len, out, nll, Tmax, V, Lmax, Smax, blank, rowoff);
 }
 // alpha (blockIdx.y == 0) and beta (blockIdx.y == 1) in one launch: each recursion is a chain of Tmax dependent steps on
 // one block per utterance - run back to back they leave the chip idle twice as long
@@ -315,14 +315,14 @@ template <typename T>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_both_kernel(
     const T* __restrict__ x, const float* __restrict__ lse, const int64_t* __restrict__ targets,
     const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len, float* __restrict__ alpha, float* __restrict__ beta,
-    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank) {
+    float* __restrict__ nll, int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank, const int32_t* __restrict__ rowoff) {
   __shared__ float a[2][CTC_MAX_S + 2];
   __shared__ int ext[CTC_MAX_S];
   __shared__ float em[CTC_CHUNK_FLOATS];
   if (blockIdx.y == 0)
-    ctc_recursion_body<T, false>(a, ext, em, x, lse, targets, in_len, tgt_len, alpha, nll, Tmax, V, Lmax, Smax, blank);
+    ctc_recursion_body<T, false>(a, ext, em, x, lse, targets, in_len, tgt_len, alpha, nll, Tmax, V, Lmax, Smax, blank, rowoff);
   else
-    ctc_recursion_body<T, true>(a, ext, em, x, lse, targets, in_len, tgt_len, beta, nullptr, Tmax, V, Lmax, Smax, blank);
+    ctc_recursion_body<T, true>(a, ext, em, x, lse, targets, in_len, tgt_len, beta, nullptr, Tmax, V, Lmax, Smax, blank, rowoff);
 }
 
 // Short targets (2L+1 <= 192 states, i.e. every LS100 / MuST-C batch): the recursion of one utterance runs in ONE wave with
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(const T* __restrict__ x, 
                                                        const int64_t* __restrict__ targets, const int64_t* __restrict__ in_len,
                                                        const int64_t* __restrict__ tgt_len, float* __restrict__ alpha,
                                                        float* __restrict__ beta, float* __restrict__ nll, int64_t Tmax, int64_t V,
-                                                       int64_t Lmax, int64_t Smax, int64_t blank) {
+                                                       int64_t Lmax, int64_t Smax, int64_t blank, const int32_t* __restrict__ rowoff) {
   __shared__ float em[2][CTCW_CHUNK * CTCW_S];
   __shared__ int ext[CTCW_S + 2];
   __shared__ float fin[CTCW_S];
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(const T* __restrict__ x, 
   const int L = (int)min(tgt_len[b], Lmax);
   const int S = 2 * L + 1;
   float* ob = (backward ? beta : alpha) + (int64_t)b * Tmax * Smax;
+  const int64_t r0 = rowoff ? (int64_t)rowoff[b] : (int64_t)b * Tmax;  // first logits / lse row of the utterance
   for (int s2 = tid; s2 < CTCW_S + 2; s2 += 256) ext[s2] = (s2 < S) ? ((s2 & 1) ? (int)targets[b * Lmax + (s2 >> 1)] : (int)blank) : -1;
   for (int64_t i = Tb * Smax + tid; i < Tmax * Smax; i += 256) ob[i] = -INFINITY;  // rows the gradient kernel never reads
   __syncthreads();
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void ctc_wave_kernel(const T* __restrict__ x, 
       const int tt = i / S, s2 = i - tt * S;
       const int64_t t = backward ? (Tb - 1 - (c0 + tt)) : (c0 + tt);
       const int lab = ext[s2];
-      dst[tt * CTCW_S + s2] = (lab >= 0 && lab < V) ? io<T>::ld(x + ((int64_t)b * Tmax + t) * V + lab) - lse[(int64_t)b * Tmax + t] : -INFINITY;
+      dst[tt * CTCW_S + s2] = (lab >= 0 && lab < V) ? io<T>::ld(x + (r0 + t) * V + lab) - lse[r0 + t] : -INFINITY;
     }
   };
   const int nchunks = (int)((Tb + CTCW_CHUNK - 1) / CTCW_CHUNK);
@@ -457,14 +458,21 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
                                                       const int64_t* __restrict__ in_len, const int64_t* __restrict__ tgt_len,
                                                       const float* __restrict__ g_dev, float scale, T* __restrict__ dx,
                                                       int64_t Tmax, int64_t V, int64_t Lmax, int64_t Smax, int64_t blank,
-                                                      int zero_inf, int ordered) {
+                                                      int zero_inf, int ordered, const int32_t* __restrict__ rowoff, int64_t rows_total) {
   extern __shared__ float row[];  // V floats
   __shared__ float occ_s[CTC_MAX_S];  // ordered form: the positions' terms and labels, summed by each label's first occurrence
   __shared__ int lab_s[CTC_MAX_S];
   const int64_t bt = blockIdx.x, b = bt / Tmax, t = bt - b * Tmax;
-  T* dr = dx + bt * V;
-  const float nl = nll[b];
   const int64_t Tb = min(in_len[b], Tmax);
+  if (rowoff) {  // packed rows: the rows behind the last utterance belong to nobody - zeroed by the grid as a whole (block bt takes rows
+                 // rowoff[B] + bt, + gridDim.x, ..: the products behind this gradient sum over all rows)
+    for (int64_t rz = (int64_t)rowoff[gridDim.x / Tmax] + bt; rz < rows_total; rz += gridDim.x)
+      for (int64_t v = threadIdx.x; v < V; v += LB) io<T>::st(dx + rz * V + v, 0.f);
+    if (t >= Tb) return;  // positions behind the utterance's length have no row
+  }
+  const int64_t rw = rowoff ? (int64_t)rowoff[b] + t : bt;  // logits / lse / gradient row; alpha / beta stay [B, Tmax, Smax]
+  T* dr = dx + rw * V;
+  const float nl = nll[b];
   const bool dead = t >= Tb || (zero_inf && isinf(nl));
   // 16-byte row accesses when the rows allow it (bf16, V % 8 == 0, aligned base)
   const bool vec = sizeof(T) == 2 && (V & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0;
@@ -477,8 +485,8 @@ __global__ __launch_bounds__(LB) void ctc_grad_kernel(const T* __restrict__ x, c
     return;
   }
   const float gs = scale * (g_dev ? *g_dev : 1.f);
-  const T* xr = x + bt * V;
-  const float l = lse[bt];
+  const T* xr = x + rw * V;
+  const float l = lse[rw];
   if (vec) {
     for (int c = threadIdx.x; c < (int)(V >> 3); c += LB) {
       const uint4 q = ((const uint4*)xr)[c];
@@ -681,7 +689,8 @@ extern "C" int js2t_sum_f32(const float* x, int64_t n, float* out, js2t_stream s
 
 extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                               const int64_t* tgt_len, float* alpha, float* beta, float* nll, float* loss_rows, int64_t B,
-                              int64_t T_, int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, js2t_stream stream) {
+                              int64_t T_, int64_t V, int64_t Lmax, int64_t blank, int zero_infinity, const int32_t* row_offsets,
+                              js2t_stream stream) {
   if (B == 0) return JS2T_OK;
   JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && nll && loss_rows, "ctc_alpha: null pointer");
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_alpha: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
@@ -689,13 +698,13 @@ extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, cons
   hipStream_t s = (hipStream_t)stream;
   if (Smax <= CTCW_S) {  // short targets: register-resident recursion, alpha (and beta when asked for) in one launch
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_wave_kernel<T>), dim3((unsigned)B, beta ? 2 : 1), dim3(256), 0, s, (const T*)logits, lse,
-                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank));
+                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank, row_offsets));
   } else if (beta) {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_both_kernel<T>), dim3((unsigned)B, 2), dim3(CTC_THREADS), 0, s, (const T*)logits, lse,
-                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank));
+                                          targets, in_len, tgt_len, alpha, beta, nll, T_, V, Lmax, Smax, blank, row_offsets));
   } else {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, false>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
-                                          (const T*)logits, lse, targets, in_len, tgt_len, alpha, nll, T_, V, Lmax, Smax, blank));
+                                          (const T*)logits, lse, targets, in_len, tgt_len, alpha, nll, T_, V, Lmax, Smax, blank, row_offsets));
   }
   JS2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(ctc_loss_rows_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, nll, loss_rows, B, zero_infinity);
@@ -706,7 +715,7 @@ extern "C" int js2t_ctc_alpha(const void* logits, int dt, const float* lse, cons
 extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const int64_t* targets, const int64_t* in_len,
                             const int64_t* tgt_len, const float* alpha, float* beta, const float* nll, const float* g_dev,
                             float scale, void* dlogits, int64_t B, int64_t T_, int64_t V, int64_t Lmax, int64_t blank,
-                            int zero_infinity, int beta_ready, js2t_stream stream) {
+                            int zero_infinity, int beta_ready, const int32_t* row_offsets, int64_t packed_rows, js2t_stream stream) {
   if (B == 0) return JS2T_OK;
   JS2T_CHECK(logits && lse && targets && in_len && tgt_len && alpha && beta && nll && dlogits, "ctc_bwd: null pointer");
   JS2T_CHECK(2 * Lmax + 1 <= CTC_MAX_S, "ctc_bwd: target length %lld exceeds %d", (long long)Lmax, (CTC_MAX_S - 1) / 2);
@@ -716,7 +725,7 @@ extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const 
   if (!beta_ready) {
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((ctc_recursion_kernel<T, true>), dim3((unsigned)B), dim3(CTC_THREADS), 0, s,
                                           (const T*)logits, lse, targets, in_len, tgt_len, beta, (float*)nullptr, T_, V, Lmax,
-                                          Smax, blank));
+                                          Smax, blank, row_offsets));
     JS2T_LAUNCH_CHECK();
   }
   const size_t lds = (size_t)V * sizeof(float);
@@ -724,12 +733,12 @@ extern "C" int js2t_ctc_bwd(const void* logits, int dt, const float* lse, const 
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const float*)logits, lse, alpha,
                        beta, nll, targets, in_len, tgt_len, g_dev, scale, (float*)dlogits, T_, V, Lmax, Smax, blank,
-                       zero_infinity, g_js2t_deterministic);
+                       zero_infinity, g_js2t_deterministic, row_offsets, packed_rows);
   } else {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)ctc_grad_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ctc_grad_kernel<uint16_t>), dim3((unsigned)(B * T_)), dim3(LB), lds, s, (const uint16_t*)logits, lse,
                        alpha, beta, nll, targets, in_len, tgt_len, g_dev, scale, (uint16_t*)dlogits, T_, V, Lmax, Smax, blank,
-                       zero_infinity, g_js2t_deterministic);
+                       zero_infinity, g_js2t_deterministic, row_offsets, packed_rows);
   }
   JS2T_LAUNCH_CHECK();
   return JS2T_OK;

@@ -129,7 +129,9 @@ class TransformerDecoder(Decoder):
         out = self.project(self.output_layer, x[:, -1:].contiguous() if kwargs.get("last_only", False) else x, torch.float32)
         ctc_output = None
         if self.ctc_output_layer is not None and kwargs.get("compute_ctc", True):
-            ctc_output = self.project(self.ctc_output_layer, encoder_output, rt.compute_dtype)
+            ctc_pack = kwargs.get("ctc_pack")  # ops.PackedRows: project the packed encoder rows -> [1, rows, V] (model._ctc_packing)
+            ctc_in = encoder_output if ctc_pack is None else Fn.PackRowsFn.apply(rt.act_in(encoder_output), ctc_pack)
+            ctc_output = self.project(self.ctc_output_layer, ctc_in, rt.compute_dtype)
         return out, x, att, None, ctc_output
 
     def __repr__(self):

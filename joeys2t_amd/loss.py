@@ -57,10 +57,20 @@ class _XentFn(torch.autograd.Function):
 
 
 class _CtcFn(torch.autograd.Function):
+    """pack (ops.PackedRows): the logits are the CTC projection of PACKED encoder rows, [1, pack.rows, V] - utterance b's frames are
+    rows pack.seg[b] .. (the branch of a ragged batch on its live positions; the recursions index rows through js2t_ctc_alpha's
+    row_offsets, alpha / beta keep their [B, T, S] layout)."""
+
     @staticmethod
-    def forward(ctx, logits, targets, in_len, tgt_len, blank, zero_infinity):
-        B, T, V = logits.shape
-        l3 = logits.contiguous()
+    def forward(ctx, logits, targets, in_len, tgt_len, blank, zero_infinity, pack=None):
+        ctx.pack, ctx.shape = pack, tuple(logits.shape)
+        if pack is None:
+            B, T, V = logits.shape
+            l3 = logits.contiguous()
+        else:
+            V = logits.shape[-1]
+            B, T = pack.B, pack.T
+            l3 = logits.reshape(-1, V).contiguous()  # [rows, V]
         # f32 logits of a bf16 projection are registered for the cross-entropy's bf16 hand-over (functional.LOGIT_GRAD_DTYPE); this
         # loss takes its gradient the ordinary way, so the entry goes now - left behind, the address could be reused by f32 logits of
         # another producer within the step and send THEIR cross-entropy onto the hand-over path
@@ -69,10 +79,10 @@ class _CtcFn(torch.autograd.Function):
         targets = targets.contiguous()
         in_len = in_len.to(torch.int64).contiguous()
         tgt_len = tgt_len.to(torch.int64).contiguous()
-        lse, _ = ops.row_lse(l3.view(B * T, V))
+        lse, _ = ops.row_lse(l3.view(-1, V))
         # when a gradient will be asked for, the beta recursion runs beside alpha in the same launch
         alpha, nll, loss_rows, beta = ops.ctc_alpha(l3, lse, targets, in_len, tgt_len, blank, zero_infinity,
-                                                    with_beta=logits.requires_grad)
+                                                    with_beta=logits.requires_grad, pack=pack)
         ctx.saved = (l3, lse, targets, in_len, tgt_len, alpha, nll, beta)
         ctx.blank, ctx.zero_infinity = blank, zero_infinity
         return ops.sum_f32(loss_rows)
@@ -81,8 +91,8 @@ class _CtcFn(torch.autograd.Function):
     def backward(ctx, g):
         l3, lse, targets, in_len, tgt_len, alpha, nll, beta = ctx.saved
         g = g.contiguous().float()
-        d = ops.ctc_bwd(l3, lse, targets, in_len, tgt_len, alpha, nll, g, 1.0, ctx.blank, ctx.zero_infinity, beta=beta)
-        return d, None, None, None, None, None
+        d = ops.ctc_bwd(l3, lse, targets, in_len, tgt_len, alpha, nll, g, 1.0, ctx.blank, ctx.zero_infinity, beta=beta, pack=ctx.pack)
+        return d.view(ctx.shape), None, None, None, None, None, None
 
 
 class XentLoss(nn.Module):
@@ -119,8 +129,8 @@ class XentCTCLoss(XentLoss):
         self.ctc_weight = ctc_weight
         self.zero_infinity = zero_infinity
 
-    def ctc(self, ctc_logits: Tensor, trg: Tensor, input_lengths: Tensor, target_lengths: Tensor) -> Tensor:
-        return _CtcFn.apply(ctc_logits, trg, input_lengths, target_lengths, int(self.bos_index), bool(self.zero_infinity))
+    def ctc(self, ctc_logits: Tensor, trg: Tensor, input_lengths: Tensor, target_lengths: Tensor, pack=None) -> Tensor:
+        return _CtcFn.apply(ctc_logits, trg, input_lengths, target_lengths, int(self.bos_index), bool(self.zero_infinity), pack)
 
     def forward(self, logits: Tensor, **kwargs) -> Tuple[Tensor, Tensor, Tensor]:
         assert "trg" in kwargs and "trg_length" in kwargs and "src_mask" in kwargs and "ctc_logits" in kwargs

@@ -28,6 +28,9 @@ def _mask_row_sums(src_mask: Tensor) -> Tensor:
     return known if known is not None else src_mask.squeeze(1).sum(dim=1)
 
 
+PACK_CTC = True  # the CTC branch of a ragged batch on packed encoder rows when the encoder packed them (tests flip this)
+
+
 class Model(nn.Module):
     def __init__(self, encoder: Encoder, decoder: Decoder, src_embed: nn.Module, trg_embed: Embeddings, src_vocab,
                  trg_vocab, task: str = "S2T") -> None:
@@ -117,6 +120,8 @@ class Model(nn.Module):
             raise ConfigurationError(f"unknown loss type {loss_type}")
         self._loss_function = loss_function
 
+    _ctc_pack = None  # set by _encode_decode(pack_ctc=True): the returned ctc logits are packed rows
+
     # ------------------------------------------------------------------ forward dispatch
     def forward(self, return_type: str = None, **kwargs) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
         if return_type is None:
@@ -136,13 +141,13 @@ class Model(nn.Module):
                     getattr(self.decoder, "ctc_output_layer", None) is not None):
                 out, ctc_out, src_mask, ctc_loss = self._encode_decode_ctc_aside(lf, **kwargs)
             else:
-                out, ctc_out, src_mask = self._encode_decode(**kwargs)
+                out, ctc_out, src_mask = self._encode_decode(pack_ctc=(return_type == "loss" and lf.require_ctc_layer), **kwargs)
             xent_loss, n_correct = lf.xent(out, kwargs["trg"])
             ret = [None, None, None, None]
             if lf.require_ctc_layer and isinstance(ctc_out, Tensor):
                 if ctc_loss is None:
                     in_len = _mask_row_sums(src_mask)  # subsampled mask (model.py:125; loss.py:159)
-                    ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+                    ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"], pack=self._ctc_pack)
                 else:  # computed on the side stream: join before the two losses meet
                     torch.cuda.current_stream().wait_stream(self.runtime.side_stream())
                     ctc_loss.record_stream(torch.cuda.current_stream())
@@ -167,14 +172,28 @@ class Model(nn.Module):
             return outputs, hidden, att_probs, ctc_out
         raise ValueError(f"unknown return_type {return_type}")
 
+    def _ctc_packing(self, encoder_output):
+        """The encoder's ops.PackedRows when the CTC branch can run on its packed rows (a ragged batch whose encoder packed them; bf16),
+        else None: projection, row log-sum-exp, the recursions' inputs, the gradient and the projection's own gradients then stay on the
+        live positions (13600 padded rows put the projection's input gradient - N = 512, K = 5000 - at 1.11 tiles per CU: two tile times)."""
+        pk = getattr(self.encoder, "last_pack", None)
+        if (PACK_CTC and pk is not None and self.runtime.compute_dtype == torch.bfloat16 and encoder_output.dim() == 3 and
+                (pk.B, pk.T) == tuple(encoder_output.shape[:2])):
+            return pk
+        return None
+
     def _encode_decode(self, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
-                       **kwargs):
+                       pack_ctc: bool = False, **kwargs):
+        """pack_ctc: the caller only wants the CTC LOSS of the returned ctc logits (return_type "loss"): they may then come as the
+        projection of the packed encoder rows, [1, rows, V], with `self._ctc_pack` saying so."""
         encoder_output, encoder_hidden, src_mask = self._encode(src=src, src_length=src_length, src_mask=src_mask, **kwargs)
         encoder_output = self._mark_cut(encoder_output)
+        self._ctc_pack = self._ctc_packing(encoder_output) if pack_ctc else None
         decoder_output, _, _, _, ctc_output = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden,
                                                            src_mask=src_mask, trg_input=trg_input,
                                                            unroll_steps=trg_input.size(1), trg_mask=trg_mask,
-                                                           memory_pack=getattr(self.encoder, "last_pack", None), **kwargs)
+                                                           memory_pack=getattr(self.encoder, "last_pack", None),
+                                                           ctc_pack=self._ctc_pack, **kwargs)
         return decoder_output, ctc_output, src_mask
 
     def _encode_decode_ctc_aside(self, lf, src: Tensor, trg_input: Tensor, src_mask: Tensor, src_length: Tensor, trg_mask: Tensor = None,
@@ -187,10 +206,16 @@ class Model(nn.Module):
         encoder_output = self._mark_cut(encoder_output)
         cur, side = torch.cuda.current_stream(), self.runtime.side_stream()
         side.wait_stream(cur)
+        pk = self._ctc_packing(encoder_output)  # ragged batch whose encoder ran on packed rows: so does the CTC branch
         with torch.cuda.stream(side):
-            ctc_out = self.decoder.project(self.decoder.ctc_output_layer, encoder_output, self.runtime.compute_dtype)
+            if pk is not None:
+                from joeys2t_amd.functional import PackRowsFn
+                enc_p = PackRowsFn.apply(self.runtime.act_in(encoder_output), pk)  # [1, rows, d]
+                ctc_out = self.decoder.project(self.decoder.ctc_output_layer, enc_p, self.runtime.compute_dtype)  # [1, rows, V]
+            else:
+                ctc_out = self.decoder.project(self.decoder.ctc_output_layer, encoder_output, self.runtime.compute_dtype)
             in_len = _mask_row_sums(src_mask)
-            ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"])
+            ctc_loss = lf.ctc(ctc_out, kwargs["trg"], in_len, kwargs["trg_length"], pack=pk)
         for tns in (encoder_output, src_mask, kwargs["trg"], kwargs["trg_length"]):
             tns.record_stream(side)
         decoder_output, _, _, _, _ = self._decode(encoder_output=encoder_output, encoder_hidden=encoder_hidden, src_mask=src_mask,

@@ -751,11 +751,22 @@ def xent_bwd(logits2d, trg1d, lse, g_dev, scale: float, pad_idx: int, smoothing:
     return d
 
 
-def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity: bool, with_beta: bool = False):
+def _ctc_geometry(logits, pack):
+    """(B, T, V, row offsets pointer): [B, T, V] logits, or - with `pack` (PackedRows) - packed [pack.rows, V] ones."""
+    if pack is None:
+        B, T, V = logits.shape
+        return B, T, V, None
+    if logits.dim() != 2 or logits.shape[0] != pack.rows or not logits.is_contiguous():
+        raise Js2tError(f"CTC over packed rows: contiguous [{pack.rows}, V] logits expected, got {tuple(logits.shape)}")
+    _dev(pack.seg)
+    return pack.B, pack.T, logits.shape[1], C.c_void_p(pack.seg.data_ptr())
+
+
+def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity: bool, with_beta: bool = False, pack: "PackedRows" = None):
     """Forward CTC recursion; with_beta=True also runs the (independent) backward recursion in the same launch and
-    returns it as the 4th value for ctc_bwd(beta=...)."""
+    returns it as the 4th value for ctc_bwd(beta=...).  pack: the logits / lse are packed rows (js2t_ctc_alpha row_offsets)."""
     _dev(logits3d, lse, targets, in_len, tgt_len)
-    B, T, V = logits3d.shape
+    B, T, V, roff = _ctc_geometry(logits3d, pack)
     Lmax = targets.shape[1]
     dev = logits3d.device
     alpha = torch.empty((B, T, 2 * Lmax + 1), dtype=torch.float32, device=dev)
@@ -764,13 +775,14 @@ def ctc_alpha(logits3d, lse, targets, in_len, tgt_len, blank: int, zero_infinity
     loss_rows = torch.empty((B,), dtype=torch.float32, device=dev)
     check(lib().js2t_ctc_alpha(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha), _p(beta),
                                _p(nll), _p(loss_rows), C.c_int64(B), C.c_int64(T), C.c_int64(V), C.c_int64(Lmax),
-                               C.c_int64(blank), int(zero_infinity), _stream()), "js2t_ctc_alpha")
+                               C.c_int64(blank), int(zero_infinity), roff, _stream()), "js2t_ctc_alpha")
     return alpha, nll, loss_rows, beta
 
 
-def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: float, blank: int, zero_infinity: bool, beta=None):
+def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: float, blank: int, zero_infinity: bool, beta=None,
+            pack: "PackedRows" = None):
     _dev(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, beta)
-    B, T, V = logits3d.shape
+    B, T, V, roff = _ctc_geometry(logits3d, pack)
     Lmax = targets.shape[1]
     ready = beta is not None
     if beta is None:
@@ -778,7 +790,8 @@ def ctc_bwd(logits3d, lse, targets, in_len, tgt_len, alpha, nll, g_dev, scale: f
     d = torch.empty_like(logits3d)
     check(lib().js2t_ctc_bwd(_p(logits3d), dt_code(logits3d), _p(lse), _p(targets), _p(in_len), _p(tgt_len), _p(alpha),
                              _p(beta), _p(nll), _p(g_dev), C.c_float(scale), _p(d), C.c_int64(B), C.c_int64(T), C.c_int64(V),
-                             C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), int(ready), _stream()), "js2t_ctc_bwd")
+                             C.c_int64(Lmax), C.c_int64(blank), int(zero_infinity), int(ready), roff,
+                             C.c_int64(0 if pack is None else pack.rows), _stream()), "js2t_ctc_bwd")
     return d
 
 

@@ -182,6 +182,76 @@ def test_decoder_reads_packed_encoder_states(device):
     assert torch.isfinite(g_pk).all() and err <= max(4.0 * noise, 2e-3 * g_pad.norm().item()), (err, noise, g_pad.norm().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_ctc_over_packed_rows_equals_padded(device, dtype):
+    """js2t_ctc_alpha / js2t_ctc_bwd with row_offsets: the recursions and the gradient read the packed logits rows of every live
+    frame - alpha, beta, the negative log-likelihoods BIT for bit those of the padded [B, T, V] logits, the gradient bit for bit on
+    every live row (an infeasible utterance and one of a single frame included); through loss._CtcFn: loss and gradient."""
+    from joeys2t_amd.loss import _CtcFn
+    lens, T, V = [40, 33, 7, 12, 1, 25], 40, 24
+    B = len(lens)
+    pk = ops.PackedRows.from_lengths(lens, T, device, round_to=16)
+    live = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None])
+    logits = (rnd(B, T, V, seed=1) * 2.0).to(dtype)
+    targets = torch.tensor([[5, 6, 6, 7, 3, 1, 1, 1], [4, 4, 9, 3, 1, 1, 1, 1], [5, 6, 7, 8, 9, 10, 11, 3], [8, 3, 1, 1, 1, 1, 1, 1],
+                            [9, 3, 1, 1, 1, 1, 1, 1], [10, 11, 12, 13, 3, 1, 1, 1]])
+    tgt_len = torch.tensor([5, 4, 8, 2, 2, 5])  # entry 2: 8 labels in 7 frames (infeasible), entry 4: 2 labels in 1 frame (infeasible)
+    in_len = torch.tensor(lens)
+    lg, tg, il, tl = logits.to(device), targets.to(device), in_len.to(device), tgt_len.to(device)
+    lg_p = ops.pack_rows(lg.view(B * T, V), pk) if dtype == torch.bfloat16 else ops.pack_rows(lg.view(B * T, V).contiguous(), pk)
+    lse, _ = ops.row_lse(lg.view(B * T, V))
+    lse_p, _ = ops.row_lse(lg_p)
+    a, nll, rows, b = ops.ctc_alpha(lg, lse, tg, il, tl, 2, True, with_beta=True)
+    a_p, nll_p, rows_p, b_p = ops.ctc_alpha(lg_p, lse_p, tg, il, tl, 2, True, with_beta=True, pack=pk)
+    assert torch.equal(nll, nll_p) and torch.equal(rows, rows_p) and torch.isinf(nll[2]) and torch.isinf(nll[4])
+    for i, (n, L) in enumerate(zip(lens, tgt_len.tolist())):  # (states behind 2 L + 1 and frames behind the length are not defined)
+        assert torch.equal(a[i, :n, :2 * L + 1], a_p[i, :n, :2 * L + 1]) and torch.equal(b[i, :n, :2 * L + 1], b_p[i, :n, :2 * L + 1])
+    g = torch.ones((), device=device)
+    d = ops.ctc_bwd(lg, lse, tg, il, tl, a, nll, g, 1.0, 2, True, beta=b)
+    d_p = ops.ctc_bwd(lg_p, lse_p, tg, il, tl, a_p, nll_p, g, 1.0, 2, True, beta=b_p, pack=pk)
+    assert d_p.shape == lg_p.shape and torch.isfinite(d_p.float()).all()
+    assert torch.equal(d_p, ops.pack_rows(d.view(B * T, V), pk))  # dead frames carry zeros in the padded form; the packed tail is zeroed
+    # through the autograd function
+    x = lg.clone().requires_grad_(True)
+    xp = lg_p.clone().unsqueeze(0).requires_grad_(True)
+    l0 = _CtcFn.apply(x, tg, il, tl, 2, True)
+    l1 = _CtcFn.apply(xp, tg, il, tl, 2, True, pk)
+    assert torch.equal(l0, l1)
+    l0.backward(), l1.backward()
+    assert torch.equal(xp.grad[0], ops.pack_rows(x.grad.view(B * T, V), pk))
+
+
+def test_ctc_branch_on_packed_rows_in_the_train_step(device):
+    """model.PACK_CTC: projection, row log-sum-exp, recursions and gradient of the CTC branch on the packed encoder rows against the
+    padded branch - loss to 1e-5, flat gradient within the padded path's run-to-run noise."""
+    from joeys2t_amd import model as model_mod
+    from test_hip_config_width import synth_batch
+    data = synth_batch(300, [400, 330, 170, 150, 90], [9, 7, 5, 6, 3], 1)
+    seen = []
+    real = ops.ctc_alpha
+
+    def spy(*a, **kw):
+        seen.append(kw.get("pack") is not None)
+        return real(*a, **kw)
+
+    ops.ctc_alpha = spy
+    try:
+        g_pk, s_pk, _, _ = _grads(device, True, data)
+        took_packed = list(seen)
+        del seen[:]
+        model_mod.PACK_CTC = False
+        g_pad, s_pad, _, _ = _grads(device, True, data)
+        g_pad2, _, _, _ = _grads(device, True, data)
+        assert seen == [False, False]
+    finally:
+        ops.ctc_alpha, model_mod.PACK_CTC = real, True
+    assert took_packed == [True]
+    assert s_pk["loss"] == pytest.approx(s_pad["loss"], rel=1e-5)
+    noise = (g_pad - g_pad2).norm().item()
+    err = (g_pk - g_pad).norm().item()
+    assert torch.isfinite(g_pk).all() and err <= max(4.0 * noise, 2e-3 * g_pad.norm().item()), (err, noise, g_pad.norm().item())
+
+
 def test_packed_rows_with_dropout_stay_finite_and_close(device):
     """dropout on: the row-wise masks differ between the layouts (the counter is the row index), the attention masks do not;
     the loss of one step stays within the spread dropout gives it anyway"""
