@@ -186,6 +186,94 @@ __global__ __launch_bounds__(LB) void xent_fwd_kernel(const T* __restrict__ x, c
   }
 }
 
+// The same on f32 logits with 16-byte rows (V % 4 == 0), ONE WAVE per row and four rows per block (round 5): a single pass of 16-byte
+// loads with a running maximum per lane (online softmax: the partial sum is rescaled when the lane's maximum moves), wave reductions
+// only - the block form above reads the row twice with 4-byte loads and crosses five block barriers per row (36 us for 2592 x 5000
+// logits = 0.18 of the HBM rate).  The sums run in another order than above: the same loss to the last bits of an f32.
+__global__ __launch_bounds__(256) void xent_fwd_wave_kernel(const float* __restrict__ x, const int64_t* __restrict__ trg,
+                                                            float* __restrict__ loss_rows, float* __restrict__ correct_rows,
+                                                            float* __restrict__ lse_out, int64_t rows, int64_t V, int64_t pad, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;  // (no barriers below)
+  const float* xr = x + r * V;
+  const int n4 = (int)(V >> 2);
+  float m = -INFINITY, s = 0.f, sx = 0.f;
+  int mi = 0x7fffffff;
+  auto take = [&](const float4& q, int c) {
+    const float m4 = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+    if (m4 > m) {  // a strictly larger value: the lane's first index of its maximum
+      mi = 4 * c + (q.x == m4 ? 0 : q.y == m4 ? 1 : q.z == m4 ? 2 : 3);
+      s *= __expf(m - m4);  // (m = -inf: s is 0 and stays 0)
+      m = m4;
+    }
+    s += (__expf(q.x - m) + __expf(q.y - m)) + (__expf(q.z - m) + __expf(q.w - m));
+    sx += (q.x + q.y) + (q.z + q.w);
+  };
+  int c = lane;
+  for (; c + 192 < n4; c += 256) {  // four 16-byte loads in flight per lane
+    const float4 q0 = ((const float4*)xr)[c], q1 = ((const float4*)xr)[c + 64], q2 = ((const float4*)xr)[c + 128], q3 = ((const float4*)xr)[c + 192];
+    take(q0, c), take(q1, c + 64), take(q2, c + 128), take(q3, c + 192);
+  }
+  for (; c < n4; c += 64) take(((const float4*)xr)[c], c);
+  const float bmx = wave_max(m);
+  s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - bmx));
+  sx = wave_sum(sx);
+  int cand = (m == bmx) ? mi : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+  if (lane == 0) {
+    const int64_t g = trg[r];
+    const float lse = bmx + __logf(s);
+    lse_out[r] = lse;
+    float loss = 0.f, ok = 0.f;
+    if (g != pad && g >= 0 && g < V) {
+      const float lpg = xr[g] - lse;
+      if (eps > 0.f) {
+        const float u = eps / (float)(V - 2);
+        const float lpp = (pad >= 0 && pad < V) ? xr[pad] - lse : 0.f;
+        const float sum_lp = sx - (float)V * lse;
+        const float cent = (1.f - eps) * __logf(1.f - eps) + eps * __logf(u);
+        loss = cent - ((1.f - eps) * lpg + u * (sum_lp - lpg - lpp));
+      } else {
+        loss = -lpg;
+      }
+      ok = (cand == (int)g) ? 1.f : 0.f;
+    }
+    loss_rows[r] = loss;
+    correct_rows[r] = ok;
+  }
+}
+// backward on the same rows: nothing to reduce, so ONE THREAD per eight logits over the whole [rows, V] array (two 16-byte loads, one or
+// two 16-byte stores, the row's gold index and log-sum-exp from cache) - 25 waves per SIMD's worth of independent requests instead of one
+// wave walking a row
+template <typename TO>
+__global__ __launch_bounds__(256) void xent_bwd_flat_kernel(const float* __restrict__ x, const int64_t* __restrict__ trg,
+                                                            const float* __restrict__ lse, const float* __restrict__ g_dev, float scale,
+                                                            TO* __restrict__ dx, int rows, int n8, int64_t V, int64_t pad, float eps) {
+  const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (chunk >= (int64_t)rows * n8) return;
+  const int r = (int)(chunk / n8), c = (int)(chunk - (int64_t)r * n8);
+  const int64_t g = trg[r];
+  const bool dead = g == pad || g < 0 || g >= V;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (!dead) {
+    const float4 qa = ((const float4*)x)[2 * chunk], qb = ((const float4*)x)[2 * chunk + 1];
+    const float gs = scale * (g_dev ? *g_dev : 1.f), l = lse[r];
+    const float u = eps > 0.f ? eps / (float)(V - 2) : 0.f, tg = eps > 0.f ? 1.f - eps : 1.f;
+    const float f[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const int gi = (int)g - 8 * c, pi = (pad >= 0 && pad < V) ? (int)pad - 8 * c : -1;  // positions of gold / pad inside this chunk (or outside 0..7)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = gs * (__expf(f[i] - l) - (i == gi ? tg : (i == pi ? 0.f : u)));
+  }
+  if constexpr (sizeof(TO) == 4) {
+    ((float4*)dx)[2 * chunk] = make_float4(o[0], o[1], o[2], o[3]);
+    ((float4*)dx)[2 * chunk + 1] = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+    ((uint4*)dx)[chunk] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+}
+
 // dx[r,v] = gscale * (softmax - t)   (0 for pad rows);  gscale = scale * (*g_dev)
 // TO: the gradient's storage type - the logits' own, or bf16 for f32 logits whose gradient feeds a bf16 product next
 // (js2t_xent_bwd_as: no f32 gradient to write and cast afterwards)
@@ -630,6 +718,12 @@ extern "C" int js2t_xent_fwd(const void* logits, int dt, const int64_t* trg, flo
                              int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(logits && trg && loss_rows && correct_rows && lse && V > 2, "xent_fwd: bad arguments");
+  if (dt == JS2T_F32 && (V & 3) == 0 && V < (int64_t(1) << 31) && (((uintptr_t)logits) & 15) == 0) {
+    hipLaunchKernelGGL(xent_fwd_wave_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)logits, trg,
+                       loss_rows, correct_rows, lse, rows, V, pad_idx, smoothing);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((xent_fwd_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
                                         (const T*)logits, trg, loss_rows, correct_rows, lse, rows, V, pad_idx, smoothing));
   JS2T_LAUNCH_CHECK();
@@ -640,6 +734,13 @@ extern "C" int js2t_xent_bwd(const void* logits, int dt, const int64_t* trg, con
                              void* dlogits, int64_t rows, int64_t V, int64_t pad_idx, float smoothing, js2t_stream stream) {
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(logits && trg && lse && dlogits && V > 2, "xent_bwd: bad arguments");
+  if (dt == JS2T_F32 && (V & 7) == 0 && V < (int64_t(1) << 31) && rows < (int64_t(1) << 31) && rows * (V >> 3) < (int64_t(1) << 31) * 256 &&
+      ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) == 0) {
+    hipLaunchKernelGGL((xent_bwd_flat_kernel<float>), dim3((unsigned)cdiv(rows * (V >> 3), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)logits, trg, lse, g_dev, scale, (float*)dlogits, (int)rows, (int)(V >> 3), V, pad_idx, smoothing);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   DISPATCH_DT(dt, T, hipLaunchKernelGGL((xent_bwd_kernel<T>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream,
                                         (const T*)logits, trg, lse, g_dev, scale, (T*)dlogits, rows, V, pad_idx, smoothing));
   JS2T_LAUNCH_CHECK();
@@ -652,6 +753,13 @@ extern "C" int js2t_xent_bwd_as(const void* logits, int dt, const int64_t* trg, 
   if (rows == 0) return JS2T_OK;
   JS2T_CHECK(logits && trg && lse && dlogits && V > 2, "xent_bwd_as: bad arguments");
   JS2T_CHECK(dt == JS2T_F32 && out_dt == JS2T_BF16, "xent_bwd_as: f32 logits -> bf16 gradient, or equal types");
+  if ((V & 7) == 0 && V < (int64_t(1) << 31) && rows < (int64_t(1) << 31) && rows * (V >> 3) < (int64_t(1) << 31) * 256 &&
+      ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) == 0) {
+    hipLaunchKernelGGL((xent_bwd_flat_kernel<uint16_t>), dim3((unsigned)cdiv(rows * (V >> 3), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)logits, trg, lse, g_dev, scale, (uint16_t*)dlogits, (int)rows, (int)(V >> 3), V, pad_idx, smoothing);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   hipLaunchKernelGGL((xent_bwd_kernel<float, uint16_t>), dim3((unsigned)rows), dim3(LB), 0, (hipStream_t)stream, (const float*)logits, trg,
                      lse, g_dev, scale, (uint16_t*)dlogits, rows, V, pad_idx, smoothing);
   JS2T_LAUNCH_CHECK();
