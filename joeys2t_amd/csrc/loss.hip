@@ -211,7 +211,14 @@ __global__ __launch_bounds__(256) void xent_fwd_wave_kernel(const float* __restr
     sx += (q.x + q.y) + (q.z + q.w);
   };
   int c = lane;
-  for (; c + 192 < n4; c += 256) {  // four 16-byte loads in flight per lane
+  for (; c + 448 < n4; c += 512) {  // eight 16-byte loads in flight per lane
+    float4 q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = ((const float4*)xr)[c + 64 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) take(q[i], c + 64 * i);
+  }
+  for (; c + 192 < n4; c += 256) {
     const float4 q0 = ((const float4*)xr)[c], q1 = ((const float4*)xr)[c + 64], q2 = ((const float4*)xr)[c + 128], q3 = ((const float4*)xr)[c + 192];
     take(q0, c), take(q1, c + 64), take(q2, c + 128), take(q3, c + 192);
   }
