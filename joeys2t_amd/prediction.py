@@ -35,7 +35,7 @@ def predict(model, batches: Iterable[Batch], *, beam_size: int = 1, beam_alpha: 
     Under a process group every rank passes ITS batches; totals are sums over ranks, and rank 0's outputs hold all ranks'
     sentences in dataset order (`batch.indices`), as in the reference (prediction.py:222-231, 250-257)."""
     model.eval()
-    all_ids, all_scores, all_att, all_indices = [], [], [], []
+    all_ids, all_scores, all_att, by_index = [], [], [], {}
     totals: Dict[str, float] = {"loss": 0.0, "n_correct": 0, "ntokens": 0, "nseqs": 0}
     ddp = use_ddp()
     for batch in batches:
@@ -67,15 +67,24 @@ def predict(model, batches: Iterable[Batch], *, beam_size: int = 1, beam_alpha: 
                                       repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
                                       return_attention=return_attention)
         if ddp:
-            # the order of merged outputs is unknown: sorted back by `indices` after the loop (prediction.py:222-231)
-            if return_prob != "ref":
+            # Hypotheses are merged ONCE: greedy search returns all ranks' rows already (its tail merges ids, scores and attention as
+            # the reference's does, search.py:333-335); beam search returns this rank's rows, so they are merged here (extension: the
+            # reference's beam search does not merge, and its assert below then fails for world_size > 1).  The order of merged
+            # outputs is unknown: they are put back by `indices` after the loop (prediction.py:222-231).
+            if return_prob != "ref" and beam_size >= 2:
                 ids = ddp_merge(torch.as_tensor(np.asarray(ids), device=device), model.pad_index).cpu().numpy()
+                if scores is not None:
+                    scores = ddp_merge(torch.as_tensor(np.asarray(scores), device=device), 0.0).cpu().numpy()
             batch_indices = ddp_merge(batch.indices.to(device).unsqueeze(1), -1).squeeze(1)
-            assert bool(torch.all(batch_indices >= 0)) and len(batch_indices) * n_best == len(ids)
-            all_ids.extend(ids)
-            all_indices.extend(np.repeat(batch_indices.cpu().numpy(), n_best).tolist())
-            if scores is not None and return_prob == "ref":
-                all_scores.extend(scores)
+            assert bool(torch.all(batch_indices >= 0)) and len(batch_indices) * n_best == len(ids) == batch_nseqs * n_best, \
+                (len(batch_indices), len(ids), batch_nseqs)
+            have_scores = scores is not None and len(scores) == len(ids)
+            for k, index in enumerate(batch_indices.cpu().tolist()):
+                # keyed by dataset index: a sentence the sampler handed out twice (its padding to a multiple of the world size)
+                # is kept once, the later copy overwriting the earlier one as in the reference (`_all_outputs[i] = row`, :250-257)
+                rows = slice(k * n_best, (k + 1) * n_best)
+                by_index[int(index)] = (list(ids[rows]), list(scores[rows]) if have_scores else None,
+                                        att[k] if att is not None else None)
         else:
             all_ids.extend(ids[sort_reverse_index])  # either hypotheses or references
             if att is not None:
@@ -83,11 +92,14 @@ def predict(model, batches: Iterable[Batch], *, beam_size: int = 1, beam_alpha: 
             if scores is not None and len(scores) == len(sort_reverse_index):
                 all_scores.extend(scores[sort_reverse_index])
         totals["nseqs"] += batch_nseqs
-    if ddp and all_indices:
-        order = np.argsort(np.asarray(all_indices), kind="stable")  # n-best rows of a sentence stay together, in rank order
-        all_ids = [all_ids[i] for i in order]
-        if all_scores:
-            all_scores = [all_scores[i] for i in order]
+    if ddp:
+        for index in sorted(by_index):  # dataset order; the n-best rows of a sentence stay together
+            rows, row_scores, row_att = by_index[index]
+            all_ids.extend(rows)
+            if row_scores is not None:
+                all_scores.extend(row_scores)
+            if row_att is not None:
+                all_att.append(row_att)
     sentences = model.trg_vocab.arrays_to_sentences(all_ids, cut_at_eos=True)
     out = [all_ids, sentences, (all_scores if len(all_scores) else None)]
     if return_attention:

@@ -106,3 +106,67 @@ def test_predict_validation_leg_two_ranks(device):
             np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
             n = min(len(gid), len(wid))
             assert np.array_equal(gid[:n], wid[:n]) and (np.asarray(wid[n:]) == 1).all() and (gid[n:] == 1).all()
+
+
+SEARCH_MODES = [dict(beam_size=1, return_prob="none"), dict(beam_size=1, return_prob="hyp"), dict(beam_size=1, return_prob="none", return_attention=True),
+                dict(beam_size=3, n_best=2, return_prob="hyp", beam_alpha=1.0), dict(beam_size=3, return_prob="none")]
+
+
+def _search_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from joeys2t_amd.prediction import predict
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("predict_loss")
+        model = _model(dev)
+        out = []
+        for mode in SEARCH_MODES:
+            # step 1: rank 0 holds rows 0-2, rank 1 rows 3-6; step 2 hands every row out a second time, to the other rank - what a
+            # sampler's padding to a multiple of the world size does to a few rows: each sentence must come back once
+            mine = [_batch(g, rank, dev, 0 if rank == 0 else 3), _batch(g, 1 - rank, dev, 3 if rank == 0 else 0)]
+            res = predict(model, mine, max_output_length=12, **mode)
+            out.append([[np.asarray(i) for i in res[0]], res[1], None if res[2] is None else [np.asarray(s) for s in res[2]],
+                        None if len(res) < 4 or res[3] is None else [np.asarray(a) for a in res[3]]])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_search_two_ranks_greedy_and_beam(device):
+    """greedy search merges its rows itself (search.py:333-335), so `predict` must not merge them again; hypothesis
+    scores and attention travel with the ids; a sentence handed out twice is kept once.  Every mode against the single-process
+    `predict` over the same sentences."""
+    from joeys2t_amd.prediction import predict
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_search_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    g = load_golden("predict_loss")
+    model = _model(device)
+    for mi, mode in enumerate(SEARCH_MODES):
+        want = predict(model, [_batch(g, 0, device), _batch(g, 1, device, 3)], max_output_length=12, **mode)
+        n_rows = 7 * mode.get("n_best", 1)
+        assert len(want[0]) == n_rows
+        for r in (0, 1):
+            ids, sentences, scores, att = ret[r][mi]
+            assert len(ids) == n_rows and sentences == want[1], (mode, r)
+            for a, b in zip(ids, want[0]):  # rows are padded to their batch's (here: the merged batch's) longest hypothesis
+                a, b = np.asarray(a), np.asarray(b)
+                n = min(len(a), len(b))
+                assert np.array_equal(a[:n], b[:n]) and (a[n:] == 1).all() and (b[n:] == 1).all(), (mode, r)
+            if mode["return_prob"] == "hyp":
+                assert scores is not None and len(scores) == n_rows
+                for a, b in zip(scores, want[2]):
+                    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+                    n = min(len(a), len(b))
+                    np.testing.assert_allclose(a[:n], b[:n], rtol=1e-4, atol=1e-4)
+                    assert (a[n:] == 0).all() and (b[n:] == 0).all()
+            else:
+                assert scores is None
+            if mode.get("return_attention"):
+                assert att is not None and len(att) == 7
+                for a, b in zip(att, want[3]):
+                    t, s = min(a.shape[0], b.shape[0]), min(a.shape[1], b.shape[1])
+                    np.testing.assert_allclose(a[:t, :s], b[:t, :s], rtol=1e-4, atol=1e-5)
