@@ -1406,6 +1406,79 @@ __device__ __forceinline__ void p192_load_bias(const js2t_gemm_desc& d, int n, f
     for (int c = 0; c < 8; ++c) bias_r[c] = has_bias ? d.bias[n + c] : 0.f;
   }
 }
+// Round 6: the bias + ReLU + dropout (+ folded LayerNorm) epilogue of FFN layer 1 at half the vector instructions (81 -> 45 per row
+// of eight outputs in the ISA; tools/isa_mix.py), same bits.  With one or two waves per SIMD nothing covers a tile's epilogue, its
+// instruction count is paid in full.  What changed, term by term:
+//  * ReLU and the dropout decision on the PACKED bf16 pair: a dropped half gets its sign bit set ((h ^ 0x8000) -sat- (thr ^ 0x8000)
+//    is negative exactly when the 16-bit hash half is below the threshold: v_pk_sub_i16 clamp), then one v_pk_max_i16 against 0
+//    zeroes dropped and negative halves alike.  ReLU commutes with the positive keep-scale and with rounding, so the stored value is
+//    the old one (a negative zero now becomes a positive one);
+//  * the row keys hash32(row ^ key): the 16 lanes of a row group share their twelve rows, so lane r computes ONE key (row
+//    16 (r >> 2) + 4 g + (r & 3)) and the others fetch it by ds_swizzle (row16_bcast: an immediate pattern, no address register) -
+//    the LDS crossbar is idle in the epilogue; every lane used to hash all twelve;
+//  * the row's address: a wave-uniform row base (scalar unit) + one lane offset for the whole tile.
+// Measured and NOT taken: rstd * acc + bias and the keep-scale as v_pk_fma_f32 / v_pk_mul_f32 over the two rows an accumulator pair
+// holds - slower (30.7 against 29.7 us; the guide's 'packed f32 is an anti-lever') and WRONG on the hardware: the compiler reads the
+// odd bias registers through op_sel straight out of a global_load_dwordx4's return, and in ~1 of 10^5 rows the low half came out
+// with the previous tile's bias in lanes 48-63 (tools/epi_diag.py; 60 wait states in front changed nothing; scalar f32: clean).
+typedef short i16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_drop_bf16x2(uint32_t packed, uint32_t h, uint32_t thr_b) {
+  const i16x2_t dd = __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2_t, h ^ 0x80008000u), __builtin_bit_cast(i16x2_t, thr_b));
+  const uint32_t x = (__builtin_bit_cast(uint32_t, dd) & 0x80008000u) | packed;
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, x), i16x2_t{0, 0}));
+}
+// x of lane 16 (lane / 16) + k, for every lane: ds_swizzle in bit-mask mode (new lane = (lane & 0x10) | k inside each half wave).
+// k is a constant at every call site after unrolling (the pattern is an immediate).
+__device__ __forceinline__ uint32_t row16_bcast(uint32_t x, int k) {
+#define JS2T_SWZ(K) case K: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x10 | (K << 5));
+  switch (k) {
+    JS2T_SWZ(0) JS2T_SWZ(1) JS2T_SWZ(2) JS2T_SWZ(3) JS2T_SWZ(4) JS2T_SWZ(5) JS2T_SWZ(6) JS2T_SWZ(7)
+    JS2T_SWZ(8) JS2T_SWZ(9) JS2T_SWZ(10) JS2T_SWZ(11) JS2T_SWZ(12) JS2T_SWZ(13) JS2T_SWZ(14)
+    default: return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x10 | (15 << 5));
+  }
+#undef JS2T_SWZ
+}
+// the key of the row this lane computes for its row group (lane r -> row 16 (r >> 2) + 4 g + (r & 3) of the wave's 48; r >= 12: unused)
+__device__ __forceinline__ uint32_t row16_own_key(int mw, int lane, uint32_t drop_key) {
+  const int g = lane >> 4, r = lane & 15;
+  return hash32((uint32_t)(mw + 16 * (r >> 2) + 4 * g + (r & 3)) ^ drop_key);
+}
+template <bool LNF>
+__device__ __forceinline__ void p192_store_tile_ffn1(const js2t_gemm_desc& d, f32x4_t (&acc)[3][8], int mw, int n0, int lane,
+                                                     const float (&bias_r)[8], uint32_t drop_key, float my_rs) {
+  const int g = lane >> 4, r = lane & 15;
+  const int M = d.M, n = n0 + 8 * r;
+  if (n >= d.N) return;
+  const float keep_scale = 1.f / (1.f - d.dropout_p);
+  const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
+  const uint32_t thr_b = ((thr ^ 0x8000u) & 0xffffu) * 0x10001u;  // (thr - 32768) in both halves: the signed twin of the unsigned compare
+  const uint32_t my_key = row16_own_key(mw, lane, drop_key);
+  const uint32_t colk = 2u * (uint32_t)(n >> 2);
+  uint16_t* const cl = (uint16_t*)d.C + (4 * g * d.ldc + n);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[8];
+      if (LNF) {
+        const float rs = __shfl(my_rs, 16 * i + 4 * g + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(rs, acc[i][j][e], bias_r[j]) * keep_scale;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (acc[i][j][e] + bias_r[j]) * keep_scale;
+      }
+      const uint32_t rowkey = row16_bcast(my_key, 4 * i + e) + colk;
+      uint4 pk;
+      uint32_t* pw = (uint32_t*)&pk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pw[q] = relu_drop_bf16x2(pack_bf16x2(v[2 * q], v[2 * q + 1]), hash32w(rowkey + (uint32_t)q), thr_b);
+      const int mu = mw + 16 * i + e;  // wave-uniform part of the row
+      if (mu + 4 * g < M) *(uint4*)(cl + (int64_t)mu * d.ldc) = pk;
+    }
+  }
+}
+
 // bias_r: the lane's 8 bias values, fetched when the tile started; drop_key: fetched when the kernel started (both
 // would otherwise expose a dependent global-load latency per tile)
 // OUT8 (the e4m3 kernels only): d.c8 != NULL adds a second output, the result as e4m3 bytes with the delayed scale of d.c8_state
@@ -1419,6 +1492,14 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
   return;
+#endif
+#ifndef JS2T_OLD_FFN1_EPI
+  if constexpr (EPI >= 0 && !OUT8 && (EPI & ~PE_LNF) == (PE_BIAS | PE_RELU | PE_DROP)) {
+    if (n0 + 128 <= d.N) {  // whole column tile (wave-uniform): every lane of a row group is there to hand its row key over
+      p192_store_tile_ffn1<(EPI & PE_LNF) != 0>(d, acc, mw, n0, lane, bias_r, drop_key, my_rs);
+      return;
+    }
+  }
 #endif
   const int g = lane >> 4, r = lane & 15;
   const int M = d.M, n = n0 + 8 * r;
@@ -1443,6 +1524,10 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
       q8_inv = S > 0.f ? 1.f / S : 0.f;
     }
   }
+  // one row key per lane, shared by row16_bcast (round 6) - in whole column tiles only: a lane outside N has returned above and
+  // cannot hand its key over
+  const bool share_keys = n0 + 128 <= d.N;
+  const uint32_t my_key = (has_drop && share_keys) ? row16_own_key(mw, lane, drop_key) : 0u;
   // residual / gate rows: block i + 1 is requested before block i is used (twelve rows at once cost too many registers)
   uint4 rg[3][4];
   auto load_rg = [&](int i) {
@@ -1483,7 +1568,7 @@ __device__ __forceinline__ void p192_store_tile(const js2t_gemm_desc& d, f32x4_t
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
       }
       if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, n/4 + h), taken straight from the hash halves
-        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
+        const uint32_t rowkey = (share_keys ? row16_bcast(my_key, 4 * i + e) : hash32((uint32_t)m ^ drop_key)) + 2u * (uint32_t)(n >> 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t h = hash32w(rowkey + (uint32_t)q);
@@ -1822,6 +1907,11 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
   const uint32_t thr = (uint32_t)(d.dropout_p * 65536.0f);
   const uint16_t* rsrc = (const uint16_t*)(has_res ? d.residual : d.gate) + n;
   const int64_t rld = has_res ? d.ldr : d.ldg;
+  // one row key per lane (the 16 lanes of a row group walk the same twelve rows), fetched by row16_bcast: a lane of this kernel owns
+  // four outputs per row, so hashing every row itself was two of its ~twelve vector instructions per output (round 6)
+  // (whole 64-column groups only: a lane outside N has returned above and cannot hand its key over)
+  const bool share_keys = n0 + 64 <= d.N;
+  const uint32_t my_key = (has_drop && share_keys) ? row16_own_key(mw, lane, drop_key) : 0u;
   uint2 rg[3][4];
   if (has_res || has_gate) {
 #pragma unroll
@@ -1864,7 +1954,7 @@ __device__ __forceinline__ void p192s_store_tile(const js2t_gemm_desc& d, f32x4_
         for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
       }
       if (has_drop) {  // the decisions of dropout_keep4_key(drop_key, m, n / 4)
-        const uint32_t rowkey = hash32((uint32_t)m ^ drop_key) + 2u * (uint32_t)(n >> 2);
+        const uint32_t rowkey = (share_keys ? row16_bcast(my_key, 4 * i + e) : hash32((uint32_t)m ^ drop_key)) + 2u * (uint32_t)(n >> 2);
         const uint32_t h0 = hash32w(rowkey), h1 = hash32w(rowkey + 1u);
         v[0] = (h0 & 0xffffu) >= thr ? v[0] * keep_scale : 0.f;
         v[1] = (h0 >> 16) >= thr ? v[1] * keep_scale : 0.f;

@@ -16,7 +16,18 @@ batches of a bucket lives in device memory the graph reads:
 All of it travels in ONE pinned buffer -> ONE host-to-device copy per step.  A bucket seen for the first time runs its batch
 eagerly (that is the training step) and is captured right after; graphs share one memory pool and are kept in an LRU list.
 Results are those of TrainStep.micro_step on the un-padded batch (tests/test_hip_graphed.py; dropout masks differ because the
-row index of a position depends on the padded length - as they differ from the reference's torch RNG anyway)."""
+row index of a position depends on the padded length - as they differ from the reference's torch RNG anyway).
+
+Round 6 - the drivers compose: accumulation x varying shapes x data parallelism (the reference's configs accumulate,
+configs/librispeech_100h.yaml:85 `batch_multiplier: 4`, librispeech_960h.yaml:85 = 8; loop at joeynmt/training.py:416-456, exchange
+at :584-588).  A bucket holds one capture per PHASE of the accumulation - (first, last) of the micro-batch inside its update: the
+first one overwrites weight-gradient slices instead of adding into them, the last one is followed by the update - so an update of k
+micro-batches of k different shapes is k replays.  Under a process group the last micro-batch's capture is CUT where the collectives
+go (`capture_cut_step`, the scheme of GraphedDDPStep): forward + decoder-side backward, the decoder side's weight-gradient pieces,
+the encoder's backward, its pieces; the update graph is shape-independent and shared.  Collectives are never captured, and the eager
+step of a bucket's first sight issues EXACTLY the collective calls of a replay (same ranges, same order: the plan's order is
+rank- and shape-independent, runtime.WgradQueue.take) - so ranks may replay different buckets, or one rank may run eagerly while the
+others replay, without any agreement between them."""
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
@@ -75,8 +86,21 @@ class _Bucket:
         b.src_pack = ops.PackedRows(d[self.slices["seg"]].view(torch.int32)[:B + 1], B, t_sub, rows) if rows > 0 else None
         self.batch = b
         self.pad_index = pad_index
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        # captures by phase (first, last) of the micro-batch inside its update: a CUDAGraph, or - the last micro-batch under a
+        # process group - the dict of capture_cut_step
+        self.graphs: Dict[tuple, object] = {}
         self.replays = 0
+
+    @property
+    def graph(self):
+        """any capture of this bucket (None: nothing captured yet)"""
+        return next(iter(self.graphs.values()), None)
+
+    @graph.setter
+    def graph(self, value):
+        if value is not None:
+            raise ValueError("captures are stored per phase (_Bucket.graphs); only None (drop them all) can be assigned")
+        self.graphs = {}
 
     def next_host(self):
         """the staging buffer for this step (waits, on the host, only if its copy of three steps ago has not run yet)"""

@@ -345,12 +345,19 @@ class WgradQueue:
         captured stays valid for every replay (its tensors live in the graph's static pool): run(plan) re-issues the launches.
         mode: 1 = the products overwrite their dW (beta 0), 2 = their epilogues leave the sums of squares with the collector."""
         from joeys2t_amd.functional import wgrad_split
-        # Largest first - by WEIGHT size x members, not by work: the order of the plan is the order in which the ranges of the flat
-        # gradient complete, i.e. the order of the all-reduces, and that must be the same on every rank.  The token count M differs
-        # from rank to rank (and the encoder-length memory K | V product sits in one plan with the target-length decoder products
-        # since the early exchange): sorted by N * K * M the order flipped at M_s / M_t of about 4 - two ranks would issue
-        # collectives of different ranges in different order.  Ties keep the order of arrival (the model's, rank-independent).
-        plan = sorted(self.groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
+        # The order of the plan is the order in which the ranges of the flat gradient complete, i.e. the order of the all-reduces,
+        # and that must be the same on every rank - while the token counts M differ from rank to rank and from batch to batch.
+        # So nothing M-dependent may decide it: products are ordered by CLASS = (N, K, bias) - largest weight x members first, ties
+        # in the order of arrival (the model's) - and inside a class the launches (one per distinct M / row stride: a grouped
+        # launch has one token count) follow each other in the order of arrival.  Round 5 sorted the (N, K, M) groups themselves:
+        # encoder and decoder products of one (N, K) were ONE group of 2n members on a rank whose B T' happened to equal B L and
+        # two groups of n elsewhere - another sort key, another order of collectives (ADVICE r5).
+        classes: Dict[tuple, list] = {}
+        for key, items in self.groups.items():  # dicts keep insertion order: first arrival of a class, of a group inside it
+            classes.setdefault((key[0], key[1], key[5]), []).append((key, items))
+        plan = []
+        for ck, members in sorted(classes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * sum(len(it) for _, it in kv[1])):
+            plan.extend(members)
         self.groups = {}
         self.pending = 0
         cand, out, written = self.cand, [], []

@@ -236,20 +236,44 @@ def test_communicator_id_reaches_every_rank():
 def test_wgrad_plan_order_does_not_depend_on_token_counts():
     """The plan's order is the order in which flat-gradient ranges complete, i.e. the order of the all-reduces: it must not
     depend on a rank's own token counts (sorted by N*K*M the encoder-length memory K|V product and the target-length
-    decoder products traded places at M_s / M_t of about 4, a ratio that differs from batch to batch and rank to rank)."""
+    decoder products traded places at M_s / M_t of about 4, a ratio that differs from batch to batch and rank to rank; ADVICE r5:
+    encoder and decoder products of one (N, K) merged into ONE group on a rank whose B T' equals its B L and stayed two groups
+    elsewhere - the uncut plan below holds both sides' feed-forward and output-projection products for that)."""
     from joeys2t_amd.runtime import WgradQueue
 
     def plan_order(m_src, m_trg):
         q = WgradQueue()
         d = 512
-        for _ in range(6):  # decoder feed-forward layers on the target rows
-            q.add(torch.empty(m_trg, 2048), torch.empty(m_trg, d), torch.empty(2048, d), torch.empty(2048))
-            q.add(torch.empty(m_trg, d), torch.empty(m_trg, 2048), torch.empty(d, 2048), torch.empty(d))
-        q.add(torch.empty(m_src, 6 * 2 * d), torch.empty(m_src, d), torch.empty(6 * 2 * d, d), torch.empty(6 * 2 * d))  # memory K|V
-        for _ in range(6):
-            q.add(torch.empty(m_trg, 3 * d), torch.empty(m_trg, d), torch.empty(3 * d, d), None)
-        return [(k[0], k[1], len(items)) for k, items in q.take()]
+        tag = {}
 
-    ref = plan_order(12000, 2592)
-    for m_src, m_trg in ((12000, 4000), (6000, 3000), (3000, 3000), (20000, 700), (640, 640)):
-        assert plan_order(m_src, m_trg) == ref, (m_src, m_trg)
+        def add(m, n, k, bias=True):
+            dw = torch.empty(n, k)
+            tag[dw.data_ptr()] = len(tag)
+            q.add(torch.empty(m, n), torch.empty(m, k), dw, torch.empty(n) if bias else None)
+
+        for _ in range(6):  # decoder layers on the target rows (backward order: the decoder comes first)
+            add(m_trg, 2048, d)
+            add(m_trg, d, 2048)
+            add(m_trg, d, d)
+        add(m_src, 6 * 2 * d, d)  # memory K|V
+        for _ in range(6):
+            add(m_trg, 3 * d, d, bias=False)
+        for _ in range(4):  # encoder layers on the source rows: the same (N, K) classes as the decoder's
+            add(m_src, 2048, d)
+            add(m_src, d, 2048)
+            add(m_src, d, d)
+            add(m_src, 3 * d, d)
+        plan = q.take()
+        launches = [(k[0], k[1], k[5], k[2], len(items)) for k, items in plan]
+        return [tag[it[2].data_ptr()] for _, items in plan for it in items], launches
+
+    ref, ref_launches = plan_order(12000, 2592)
+    assert len(ref) == len(set(ref)) == 6 * 3 + 1 + 6 + 4 * 4
+    for m_src, m_trg in ((12000, 4000), (6000, 3000), (3000, 3000), (20000, 700), (640, 640), (2592, 2592)):
+        order, launches = plan_order(m_src, m_trg)
+        assert order == ref, (m_src, m_trg)  # the products - hence the ranges they complete - in one order on every rank
+        if m_src == m_trg:  # here the two sides of a class share one launch ...
+            assert len(launches) < len(ref_launches)
+    # ... and with different token counts they are two launches that FOLLOW each other (one class, one place in the order)
+    classes = [c[:3] for c in ref_launches]
+    assert all(classes.index(c) + classes.count(c) - 1 == len(classes) - 1 - classes[::-1].index(c) for c in set(classes))
