@@ -123,15 +123,17 @@ class GraphedTrainStep:
     """step = GraphedTrainStep(TrainStep(model, ...), SpeechProcessor(...)); step.run(wave, n_samples, trg, trg_len) per batch.
 
     wave f32 [B, N] on the device (raw 16 kHz samples, e.g. from datasets.PrefetchLoader), n_samples: host list, trg int64
-    [B, L] on the host (BOS ... EOS, padded with pad_index), trg_len: host list / tensor (including BOS and EOS)."""
+    [B, L] on the host (BOS ... EOS, padded with pad_index), trg_len: host list / tensor (including BOS and EOS).
+
+    `run` takes one MICRO-batch: with TrainStep(batch_multiplier=k) every k-th call ends in the update (training.py:436-456); with a
+    process group up (TrainStep.reducer) the k-th call also carries the gradient exchange - one exchange per update, on the summed
+    gradient (the reference's DistributedDataParallel exchanges in every backward pass, training.py:584-588: the same sum)."""
 
     def __init__(self, step: TrainStep, proc: SpeechProcessor, compute_dtype=torch.bfloat16, frame_bucket: int = 64,
                  target_bucket: int = 8, max_graphs: int = 128, pad_index: int = 1, eos_index: int = 3, use_graphs: bool = True,
                  row_bucket: int = 384, pack_min_saving: float = 0.04):
-        if step.batch_multiplier != 1:
-            raise NotImplementedError("GraphedTrainStep: one optimizer update per batch (batch_multiplier 1)")
-        if step.reducer is not None:
-            raise NotImplementedError("GraphedTrainStep: single-GPU steps (the data-parallel step is cut around its RCCL calls, bench.py)")
+        if step.reducer is not None and step.rt.wgrad_queue is None:
+            raise ops.Js2tError("GraphedTrainStep under a process group needs the deferred weight-gradient products (TrainStep(defer_wgrads=True))")
         if step.normalization == "tokens":
             raise NotImplementedError("GraphedTrainStep: 'tokens' normalisation changes a captured constant per batch; use 'batch'")
         self.step, self.proc, self.dtype = step, proc, compute_dtype
@@ -155,6 +157,9 @@ class GraphedTrainStep:
         step.external_lr = True                # ... and the rate arrives with the batch (one copy), not by a fill per step
         self.ntokens = 0
         self.counts = {"eager": 0, "replay": 0, "captured": 0, "evicted": 0}
+        self.update_graph: Optional[torch.cuda.CUDAGraph] = None  # clip + AdamW behind the last collective (process group only; any shape)
+        self.capture_errors: List[str] = []  # a bucket whose capture failed keeps running eagerly (same collectives: no agreement needed)
+        self.inject_failure: Optional[str] = None  # tests: "forward" / "pieces" make the cut capture raise at that stage
         self._plan_generation = step.optimizer.plan_generation  # update plan the captured graphs were made with (builders._fused_plan)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -176,7 +181,28 @@ class GraphedTrainStep:
             frames = (frames + 2 * (k // 2) - (k - 1) - 1) // 2 + 1
         return frames
 
-    def _body(self, bk: _Bucket):
+    def _phase(self) -> tuple:
+        """(first, last) of the coming micro-batch inside its update"""
+        k = self.step.batch_multiplier
+        j = self.step.micro % k
+        return (j == 0, j == k - 1)
+
+    def _phases(self) -> List[tuple]:
+        """the distinct phases of an update with a micro counter that has each: [((first, last), micro index)]"""
+        k = self.step.batch_multiplier
+        seen, out = set(), []
+        for j in range(k):
+            ph = (j == 0, j == k - 1)
+            if ph not in seen:
+                seen.add(ph)
+                out.append((ph, j))
+        return out
+
+    def _body(self, bk: _Bucket, how: str = "plain", cut_hook=None):
+        """One micro-batch over the bucket's static inputs.  how: "plain" - micro_step with its flush (and, behind the last
+        micro-batch of an update on a single GPU, the update); "exchange" - the last micro-batch under a process group, launched
+        eagerly: the cut backward pass, the overlapped exchange, the update (what a replay of the cut capture does, call for call);
+        "cut" - the same micro-batch for capture_cut_step: products stay queued, `cut_hook` between the halves, no update."""
         B, Tb = bk.key[0], bk.key[1]
         step = self.step
         step.optimizer.lr_dev.copy_(bk.lr)  # the step's learning rate, as it arrived in the packed buffer
@@ -185,7 +211,64 @@ class GraphedTrainStep:
         b = bk.batch
         b.src = feats
         b.trg_mask = (b.trg != self.pad_index).unsqueeze(1)
-        return step.micro_step(b, sort=False, update=True, overlap=False)
+        if how == "cut":
+            return step.micro_step(b, sort=False, update=False, overlap=False, flush=False, cut_hook=cut_hook)
+        return step.micro_step(b, sort=False, update=True, overlap=(how == "exchange"))
+
+    def _capture(self, bk: _Bucket, phase: tuple, micro_at: int) -> bool:
+        """Capture `phase` of the bucket (nothing runs; host-side counters are put back).  A failure leaves the bucket without that
+        capture - it keeps running eagerly - and is recorded in `capture_errors`."""
+        step = self.step
+        micro, t, steps = step.micro, step.optimizer.t, step.steps
+        step.micro = micro_at
+        try:
+            if step.reducer is not None and phase[1]:
+                cap = capture_cut_step(step, lambda hook: self._body(bk, "cut", hook), pool=self.pool, fail=self.inject_failure)
+                if self.update_graph is None:
+                    gu = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gu, pool=self.pool, capture_error_mode="thread_local"):
+                        step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+                    self.update_graph = gu
+            else:
+                cap = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(cap, pool=self.pool, capture_error_mode="thread_local" if step.reducer is not None else "global"):
+                        self._body(bk)
+                except BaseException:
+                    if step.rt.wgrad_queue is not None:
+                        step.rt.wgrad_queue.take()  # nothing of a half-made capture may stay queued
+                    raise
+        except Exception as exc:  # noqa: BLE001
+            torch.cuda.synchronize()
+            if step.reducer is None:
+                raise  # a single process fails loudly (counters and queue are back where they were: `finally` below, cleanup above)
+            # under a process group the eager step is still there and issues the collectives a replay would: this rank goes on
+            # eagerly for this (bucket, phase), the others need not know
+            self.capture_errors.append(f"{bk.key} {phase}: {repr(exc)[:200]}")
+            self.counts["capture_failed"] = self.counts.get("capture_failed", 0) + 1
+            bk.failed = getattr(bk, "failed", set()) | {phase}
+            return False
+        finally:
+            step.micro, step.optimizer.t, step.steps = micro, t, steps
+        bk.graphs[phase] = cap
+        self.counts["captured"] += 1
+        return True
+
+    def _replay(self, bk: _Bucket, phase: tuple):
+        step, cap = self.step, bk.graphs[phase]
+        if isinstance(cap, dict):  # the last micro-batch under a process group: graphs cut where the collectives go
+            replay_cut_step(step, cap)
+            self.update_graph.replay()
+        else:
+            cap.replay()
+        bk.replays += 1
+        step.micro += 1
+        if phase[1]:
+            # the host's count of updates (checkpoints write it, builders.py torch_state_dict) moves once per REAL update:
+            # the replayed kernel counts on the device (step_dev) and never passes FlatAdamW.clip_and_step's `t += 1`
+            step.optimizer.t += 1
+            step.after_update()
+        self.counts["replay"] += 1
 
     def bucket_key(self, n_samples: Sequence[int], trg_len) -> tuple:
         """The bucket a batch falls into - host arithmetic on lengths only, so a loader that knows its epoch (samplers are
@@ -202,27 +285,28 @@ class GraphedTrainStep:
         return (B, Tb, _round_up(max(trg_len), self.target_bucket), rows)
 
     def precapture(self, key: tuple) -> bool:
-        """Capture the graph of a bucket BEFORE its first batch arrives.  Capturing executes nothing (no kernel runs, the model, the
-        optimizer and the RNG stay where they are - the host-side counters the capture pass touches are put back), so it can be done
-        at any point between two steps; it needs one earlier eager step of any shape (lazily built tables, the allocator's pools).
-        Returns False when the bucket was captured already."""
+        """Capture the graphs of a bucket (every phase of the accumulation) BEFORE its first batch arrives.  Capturing executes
+        nothing (no kernel runs, no collective is issued, the model, the optimizer and the RNG stay where they are - the host-side
+        counters the capture pass touches are put back), so it can be done at any point between two micro-batches; it needs one
+        earlier eager update of any shape (lazily built tables, the allocator's pools, the weight-gradient ranges the first update
+        learns to overwrite).  Returns False when the bucket was captured already (or cannot be)."""
         if not self.use_graphs:
             return False
-        if not self.counts["eager"]:
-            raise ops.Js2tError("GraphedTrainStep.precapture: run one batch first (the first step of a run builds what captures reuse)")
-        bk = self._bucket(tuple(key))
-        if bk.graph is not None:
+        if self.counts["eager"] < self.step.batch_multiplier:
+            raise ops.Js2tError("GraphedTrainStep.precapture: run one update first (the first steps of a run build what captures reuse)")
+        key = tuple(key)
+        if key not in self.buckets and len(self.buckets) >= self.max_graphs:
+            # a loader that lists more buckets than the LRU holds would silently push out captures it made a moment ago
+            self.counts["precapture_refused"] = self.counts.get("precapture_refused", 0) + 1
             return False
-        step = self.step
-        g = torch.cuda.CUDAGraph()
-        micro, t, steps = step.micro, step.optimizer.t, step.steps
-        with torch.cuda.graph(g, pool=self.pool):
-            self._body(bk)
-        step.micro, step.optimizer.t, step.steps = micro, t, steps
-        bk.graph = g
-        self.counts["captured"] += 1
-        self.counts["precaptured"] = self.counts.get("precaptured", 0) + 1
-        return True
+        bk = self._bucket(key)
+        made = False
+        for phase, j in self._phases():
+            if phase not in bk.graphs and phase not in getattr(bk, "failed", ()):
+                made = self._capture(bk, phase, j) or made
+        if made:
+            self.counts["precaptured"] = self.counts.get("precaptured", 0) + 1
+        return made
 
     def run(self, wave: torch.Tensor, n_samples: Sequence[int], trg: torch.Tensor, trg_len) -> str:
         """One training step on this batch; returns how it ran ("eager" on a bucket's first sight, else "replay")."""
@@ -276,28 +360,20 @@ class GraphedTrainStep:
             # captured: those graphs bake in the old tables and keep flags - a stale-plus-new gradient waiting to happen.  Drop them;
             # every bucket is captured again at its next batch.
             for other in self.buckets.values():
-                other.graph = None
+                other.graphs = {}
+            self.update_graph = None
             self.counts["recaptured_after_plan_change"] = self.counts.get("recaptured_after_plan_change", 0) + 1
             self._plan_generation = step.optimizer.plan_generation
-        if bk.graph is not None:
-            bk.graph.replay()
-            bk.replays += 1
-            # the host's count of updates (checkpoints write it, builders.py torch_state_dict) moves once per REAL update:
-            # the replayed kernel counts on the device (step_dev) and never passes FlatAdamW.clip_and_step's `t += 1`
-            step.optimizer.t += 1
-            step.after_update()
-            self.counts["replay"] += 1
+        phase = self._phase()
+        if phase in bk.graphs:
+            self._replay(bk, phase)
             return "replay"
-        self._body(bk)  # first sight of this bucket: the step runs eagerly (micro_step -> update -> after_update) ...
+        # first sight of this (bucket, phase): the micro-batch runs eagerly (micro_step -> [exchange ->] update -> after_update) ...
+        self._body(bk, "exchange" if (step.reducer is not None and phase[1]) else "plain")
         self.counts["eager"] += 1
-        if self.use_graphs:  # ... and is captured over the same static inputs for every later batch of the bucket
-            g = torch.cuda.CUDAGraph()
-            micro, t = step.micro, step.optimizer.t  # the capture pass is not a step: host-side counters stay
-            with torch.cuda.graph(g, pool=self.pool):
-                self._body(bk)
-            step.micro, step.optimizer.t = micro, t
-            bk.graph = g
-            self.counts["captured"] += 1
+        if self.use_graphs and phase not in getattr(bk, "failed", ()):
+            # ... and is captured over the same static inputs for every later batch of the bucket (the capture pass is not a step)
+            self._capture(bk, phase, (step.micro - 1) % step.batch_multiplier)
         return "eager"
 
     def read_stats(self, reset: bool = True):
@@ -306,6 +382,122 @@ class GraphedTrainStep:
         if reset:
             self.ntokens = 0
         return out
+
+
+def _cut_pieces(red, plan_part):
+    """one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start): groups that
+    finish no range ride with the next one that does"""
+    pend = [0] * len(red.ranges)
+    for _, items in plan_part:
+        for it in items:
+            pend[red.bucket_of_tensor(it[2])] += 1
+    pieces, cur = [], []
+    for entry in plan_part:
+        cur.append(entry)
+        done = False
+        for it in entry[1]:
+            bi = red.bucket_of_tensor(it[2])
+            pend[bi] -= 1
+            done = done or pend[bi] == 0
+        if done:
+            pieces.append(cur)
+            cur = []
+    if cur:
+        pieces.append(cur)
+    return pieces
+
+
+def capture_cut_step(step: TrainStep, body, pool=None, fail: Optional[str] = None, mode: str = "thread_local") -> Dict[str, object]:
+    """One micro-batch under a process group as graphs CUT where the collectives go: `body(cut_hook)` must end in
+    `step.micro_step(batch, sort=False, update=False, overlap=False, flush=False, cut_hook=cut_hook)`.  Returns
+    {"step": graph 1 (front end, forward, backward down to the encoder's output), "step2": the encoder's backward (None when the
+    pass could not be cut), "plan_dec" / "pieces_dec" / "wgrad_dec": the decoder side's deferred weight-gradient products, cut into
+    pieces at the points where a range of the flat gradient completes, and a graph per piece, "plan" / "pieces" / "wgrad": the same
+    for what is queued at the end of backward, "pool"}.  Capturing executes nothing and issues no collective; on failure the queue
+    is emptied and the error propagates (host-side counters are the caller's to put back).  thread_local: the RCCL watchdog thread
+    may query its events while this thread captures.  `fail` (tests): "forward" / "pieces" raise at that stage."""
+    from joeys2t_amd.runtime import WgradQueue
+    red = step.reducer
+    device = step.store.device
+    g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    st = {"plan_dec": None, "open": None}
+
+    def inject(stage):
+        if fail == stage:
+            raise RuntimeError(f"injected capture failure at '{stage}'")
+
+    def at_cut():
+        g.capture_end()
+        st["open"] = None
+        st["plan_dec"] = step.rt.wgrad_queue.take(final=False)
+        g2.capture_begin(pool=g.pool(), capture_error_mode=mode)
+        st["open"] = g2
+
+    cap = torch.cuda.Stream(device=device)
+    cap.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(cap):
+            if pool is None:
+                g.capture_begin(capture_error_mode=mode)
+            else:
+                g.capture_begin(pool=pool, capture_error_mode=mode)
+            st["open"] = g
+            try:
+                inject("forward")
+                body(at_cut)
+            finally:
+                if st["open"] is not None:  # only the graph that is open is ended (ADVICE r5: a failure inside at_cut() between
+                    st["open"].capture_end()  # the two captures used to end the first one a second time and mask the real error)
+                    st["open"] = None
+        torch.cuda.current_stream().wait_stream(cap)
+        # the products queued during capture reference the graphs' static buffers: they are the per-step plan
+        plan = step.rt.wgrad_queue.take()
+
+        def capture_pieces(pieces):
+            out = []
+            for piece in pieces:
+                gw = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
+                    inject("pieces")
+                    WgradQueue.run(piece)
+                out.append(gw)
+            return out
+
+        pieces = _cut_pieces(red, plan)
+        pieces_dec = _cut_pieces(red, st["plan_dec"]) if st["plan_dec"] is not None else []
+        gw, gw_dec = capture_pieces(pieces), capture_pieces(pieces_dec)
+    except BaseException:
+        step.rt.wgrad_queue.take()  # nothing of a half-made capture may stay queued
+        torch.cuda.synchronize()
+        raise
+    return {"step": g, "step2": g2 if st["plan_dec"] is not None else None, "plan": plan, "plan_dec": st["plan_dec"], "pieces": pieces,
+            "pieces_dec": pieces_dec, "wgrad": gw, "wgrad_dec": gw_dec, "pool": g.pool()}
+
+
+def replay_cut_step(step: TrainStep, cap: Dict[str, object], exchange: bool = True):
+    """Replay what capture_cut_step captured, with the collectives between the graphs: each range of the flat gradient goes to
+    RCCL (the reducer's side stream) as soon as the piece that completes it has been launched; returns behind the last collective
+    (the caller replays its update graph)."""
+    red = step.reducer
+    cap["step"].replay()
+    if cap.get("step2") is not None:  # the decoder side's products and ranges, then the encoder's backward
+        if exchange:
+            red.exchange_begin(cap["plan_dec"], partial=True)
+        for piece, gw in zip(cap["pieces_dec"], cap["wgrad_dec"]):
+            gw.replay()
+            if exchange:
+                for _, items in piece:
+                    red.entries_done(items)
+        cap["step2"].replay()
+    if exchange:
+        red.exchange_begin(cap["plan"])
+    for piece, gw in zip(cap["pieces"], cap["wgrad"]):
+        gw.replay()
+        if exchange:
+            for _, items in piece:
+                red.entries_done(items)
+    if exchange:
+        red.finish()
 
 
 class GraphedDDPStep:
@@ -362,42 +554,12 @@ class GraphedDDPStep:
         self.counts["eager"] += 1
         return out
 
-    def _cut_pieces(self, plan_part):
-        """one piece per point at which a range of the flat gradient becomes complete (and its all-reduce can start): groups
-        that finish no range ride with the next one that does"""
-        red = self.step.reducer
-        pend = [0] * len(red.ranges)
-        for _, items in plan_part:
-            for it in items:
-                pend[red.bucket_of_tensor(it[2])] += 1
-        pieces, cur = [], []
-        for entry in plan_part:
-            cur.append(entry)
-            done = False
-            for it in entry[1]:
-                bi = red.bucket_of_tensor(it[2])
-                pend[bi] -= 1
-                done = done or pend[bi] == 0
-            if done:
-                pieces.append(cur)
-                cur = []
-        if cur:
-            pieces.append(cur)
-        return pieces
-
-    def _fail(self, stage: str):
-        if self.inject_failure == stage:
-            raise RuntimeError(f"GraphedDDPStep: injected capture failure at '{stage}'")
-
     def capture(self, warm: int = 2):
         """`warm` eager steps (real training steps: allocator, autotuned choices, RCCL's first calls), then the captures.  Capturing
         executes nothing and issues no collective - a rank whose capture fails has made exactly the collective calls of the ranks whose
         capture went through (try_capture relies on that)."""
         import gc
-        from joeys2t_amd.runtime import WgradQueue
-        step, red = self.step, self.step.reducer
-        # thread_local: the RCCL watchdog thread may query its events while this thread captures
-        mode = "thread_local"
+        step = self.step
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -405,58 +567,27 @@ class GraphedDDPStep:
                 self.eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        st = {"plan_dec": None}
-
-        def at_cut():
-            g.capture_end()
-            st["plan_dec"] = step.rt.wgrad_queue.take(final=False)
-            g2.capture_begin(pool=g.pool(), capture_error_mode=mode)
-
         self.pre_step()
         gc.collect()
         torch.cuda.empty_cache()
         micro, t_opt = step.micro, step.optimizer.t  # the capture pass is not a step: host-side counters stay
-        cap = torch.cuda.Stream(device=self.device)
-        cap.wait_stream(torch.cuda.current_stream())
         try:
-            with torch.cuda.stream(cap):
-                g.capture_begin(capture_error_mode=mode)
-                try:
-                    self._fail("forward")
-                    self.body(at_cut)
-                finally:
-                    (g2 if st["plan_dec"] is not None else g).capture_end()
-            torch.cuda.current_stream().wait_stream(cap)
-            # the products queued during capture reference the graphs' static buffers: they are the per-step plan
-            plan = step.rt.wgrad_queue.take()
-
-            def capture_pieces(pieces):
-                out = []
-                for piece in pieces:
-                    gw = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gw, pool=g.pool(), capture_error_mode=mode):
-                        self._fail("pieces")
-                        WgradQueue.run(piece)
-                    out.append(gw)
-                return out
-
-            pieces = self._cut_pieces(plan)
-            pieces_dec = self._cut_pieces(st["plan_dec"]) if st["plan_dec"] is not None else []
-            gw, gw_dec = capture_pieces(pieces), capture_pieces(pieces_dec)
+            cap = capture_cut_step(step, self.body, fail=self.inject_failure if self.inject_failure in ("forward", "pieces") else None)
             gu = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gu, pool=g.pool(), capture_error_mode=mode):
-                self._fail("update")
+            with torch.cuda.graph(gu, pool=cap["pool"], capture_error_mode="thread_local"):
+                if self.inject_failure == "update":
+                    raise RuntimeError("GraphedDDPStep: injected capture failure at 'update'")
                 step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
         except BaseException:
             # leave the step usable for eager_step(): nothing of a half-made capture may stay queued or counted
             step.rt.wgrad_queue.take()
-            step.micro, step.optimizer.t = micro, t_opt
             torch.cuda.synchronize()
             raise
-        step.micro, step.optimizer.t = micro, t_opt
-        self.plan, self.plan_dec, self.pieces, self.pieces_dec = plan, st["plan_dec"], pieces, pieces_dec
-        self.graphs = {"step": g, "step2": g2 if st["plan_dec"] is not None else None, "wgrad": gw, "wgrad_dec": gw_dec, "update": gu}
+        finally:
+            step.micro, step.optimizer.t = micro, t_opt
+        self.cut = cap
+        self.plan, self.plan_dec, self.pieces, self.pieces_dec = cap["plan"], cap["plan_dec"], cap["pieces"], cap["pieces_dec"]
+        self.graphs = {"step": cap["step"], "step2": cap["step2"], "wgrad": cap["wgrad"], "wgrad_dec": cap["wgrad_dec"], "update": gu}
 
     def try_capture(self, warm: int = 2) -> Optional[str]:
         """capture(); on failure - here or on ANY rank - drop the graphs everywhere and return what went wrong (None: captured).
@@ -482,28 +613,10 @@ class GraphedDDPStep:
         return bool(self.graphs)
 
     def replay_step(self):
-        step, red, gr = self.step, self.step.reducer, self.graphs
+        step = self.step
         self.pre_step()
-        gr["step"].replay()
-        if gr.get("step2") is not None:  # the decoder side's products and ranges, then the encoder's backward
-            if self.exchange:
-                red.exchange_begin(self.plan_dec, partial=True)
-            for piece, gw in zip(self.pieces_dec, gr["wgrad_dec"]):
-                gw.replay()
-                if self.exchange:
-                    for _, items in piece:
-                        red.entries_done(items)
-            gr["step2"].replay()
-        if self.exchange:
-            red.exchange_begin(self.plan)
-        for piece, gw in zip(self.pieces, gr["wgrad"]):
-            gw.replay()
-            if self.exchange:
-                for _, items in piece:
-                    red.entries_done(items)
-        if self.exchange:
-            red.finish()
-        gr["update"].replay()
+        replay_cut_step(step, self.cut, exchange=self.exchange)
+        self.graphs["update"].replay()
         step.optimizer.t += 1  # the replayed kernel counts on the device; checkpoints write the host's count
         step.after_update()
         self.counts["replay"] += 1
