@@ -107,9 +107,11 @@ def build_step(device, world, dtype=torch.bfloat16, seed=42, ragged=False, host_
     model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
     model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
     model.finalize(device, dtype, seed=seed)
-    # gradient exchange: bf16 over RCCL by default (JS2T_COMM_DTYPE=fp32 for the reference's fp32 all-reduce); gloo: fp32
+    # gradient exchange of the scored line: fp32, the reference's all-reduce (torch DistributedDataParallel, prediction.py:508-515).
+    # bf16 staging (half the bytes on xGMI, a 2^-9 rounding of gradients that come out of bf16 products) is timed as a SIDE figure
+    # behind it (config.grad_exchange carries both); JS2T_COMM_DTYPE=bf16 makes it the headline's exchange instead.
     comm_dtype = None
-    if ddp and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and os.environ.get("JS2T_COMM_DTYPE", "bf16") == "bf16":
+    if ddp and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and os.environ.get("JS2T_COMM_DTYPE", "fp32") == "bf16":
         comm_dtype = torch.bfloat16
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0,
                      learning_rate_warmup=10000, learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1,
@@ -383,6 +385,85 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
             "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/384) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
+
+
+def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, seed=42, merged=True):
+    """The train step AS THE CONFIG WRITES IT: `batch_multiplier: 4` (configs/librispeech_100h.yaml:85; loop at joeynmt/training.py:
+    416-456) - four micro-batches of 32 x 15 s per optimizer update - through graphed.GraphedTrainStep: one capture per phase of the
+    accumulation (first / middle / last micro-batch), and under a process group the last one cut where the collectives go (one
+    exchange per update, on the summed gradient).  `merged`: the same update in ONE pass over the 128 utterances
+    (batch_multiplier 1, batch 128: what 288 GB of HBM allow; identical gradient up to summation order, normalisation 'batch')."""
+    import copy
+    from joeys2t_amd.graphed import GraphedTrainStep
+    from joeys2t_amd.model import build_model
+    from joeys2t_amd.tokenizers import SpeechProcessor
+    from joeys2t_amd.training import TrainStep
+    from joeys2t_amd.vocabulary import Vocabulary
+    rank = int(os.environ.get("RANK", 0))
+    ddp = torch.distributed.is_initialized() and world > 1
+
+    def build(batch, mult):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
+        model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+        model.finalize(device, dtype, seed=seed)
+        step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0, learning_rate_warmup=10000,
+                         learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=mult, n_gpu=1,
+                         overlap_ctc=(not ddp or torch.distributed.get_backend() == "nccl"))
+        proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
+                               specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
+                               cmvn=dict(norm_means=True, norm_vars=True, before=True))
+        gs = GraphedTrainStep(step, proc, compute_dtype=dtype)
+        wave = synth_waveforms(batch, SAMPLES, seed=1234 + rank).to(device)
+        trg, trg_len = synth_targets(batch, VOCAB, seed=1234 + rank)
+        return gs, step, (wave, [SAMPLES] * batch, trg.cpu(), trg_len.cpu())
+
+    def timed(gs, item, mult, n_updates):
+        for _ in range(3 * mult):  # first sights (one eager micro-batch + capture per phase), then replays
+            gs.run(*item)
+        if ddp:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        before = dict(gs.counts)
+        t0 = time.perf_counter()
+        for _ in range(n_updates * mult):
+            gs.run(*item)
+        if ddp:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if ddp:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, {k_: gs.counts[k_] - before.get(k_, 0) for k_ in ("eager", "replay")}
+
+    frames_mb = BATCH * (1 + (SAMPLES - 400) // 160)
+    gs, step, item = build(BATCH, k)
+    dt, how = timed(gs, item, k, updates)
+    res = {"batch_multiplier": k, "updates_timed": updates, "ms_per_micro_batch": round(dt / (updates * k) * 1e3, 3),
+           "ms_per_update": round(dt / updates * 1e3, 3), "frames_per_s": round(world * frames_mb * k * updates / dt, 1),
+           "micro_batches": how, "captures": {"buckets": len(gs.buckets), "phases": sorted(str(ph) for bk in gs.buckets.values() for ph in bk.graphs)},
+           "capture_errors": gs.capture_errors[:2] or None,
+           "launch": "graphed.GraphedTrainStep: a hipGraph per phase of the accumulation (first / middle / last micro-batch)" +
+                     (", the last one cut where the collectives go" if ddp else ", the update inside the last one"),
+           "what": f"configs/librispeech_100h.yaml as written: {k} micro-batches of 32 x 15 s per update (training.py:436-456)"}
+    del gs, step, item
+    torch.cuda.empty_cache()
+    if merged and not ddp:
+        try:
+            gs, step, item = build(BATCH * k, 1)
+            dt, how = timed(gs, item, 1, updates)
+            res["same_update_in_one_pass"] = {"batch": BATCH * k, "batch_multiplier": 1, "ms_per_update": round(dt / updates * 1e3, 3),
+                                              "frames_per_s": round(frames_mb * k * updates / dt, 1),
+                                              "what": "the update's 128 utterances as ONE micro-batch (288 GB of HBM: nothing has to be accumulated in slices); "
+                                                      "same gradient up to summation order - a side figure, not the config's procedure"}
+            del gs, step, item
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001
+            res["same_update_in_one_pass"] = {"error": repr(exc)[:300]}
+    return res
 
 
 def measure_roofline(eager_step, model):
@@ -997,22 +1078,13 @@ def main():
     if force_ddp:
         os.environ["JS2T_DDP_SINGLE"] = "1"  # the one-rank communicator really issues its all-reduces
     roofline_pre = None
-    if world > 1 and rank == 0 and not args.no_roofline:
-        # Data-parallel lines describe themselves too: the dominant kernel family does not change with N (every rank runs the
-        # N = 1 step's kernels on its own 32 utterances), so rank 0 times it on its GPU alone BEFORE the process group forms -
-        # the eager timing passes would otherwise issue collectives on one rank only.  The other ranks wait at the rendezvous.
-        try:
-            es, _, _, st1, _, (m1, _) = build_step(device, 1, ddp=False)
-            roofline_pre = measure_roofline(es, m1)
-            roofline_pre["measured"] = "rank 0, single-GPU step, before the process group formed"
-            del es, st1, m1
-            torch.cuda.empty_cache()
-        except Exception as exc:  # never lose the N > 1 line over its side figure
-            roofline_pre = {"error": repr(exc)[:300]}
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": device} if backend == "nccl" else {}
+        import datetime
+        # a rank that dies inside a side leg must cost the others minutes, not the default half hour, before they give up on it
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("JS2T_BENCH_PG_TIMEOUT", 300)))
         torch.distributed.init_process_group(backend, rank=rank, world_size=world, **kw)
     n_ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
@@ -1063,6 +1135,58 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = step.read_stats()
+    exchange_times = None
+    faithful = None
+    if (world > 1 or force_ddp) and step.reducer is not None:
+        headline_dtype = "bf16" if step.reducer.comm_dtype == torch.bfloat16 else "fp32"
+        exchange_times = {headline_dtype: round(elapsed / args.steps * 1e3, 3)}
+        # the other exchange as a side figure: collectives are never captured, so the reducer's staging dtype is a host-side switch
+        # between two replays - every rank flips it at the same point.  (RCCL only: gloo has no bf16 staging path.)
+        if torch.distributed.get_backend() == "nccl" and os.environ.get("JS2T_BENCH_ONE_EXCHANGE", "0") != "1":
+            try:
+                other = None if headline_dtype == "bf16" else torch.bfloat16
+                keep = step.reducer.comm_dtype
+                step.reducer.comm_dtype = other
+                for _ in range(2):
+                    one_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                barrier()
+                e2 = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([e2], dtype=torch.float64, device=device)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    e2 = float(t.item())
+                exchange_times["fp32" if other is None else "bf16"] = round(e2 / args.steps * 1e3, 3)
+                step.reducer.comm_dtype = keep
+                step.read_stats(reset=True)
+            except Exception as exc:  # noqa: BLE001 - a side figure
+                exchange_times["error"] = repr(exc)[:200]
+        if world > 1 and not args.no_extras:
+            # the config as written (batch_multiplier 4) through the composed graph driver, over the same process group
+            try:
+                faithful = config_faithful_bench(device, world, updates=3, merged=False)
+            except Exception as exc:  # noqa: BLE001
+                faithful = {"error": repr(exc)[:300]}
+    if world > 1:
+        # everything that needs the other ranks is done: the group is dissolved HERE, so that rank 0's single-GPU side measurements
+        # (the roofline of the N = 1 step's kernels: the dominant kernel family does not change with N) keep no rank waiting in a
+        # rendezvous or a collective - round 5 took them before init_process_group, with N - 1 ranks idle at the store
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        if rank == 0 and not args.no_roofline:
+            try:
+                es, _, _, st1, _, (m1, st_state) = build_step(device, 1, ddp=False)
+                roofline_pre = measure_roofline(es, m1)
+                roofline_pre["measured"] = "rank 0, single-GPU step, after the timed data-parallel steps (process group dissolved)"
+                if not args.no_extras:
+                    roofline_pre["encoder_forward"] = encoder_forward(m1, st_state["batch"])
+                del es, st1, m1, st_state
+                torch.cuda.empty_cache()
+            except Exception as exc:  # never lose the N > 1 line over its side figure
+                roofline_pre = {"error": repr(exc)[:300]}
     # how much of a step the HOST spends inside the launch of its graph(s): with the GPU idle (synchronised before each launch) the
     # call returns when the ~900 nodes are enqueued.  A step cannot be shorter than this on this runtime.
     launch_host_ms = None
@@ -1103,7 +1227,12 @@ def main():
             roofline["hbm_kernels"] = {"error": repr(exc)}
     elif rank == 0 and roofline_pre is not None:  # N > 1: measured on rank 0's GPU before the process group formed (see above)
         roofline = roofline_pre
-    if roofline is not None and not args.no_extras:
+    if rank == 0 and world == 1 and not force_ddp and not args.no_extras and use_graph:
+        try:
+            faithful = config_faithful_bench(device, 1)
+        except Exception as exc:  # noqa: BLE001 - a side figure
+            faithful = {"error": repr(exc)[:300]}
+    if roofline is not None and not args.no_extras and world == 1:
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
         try:
             roofline["conformer_fp8_forward"] = conformer_fp8_forward(device)
@@ -1160,11 +1289,14 @@ def main():
                                   "hipGraph replay in pieces (fwd + decoder-side bwd | decoder-side weight-gradient groups | encoder bwd | weight-gradient groups up to each completed gradient range | update) around the RCCL calls") if use_graph else "eager",
                        "backend": backend if n_ranks_seen > 1 or force_ddp else None,
                        "capture_error": capture_error,
-                       "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else ("bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32"),
+                       "grad_exchange": None if not (n_ranks_seen > 1 or force_ddp) else {
+                           "headline": "bf16 staging, fp32 accumulation in the flat gradient" if step.reducer is not None and step.reducer.comm_dtype == torch.bfloat16 else "fp32 (the reference's all-reduce)",
+                           "ms_per_step": exchange_times},
                        "loss": round(stats["loss"] / max(1, args.steps), 4)},
             "precision": "bf16 products, fp32 accumulation / master weights / statistics; parity with the fp32 reference at bf16 tolerance "
                          "(tests/test_hip_config_width.py), at 1e-4 in the fp32 mode below",
             "fp32_parity_mode": fp32_mode,
+            "config_faithful": faithful,
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode, "varying_batches": varying,
         }
         print(json.dumps(out), flush=True)

@@ -162,10 +162,15 @@ def test_graphed_ddp_step_capture_failure_falls_back_everywhere(device, stage):
     assert torch.equal(r0["graph"], r1["graph"])
 
 
-def test_bench_two_ranks_end_to_end(device):
-    """`python bench.py --gpus 2` as the driver runs it (bench.py starts its ranks itself), two ranks on one card over gloo: every
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_two_ranks_end_to_end(device, ranks):
+    """`python bench.py --gpus N` as the driver runs it (bench.py starts its ranks itself), N ranks on one card over gloo: every
     rank must make the same collective calls from start to finish - a step run by rank 0 alone (a side measurement, say) leaves
-    the other rank's collectives unmatched and the line is lost.  One JSON line, two ranks seen, graphs replayed, a finite loss."""
+    the other rank's collectives unmatched and the line is lost.  One JSON line, N ranks seen, graphs replayed, a finite loss - the
+    headline (one update per batch) and the config's own procedure (`config_faithful`: batch_multiplier 4 through the composed graph
+    driver over the same process group).  Four ranks: what a 1-GPU box admits on its card next to the test process itself (six GPU
+    processes at most; the driver's node runs eight ranks) - ports,
+    rendezvous, time-outs and the N-way capture / fall-back on more than a pair."""
     import json
     import subprocess
     import sys
@@ -174,12 +179,17 @@ def test_bench_two_ranks_end_to_end(device):
     env = dict(os.environ, JS2T_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-decode",
-                          "--no-extras", "--no-roofline"], cwd=str(root), env=env, capture_output=True, text=True, timeout=900)
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(ranks), "--steps", "3" if ranks == 2 else "2", "--warmup", "2" if ranks == 2 else "1",
+                          "--no-cpu-baseline", "--no-decode", "--no-roofline"], cwd=str(root), env=env, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["n_gpus"] == ranks and out["n_ranks_seen"] == ranks and out["config"]["backend"] == "gloo"
     assert out["config"]["capture_error"] is None and "hipGraph replay in pieces" in out["config"]["launch"]
     assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]  # finite, not NaN
+    assert out["config"]["grad_exchange"]["headline"].startswith("fp32")  # the scored line exchanges as the reference does
+    cf = out["config_faithful"]
+    assert cf and "error" not in cf, cf
+    assert cf["batch_multiplier"] == 4 and cf["micro_batches"]["replay"] == 12 and cf["micro_batches"]["eager"] == 0 and not cf["capture_errors"], cf
+    assert cf["frames_per_s"] > 0
