@@ -387,7 +387,21 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}
 
 
-def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, seed=42, merged=True):
+def train_step_flop(cfg, vocab, batch, t_sub, l_trg):
+    """Algorithmic FLOP of one S2T train micro-batch (3 x forward: backward = input + weight gradients; the convention of
+    roofline.conformer_train_step): per token and layer 2 x (projections + feed-forward) weights + attention 4 T d per side,
+    sub-sampler 41 GFLOP per 32 x 15 s, both output layers."""
+    e, dc = cfg["encoder"], cfg["decoder"]
+    d, ff = e["hidden_size"], e["ff_size"]
+    ne, nd = batch * t_sub, batch * l_trg
+    enc = e["num_layers"] * ne * (2 * (4 * d * d + 2 * d * ff) + 4 * t_sub * d) + 41e9 * (batch / 32)
+    dd, dff = dc["hidden_size"], dc["ff_size"]
+    dec = dc["num_layers"] * (nd * (2 * (4 * dd * dd + 2 * dd * dd + 2 * dd * dff) + 4 * l_trg * dd + 4 * t_sub * dd) + ne * 2 * 2 * dd * dd)
+    return 3.0 * (enc + dec + 2 * nd * dd * vocab + 2 * ne * d * vocab)
+
+
+def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, seed=42, merged=True, model_cfg=None, vocab=None,
+                          loss=("crossentropy-ctc", 0.1, 0.3), what=None):
     """The train step AS THE CONFIG WRITES IT: `batch_multiplier: 4` (configs/librispeech_100h.yaml:85; loop at joeynmt/training.py:
     416-456) - four micro-batches of 32 x 15 s per optimizer update - through graphed.GraphedTrainStep: one capture per phase of the
     accumulation (first / middle / last micro-batch), and under a process group the last one cut where the collectives go (one
@@ -401,12 +415,14 @@ def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, s
     from joeys2t_amd.vocabulary import Vocabulary
     rank = int(os.environ.get("RANK", 0))
     ddp = torch.distributed.is_initialized() and world > 1
+    model_cfg = LS100_MODEL if model_cfg is None else model_cfg
+    vocab = VOCAB if vocab is None else vocab
 
     def build(batch, mult):
         torch.manual_seed(seed)
         np.random.seed(seed)
-        model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
-        model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
+        model = build_model(copy.deepcopy(model_cfg), None, Vocabulary.synthetic(vocab))
+        model.loss_function = loss
         model.finalize(device, dtype, seed=seed)
         step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0, learning_rate_warmup=10000,
                          learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=mult, n_gpu=1,
@@ -416,7 +432,7 @@ def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, s
                                cmvn=dict(norm_means=True, norm_vars=True, before=True))
         gs = GraphedTrainStep(step, proc, compute_dtype=dtype)
         wave = synth_waveforms(batch, SAMPLES, seed=1234 + rank).to(device)
-        trg, trg_len = synth_targets(batch, VOCAB, seed=1234 + rank)
+        trg, trg_len = synth_targets(batch, vocab, seed=1234 + rank)
         return gs, step, (wave, [SAMPLES] * batch, trg.cpu(), trg_len.cpu())
 
     def timed(gs, item, mult, n_updates):
@@ -442,13 +458,18 @@ def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, s
     frames_mb = BATCH * (1 + (SAMPLES - 400) // 160)
     gs, step, item = build(BATCH, k)
     dt, how = timed(gs, item, k, updates)
-    res = {"batch_multiplier": k, "updates_timed": updates, "ms_per_micro_batch": round(dt / (updates * k) * 1e3, 3),
+    key = next(iter(gs.buckets))  # (B, frame bucket, target bucket, packed rows): the shapes the kernels ran on
+    flop = train_step_flop(model_cfg, vocab, BATCH, gs._sub_len(key[1]), key[2] - 1)
+    ms_mb = dt / (updates * k) * 1e3
+    res = {"batch_multiplier": k, "updates_timed": updates, "ms_per_micro_batch": round(ms_mb, 3),
            "ms_per_update": round(dt / updates * 1e3, 3), "frames_per_s": round(world * frames_mb * k * updates / dt, 1),
+           "flop_per_micro_batch": flop, "achieved_tflops": round(flop / (ms_mb * 1e-3) / 1e12, 1),
+           "frac_of_bf16_peak": round(flop / (ms_mb * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "micro_batches": how, "captures": {"buckets": len(gs.buckets), "phases": sorted(str(ph) for bk in gs.buckets.values() for ph in bk.graphs)},
            "capture_errors": gs.capture_errors[:2] or None,
            "launch": "graphed.GraphedTrainStep: a hipGraph per phase of the accumulation (first / middle / last micro-batch)" +
                      (", the last one cut where the collectives go" if ddp else ", the update inside the last one"),
-           "what": f"configs/librispeech_100h.yaml as written: {k} micro-batches of 32 x 15 s per update (training.py:436-456)"}
+           "what": what or f"configs/librispeech_100h.yaml as written: {k} micro-batches of 32 x 15 s per update (training.py:436-456)"}
     del gs, step, item
     torch.cuda.empty_cache()
     if merged and not ddp:
@@ -464,6 +485,26 @@ def config_faithful_bench(device, world, k=4, updates=5, dtype=torch.bfloat16, s
         except Exception as exc:  # noqa: BLE001
             res["same_update_in_one_pass"] = {"error": repr(exc)[:300]}
     return res
+
+
+def train_step_by_config(device):
+    """The other BASELINE configs' train steps, as their files write them, on 32 x 15 s micro-batches:
+    configs/mustc_st.yaml (12 + 6 layers, 8 heads of 64 - the head-size-64 attention kernels -, xavier_normal, ctc_weight 0.1,
+    batch_multiplier 8) and configs/librispeech_960h.yaml (16 + 8 layers, V = 10000, ctc_weight 0.3, batch_multiplier 8), each through
+    graphed.GraphedTrainStep; ms per micro-batch, frames/s and the fraction of the bf16 peak by train_step_flop's count."""
+    import copy
+    out = {}
+    ls960 = copy.deepcopy(LS100_MODEL)  # librispeech_960h.yaml:108-137 is the LS100 stack; what differs is the vocabulary (:39) and the loop (:85)
+    for name, kw in (("mustc_st", dict(model_cfg=MUSTC_MODEL, vocab=5000, loss=("crossentropy-ctc", 0.1, 0.1), k=8,
+                                       what="configs/mustc_st.yaml:83-142 as written: 8 micro-batches of 32 x 15 s per update, 12 + 6 layers, 8 heads of 64")),
+                     ("librispeech_960h", dict(model_cfg=ls960, vocab=10000, loss=("crossentropy-ctc", 0.1, 0.3), k=8,
+                                               what="configs/librispeech_960h.yaml:39,85,98 as written: V = 10000, 8 micro-batches of 32 x 15 s per update"))):
+        try:
+            out[name] = config_faithful_bench(device, 1, updates=3, merged=False, **kw)
+        except Exception as exc:  # noqa: BLE001 - side figures
+            out[name] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
+    return out
 
 
 def measure_roofline(eager_step, model):
@@ -985,7 +1026,7 @@ MUSTC_MODEL = {
 }
 
 
-def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos_scale=0.0, n_utts=BATCH):
+def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos_scale=0.0, n_utts=BATCH, ctc_weight=0.0, return_ids=False):
     """Second half of BASELINE.json's metric: beam-5 decode real-time factor on configs/mustc_st.yaml shapes
     (12+6 layers, H=8, beam 5, alpha 1.0, max_output_length 100), 32 synthetic 15 s utterances resident in HBM.
     RTF = wall time of front-end + encode + beam search / seconds of audio."""
@@ -1015,7 +1056,8 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos
                   trg_prompt_mask=None, indices=torch.arange(n_utts), device=device, pad_index=1, eos_index=3, is_train=False,
                   task="S2T", n_gpu=1)
         b.sort_by_src_length()
-        ids, _, _ = search(model, b, max_output_length=max_len, beam_size=beam, beam_alpha=alpha, n_best=1)
+        extra = {"ctc_weight": ctc_weight, "ctc_candidates": 8} if ctc_weight > 0 else {}
+        ids, _, _ = search(model, b, max_output_length=max_len, beam_size=beam, beam_alpha=alpha, n_best=1, **extra)
         return ids
 
     run()
@@ -1037,11 +1079,59 @@ def decode_rtf(device, dtype=torch.bfloat16, beam=5, alpha=1.0, max_len=100, eos
     uncached = sum(rows * ((t + 1) * per_pos + nl * (4 * d * (t + 1) * (t + 2) // 2 + 4 * d * S * (t + 1)) + nl * S * 4 * d * d + 2 * d * VOCAB)
                    for t in range(steps))
     hyp_len = [int((row != 1).sum()) for row in np.asarray(ids)]  # non-pad tokens per best hypothesis (EOS cut by the search)
+    if return_ids:
+        return np.asarray(ids), dt
     return {"rtf": round(dt / audio_s, 6), "wall_s": round(dt, 3), "audio_s": audio_s, "beam": beam, "alpha": alpha,
             "n_utts": n_utts, "steps": steps, "steps_per_s": round(steps / dt, 1),
             "hyp_len_min_median_max": [int(np.min(hyp_len)), int(np.median(hyp_len)), int(np.max(hyp_len))], "decoder_tflop_kv_cached": round(cached / 1e12, 3),
             "decoder_tflop_full_prefix": round(uncached / 1e12, 3), "model": "mustc_st.yaml shapes, random init", "dtype": "bf16",
             "decoding": "KV-cached, hipGraph-replayed step"}
+
+
+def decode_extras(device, beam=5, alpha=1.0, max_len=100):
+    """(i) joint CTC / attention decoding (search(ctc_weight=0.3): f3, an extension - the reference returns `ctc_out`,
+    model.py:162-166, and has no consumer) timed on the headline decode's workload; (ii) how often the bf16 decode returns the
+    hypothesis of the fp32 mode (the mode whose ids the parity tests pin bit for bit) from the same weights: on a model whose
+    hypotheses END (eos_scale 0.2: a random-init model otherwise never emits EOS), share of identical best hypotheses and the mean
+    length of the common prefix."""
+    out = {}
+    audio_s = BATCH * SAMPLES / 16000.0
+    try:
+        dt_j = dt_a = float("inf")
+        for _ in range(2):  # the better of two: a 0.1 s decode moves by 10 % from run to run
+            ids_j, t = decode_rtf(device, beam=beam, alpha=alpha, max_len=max_len, ctc_weight=0.3, return_ids=True)
+            dt_j = min(dt_j, t)
+            ids_a, t = decode_rtf(device, beam=beam, alpha=alpha, max_len=max_len, return_ids=True)
+            dt_a = min(dt_a, t)
+        out["joint_ctc"] = {"ctc_weight": 0.3, "ctc_candidates": 8, "rtf": round(dt_j / audio_s, 6), "wall_s": round(dt_j, 3), "steps": int(ids_j.shape[1]),
+                            "attention_only_wall_s": round(dt_a, 3), "ms_per_step_added": round((dt_j - dt_a) / max(1, int(ids_j.shape[1])) * 1e3, 3),
+                            "what": "js2t_beam_pick + js2t_ctc_prefix_step per step on top of the KV-cached beam step, MuST-C shapes, 32 x 15 s, bf16"}
+    except Exception as exc:  # noqa: BLE001
+        out["joint_ctc"] = {"error": repr(exc)[:300]}
+    try:
+        cmp = {}
+        for label, eos_scale in (("hypotheses_that_end", 0.2), ("free_running_100_tokens", 0.0)):
+            ids = {}
+            for name, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+                ids[name], _ = decode_rtf(device, dtype=dt_, beam=beam, alpha=alpha, max_len=max_len, eos_scale=eos_scale, return_ids=True)
+            same, prefix, lens = 0, [], []
+            for ra, rb in zip(ids["bf16"], ids["fp32"]):
+                ra, rb = [int(v) for v in ra if v != 1], [int(v) for v in rb if v != 1]
+                same += int(ra == rb)
+                n = 0
+                while n < min(len(ra), len(rb)) and ra[n] == rb[n]:
+                    n += 1
+                prefix.append(n)
+                lens.append(len(rb))
+            cmp[label] = {"n_utts": len(prefix), "identical_hypotheses": same, "share_identical": round(same / max(1, len(prefix)), 3),
+                          "mean_common_prefix_tokens": round(float(np.mean(prefix)), 2), "mean_fp32_length": round(float(np.mean(lens)), 2)}
+        cmp["what"] = ("best beam-5 hypothesis per utterance, bf16 (the timed mode) against fp32 (the mode of the bit-exact id tests) from one random-init "
+                       "MuST-C-size model: with its EOS row scaled so that hypotheses end, and free-running for 100 tokens (near-uniform next-token "
+                       "distributions: every step is a near-tie, the hardest case for equality; a trained model's margins are wider)")
+        out["bf16_vs_fp32"] = cmp
+    except Exception as exc:  # noqa: BLE001
+        out["bf16_vs_fp32"] = {"error": repr(exc)[:300]}
+    return out
 
 
 def main():
@@ -1232,6 +1322,9 @@ def main():
             faithful = config_faithful_bench(device, 1)
         except Exception as exc:  # noqa: BLE001 - a side figure
             faithful = {"error": repr(exc)[:300]}
+    by_config = None
+    if rank == 0 and world == 1 and not force_ddp and not args.no_extras and use_graph and not args.no_roofline:
+        by_config = train_step_by_config(device)
     if roofline is not None and not args.no_extras and world == 1:
         roofline["encoder_forward"] = encoder_forward(model, state["batch"])
         try:
@@ -1257,6 +1350,8 @@ def main():
             # host-side bookkeeping of finished hypotheses (search.py:683-717) then runs in all 100 steps
             fin = decode_rtf(device, eos_scale=0.2)
             decode["with_hypotheses_finishing_every_step"] = {k: fin[k] for k in ("rtf", "wall_s", "steps", "hyp_len_min_median_max")}
+            if not args.no_extras:
+                decode.update(decode_extras(device))
         except Exception as exc:
             decode = {"error": repr(exc)}
     if rank == 0:
@@ -1296,7 +1391,7 @@ def main():
             "precision": "bf16 products, fp32 accumulation / master weights / statistics; parity with the fp32 reference at bf16 tolerance "
                          "(tests/test_hip_config_width.py), at 1e-4 in the fp32 mode below",
             "fp32_parity_mode": fp32_mode,
-            "config_faithful": faithful,
+            "config_faithful": faithful, "train_step_by_config": by_config,
             "roofline": roofline, "cpu_baseline": cpu, "decode_beam5": decode, "varying_batches": varying,
         }
         print(json.dumps(out), flush=True)

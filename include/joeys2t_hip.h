@@ -615,6 +615,9 @@ int js2t_ctc_prefix_step(const float* ctc_log_probs, const int64_t* in_len, cons
                          const int64_t* cand, const float* cand_lp, const float* psi_prev, float* local, float* psi_out, float* r_new,
                          int64_t rows, int32_t beam, int32_t n_cand, int32_t T, int64_t V, int32_t n_out, int32_t blank, int32_t eos,
                          float weight, js2t_stream stream);
+/* Test hook: 1 = the thread-per-pair form of js2t_ctc_prefix_step (round 5; also what runs when an utterance's frames do not fit
+ * 64 KB of LDS), 0 = the default, a block per hypothesis with the operands staged through LDS.  Bit-identical results. */
+void js2t_debug_ctc_prefix_thread_per_pair(int on);
 
 /* penalize_repetition (search.py:972-1001): for every id in tokens[row, 0..L) (int64[rows, L]; hypothesis prefix or
  * source tokens) log_probs[row, id] := x * penalty if x < 0 else x / penalty, x = the value BEFORE this call (gather,

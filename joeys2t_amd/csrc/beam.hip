@@ -291,6 +291,104 @@ __global__ __launch_bounds__(64) void ctc_prefix_step_kernel(const float* __rest
   local[idx] = loc;
 }
 
+// Round 6: the same step with the operands staged through LDS.  The recursion is a chain over the frames, but nothing it READS
+// depends on the chain - the thread-per-pair kernel above still waited out a cold 20 KB-strided gather (and two loads of the
+// hypothesis' variables) in every one of its T iterations: 375 dependent ~1.1 us round trips = 0.44 ms on every 1 ms decode step
+// (bench.py decode_beam5.joint_ctc, round 5).  Here a block owns ONE hypothesis: its 64 threads first fetch x[t, c] of the C
+// candidates, x[t, blank] and the hypothesis' (r_n, r_b) for all frames - (C + 3) T independent loads in flight at once - into
+// LDS, then C threads walk the chain from LDS (no memory latency left on it: ~100 cycles of logaddexp arithmetic per frame) and
+// write the new variables as they go.  That alone changed nothing (557 against 492 us, tools/ctc_prefix_bench.py): the compiler had
+// the round-5 kernel's loads ahead of their use already - what a frame really costs is the CHAIN's arithmetic, three logaddexp of
+// log1pf(expf()) each (the accurate library forms: ~300 dependent vector instructions per frame on a wave with eight live lanes).
+// Here logaddexp is max + log(1 + exp(-|a - b|)) on the hardware's v_exp_f32 / v_log_f32 (ctc_lae_fast: ~10 instructions; absolute
+// error ~1e-7 per call, against sums of magnitude 10^3 whose f32 spacing is 1e-4): same results within f32 rounding of the sums
+// (tests/test_hip_search_ctc.py: the oracle's recursion at 1e-4, the round-5 kernel at full size, ids of the golden models bit-exact).
+__device__ __forceinline__ float ctc_lae_fast(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m <= 0.5f * CTC_LOG0 ? CTC_LOG0 : m + __logf(1.f + __expf(-fabsf(a - b)));
+}
+__global__ __launch_bounds__(64) void ctc_prefix_step_lds_kernel(const float* __restrict__ x, const int64_t* __restrict__ in_len,
+                                                                const float* __restrict__ r_prev, const int64_t* __restrict__ last_tok,
+                                                                const int64_t* __restrict__ cand, const float* __restrict__ cand_lp,
+                                                                const float* __restrict__ psi_prev, float* __restrict__ local,
+                                                                float* __restrict__ psi_out, float* __restrict__ r_new, int k, int C, int T,
+                                                                int64_t V, int n_out, int blank, int eos, float w) {
+  // LDS: [C + 1][T] log-probabilities x[t, c_j] (row C: the blank), [T] phi of the hypothesis (logaddexp of its two variables),
+  // [T][2] the variables themselves, [C] partial prefix scores
+  extern __shared__ float ctc_lds[];
+  const int64_t row = blockIdx.x, b = row / k;
+  const int tid = threadIdx.x;
+  const int Tb = (int)min((int64_t)T, in_len[b]);
+  const float* xb = x + b * (int64_t)T * V;
+  const float2* rp = (const float2*)(r_prev + row * (int64_t)T * 2);
+  float* xs = ctc_lds;
+  float* phis = ctc_lds + (int64_t)(C + 1) * T;
+  float2* rs = (float2*)(phis + T);
+  const int start = max(n_out, 1);
+  for (int j = 0; j <= C; ++j) {
+    const int64_t c = j < C ? cand[row * C + j] : (int64_t)blank;
+    for (int t = start + tid; t < Tb; t += 64) xs[j * T + t] = xb[(int64_t)t * V + c];
+  }
+  for (int t = tid; t < T; t += 64) {
+    const float2 v = rp[t];
+    rs[t] = v;
+    phis[t] = ctc_lae_fast(v.x, v.y);
+  }
+  // the variables no frame of the chain writes: log 0 (frame 0 of a first label is written by its chain thread below)
+  for (int j = 0; j < C; ++j) {
+    float2* rn = (float2*)(r_new + (row * C + j) * (int64_t)T * 2);
+    for (int t = tid; t < T; t += 64)
+      if ((t < start || t >= Tb) && !(t == 0 && n_out == 0 && Tb > 0)) rn[t] = make_float2(CTC_LOG0, CTC_LOG0);
+  }
+  __syncthreads();
+  // The prefix score psi = logaddexp over t of (phi[t - 1] + x[t, c]) reads nothing of the chain: 64 / C lanes per candidate sum
+  // their frames and leave the partial sums in LDS for the candidate's chain thread - the chain keeps two independent logaddexp per frame.
+  const int lanes_per = 64 / C, j_mine = tid / lanes_per, sub = tid % lanes_per;  // C <= 64 (host check); lanes beyond C * lanes_per idle
+  float* parts = (float*)(rs + T);  // [C][lanes_per] <= 64 values
+  if (j_mine < C) {
+    const bool rep_mine = n_out > 0 && cand[row * C + j_mine] == last_tok[row];
+    float part = CTC_LOG0;
+    for (int t = start + sub; t < Tb; t += lanes_per) part = ctc_lae_fast(part, (rep_mine ? rs[t - 1].y : phis[t - 1]) + xs[j_mine * T + t]);
+    parts[j_mine * lanes_per + sub] = part;
+  }
+  __syncthreads();
+  if (tid >= C) return;
+  const int64_t idx = row * C + tid;
+  const int64_t c = cand[idx];
+  const bool repeat = n_out > 0 && c == last_tok[row];
+  float2* rn = (float2*)(r_new + idx * (int64_t)T * 2);
+  const float* xc = xs + tid * T;
+  const float* xblk = xs + C * T;
+  float r_n = CTC_LOG0, r_b = CTC_LOG0, psi = CTC_LOG0;
+  for (int q = 0; q < lanes_per; ++q) psi = ctc_lae_fast(psi, parts[tid * lanes_per + q]);
+  if (n_out == 0 && Tb > 0) {
+    r_n = xb[c];
+    rn[0] = make_float2(r_n, CTC_LOG0);
+  }
+  if (start - 1 < Tb && n_out == 0) psi = ctc_lae_fast(psi, r_n);  // r[start - 1, 0]: only the first label can have been emitted by frame 0
+  // the chain: operands of frame t + 1 are read from LDS while frame t is computed
+  float phi = 0.f, xt = 0.f, xblank = 0.f;
+  if (start < Tb) phi = repeat ? rs[start - 1].y : phis[start - 1], xt = xc[start], xblank = xblk[start];
+  for (int t = start; t < Tb; ++t) {
+    const int tn = min(t + 1, Tb - 1);
+    const float phi_n = repeat ? rs[tn - 1].y : phis[tn - 1], xt_n = xc[tn], xblank_n = xblk[tn];
+    const float nn = ctc_lae_fast(r_n, phi) + xt;
+    const float nb = ctc_lae_fast(r_n, r_b) + xblank;
+    r_n = fmaxf(nn, CTC_LOG0), r_b = fmaxf(nb, CTC_LOG0);
+    rn[t] = make_float2(r_n, r_b);
+    phi = phi_n, xt = xt_n, xblank = xblank_n;
+  }
+  if (c == eos) psi = Tb > 0 ? ctc_lae_fast(rs[Tb - 1].x, rs[Tb - 1].y) : CTC_LOG0;
+  if (c == blank) psi = CTC_LOG0;
+  psi = fmaxf(psi, CTC_LOG0);
+  psi_out[idx] = psi;
+  const float att = cand_lp[idx], pp = psi_prev[row];
+  float loc = (1.f - w) * att;
+  if (w > 0.f) loc = (psi <= 0.5f * CTC_LOG0 || pp <= 0.5f * CTC_LOG0) ? -INFINITY : loc + w * (psi - pp);
+  if (!(att > -INFINITY)) loc = -INFINITY;
+  local[idx] = loc;
+}
+
 }  // namespace
 
 // The n_pick best tokens of EVERY row (log-softmax, forbidden ids masked, + the row's entry of row_scores): the candidate
@@ -311,6 +409,9 @@ extern "C" int js2t_beam_pick(const float* logits, const float* row_scores, floa
   return JS2T_OK;
 }
 
+static bool g_ctc_prefix_thread_per_pair = false;  // test hook: the round-5 kernel (also taken when the frames do not fit 64 KB of LDS)
+extern "C" void js2t_debug_ctc_prefix_thread_per_pair(int on) { g_ctc_prefix_thread_per_pair = on != 0; }
+
 extern "C" int js2t_ctc_prefix_step(const float* ctc_log_probs, const int64_t* in_len, const float* r_prev, const int64_t* last_tok,
                                     const int64_t* cand, const float* cand_lp, const float* psi_prev, float* local, float* psi_out,
                                     float* r_new, int64_t rows, int32_t beam, int32_t n_cand, int32_t T, int64_t V, int32_t n_out,
@@ -320,6 +421,13 @@ extern "C" int js2t_ctc_prefix_step(const float* ctc_log_probs, const int64_t* i
   JS2T_CHECK(beam >= 1 && n_cand >= 1 && T >= 1 && V >= 1 && rows % beam == 0 && n_out >= 0, "ctc_prefix_step: bad sizes");
   JS2T_CHECK(blank >= 0 && blank < V && eos >= 0 && eos < V && weight >= 0.f && weight <= 1.f, "ctc_prefix_step: bad blank / eos / weight");
   const int64_t n = rows * n_cand;
+  const size_t lds = ((size_t)(n_cand + 1) * T + 3 * (size_t)T + 64) * sizeof(float);
+  if (n_cand <= 64 && lds <= 64 * 1024 && !g_ctc_prefix_thread_per_pair) {  // a block per hypothesis, operands through LDS (the default)
+    hipLaunchKernelGGL(ctc_prefix_step_lds_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream, ctc_log_probs, in_len, r_prev, last_tok,
+                       cand, cand_lp, psi_prev, local, psi_out, r_new, beam, n_cand, T, V, n_out, blank, eos, weight);
+    JS2T_LAUNCH_CHECK();
+    return JS2T_OK;
+  }
   hipLaunchKernelGGL(ctc_prefix_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, ctc_log_probs, in_len, r_prev,
                      last_tok, cand, cand_lp, psi_prev, local, psi_out, r_new, n, beam, n_cand, T, V, n_out, blank, eos, weight);
   JS2T_LAUNCH_CHECK();

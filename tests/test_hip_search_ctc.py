@@ -101,3 +101,72 @@ def test_joint_ctc_beam_search_matches_oracle(device, name, weight):
     ids0, scores0, _ = search(model, b, max_output_length=12, beam_size=k, beam_alpha=alpha, n_best=k, return_prob="hyp", ctc_weight=0.0)
     assert np.array_equal(ids0, g["beam_ids"])
     np.testing.assert_allclose(scores0, g["beam_scores"], rtol=1e-4, atol=1e-4)
+
+
+def test_ctc_prefix_step_lds_kernel_against_thread_per_pair_at_full_size(device):
+    """Round 6: a block per hypothesis with the operands staged through LDS and logaddexp on the hardware's exp / log against the
+    thread-per-pair kernel of round 5 (library log1pf / expf) - T' = 375 frames, V = 5000, 32 utterances x beam 5, 8 candidates (the
+    decode the bench times), ragged input lengths, three extension steps chained through the winners' variables; a repeated label,
+    EOS and the blank among the candidates: the same numbers within f32 rounding of sums of magnitude 10^3 (spacing 1e-4)."""
+    from joeys2t_amd import ops
+    from joeys2t_amd._lib import lib
+    g = torch.Generator().manual_seed(12)
+    B, k, T, V, C = 32, 5, 375, 5000, 8
+    blank, eos = 2, 3
+    logp = torch.log_softmax(torch.randn(B, T, V, generator=g) * 2.0, -1).to(device)
+    in_len = torch.cat([torch.tensor([T, 1, 2]), torch.randint(150, T + 1, (B - 3, ), generator=g)]).to(device)
+    rows = B * k
+    r_prev = ops.ctc_prefix_init(logp, in_len, k, blank)
+    psi_prev = torch.zeros(rows, device=device)
+    last = torch.full((rows, ), blank, dtype=torch.int64, device=device)
+    for n_out in range(3):
+        cand = torch.randint(4, V, (rows, C), generator=g)
+        cand[:, 0] = last.cpu() if n_out else cand[:, 0]  # a repeat of the hypothesis' last label
+        cand[:, 1], cand[:, 2] = eos, blank
+        cand = cand.to(device)
+        cand_lp = torch.log_softmax(torch.randn(rows, C, generator=g), -1).to(device)
+        outs = []
+        for mode in (1, 0):
+            lib().js2t_debug_ctc_prefix_thread_per_pair(mode)
+            try:
+                outs.append(ops.ctc_prefix_step(logp, in_len, r_prev, last, cand, cand_lp, psi_prev, n_out, k, blank, eos, 0.3))
+            finally:
+                lib().js2t_debug_ctc_prefix_thread_per_pair(0)
+        torch.cuda.synchronize()
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(torch.isinf(a), torch.isinf(b)) and torch.equal(a < -1e29, b < -1e29)  # log 0 / -inf in the same places
+            live = ~(torch.isinf(a) | (a < -1e29))
+            torch.testing.assert_close(a[live], b[live], rtol=2e-6, atol=2e-3)
+        assert torch.isfinite(outs[1][1][:, 3:]).all() and not torch.isnan(outs[1][0]).any()
+        pick = 3 + n_out  # the next step extends every hypothesis by one of its ordinary candidates
+        r_prev = outs[1][2][:, pick].contiguous()
+        psi_prev = outs[1][1][:, pick].contiguous()
+        last = cand[:, pick].contiguous()
+
+
+def test_joint_ctc_decoding_properties_at_full_size(device):
+    """search(ctc_weight=...) at configs/mustc_st.yaml size (12 + 6 layers, 8 heads of 64, 32 ragged utterances of up to 1498 frames,
+    fp32) - beyond what the CPU oracle finishes in seconds, so through properties: hypotheses and scores do not depend on the order of
+    the utterances in the batch; the thread-per-pair kernel gives the same search; weight 0 IS the reference's beam search; and the
+    CTC term does change the outcome (the property test sees it)."""
+    from joeys2t_amd._lib import lib
+    from joeys2t_amd.search import search
+    from test_hip_full_size import B, _decode_batch, _mustc_decode_case
+    model, src, lengths = _mustc_decode_case(device, torch.float32)
+    order = list(range(B))
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(8)).tolist()
+    kw = dict(max_output_length=12, beam_size=5, beam_alpha=1.0, n_best=1, return_prob="hyp")
+    ids0, sc0, _ = search(model, _decode_batch(src, lengths, order, device), ctc_weight=0.3, ctc_candidates=8, **kw)
+    idsp, scp, _ = search(model, _decode_batch(src, lengths, perm, device), ctc_weight=0.3, ctc_candidates=8, **kw)
+    assert np.array_equal(ids0[perm], idsp)
+    np.testing.assert_allclose(np.asarray(sc0)[perm], np.asarray(scp), rtol=1e-4, atol=1e-4)
+    lib().js2t_debug_ctc_prefix_thread_per_pair(1)
+    try:
+        ids1, sc1, _ = search(model, _decode_batch(src, lengths, order, device), ctc_weight=0.3, ctc_candidates=8, **kw)
+    finally:
+        lib().js2t_debug_ctc_prefix_thread_per_pair(0)
+    assert np.array_equal(ids0, ids1) and np.array_equal(np.asarray(sc0), np.asarray(sc1))
+    ida, sca, _ = search(model, _decode_batch(src, lengths, order, device), **kw)
+    idw, scw, _ = search(model, _decode_batch(src, lengths, order, device), ctc_weight=0.0, **kw)
+    assert np.array_equal(ida, idw) and np.array_equal(np.asarray(sca), np.asarray(scw))
+    assert not np.array_equal(ids0, ida)
