@@ -195,3 +195,53 @@ def test_sync_free_beam_search_files_the_same_hypotheses(device, name):
         c = search(model, b, max_output_length=L, beam_size=k, beam_alpha=alpha, n_best=nb, return_prob="hyp", sync_free=False)
         assert np.array_equal(a[0], c[0]), (k, nb)
         np.testing.assert_array_equal(a[1], c[1])
+
+
+def test_wer_on_64_held_out_utterances_at_mustc_width_equals_cpu_oracle(device):
+    """north_star: "WER on a held-out synthetic set equal to the CPU reference" - beyond the 16-wide golden model (the test above):
+    configs/mustc_st.yaml WIDTH (d 512, ff 2048, 8 heads of 64, V 5000, xavier_normal with the DeepNet residual scale of the 12 + 6
+    stack; depth cut to 2 + 1 so that the oracle's full-prefix beam search finishes in seconds), 64 utterances of 120 - 260 frames in
+    four ragged batches, beam 5, alpha 1 (configs/mustc_st.yaml:57-58).  The HIP path (fp32, KV-cached search through `predict`)
+    must return the oracle's hypotheses token for token - hence its WER against any references."""
+    from golden_cfg import SPECIALS
+    from joeys2t_amd.batch import Batch
+    from joeys2t_amd.metrics import wer
+    from joeys2t_amd.prediction import predict
+    from joeys2t_amd.vocabulary import Vocabulary
+    from oracle import s2t_oracle as O
+    from test_hip_config_width import MUSTC_ALPHA, make_model, width_cfg
+    import copy
+    V = 5000
+    cfg = width_cfg(8, 2, 1, "xavier_normal")
+    torch.manual_seed(23)
+    base = make_model(cfg, V, None, None, None, 0.1)
+    sd = {k: v.clone() for k, v in base.state_dict().items()}
+    for k in sd:  # an untrained decoder all but ignores the audio (every utterance decodes to one of three strings): turn the
+        if "src_trg_att.output_layer.weight" in k:  # cross-attention's contribution up until the hypotheses follow the input
+            sd[k] *= 30.0
+    model = make_model(cfg, V, sd, device, torch.float32, 0.1, alpha=MUSTC_ALPHA)
+    model.eval()
+    ocfg = copy.deepcopy(cfg)
+    ocfg["encoder"]["alpha"], ocfg["decoder"]["alpha"] = MUSTC_ALPHA
+    vocab = Vocabulary.synthetic(V)
+    hyp_hip, hyp_cpu, refs = [], [], []
+    for seed in (601, 602, 603, 604):
+        gen = torch.Generator().manual_seed(seed)
+        B = 16
+        lengths = torch.randint(120, 261, (B, ), generator=gen)
+        T = int(lengths.max())
+        src = torch.randn(B, T, 80, generator=gen)
+        for b in range(B):
+            src[b, lengths[b]:] = 1.0
+        ref_ids = [torch.randint(4, V, (int(n), ), generator=gen).tolist() for n in torch.randint(3, 9, (B, ), generator=gen)]
+        refs += [" ".join(vocab.array_to_sentence(r)) for r in ref_ids]
+        batch = Batch(src=src, src_length=lengths, src_prompt_mask=None, trg=None, trg_length=None, trg_prompt_mask=None,
+                      indices=torch.arange(B), device=device, pad_index=1, eos_index=3, is_train=False, task="S2T", n_gpu=1)
+        _, sents, _ = predict(model, [batch], beam_size=5, beam_alpha=1.0, n_best=1, max_output_length=10)
+        hyp_hip += [" ".join(s) for s in sents]
+        enc, mask, _ = O.encoder_forward(sd, ocfg, src, lengths)
+        ids, _ = O.beam_search(sd, ocfg, SPECIALS, enc, mask, beam_size=5, max_output_length=10, alpha=1.0, n_best=1)
+        hyp_cpu += [" ".join(vocab.array_to_sentence(row.tolist(), cut_at_eos=True)) for row in ids]
+    assert len(hyp_hip) == 64 and len(set(hyp_hip)) > 8  # 64 utterances that do not all decode to one string (random weights: 13 distinct)
+    assert hyp_hip == hyp_cpu
+    assert wer(hyp_hip, refs) == wer(hyp_cpu, refs)
