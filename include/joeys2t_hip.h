@@ -534,7 +534,31 @@ int js2t_feature_transform(float* feat, const int64_t* frame_off, int32_t U, int
  *     integers (integer atomics commute) in a scratch buffer the library owns, then converted and added into d_rel_bias;
  *   js2t_dwconv_outer_bwd (weight gradient), js2t_bn_act_fwd / _bwd (batch statistics, parameter-gradient sums): ONE block per
  *     64 columns walks all rows, so every output receives a single sum formed in a fixed order - slower, deterministic.
- * A process-wide switch, read at launch time.  The first call in this mode allocates the scratch (never inside a hipGraph capture). */
+ * The first call in this mode allocates the scratch (never inside a hipGraph capture).
+ *
+ * Round 6 - the mode belongs to a CALLER, not to the process (a thin, stateless boundary).  js2t_ctx: a handful of
+ * settings a caller binds to ITS THREAD around its launches (js2t_ctx_bind returns what was bound before, to be put back; NULL =
+ * nothing bound); every entry point reads the settings of the launch it makes from there.  Keys: JS2T_CTX_DETERMINISTIC (1 = the
+ * ordered forms above) and the kernel-selection rules of js2t_gemm / js2t_gemm_grouped, which never change a result
+ * (JS2T_CTX_GEMM_P192_MODE / _P192_RING / _WG256_MODE / _PANEL_MODE: the values of the setters of the same names; -1 = the automatic
+ * rule).  Two train steps in one process - one of them deterministic - no longer share a switch (tests/test_abi.py).
+ * js2t_set_deterministic and the js2t_gemm_*_mode setters remain as process-wide TEST overrides: set, they win over any context.
+ * js2t_ctx_effective(key): the value the calling thread's next launch would see. */
+typedef struct js2t_ctx_s* js2t_ctx;
+enum {
+  JS2T_CTX_DETERMINISTIC = 0,
+  JS2T_CTX_GEMM_P192_MODE = 1,
+  JS2T_CTX_GEMM_P192_RING = 2,
+  JS2T_CTX_GEMM_WG256_MODE = 3,
+  JS2T_CTX_GEMM_PANEL_MODE = 4,
+  JS2T_CTX_NKEYS = 5
+};
+js2t_ctx js2t_ctx_create(void);
+void js2t_ctx_destroy(js2t_ctx ctx);
+int js2t_ctx_set(js2t_ctx ctx, int32_t key, int32_t value);
+int js2t_ctx_get(js2t_ctx ctx, int32_t key);
+js2t_ctx js2t_ctx_bind(js2t_ctx ctx);
+int js2t_ctx_effective(int32_t key);
 void js2t_set_deterministic(int on);
 int js2t_get_deterministic(void);
 

@@ -101,6 +101,12 @@ def lib():
         _lib.js2t_cmvn_stats_workspace.restype = C.c_int64
         _lib.js2t_gemm_grouped_blocks.restype = C.c_int64
         _lib.js2t_gemm_grouped_blocks.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        _lib.js2t_ctx_create.restype = C.c_void_p
+        _lib.js2t_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.js2t_ctx_set.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        _lib.js2t_ctx_get.argtypes = [C.c_void_p, C.c_int32]
+        _lib.js2t_ctx_bind.restype = C.c_void_p
+        _lib.js2t_ctx_bind.argtypes = [C.c_void_p]
         if "JS2T_P192" in os.environ:  # kernel-selection override for A/B measurements (see js2t_gemm_p192_mode)
             _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
         if "JS2T_WG256" in os.environ:  # 0 / 1 / -1: the 256x128 kernel of the grouped weight gradients (js2t_gemm_wg256_mode)
@@ -114,3 +120,53 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().js2t_last_error().decode("utf-8", "replace")
         raise Js2tError(f"libjoeys2t_hip: {what} failed (rc={rc}): {msg}")
+
+
+CTX_KEYS = {"deterministic": 0, "gemm_p192_mode": 1, "gemm_p192_ring": 2, "gemm_wg256_mode": 3, "gemm_panel_mode": 4}
+
+
+class Context:
+    """A js2t_ctx (include/joeys2t_hip.h): the settings one caller's launches run with - deterministic mode, kernel-selection rules -
+    bound to the calling thread for the length of a `with` block (the previous binding comes back at its end; blocks nest).
+
+        ctx = Context(deterministic=True)
+        with ctx:
+            ...  # every library call made by this thread in here sees deterministic = 1
+
+    Autograd's backward runs the library's kernels on worker threads unless told otherwise: TrainStep runs its backward passes under
+    torch.autograd.set_multithreading_enabled(False), i.e. on the thread that holds the binding."""
+
+    def __init__(self, **settings):
+        self._h = lib().js2t_ctx_create()
+        if not self._h:
+            raise Js2tError("js2t_ctx_create failed")
+        self._prev = []
+        for k, v in settings.items():
+            self.set(k, v)
+
+    def set(self, key: str, value) -> None:
+        check(lib().js2t_ctx_set(self._h, CTX_KEYS[key], int(value)), "js2t_ctx_set")
+
+    def get(self, key: str) -> int:
+        return int(lib().js2t_ctx_get(self._h, CTX_KEYS[key]))
+
+    def __enter__(self):
+        self._prev.append(lib().js2t_ctx_bind(self._h))
+        return self
+
+    def __exit__(self, *exc):
+        lib().js2t_ctx_bind(self._prev.pop())
+        return False
+
+    def __del__(self):
+        try:
+            if self._h and _lib is not None:
+                _lib.js2t_ctx_destroy(self._h)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+        self._h = None
+
+
+def effective(key: str) -> int:
+    """the value of a context key the calling thread's next launch would see (process-wide test override > bound context > default)"""
+    return int(lib().js2t_ctx_effective(CTX_KEYS[key]))

@@ -29,7 +29,12 @@ void js2t_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
-extern int g_js2t_deterministic;  // js2t_set_deterministic (core.cpp): ordered sums instead of floating-point atomics
+// Per-caller settings (core.cpp, js2t_ctx_* of the header): the value of `key` for the launch being made - the process-wide test
+// override if one is set, else the context bound to the calling thread (js2t_ctx_bind), else the built-in default.
+int js2t_ctx_value(int key);
+void js2t_ctx_override(int key, int value);  // what the process-wide setters (js2t_set_deterministic, js2t_gemm_*_mode) write
+// ordered sums instead of floating-point atomics (js2t_ctx_set(ctx, JS2T_CTX_DETERMINISTIC, 1), or the test override js2t_set_deterministic)
+#define g_js2t_deterministic js2t_ctx_value(JS2T_CTX_DETERMINISTIC)
 
 // Deterministic mode of the histogram-shaped sums (relative-position bias gradient): the addends are rounded ONCE to 2^-32 fixed
 // point and summed as 64-bit integers - integer atomics commute, so LDS and global atomics in any order give the same bits.

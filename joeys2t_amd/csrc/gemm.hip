@@ -2812,7 +2812,7 @@ __global__ __launch_bounds__(768, 1) void gemm_bf16_wg256_kernel(js2t_gemm_desc 
 }
 
 // 0 = never, 1 = whenever the product qualifies, -1 = when it qualifies and fills the chip (default)
-int g_p192_mode = -1;
+#define g_p192_mode js2t_ctx_value(JS2T_CTX_GEMM_P192_MODE)
 inline bool p192_eligible(const js2t_gemm_desc& d) {
   if (g_p192_mode == 0) return false;
   if (d.trans_a || d.trans_b || d.conv || d.split_k > 1 || d.batch != 1 || d.dtype_c != JS2T_BF16) return false;
@@ -2829,7 +2829,7 @@ inline bool p192_eligible(const js2t_gemm_desc& d) {
 //    gradient x1.23, CTC projection x1.11 over the single block with a three-slot ring);
 //  * fewer (N = 512: one tile per CU) -> ONE block of eight multiplying + four requesting waves (gemm_bf16_p192s_kernel:
 //    FFN2 x1.15, dQKV x1.16, dFFN1 x1.16, output projection x1.15); two blocks per CU lose 3-10 % there.
-int g_p192_ring = -1;
+#define g_p192_ring js2t_ctx_value(JS2T_CTX_GEMM_P192_RING)
 template <int EPI>
 int launch_bf16_p192_epi(const js2t_gemm_desc& d, hipStream_t s) {
   static int n_cu = 0;
@@ -3019,8 +3019,8 @@ extern "C" int js2t_debug_p192_prof2(unsigned long long* out8, int reset) {
   return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_p192_prof2), 64);
 }
 #endif
-extern "C" void js2t_gemm_p192_ring(int nst) { g_p192_ring = (nst >= 2 && nst <= 4) ? nst : -1; }
-extern "C" void js2t_gemm_p192_mode(int mode) { g_p192_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode); }
+extern "C" void js2t_gemm_p192_ring(int nst) { js2t_ctx_override(JS2T_CTX_GEMM_P192_RING, (nst >= 2 && nst <= 4) ? nst : -1); }
+extern "C" void js2t_gemm_p192_mode(int mode) { js2t_ctx_override(JS2T_CTX_GEMM_P192_MODE, mode < 0 ? -1 : (mode > 2 ? 1 : mode)); }
 
 template <bool SPLITK>
 static int launch_grouped_tt(const js2t_gemm_desc& d, const GemmGroup& grp, int count, hipStream_t s) {
@@ -3075,8 +3075,8 @@ static int launch_grouped_p192t(const js2t_gemm_desc& d, const GemmGroup& grp, i
 }
 
 // -1 (default): the grouped launches that fill the chip with 256x128 tiles over a long reduction; 0: never; 1: whenever the shape allows
-int g_wg256_mode = -1;
-extern "C" void js2t_gemm_wg256_mode(int mode) { g_wg256_mode = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+#define g_wg256_mode js2t_ctx_value(JS2T_CTX_GEMM_WG256_MODE)
+extern "C" void js2t_gemm_wg256_mode(int mode) { js2t_ctx_override(JS2T_CTX_GEMM_WG256_MODE, mode < 0 ? -1 : (mode > 1 ? 1 : mode)); }
 static bool wg256_eligible(const js2t_gemm_desc& d, int count) {
   if (g_wg256_mode == 0 || d.dtype_c != JS2T_F32 || (d.split_k > 1 && d.sumsq_partial)) return false;
   if ((d.M & 255) || (d.N & 127) || (d.ldc & 3) || d.K < 192 * d.split_k || d.split_k > ((d.K + 63) >> 6) / 4) return false;

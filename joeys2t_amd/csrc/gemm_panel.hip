@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pan96_kernel(js2t_gemm_desc 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int g_pan_mode = -1;  // js2t_gemm_panel_mode: -1 = products big enough for it, 0 = never, 1 = every product that qualifies
+#define g_pan_mode js2t_ctx_value(JS2T_CTX_GEMM_PANEL_MODE)  // js2t_gemm_panel_mode / JS2T_CTX_GEMM_PANEL_MODE: -1 = products big enough for it, 0 = never, 1 = every product that qualifies
 
 template <int EPI>
 int launch_pan96_epi(const js2t_gemm_desc& d, hipStream_t s) {
@@ -386,7 +386,7 @@ inline bool al(const void* p, uintptr_t a) { return (((uintptr_t)p) & (a - 1)) =
 
 }  // namespace
 
-extern "C" void js2t_gemm_panel_mode(int mode) { g_pan_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
+extern "C" void js2t_gemm_panel_mode(int mode) { js2t_ctx_override(JS2T_CTX_GEMM_PANEL_MODE, mode < 0 ? -1 : (mode > 0 ? 1 : 0)); }
 
 int launch_bf16_pan96(const js2t_gemm_desc& d, int mask, hipStream_t s) {
   if (g_pan_mode == 0) return -1;

@@ -226,7 +226,7 @@ class GraphedTrainStep:
                 cap = capture_cut_step(step, lambda hook: self._body(bk, "cut", hook), pool=self.pool, fail=self.inject_failure)
                 if self.update_graph is None:
                     gu = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gu, pool=self.pool, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(gu, pool=self.pool, capture_error_mode="thread_local"), step.ctx:
                         step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
                     self.update_graph = gu
             else:
@@ -465,7 +465,8 @@ def capture_cut_step(step: TrainStep, body, pool=None, fail: Optional[str] = Non
 
         pieces = _cut_pieces(red, plan)
         pieces_dec = _cut_pieces(red, st["plan_dec"]) if st["plan_dec"] is not None else []
-        gw, gw_dec = capture_pieces(pieces), capture_pieces(pieces_dec)
+        with step.ctx:  # the deferred products are launched outside micro_step: this step's settings (deterministic: un-split) apply to them too
+            gw, gw_dec = capture_pieces(pieces), capture_pieces(pieces_dec)
     except BaseException:
         step.rt.wgrad_queue.take()  # nothing of a half-made capture may stay queued
         torch.cuda.synchronize()
@@ -549,7 +550,8 @@ class GraphedDDPStep:
         self.pre_step()
         out = self.body(None)
         step.exchange_and_flush()
-        step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
+        with step.ctx:
+            step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)
         step.after_update()
         self.counts["eager"] += 1
         return out
@@ -574,7 +576,7 @@ class GraphedDDPStep:
         try:
             cap = capture_cut_step(step, self.body, fail=self.inject_failure if self.inject_failure in ("forward", "pieces") else None)
             gu = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gu, pool=cap["pool"], capture_error_mode="thread_local"):
+            with torch.cuda.graph(gu, pool=cap["pool"], capture_error_mode="thread_local"), step.ctx:
                 if self.inject_failure == "update":
                     raise RuntimeError("GraphedDDPStep: injected capture failure at 'update'")
                 step.optimizer.clip_and_step(step.clip_grad_norm, zero_grad=True)

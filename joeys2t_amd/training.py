@@ -38,12 +38,14 @@ class TrainStep:
                  defer_wgrads: bool = True, overlap_ctc: bool = False, comm_dtype: Optional[torch.dtype] = None, comm=None,
                  deterministic: bool = False):
         self.model = model
-        # deterministic=True: the reference's set_seed asks cuDNN for deterministic kernels (helpers.py:93-104); here the library's
-        # process-wide switch (js2t_set_deterministic) puts every floating-point-atomic sum of the train step on an ordered form -
-        # two runs from one state then agree bit for bit (tests/test_hip_deterministic.py), at a price bench.py reports
-        from joeys2t_amd._lib import lib as _lib
+        # deterministic=True: the reference's set_seed asks cuDNN for deterministic kernels (helpers.py:93-104); here every
+        # floating-point-atomic sum of the train step takes an ordered form - two runs from one state then agree bit for bit
+        # (tests/test_hip_deterministic.py), at a price bench.py reports.  The setting lives in THIS step's js2t_ctx, bound to the
+        # thread around the step's launches (`with self.ctx:`): another TrainStep in the same process keeps its own (round 5 wrote
+        # a process-wide switch here - the last constructor won).
+        from joeys2t_amd._lib import Context
         self.deterministic = bool(deterministic) or os.environ.get("JS2T_DETERMINISTIC", "0") == "1"
-        _lib().js2t_set_deterministic(int(self.deterministic))
+        self.ctx = Context(deterministic=int(self.deterministic))
         model.overlap_ctc = bool(overlap_ctc)
         self.rt = model.runtime
         self.store = self.rt.store
@@ -112,14 +114,15 @@ class TrainStep:
         gradient goes to RCCL (side stream) as soon as the last product writing into it has been launched.  `plan`: a
         WgradQueue plan kept from a hipGraph capture (replayed steps), default: whatever the queue holds now."""
         q = self.rt.wgrad_queue
-        if plan is None:
-            plan = q.take() if q is not None else []
-        if self.reducer is None:
-            WgradQueue.run(plan)
-            return
-        self.reducer.exchange_begin(plan)
-        WgradQueue.run(plan, self.reducer.entries_done)
-        self.reducer.finish()
+        with self.ctx:
+            if plan is None:
+                plan = q.take() if q is not None else []
+            if self.reducer is None:
+                WgradQueue.run(plan)
+                return
+            self.reducer.exchange_begin(plan)
+            WgradQueue.run(plan, self.reducer.entries_done)
+            self.reducer.finish()
 
     def micro_step(self, batch: Batch, sort: bool = True, update: bool = True, overlap: bool = True, flush: bool = True, cut_hook=None):
         """One micro-batch: forward, normalised loss, backward.  Returns the (device) normalised loss.
@@ -129,6 +132,12 @@ class TrainStep:
         `flush=False` leaves the deferred weight-gradient products queued (the caller keeps them as a plan);
         `cut_hook`: called between the two halves of the backward pass (cut at the encoder's output) INSTEAD of the partial exchange
         - for a caller that captures the halves as two hipGraphs and runs the exchange itself between their replays (bench.py)."""
+        # this step's settings for every launch below; the backward passes run on THIS thread (autograd's device threads would not
+        # see the binding)
+        with self.ctx, torch.autograd.set_multithreading_enabled(False):
+            return self._micro_step(batch, sort, update, overlap, flush, cut_hook)
+
+    def _micro_step(self, batch: Batch, sort: bool, update: bool, overlap: bool, flush: bool, cut_hook):
         model = self.model
         model.train()
         self.rt.rng.begin_step()
@@ -223,7 +232,8 @@ class TrainStep:
 
     def update(self):
         """clip -> AdamW -> scheduler.step(steps) -> (grads cleared in the kernel) -> steps += 1."""
-        self.optimizer.clip_and_step(self.clip_grad_norm, zero_grad=True)
+        with self.ctx:
+            self.optimizer.clip_and_step(self.clip_grad_norm, zero_grad=True)
         if torch.cuda.is_current_stream_capturing():
             return  # host-side schedule bookkeeping happens per replay: after_replay()
         self.after_update()

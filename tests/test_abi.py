@@ -123,3 +123,31 @@ def test_sub_sampled_lengths_on_the_host():
         lens = torch.arange(1, 400)
         want = sub.get_out_seq_lens_tensor(lens).tolist()
         assert [sub.out_len(int(n)) for n in lens] == want
+
+
+def test_context_settings_are_per_caller_not_per_process():
+    """js2t_ctx (include/joeys2t_hip.h): settings bound to the calling thread around a caller's launches - no GPU needed to check the
+    plumbing: nesting, per-thread binding, the process-wide setters as overrides.  (The numerical side - two train steps in one
+    process, one of them deterministic - is tests/test_hip_deterministic.py::test_two_steps_in_one_process_one_deterministic.)"""
+    import threading
+    from joeys2t_amd import _lib
+    from joeys2t_amd._lib import Context, lib
+    a, b = Context(deterministic=1, gemm_p192_ring=2), Context()
+    assert a.get("deterministic") == 1 and b.get("deterministic") == -1 and _lib.effective("deterministic") == 0
+    with a:
+        assert _lib.effective("deterministic") == 1 and _lib.effective("gemm_p192_ring") == 2
+        with b:  # nested: the inner binding counts, the outer one comes back
+            assert _lib.effective("deterministic") == 0 and _lib.effective("gemm_p192_ring") == -1
+        assert _lib.effective("deterministic") == 1
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(_lib.effective("deterministic")))  # another thread: nothing bound there
+        t.start()
+        t.join()
+        assert seen == [0]
+        lib().js2t_gemm_p192_ring(4)  # the test override wins over the context ...
+        try:
+            assert _lib.effective("gemm_p192_ring") == 4
+        finally:
+            lib().js2t_gemm_p192_ring(-1)
+        assert _lib.effective("gemm_p192_ring") == 2  # ... and gives way again
+    assert _lib.effective("deterministic") == 0 and _lib.effective("gemm_p192_ring") == -1
