@@ -1034,8 +1034,8 @@ int launch_bwd(const js2t_attn_desc* d, hipStream_t s) {
   // (x 1 / (1 - p)) and added into d_rel_bias behind the kernels
   const int64_t n_fix = (REL && g_js2t_deterministic && d->d_rel_bias) ? (int64_t)d->H * (2 * d->rel_R + 1) : 0;
   if (n_fix) {
-    long long* fix = js2t_fixed_scratch((size_t)n_fix);
-    JS2T_CHECK(fix != nullptr, "flash_attn_bwd: scratch allocation failed");
+    long long* fix = js2t_fixed_scratch((size_t)n_fix, s);
+    if (!fix) return JS2T_ERR_INVALID;  // (the error string says why)
     JS2T_CHECK(hipMemsetAsync(fix, 0, (size_t)n_fix * sizeof(long long), s) == hipSuccess, "flash_attn_bwd: memset failed");
     a.d_rel_fix = (unsigned long long*)fix;
   }

@@ -41,7 +41,7 @@ void js2t_ctx_override(int key, int value);  // what the process-wide setters (j
 // js2t_fixed_scratch: a device buffer of n zeroed-by-the-caller int64 words owned by the library (allocated at first use - which
 // must not be inside a hipGraph capture: the first step of a run is eager); js2t_fixed_to_float_add: dst[i] += src[i] * 2^-32 * scale.
 constexpr float JS2T_FIX_SCALE = 4294967296.0f;
-long long* js2t_fixed_scratch(size_t n);
+long long* js2t_fixed_scratch(size_t n, hipStream_t s);
 int js2t_fixed_to_float_add(const long long* src, float* dst, int64_t n, float scale, hipStream_t s);
 __device__ __forceinline__ unsigned long long js2t_to_fixed(float v) { return (unsigned long long)__float2ll_rn(v * JS2T_FIX_SCALE); }
 

@@ -797,15 +797,29 @@ __global__ void rel_bias_grad_fixed_kernel(const T* __restrict__ dS, unsigned lo
 }
 }  // namespace
 
-long long* js2t_fixed_scratch(size_t n) {
+// One buffer for the life of the process, allocated ONCE at its full size by the first call and never moved: hipGraphs captured
+// later keep its address in their memset, kernel and conversion nodes (round 5 grew it by hipFree + hipMalloc when a request passed
+// the capacity - graphs captured before then replayed onto freed memory, and growing inside a capture is an illegal hipMalloc;
+// ADVICE r5).  A request beyond the capacity, or a FIRST call while `s` is capturing, fails (nullptr + the error string) instead.
+// Single-stream: the deterministic launches that share it are ordered on the caller's stream.
+constexpr size_t JS2T_FIXED_SCRATCH_WORDS = size_t(1) << 20;  // 8 MB: H (2 R + 1) of 128 heads at clip distance 4095
+long long* js2t_fixed_scratch(size_t n, hipStream_t s) {
   static long long* buf = nullptr;
-  static size_t cap = 0;
-  if (n > cap) {
-    if (buf) (void)hipFree(buf);
-    buf = nullptr, cap = 0;
-    const size_t want = n < 65536 ? 65536 : n;
-    if (hipMalloc(&buf, want * sizeof(long long)) != hipSuccess) return nullptr;
-    cap = want;
+  if (n > JS2T_FIXED_SCRATCH_WORDS) {
+    js2t_set_error("deterministic scratch: %zu words asked for, %zu there (heads x (2 R + 1) too large for the ordered histogram)", n,
+                   JS2T_FIXED_SCRATCH_WORDS);
+    return nullptr;
+  }
+  if (!buf) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      js2t_set_error("deterministic scratch: first use inside a hipGraph capture (run one eager step in this mode first)");
+      return nullptr;
+    }
+    if (hipMalloc(&buf, JS2T_FIXED_SCRATCH_WORDS * sizeof(long long)) != hipSuccess) {
+      buf = nullptr;
+      js2t_set_error("deterministic scratch: hipMalloc of %zu bytes failed", JS2T_FIXED_SCRATCH_WORDS * sizeof(long long));
+    }
   }
   return buf;
 }
@@ -822,8 +836,8 @@ extern "C" int js2t_rel_bias_grad(const void* dS, float* d_rel_bias, int64_t B, 
   const int64_t rows = B * Tq, rpb = 64;
   if (g_js2t_deterministic) {  // js2t_set_deterministic: fixed-point histogram, then one conversion pass
     const int64_t n = H * (2 * R + 1);
-    long long* fix = js2t_fixed_scratch((size_t)n);
-    JS2T_CHECK(fix != nullptr, "rel_bias_grad: scratch allocation failed");
+    long long* fix = js2t_fixed_scratch((size_t)n, (hipStream_t)stream);
+    if (!fix) return JS2T_ERR_INVALID;  // (the error string says why)
     JS2T_CHECK(hipMemsetAsync(fix, 0, (size_t)n * sizeof(long long), (hipStream_t)stream) == hipSuccess, "rel_bias_grad: memset failed");
     DISPATCH_DT(dt, T, hipLaunchKernelGGL((rel_bias_grad_fixed_kernel<T>), dim3((unsigned)cdiv(rows, rpb), (unsigned)H), dim3(256),
                                           (size_t)(2 * R + 1) * sizeof(unsigned long long), (hipStream_t)stream, (const T*)dS,

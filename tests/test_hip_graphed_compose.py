@@ -154,3 +154,28 @@ def test_capture_failure_on_one_rank_only(device):
     for r in (r0, r1):
         assert r["steps"] == 4 and torch.equal(r["graph"], r["eager"])
     assert torch.equal(r0["graph"], r1["graph"])
+
+
+def test_precaptured_bucket_first_replay_equals_eager_bit_for_bit(device):
+    """a bucket captured AHEAD of its first batch never ran eagerly - any per-shape device constant built lazily inside
+    that capture is filled only by that graph's replays.  One eager step at shape A, precapture of shape B (other utterance count,
+    frame bucket and packed row count), then B's batches arrive as replays from their first sight: parameters after five updates
+    bit for bit those of the eager-only run (deterministic mode)."""
+    from joeys2t_amd.graphed import GraphedTrainStep
+    sd = _sd()
+    a, b = _batches(5, 2), _batches(7, 3, B=3, lo=52000, hi=56000)
+    order = [a[0], b[0], b[1], a[1], b[2]]
+    how_e, flat_e, _ = _run(_step(sd, device, torch.bfloat16, 1), order, device, torch.bfloat16, False)
+    np.random.seed(11)
+    step = _step(sd, device, torch.bfloat16, 1)
+    gs = GraphedTrainStep(step, _proc(), compute_dtype=torch.bfloat16, frame_bucket=128, target_bucket=16)
+    how = [gs.run(order[0][0].to(device), *order[0][1:])]
+    key_b = gs.bucket_key(b[0][1], b[0][3])
+    assert key_b not in gs.buckets and gs.precapture(key_b) and not gs.precapture(key_b)
+    flat_before = step.store.flat.detach().clone()
+    how += [gs.run(w.to(device), ns, trg, tl) for w, ns, trg, tl in order[1:]]
+    torch.cuda.synchronize()
+    assert how == ["eager", "replay", "replay", "replay", "replay"], how  # B replays from its FIRST sight; A's second batch replays A's capture
+    assert not torch.equal(flat_before.cpu(), step.store.flat.cpu())
+    assert torch.equal(step.store.flat.detach().cpu(), flat_e)
+    assert step.steps == 5 and step.optimizer.t == 5
