@@ -179,3 +179,34 @@ def test_precaptured_bucket_first_replay_equals_eager_bit_for_bit(device):
     assert not torch.equal(flat_before.cpu(), step.store.flat.cpu())
     assert torch.equal(step.store.flat.detach().cpu(), flat_e)
     assert step.steps == 5 and step.optimizer.t == 5
+
+
+def _rccl_single_worker(rank, port, ret):
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["JS2T_DDP_SINGLE"] = "1"  # a one-rank communicator exchanges nothing unless asked to
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sd = _sd()
+        batches = _rank_batches(0)
+        how_e, flat_e, _ = _run(_step(sd, dev, torch.bfloat16, 2), batches, dev, torch.bfloat16, False)
+        how_g, flat_g, gs = _run(_step(sd, dev, torch.bfloat16, 2), batches, dev, torch.bfloat16, True)
+        cut = sum(1 for bk in gs.buckets.values() for c in bk.graphs.values() if isinstance(c, dict))
+        ret["res"] = dict(how_g=how_g, eager=flat_e, graph=flat_g, cut=cut, errors=list(gs.capture_errors), steps=gs.step.steps,
+                          n_launched=sum(1 for l in gs.step.reducer.launched if l), n_ranges=len(gs.step.reducer.ranges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_composed_driver_on_a_real_rccl_communicator(device):
+    """The same driver over RCCL itself (one rank: the 1-GPU box cannot host two; JS2T_DDP_SINGLE makes the communicator issue its
+    all-reduces anyway): captures under RCCL's watchdog thread, the side-stream collectives between replays of the cut graphs."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_single_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    r = ret["res"]
+    assert not r["errors"] and r["cut"] >= 1 and r["steps"] == 4 and r["how_g"].count("replay") >= 2, (r["errors"], r["how_g"])
+    assert r["n_launched"] == r["n_ranges"]
+    assert torch.equal(r["graph"], r["eager"])
