@@ -1225,6 +1225,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     stats = step.read_stats()
+    # how much of a step the HOST spends inside the launch of its graph(s): with the GPU idle (synchronised before each launch) the
+    # call returns when the ~900 nodes are enqueued.  A step cannot be shorter than this on this runtime.
+    launch_host_ms = None
+    if use_graph:
+        # N > 1: a step is collectives too - EVERY rank runs these eight steps (never a subset of the ranks); the figure is rank 0's:
+        # what its host spends launching the step's ~15 graphs and handing the ranges to RCCL between them, with the GPU idle
+        ts = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            one_step()
+            ts.append((time.perf_counter() - h0) * 1e3)
+        torch.cuda.synchronize()
+        launch_host_ms = round(sorted(ts)[len(ts) // 2], 3)
+        step.read_stats(reset=True)
+
     exchange_times = None
     faithful = None
     if (world > 1 or force_ddp) and step.reducer is not None:
@@ -1277,20 +1293,6 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:  # never lose the N > 1 line over its side figure
                 roofline_pre = {"error": repr(exc)[:300]}
-    # how much of a step the HOST spends inside the launch of its graph(s): with the GPU idle (synchronised before each launch) the
-    # call returns when the ~900 nodes are enqueued.  A step cannot be shorter than this on this runtime.
-    launch_host_ms = None
-    if use_graph and world == 1 and not force_ddp:  # (N > 1: a step is collectives too - never run one on a subset of the ranks)
-        ts = []
-        for _ in range(8):
-            torch.cuda.synchronize()
-            h0 = time.perf_counter()
-            one_step()
-            ts.append((time.perf_counter() - h0) * 1e3)
-        torch.cuda.synchronize()
-        launch_host_ms = round(sorted(ts)[len(ts) // 2], 3)
-        step.read_stats(reset=True)
-
     varying = None
     if rank == 0 and world == 1 and not args.no_roofline and not args.no_extras and use_graph:
         try:  # side figure: a new batch every step through sampler + loader + one graph per shape bucket
