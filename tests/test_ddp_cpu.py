@@ -277,3 +277,74 @@ def test_wgrad_plan_order_does_not_depend_on_token_counts():
     # ... and with different token counts they are two launches that FOLLOW each other (one class, one place in the order)
     classes = [c[:3] for c in ref_launches]
     assert all(classes.index(c) + classes.count(c) - 1 == len(classes) - 1 - classes[::-1].index(c) for c in set(classes))
+
+
+class _TwoSidedWide(torch.nn.Module):
+    """encoder and decoder stacks that share their (N, K) classes - so that one class holds products of both sides"""
+
+    def __init__(self):
+        super().__init__()
+        mk = lambda: torch.nn.Sequential(torch.nn.Linear(16, 48), torch.nn.Linear(16, 16), torch.nn.Linear(16, 64), torch.nn.Linear(64, 16))
+        self.encoder = torch.nn.ModuleList([mk() for _ in range(3)])
+        self.decoder = torch.nn.ModuleList([mk() for _ in range(2)])
+
+
+def _eight_rank_exchange(rank, world):
+    """One data-parallel update's exchange as TrainStep drives it - deferred products queued in backward order, the pass cut at the
+    encoder's output, ranges handed over as the plan's groups complete them - with token counts that differ on EVERY rank (on rank 3
+    source and target counts coincide: encoder and decoder products of a class then share a launch there and nowhere else)."""
+    from joeys2t_amd.helpers_for_ddp import FlatGradReducer
+    from joeys2t_amd.runtime import ParamStore, WgradQueue
+    torch.manual_seed(0)
+    net = _TwoSidedWide()
+    store = ParamStore(net, torch.device("cpu"))
+    store.attach_grads()
+    red = FlatGradReducer(store, ranges=store.type_ranges)
+    g = torch.Generator().manual_seed(7 + rank)
+    store.flat_grad.copy_(torch.randn(store.total, generator=g))
+    local = store.flat_grad.clone()
+    order = []
+    launch = red._launch
+
+    def recording_launch(bi):
+        if not red.launched[bi]:
+            order.append(bi)
+        launch(bi)
+
+    red._launch = recording_launch
+    m_src, m_trg = 40 + 8 * rank, 64 if rank == 3 else 96 - 8 * rank
+    q = WgradQueue()
+
+    def queue(stack, m):
+        for block in reversed(list(stack)):  # backward order
+            for lin in reversed(list(block)):
+                n, k = lin.weight.shape
+                q.add(torch.empty(m, n), torch.empty(m, k), lin.weight.grad, lin.bias.grad)
+
+    queue(net.decoder, m_trg)
+    plan_dec = q.take(final=False)
+    red.exchange_begin(plan_dec, partial=True)
+    for _, items in plan_dec:
+        red.entries_done(items)
+    n_early = len(order)
+    queue(net.encoder, m_src)
+    plan = q.take()
+    red.exchange_begin(plan)
+    for _, items in plan:
+        red.entries_done(items)
+    red.finish()
+    launches = [(k[0], k[1], k[2], len(items)) for k, items in plan_dec + plan]
+    return local, store.flat_grad.clone(), order, n_early, launches
+
+
+def test_eight_ranks_with_different_token_counts_issue_one_order_of_collectives():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(8, _free_port(), _eight_rank_exchange, ret), nprocs=8, join=True)
+    mean = sum(ret[r][0] for r in range(8)) / 8
+    for r in range(8):
+        torch.testing.assert_close(ret[r][1], mean, rtol=1e-5, atol=1e-6)  # every rank ends on the mean of the local gradients
+        assert ret[r][2] == ret[0][2] and ret[r][3] == ret[0][3], (r, ret[r][2], ret[0][2])  # ... having sent the ranges in ONE order
+        assert ret[r][3] >= 1 and len(set(ret[r][2])) == len(ret[r][2])  # decoder-side ranges left first; each range exactly once
+    # the ranks really launched different things: other token counts everywhere, and rank 3's equal counts change nothing about the order
+    assert len({tuple(ret[r][4]) for r in range(8)}) == 8
