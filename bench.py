@@ -267,8 +267,10 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
     model = build_model(copy.deepcopy(LS100_MODEL), None, Vocabulary.synthetic(VOCAB))
     model.loss_function = ("crossentropy-ctc", 0.1, 0.3)
     model.finalize(device, dtype, seed=seed)
+    # JS2T_VARY_MULT=k: the config's accumulation over the varying batches too (k micro-batches of k different shapes per update)
     step = TrainStep(model, learning_rate=2.0e-3, adam_betas=(0.9, 0.98), weight_decay=0.0, clip_grad_norm=10.0, learning_rate_warmup=10000,
-                     learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=1, n_gpu=1, overlap_ctc=True)
+                     learning_rate_min=1.0e-6, normalization="batch", batch_multiplier=int(os.environ.get("JS2T_VARY_MULT", 1)), n_gpu=1,
+                     overlap_ctc=True)
     proc = SpeechProcessor(num_freq=80, min_length=10, max_length=6000,
                            specaugment=dict(freq_mask_n=2, freq_mask_f=27, time_mask_n=2, time_mask_t=100, time_mask_p=1.0),
                            cmvn=dict(norm_means=True, norm_vars=True, before=True))
@@ -337,7 +339,8 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
         n_frames += nf
         return how
 
-    one()  # the first step of the run: eager + capture of its own bucket
+    for _ in range(step.batch_multiplier):
+        one()  # the first update of the run: eager + capture of its own buckets
     # The loader knows its epoch: the samplers are deterministic given their seeds, so an identical second sampler lists the batches
     # to come and every bucket they fall into is captured BEFORE its first batch arrives (GraphedTrainStep.precapture: capturing
     # executes nothing).  JS2T_BENCH_NO_PRECAPTURE=1: first sight = eager step + capture inside the timed loop, as in round 4.
@@ -382,6 +385,7 @@ def varying_bench(device, steps, warmup, dtype=torch.bfloat16, seed=42, pool_utt
                                                            "sum": round(sum(first_ms), 1)},
                                "later_launches": {"steps": len(later_ms), "median": round(later_ms[len(later_ms) // 2], 2) if later_ms else None,
                                                   "max": round(later_ms[-1], 2) if later_ms else None}},
+            "batch_multiplier": step.batch_multiplier, "updates": step.steps, "capture_errors": gstep.capture_errors[:2] or None,
             "loss": round(stats["loss"] / steps, 4), "launch": "hipGraph per (B, frames/64, target length/8, packed rows/384) bucket" if use_graphs else "eager",
             "what": "LS100 train step, a NEW batch every step: TokenBatchSampler over a shuffled corpus of 10-17 s utterances, PrefetchLoader "
                     "(pinned rows -> HBM one batch ahead), graphed.GraphedTrainStep"}

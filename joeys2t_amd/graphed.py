@@ -292,7 +292,7 @@ class GraphedTrainStep:
         learns to overwrite).  Returns False when the bucket was captured already (or cannot be)."""
         if not self.use_graphs:
             return False
-        if self.counts["eager"] < self.step.batch_multiplier:
+        if not self.counts["eager"] or self.step.micro < self.step.batch_multiplier:
             raise ops.Js2tError("GraphedTrainStep.precapture: run one update first (the first steps of a run build what captures reuse)")
         key = tuple(key)
         if key not in self.buckets and len(self.buckets) >= self.max_graphs:
