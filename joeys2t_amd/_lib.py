@@ -111,6 +111,8 @@ def lib():
             _lib.js2t_gemm_p192_mode(int(os.environ["JS2T_P192"]))
         if "JS2T_WG256" in os.environ:  # 0 / 1 / -1: the 256x128 kernel of the grouped weight gradients (js2t_gemm_wg256_mode)
             _lib.js2t_gemm_wg256_mode(int(os.environ["JS2T_WG256"]))
+        if "JS2T_PANEL" in os.environ:  # 0 / 1 / -1: the panel-resident kernel (js2t_gemm_panel_mode)
+            _lib.js2t_gemm_panel_mode(int(os.environ["JS2T_PANEL"]))
         if "JS2T_P192_RING" in os.environ:  # 2 = two blocks per CU with a two-slot ring (js2t_gemm_p192_ring)
             _lib.js2t_gemm_p192_ring(int(os.environ["JS2T_P192_RING"]))
     return _lib
